@@ -1,0 +1,224 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules in the build
+container, and check the oracle restatement (oracle/ref_cpu.py) against them.
+
+TEST INFRASTRUCTURE.  Runs only where /root/reference exists (the build container).
+The fixtures it writes are data only (seeded inputs + the reference's outputs); no
+reference source text or bytecode is stored.
+
+Reference modules imported (by file path):
+  distillers.py, utils.py                          -- import as-is (torch only)
+  model/classifiers/e_dist_fc2.py                  -- import as-is
+  model/classifiers/TRX_2fcsup.py                  -- needs two test-only shims: an empty
+      `torchvision.models` stub for a dead import (TRX_2fcsup.py:12) and
+      `Tensor.cuda = identity` for the tuple-index tensors (TRX_2fcsup.py:71)
+
+usage: python oracle/gen_golden.py [--check-only]
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import ref_cpu as O  # noqa: E402
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def load_reference():
+    sys.path.insert(0, REF)
+    mods = {}
+    mods["distillers"] = _load("ref_distillers", os.path.join(REF, "distillers.py"))
+    mods["utils"] = _load("utils", os.path.join(REF, "utils.py"))       # TRX imports `utils`
+    sys.modules["utils"] = mods["utils"]
+    mods["e_dist_fc2"] = _load("ref_e_dist_fc2", os.path.join(REF, "model/classifiers/e_dist_fc2.py"))
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tv.models = types.ModuleType("torchvision.models")
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.models"] = tv.models
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    mods["trx"] = _load("ref_TRX_2fcsup", os.path.join(REF, "model/classifiers/TRX_2fcsup.py"))
+    return mods
+
+
+class Args:
+    way = 5
+    shot = 5
+    seq_len = 8
+    trans_linear_out_dim = 1152
+    trans_linear_in_dim = 2048
+    trans_dropout = 0.1
+    query_per_class = 5
+
+
+def gsum(g):
+    """compact digest of a [N,8,2048] gradient: 64-wide chunk sums (keeps fixtures small)."""
+    return g.reshape(g.shape[0], 8, 32, 64).sum(-1)
+
+
+def t2n(d):
+    return {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def gen_distill(mods):
+    """kd_loss / inter_class_relation / fc_2_sup_dist / KD / Dist_KD values + input grads."""
+    D = mods["distillers"]
+    out = {}
+    for case, (nq, seed) in enumerate([(25, 11), (25, 12), (5, 13)]):
+        g = torch.Generator().manual_seed(seed)
+        s = {"kl": (torch.randn(nq, 5, generator=g) * 30 - 300).requires_grad_(),
+             "ce": (torch.randn(nq, 5, generator=g) * 30 - 300).requires_grad_(),
+             "sup": (torch.randn(5, 4, generator=g) * 20 - 100).requires_grad_()}
+        t = {"kl": torch.randn(nq, 5, generator=g) * 30 - 300,
+             "sup": torch.randn(5, 4, generator=g) * 20 - 100}
+        labels = torch.randint(0, 5, (nq,), generator=g)
+        dist = D.Distiller("fc_2_sup_dist", O.DEFAULT_CFG, torch.device("cpu"))
+        r = dist.fc_2_sup_dist(s, t, labels)
+        r["loss"].backward()
+        pre = "c%d_" % case
+        out.update({pre + "s_kl": s["kl"], pre + "s_ce": s["ce"], pre + "s_sup": s["sup"],
+                    pre + "t_kl": t["kl"], pre + "t_sup": t["sup"], pre + "labels": labels,
+                    pre + "loss": r["loss"], pre + "soft": r["soft_loss"], pre + "hard": r["hard_loss"],
+                    pre + "g_kl": s["kl"].grad, pre + "g_ce": s["ce"].grad, pre + "g_sup": s["sup"].grad,
+                    pre + "kd": D.kd_loss(s["kl"], t["kl"], 4), pre + "icr": D.inter_class_relation(s["sup"], t["sup"])})
+        # single-logit methods
+        s1 = s["kl"].detach().clone().requires_grad_()
+        r = dist.KD(s1, t["kl"], labels)
+        r["loss"].backward()
+        out.update({pre + "KD_loss": r["loss"], pre + "KD_g": s1.grad})
+        s2 = s["kl"].detach().clone().requires_grad_()
+        r = dist.Dist_KD(s2, t["kl"], labels)
+        r["loss"].backward()
+        out.update({pre + "DistKD_loss": r["loss"], pre + "DistKD_g": s2.grad})
+        acc = mods["utils"].aggregate_accuracy(s["kl"].detach() + s["ce"].detach(), labels)
+        out.update({pre + "acc": acc, pre + "argmax": torch.argmax(s["kl"].detach() + s["ce"].detach(), -1)})
+    return out
+
+
+def feature_case(seed, ns=25, nq=25, scale=1.0, shuffle=True):
+    g = torch.Generator().manual_seed(seed)
+    sup = torch.randn(ns, 8, 2048, generator=g) * scale
+    qry = torch.randn(nq, 8, 2048, generator=g) * scale
+    lab = torch.arange(5).repeat_interleave(ns // 5)
+    if shuffle:
+        lab = lab[torch.randperm(ns, generator=g)]
+    return sup, lab.float(), qry
+
+
+def gen_edist(mods):
+    E = mods["e_dist_fc2"]
+    args = Args()
+    out = {}
+    for case, (seed, ns, nq, shuffle) in enumerate([(21, 25, 25, True), (22, 25, 5, False), (23, 5, 25, True)]):
+        args.shot = ns // 5
+        sup, lab, qry = feature_case(seed, ns, nq, 1.0, shuffle)
+        sup.requires_grad_()
+        qry.requires_grad_()
+        clf = E.e_dist_1fc_sup(args)
+        r = clf(sup, lab, qry)["logits"]
+        w_kl = torch.linspace(-1, 1, nq * 5).reshape(nq, 5)
+        w_sup = torch.linspace(1, -1, 20).reshape(5, 4)
+        ((r["kl"] * w_kl).sum() + (r["sup"] * w_sup).sum() * 1e-3).backward()
+        pre = "c%d_" % case
+        out.update({pre + "seed": seed, pre + "ns": ns, pre + "nq": nq, pre + "shuffle": int(shuffle),
+                    pre + "kl": r["kl"], pre + "sup": r["sup"],
+                    pre + "g_sup_feat": gsum(sup.grad), pre + "g_qry_feat": gsum(qry.grad),
+                    pre + "g_sup_row0": sup.grad[0, :, :128].clone(), pre + "g_qry_row0": qry.grad[0, :, :128].clone()})
+    return out
+
+
+def gen_trx(mods):
+    """TRX_2fcsup / TRX_2fcsup_fixed in eval() (dropout off), weights = oracle.make_trx_params(seed)."""
+    T = mods["trx"]
+    out = {}
+    for case, (seed, ns, nq, shuffle) in enumerate([(31, 25, 25, True), (32, 5, 25, True), (33, 25, 5, False)]):
+        args = Args()
+        args.shot = ns // 5
+        g = torch.Generator().manual_seed(1000 + seed)
+        p = O.make_trx_params(g)
+        # non-trivial LayerNorm affine so the test sees it
+        p["norm_k.weight"] = 1 + 0.1 * torch.randn(1152, generator=g)
+        p["norm_k.bias"] = 0.1 * torch.randn(1152, generator=g)
+        clf = T.TRX_2fcsup(args).eval()
+        sd = clf.state_dict()
+        for k, v in p.items():
+            sd["transformers." + k].copy_(v)
+        sup1, lab, qry1 = feature_case(seed, ns, nq, 0.5, shuffle)
+        sup2, _, qry2 = feature_case(seed + 100, ns, nq, 0.5, shuffle)
+        for x in (sup1, qry1, sup2, qry2):
+            x.requires_grad_()
+        ctx = {"context_features_1": sup1, "context_features_2": sup2}
+        tgt = {"target_features_1": qry1, "target_features_2": qry2}
+        r = clf(ctx, lab, tgt)["logits"]
+        w = torch.linspace(-1, 1, nq * 5).reshape(nq, 5)
+        w_sup = torch.linspace(1, -1, 20).reshape(5, 4)
+        ((r["kl"] * w).sum() * 1e-2 + (r["ce"] * w.flip(0)).sum() * 1e-2 + (r["sup"] * w_sup).sum() * 1e-3).backward()
+        pre = "c%d_" % case
+        tr = clf.transformers
+        out.update({pre + "seed": seed, pre + "ns": ns, pre + "nq": nq, pre + "shuffle": int(shuffle),
+                    pre + "kl": r["kl"], pre + "ce": r["ce"], pre + "sup": r["sup"],
+                    pre + "g_sup1": gsum(sup1.grad), pre + "g_qry1": gsum(qry1.grad),
+                    pre + "g_sup2": gsum(sup2.grad), pre + "g_qry2": gsum(qry2.grad),
+                    pre + "g_sup1_row0": sup1.grad[0, :, :128].clone(), pre + "g_qry1_row0": qry1.grad[0, :, :128].clone(),
+                    pre + "g_kw_sum": tr.k_linear.weight.grad.sum(dim=1), pre + "g_kb": tr.k_linear.bias.grad,
+                    pre + "g_vw_sum": tr.v_linear.weight.grad.sum(dim=1), pre + "g_vb": tr.v_linear.bias.grad,
+                    pre + "g_nkw": tr.norm_k.weight.grad, pre + "g_nkb": tr.norm_k.bias.grad})
+        fx = T.TRX_2fcsup_fixed(args).eval()
+        fsd = fx.state_dict()
+        for k, v in p.items():
+            fsd["transformers." + k].copy_(v)
+        rf = fx(sup1.detach(), lab, qry1.detach())["logits"]
+        out.update({pre + "fixed_kl": rf["kl"], pre + "fixed_sup": rf["sup"]})
+    return out
+
+
+def trx_case_inputs(seed, ns, nq, shuffle):
+    """Re-creates the exact inputs/weights of gen_trx (used by tests; no reference needed)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    p = O.make_trx_params(g)
+    p["norm_k.weight"] = 1 + 0.1 * torch.randn(1152, generator=g)
+    p["norm_k.bias"] = 0.1 * torch.randn(1152, generator=g)
+    sup1, lab, qry1 = feature_case(seed, ns, nq, 0.5, shuffle)
+    sup2, _, qry2 = feature_case(seed + 100, ns, nq, 0.5, shuffle)
+    return p, sup1, qry1, sup2, qry2, lab
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check-only", action="store_true")
+    a = ap.parse_args()
+    if not os.path.isdir(REF):
+        sys.exit("reference not present: fixtures can only be (re)generated in the build container")
+    torch.manual_seed(0)
+    mods = load_reference()
+    os.makedirs(GOLD, exist_ok=True)
+    for name, fn in (("distill", gen_distill), ("edist", gen_edist), ("trx", gen_trx)):
+        data = t2n(fn(mods))
+        path = os.path.join(GOLD, name + ".npz")
+        if a.check_only:
+            old = np.load(path)
+            for k in data:
+                np.testing.assert_allclose(old[k], data[k], rtol=1e-5, atol=1e-6, err_msg=k)
+            print("checked", path)
+        else:
+            np.savez_compressed(path, **data)
+            print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,488 @@
+"""CPU oracle for the Lite-MKD per-episode hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain PyTorch-CPU fp32 restatement of the reference algorithm.  It
+is the *checker*: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product path
+(``lite-mkd_amd/``) never imports anything from ``oracle/`` and fails loudly when
+the HIP extension is missing.
+
+Parity pins (see oracle/gen_golden.py, tests/golden/):
+  * distillers / e_dist / SupportDK / TRX_2fcsup(+_fixed) / aggregate_accuracy are
+    pinned against outputs of the reference's own modules imported in the build
+    container (fixtures committed under tests/golden/).
+  * The ResNet-18 trunk arithmetic lives in torchvision==0.14.0 (pinned in the
+    reference's envirment.yml:128), which is absent from /root/reference and from
+    this image: the trunk restatement below follows the published ResNet-18
+    definition and is anchored on the reference call sites
+    (model/backbone/resnet18_2fc.py:30-33,41-42), the parameter count 11 176 512 and
+    the state-dict key names.  The reference holds no tests or golden vectors for it:
+    TRUNK PARITY UNPINNED BY THE REFERENCE.
+  * The MFM fusion (teacher/code/model.py) cannot be imported here (needs timm,
+    tkinter, ...): restated from source text, PARITY UNPINNED.
+
+All citations are file:line under /root/reference.
+"""
+import math
+from itertools import combinations
+
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------
+# A2  ResNet-18 trunk  (torchvision resnet18().children()[:-2],
+#     model/backbone/resnet18_2fc.py:30-33, called at :41-42)
+# ----------------------------------------------------------------------------
+# (stage index in nn.Sequential, in_ch, out_ch, first-block stride)
+RESNET18_STAGES = [(4, 64, 64, 1), (5, 64, 128, 2), (6, 128, 256, 2), (7, 256, 512, 2)]
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def resnet18_trunk_param_shapes():
+    """state_dict-style key -> shape for nn.Sequential(*children()[:-2])."""
+    shapes = {"0.weight": (64, 3, 7, 7)}
+
+    def bn(prefix, c):
+        shapes[prefix + ".weight"] = (c,)
+        shapes[prefix + ".bias"] = (c,)
+        shapes[prefix + ".running_mean"] = (c,)
+        shapes[prefix + ".running_var"] = (c,)
+        shapes[prefix + ".num_batches_tracked"] = ()
+
+    bn("1", 64)
+    for idx, cin, cout, stride in RESNET18_STAGES:
+        for b in range(2):
+            p = "%d.%d" % (idx, b)
+            shapes[p + ".conv1.weight"] = (cout, cin if b == 0 else cout, 3, 3)
+            bn(p + ".bn1", cout)
+            shapes[p + ".conv2.weight"] = (cout, cout, 3, 3)
+            bn(p + ".bn2", cout)
+            if b == 0 and (stride != 1 or cin != cout):
+                shapes[p + ".downsample.0.weight"] = (cout, cin, 1, 1)
+                bn(p + ".downsample.1", cout)
+    return shapes
+
+
+def init_resnet18_trunk(gen):
+    """Seeded random init (no pretrained weights offline): Kaiming-normal fan_out
+    convs, BN gamma=1 beta=0 — torchvision's ResNet.__init__ scheme."""
+    sd = {}
+    for k, shp in resnet18_trunk_param_shapes().items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_mean"):
+            sd[k] = torch.zeros(shp)
+        elif k.endswith("running_var"):
+            sd[k] = torch.ones(shp)
+        elif len(shp) == 4:
+            fan_out = shp[0] * shp[2] * shp[3]
+            sd[k] = torch.randn(shp, generator=gen) * math.sqrt(2.0 / fan_out)
+        elif k.endswith(".weight"):
+            sd[k] = torch.ones(shp)
+        else:
+            sd[k] = torch.zeros(shp)
+    return sd
+
+
+def _bn(x, sd, prefix, training, update_running=True):
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if training and not update_running:
+        rm, rv = rm.clone(), rv.clone()
+    return F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"],
+                        training, BN_MOMENTUM, BN_EPS)
+
+
+def resnet18_trunk(x, sd, training=True, update_running=True, taps=None):
+    """[F,3,H,W] -> [F,512,H/32,W/32].  BN in train mode uses the batch statistics of
+    THIS call (reference: Student.__init__ calls self.train(), model_select.py:21)."""
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+    x = F.conv2d(x, sd["0.weight"], None, 2, 3)
+    tap("conv1", x)
+    x = F.relu(_bn(x, sd, "1", training, update_running))
+    x = F.max_pool2d(x, 3, 2, 1)
+    tap("pool", x)
+    for idx, cin, cout, stride in RESNET18_STAGES:
+        for b in range(2):
+            p = "%d.%d" % (idx, b)
+            s = stride if b == 0 else 1
+            idn = x
+            out = F.conv2d(x, sd[p + ".conv1.weight"], None, s, 1)
+            out = F.relu(_bn(out, sd, p + ".bn1", training, update_running))
+            out = F.conv2d(out, sd[p + ".conv2.weight"], None, 1, 1)
+            out = _bn(out, sd, p + ".bn2", training, update_running)
+            if (p + ".downsample.0.weight") in sd:
+                idn = F.conv2d(x, sd[p + ".downsample.0.weight"], None, s, 0)
+                idn = _bn(idn, sd, p + ".downsample.1", training, update_running)
+            x = F.relu(out + idn)
+            tap(p, x)
+    return x
+
+
+# ----------------------------------------------------------------------------
+# A3  pooled head (model/backbone/resnet18_2fc.py:44-77, resnet18_student.py:41-60)
+# ----------------------------------------------------------------------------
+def pooled_frame_features(fmap):
+    """AdaptiveMaxPool2d((4,4)) -> reshape [F,C,16] -> permute -> mean over the 16
+    patches (resnet18_2fc.py:44-54)."""
+    p = F.adaptive_max_pool2d(fmap, (4, 4))
+    p = p.reshape(p.shape[0], p.shape[1], 16).permute(0, 2, 1)
+    return p.mean(dim=1)
+
+
+def backbone_resnet18_2fc(ctx_imgs, tgt_imgs, params, seq_len=8, training=True, update_running=True):
+    """resnet18_2fc.forward (resnet18_2fc.py:37-77). params: 'resnet.<k>', 'fc1.*', 'fc2.*'."""
+    sd = {k[len("resnet."):]: v for k, v in params.items() if k.startswith("resnet.")}
+    cf = pooled_frame_features(resnet18_trunk(ctx_imgs, sd, training, update_running))
+    tf = pooled_frame_features(resnet18_trunk(tgt_imgs, sd, training, update_running))
+    out_c, out_t = {}, {}
+    for h in (1, 2):
+        w, b = params["fc%d.weight" % h], params["fc%d.bias" % h]
+        out_c["context_features_%d" % h] = F.linear(cf, w, b).reshape(-1, seq_len, 2048)
+        out_t["target_features_%d" % h] = F.linear(tf, w, b).reshape(-1, seq_len, 2048)
+    return out_c, out_t
+
+
+def backbone_resnet18_student(ctx_imgs, tgt_imgs, params, seq_len=8, training=True, update_running=True):
+    """resnet18_student.forward (resnet18_student.py:36-60): single 512->2048 head."""
+    sd = {k[len("resnet."):]: v for k, v in params.items() if k.startswith("resnet.")}
+    cf = pooled_frame_features(resnet18_trunk(ctx_imgs, sd, training, update_running))
+    tf = pooled_frame_features(resnet18_trunk(tgt_imgs, sd, training, update_running))
+    w, b = params["res18_2048.weight"], params["res18_2048.bias"]
+    return (F.linear(cf, w, b).reshape(-1, seq_len, 2048),
+            F.linear(tf, w, b).reshape(-1, seq_len, 2048))
+
+
+# ----------------------------------------------------------------------------
+# A4  PositionalEncoding (model/classifiers/TRX_2fcsup.py:24-48)
+# ----------------------------------------------------------------------------
+def positional_encoding_table(d_model=2048, max_len=12, scale=0.1):
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2) * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term) * scale
+    pe[:, 1::2] = torch.cos(position * div_term) * scale
+    return pe.unsqueeze(0)
+
+
+# ----------------------------------------------------------------------------
+# A5  TemporalCrossTransformer.forward (TRX_2fcsup.py:74-148); dropout off (p=0)
+# ----------------------------------------------------------------------------
+def frame_tuples(seq_len=8, card=2):
+    return [list(c) for c in combinations(range(seq_len), card)]
+
+
+def trx_logits(support, labels, queries, p, way=5, seq_len=8, out_dim=1152):
+    """p: dict with k_linear.{weight,bias}, v_linear.{weight,bias}, norm_k.{weight,bias}, pe.pe"""
+    n_q, n_s = queries.shape[0], support.shape[0]
+    pe = p["pe.pe"][:, :seq_len]
+    support = support + pe
+    queries = queries + pe
+    tuples = frame_tuples(seq_len, 2)
+    s = torch.stack([support[:, t, :].reshape(n_s, -1) for t in tuples], dim=-2)
+    q = torch.stack([queries[:, t, :].reshape(n_q, -1) for t in tuples], dim=-2)
+    T = len(tuples)
+    s_k = F.linear(s, p["k_linear.weight"], p["k_linear.bias"])
+    q_k = F.linear(q, p["k_linear.weight"], p["k_linear.bias"])
+    s_v = F.linear(s, p["v_linear.weight"], p["v_linear.bias"])
+    q_v = F.linear(q, p["v_linear.weight"], p["v_linear.bias"])
+    s_k = F.layer_norm(s_k, (out_dim,), p["norm_k.weight"], p["norm_k.bias"], 1e-5)
+    q_k = F.layer_norm(q_k, (out_dim,), p["norm_k.weight"], p["norm_k.bias"], 1e-5)
+    cols = []
+    for c in torch.unique(labels):
+        idx = torch.nonzero(labels == c).reshape(-1)
+        ck, cv = s_k[idx], s_v[idx]
+        sc = torch.matmul(q_k.unsqueeze(1), ck.transpose(-2, -1)) / math.sqrt(out_dim)
+        sc = sc.permute(0, 2, 1, 3).reshape(n_q, T, -1)
+        sc = torch.softmax(sc, dim=-1)          # Softmax(dim=1) of each per-query 2-D slice (:66,127)
+        sc = sc.reshape(n_q, T, -1, T).permute(0, 2, 1, 3)
+        proto = torch.matmul(sc, cv).sum(dim=1)
+        diff = q_v - proto
+        dist = -(diff.pow(2).sum(dim=(-2, -1))) / T   # norm(dim=[-2,-1])**2 / tuples_len (:139-143)
+        cols.append((int(c.long()), dist))
+    out = torch.stack([dict(cols).get(j, torch.zeros(n_q)) for j in range(way)], dim=1)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# A6  SupportDK.forward (TRX_2fcsup.py:162-189 == e_dist_fc2.py:17-44)
+# ----------------------------------------------------------------------------
+def support_dk(support, way=5, shot=5, seq_len=8):
+    proto = support.reshape(way, shot, seq_len, 2048).mean(dim=1)
+    rows = []
+    for i in range(way):
+        rows.append(torch.stack([-(proto[i] - proto[n]).pow(2).sum() / seq_len
+                                 for n in range(way) if n != i]))
+    return torch.stack(rows)
+
+
+# ----------------------------------------------------------------------------
+# A9  e_dist.forward (e_dist_fc2.py:52-91)
+# ----------------------------------------------------------------------------
+def e_dist_logits(support, labels, queries, way=5):
+    sup = support.reshape(-1, 8, 2048)
+    q = queries.reshape(-1, 8, 2048).mean(dim=1)
+    cols = {}
+    for c in torch.unique(labels):
+        idx = torch.nonzero(labels == c).reshape(-1)
+        sc = sup[idx].mean(dim=1)
+        cols[int(c.long())] = -torch.cdist(q, sc, p=2).mean(dim=1)
+    return torch.stack([cols.get(j, torch.zeros(q.shape[0])) for j in range(way)], dim=1)
+
+
+# A7/A8 + wrappers -----------------------------------------------------------
+def clf_TRX_2fcsup(ctx, labels, tgt, p, way=5, shot=5):
+    """TRX_2fcsup.forward (TRX_2fcsup.py:205-224)."""
+    return {"kl": trx_logits(ctx["context_features_1"], labels, tgt["target_features_1"], p, way),
+            "ce": trx_logits(ctx["context_features_2"], labels, tgt["target_features_2"], p, way),
+            "sup": support_dk(ctx["context_features_2"], way, shot)}
+
+
+def clf_TRX_2fcsup_fixed(ctx, labels, tgt, p, way=5, shot=5):
+    """TRX_2fcsup_fixed.forward (TRX_2fcsup.py:241-256), no_grad."""
+    with torch.no_grad():
+        return {"kl": trx_logits(ctx, labels, tgt, p, way), "sup": support_dk(ctx, way, shot)}
+
+
+def clf_e_dist_fc2_sup(ctx, labels, tgt, way=5, shot=5):
+    """e_dist_fc2_sup.forward (e_dist_fc2.py:139-172)."""
+    return {"kl": e_dist_logits(ctx["context_features_1"], labels, tgt["target_features_1"], way),
+            "ce": e_dist_logits(ctx["context_features_2"], labels, tgt["target_features_2"], way),
+            "sup": support_dk(ctx["context_features_2"], way, shot)}
+
+
+def clf_e_dist_1fc_sup(ctx, labels, tgt, way=5, shot=5):
+    """e_dist_1fc_sup / e_dist_fc2_sup_fixed .forward (e_dist_fc2.py:175-231)."""
+    return {"kl": e_dist_logits(ctx, labels, tgt, way), "sup": support_dk(ctx, way, shot)}
+
+
+# ----------------------------------------------------------------------------
+# A11-A13  distillers.py:7-30, 42-74, 286-337
+# ----------------------------------------------------------------------------
+def kd_loss(s, t, T):
+    lp = F.log_softmax(s / T, dim=1)
+    pt = F.softmax(t / T, dim=1)
+    return F.kl_div(lp, pt, reduction="none").sum(1).mean() * T ** 2
+
+
+def cosine_similarity(x, y, eps=1e-8):
+    return (x * y).sum(1) / (x.norm(dim=1) * y.norm(dim=1) + eps)
+
+
+def pearson_correlation(x, y, eps=1e-8):
+    return cosine_similarity(x - x.mean(1).unsqueeze(1), y - y.mean(1).unsqueeze(1), eps)
+
+
+def inter_class_relation(y_s, y_t):
+    return 1 - pearson_correlation(y_s.softmax(dim=1), y_t.softmax(dim=1)).mean()
+
+
+DEFAULT_CFG = {"soft_loss_weight_support": 1, "soft_loss_weight_query": 1, "hard_loss_weight": 1,
+               "soft_loss_weight": 2, "feature_loss_weight": 1, "temperature": 4,
+               "fcwsl_aerfa": 0.5, "fcwsl_beta": 1}       # options.py:51-60
+
+
+def distill_fc_2_sup_dist(s, t, labels, cfg=DEFAULT_CFG):
+    """Distiller.fc_2_sup_dist (distillers.py:295-337)."""
+    kl = kd_loss(s["kl"], t["kl"], cfg["temperature"])
+    sup = inter_class_relation(s["sup"], t["sup"])
+    ce = F.cross_entropy(s["ce"], labels) / 16
+    return {"soft_loss": kl, "hard_loss": 0.5 * sup + ce, "loss": kl + 0.5 * sup + ce}
+
+
+def distill_KD(s, t, labels, cfg=DEFAULT_CFG):
+    """Distiller.KD (distillers.py:42-74)."""
+    ce = cfg["hard_loss_weight"] * F.cross_entropy(s, labels) / 16
+    kl = cfg["soft_loss_weight"] * kd_loss(s, t, cfg["temperature"])
+    return {"hard_loss": ce, "soft_loss": kl, "loss": ce + kl}
+
+
+def distill_Dist_KD(s, t, labels, cfg=DEFAULT_CFG):
+    """Distiller.Dist_KD (distillers.py:286-293)."""
+    ce = cfg["hard_loss_weight"] * F.cross_entropy(s, labels) / 16
+    d = cfg["soft_loss_weight"] * inter_class_relation(s, t)
+    return {"soft_loss": d, "hard_loss": ce, "loss": ce + d}
+
+
+# A14 ------------------------------------------------------------------------
+def aggregate_accuracy(logits, labels):
+    """utils.py:116-121."""
+    return torch.mean(torch.eq(labels, torch.argmax(logits, dim=-1)).float())
+
+
+# ----------------------------------------------------------------------------
+# A10  MFM fusion  (teacher/code/model.py:1135-1151, 1300-1331, 1361-1392, 1648-1664)
+#      eval mode (dropout off); nn.TransformerEncoderLayer defaults: post-norm, ReLU,
+#      dim_feedforward 2048, LayerNorm eps 1e-5, batch_first.
+# ----------------------------------------------------------------------------
+def _trainable_pe(x, p, prefix):
+    L = x.shape[1]
+    emb = p[prefix + ".position_embeddings.weight"][:L].unsqueeze(0)
+    return F.layer_norm(x + emb, (x.shape[-1],), p[prefix + ".LayerNorm.weight"],
+                        p[prefix + ".LayerNorm.bias"], 1e-5)
+
+
+def _encoder_layer(x, p, prefix, nhead):
+    B, L, D = x.shape
+    hd = D // nhead
+    qkv = F.linear(x, p[prefix + ".self_attn.in_proj_weight"], p[prefix + ".self_attn.in_proj_bias"])
+    q, k, v = qkv.chunk(3, dim=-1)
+    q = q.reshape(B, L, nhead, hd).transpose(1, 2)
+    k = k.reshape(B, L, nhead, hd).transpose(1, 2)
+    v = v.reshape(B, L, nhead, hd).transpose(1, 2)
+    att = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(hd), dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(B, L, D)
+    o = F.linear(o, p[prefix + ".self_attn.out_proj.weight"], p[prefix + ".self_attn.out_proj.bias"])
+    x = F.layer_norm(x + o, (D,), p[prefix + ".norm1.weight"], p[prefix + ".norm1.bias"], 1e-5)
+    ff = F.linear(F.relu(F.linear(x, p[prefix + ".linear1.weight"], p[prefix + ".linear1.bias"])),
+                  p[prefix + ".linear2.weight"], p[prefix + ".linear2.bias"])
+    return F.layer_norm(x + ff, (D,), p[prefix + ".norm2.weight"], p[prefix + ".norm2.bias"], 1e-5)
+
+
+def mfm_three_fusion(x, y, z, p, prefix="three_fusion", num_layers=2):
+    h = torch.cat((_trainable_pe(x, p, prefix + ".positionEncoding1"),
+                   _trainable_pe(y, p, prefix + ".positionEncoding2"),
+                   _trainable_pe(z, p, prefix + ".positionEncoding3")), dim=-1)
+    for l in range(num_layers):
+        h = _encoder_layer(h, p, "%s.transformer_encoder.layers.%d" % (prefix, l), 3)
+    return F.linear(h, p[prefix + ".f1.weight"], p[prefix + ".f1.bias"])
+
+
+def mfm_two_fusion(x, y, p, prefix="fusion", num_layers=2):
+    h = torch.cat((_trainable_pe(x, p, prefix + ".positionEncoding1"),
+                   _trainable_pe(y, p, prefix + ".positionEncoding2")), dim=-1)
+    for l in range(num_layers):
+        h = _encoder_layer(h, p, "%s.transformer_encoder.layers.%d" % (prefix, l), 2)
+    return F.linear(h, p[prefix + ".f1.weight"], p[prefix + ".f1.bias"])
+
+
+def mfm_extract_feature(rgb, depth, flow, p, shirt_num=1, num_layers=2):
+    """ThreeTRXShiftLoopTime.extract_feature (teacher/code/model.py:1648-1664)."""
+    f1 = mfm_three_fusion(rgb, depth, flow, p, num_layers=num_layers)
+    d2 = torch.cat((depth[:, shirt_num:], depth[:, :shirt_num]), dim=1)
+    f2 = mfm_two_fusion(rgb, d2, p, num_layers=num_layers)
+    fl = torch.cat((flow[:, shirt_num:], flow[:, :shirt_num]), dim=1)
+    f3 = mfm_two_fusion(rgb, fl, p, num_layers=num_layers)
+    return f1 + f2 + f3
+
+
+def mfm_param_shapes(d=2048, seq_len=8, num_layers=2, dff=2048):
+    shp = {}
+
+    def pe(prefix):
+        shp[prefix + ".position_embeddings.weight"] = (seq_len, d)
+        shp[prefix + ".LayerNorm.weight"] = (d,)
+        shp[prefix + ".LayerNorm.bias"] = (d,)
+
+    def enc(prefix, D):
+        for l in range(num_layers):
+            q = "%s.transformer_encoder.layers.%d" % (prefix, l)
+            shp[q + ".self_attn.in_proj_weight"] = (3 * D, D)
+            shp[q + ".self_attn.in_proj_bias"] = (3 * D,)
+            shp[q + ".self_attn.out_proj.weight"] = (D, D)
+            shp[q + ".self_attn.out_proj.bias"] = (D,)
+            shp[q + ".linear1.weight"] = (dff, D)
+            shp[q + ".linear1.bias"] = (dff,)
+            shp[q + ".linear2.weight"] = (D, dff)
+            shp[q + ".linear2.bias"] = (D,)
+            for n in ("norm1", "norm2"):
+                shp[q + "." + n + ".weight"] = (D,)
+                shp[q + "." + n + ".bias"] = (D,)
+        shp[prefix + ".f1.weight"] = (d, D)
+        shp[prefix + ".f1.bias"] = (d,)
+
+    for i in (1, 2, 3):
+        pe("three_fusion.positionEncoding%d" % i)
+    enc("three_fusion", 3 * d)
+    for i in (1, 2):
+        pe("fusion.positionEncoding%d" % i)
+    enc("fusion", 2 * d)
+    return shp
+
+
+# ----------------------------------------------------------------------------
+# synthetic episodes + seeded weights — shared by tests and bench
+# ----------------------------------------------------------------------------
+def make_student_params(seed, backbone="resnet18_2fc", out_dim=1152, seq_len=8):
+    g = torch.Generator().manual_seed(seed)
+    params = {"backbone.resnet." + k: v for k, v in init_resnet18_trunk(g).items()}
+
+    def linear(prefix, fout, fin):
+        bound = 1.0 / math.sqrt(fin)
+        params[prefix + ".weight"] = (torch.rand(fout, fin, generator=g) * 2 - 1) * bound
+        params[prefix + ".bias"] = (torch.rand(fout, generator=g) * 2 - 1) * bound
+
+    if backbone == "resnet18_2fc":
+        linear("backbone.fc1", 2048, 512)
+        linear("backbone.fc2", 2048, 512)
+    else:
+        linear("backbone.res18_2048", 2048, 512)
+    params.update({"classifier.transformers." + k: v
+                   for k, v in make_trx_params(g, out_dim, seq_len).items()})
+    return params
+
+
+def make_trx_params(g, out_dim=1152, seq_len=8):
+    p = {}
+    bound = 1.0 / math.sqrt(4096)
+    for n in ("k_linear", "v_linear"):
+        p[n + ".weight"] = (torch.rand(out_dim, 4096, generator=g) * 2 - 1) * bound
+        p[n + ".bias"] = (torch.rand(out_dim, generator=g) * 2 - 1) * bound
+    for n in ("norm_k", "norm_v"):
+        p[n + ".weight"] = torch.ones(out_dim)
+        p[n + ".bias"] = torch.zeros(out_dim)
+    p["pe.pe"] = positional_encoding_table(2048, int(seq_len * 1.5))
+    return p
+
+
+def make_episode(seed, way=5, shot=5, query=5, seq_len=8, img=224, frames=True):
+    """support_set/target_set ~ U[0,1) (ToTensor range, video_reader.py:384), teacher
+    features ~ N(0,1), labels = seeded permutation of repeat_interleave(arange(way))."""
+    g = torch.Generator().manual_seed(seed)
+    ns, nq = way * shot, way * query
+    ep = {}
+    if frames:
+        ep["support_set"] = torch.rand(ns * seq_len, 3, img, img, generator=g)
+        ep["target_set"] = torch.rand(nq * seq_len, 3, img, img, generator=g)
+    ep["support_set_feature_teacher"] = torch.randn(ns, seq_len, 2048, generator=g)
+    ep["target_set_feature_teacher"] = torch.randn(nq, seq_len, 2048, generator=g)
+    sl = torch.arange(way).repeat_interleave(shot)[torch.randperm(ns, generator=g)]
+    tl = torch.arange(way).repeat_interleave(query)[torch.randperm(nq, generator=g)]
+    ep["support_labels"] = sl.float()
+    ep["target_labels"] = tl.float()
+    return ep
+
+
+def student_forward(ep, params, way=5, shot=5, classifier="TRX_2fcsup", backbone="resnet18_2fc",
+                    training=True, update_running=True):
+    """Student.forward (model_select.py:26-36) for the default plugins."""
+    bp = {k[len("backbone."):]: v for k, v in params.items() if k.startswith("backbone.")}
+    cp = {k[len("classifier.transformers."):]: v for k, v in params.items()
+          if k.startswith("classifier.transformers.")}
+    if backbone == "resnet18_2fc":
+        ctx, tgt = backbone_resnet18_2fc(ep["support_set"], ep["target_set"], bp, 8, training, update_running)
+    else:
+        ctx, tgt = backbone_resnet18_student(ep["support_set"], ep["target_set"], bp, 8, training, update_running)
+    if classifier == "TRX_2fcsup":
+        logits = clf_TRX_2fcsup(ctx, ep["support_labels"], tgt, cp, way, shot)
+    elif classifier == "e_dist_fc2_sup":
+        logits = clf_e_dist_fc2_sup(ctx, ep["support_labels"], tgt, way, shot)
+    elif classifier == "e_dist_1fc_sup":
+        logits = clf_e_dist_1fc_sup(ctx, ep["support_labels"], tgt, way, shot)
+    else:
+        raise KeyError(classifier)
+    return {"logits": logits, "context_features": ctx, "target_features": tgt}
+
+
+def train_episode(ep, params, teacher_params, way=5, shot=5, cfg=DEFAULT_CFG):
+    """train_task (trainwandb.py:190-287): student fwd, teacher fwd, fc_2_sup_dist,
+    accuracy on kl+ce, backward.  `params` tensors with requires_grad accumulate .grad."""
+    out = student_forward(ep, params, way, shot)
+    t_logits = clf_TRX_2fcsup_fixed(ep["support_set_feature_teacher"], ep["support_labels"],
+                                    ep["target_set_feature_teacher"], teacher_params, way, shot)
+    labels = ep["target_labels"].long()
+    loss = distill_fc_2_sup_dist(out["logits"], t_logits, labels, cfg)
+    acc = aggregate_accuracy(out["logits"]["kl"] + out["logits"]["ce"], labels)
+    loss["loss"].backward()
+    return loss["loss"].detach(), acc, out, t_logits

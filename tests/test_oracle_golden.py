@@ -1,0 +1,120 @@
+"""CPU: the oracle restatement (oracle/ref_cpu.py) against the golden vectors produced by
+the reference's own modules (oracle/gen_golden.py, run in the build container)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import ref_cpu as O
+from oracle.gen_golden import feature_case, gsum, trx_case_inputs
+
+RTOL, ATOL = 2e-5, 2e-5     # fp32, same library (torch CPU) on both sides
+
+
+def T(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    np.testing.assert_allclose(a.detach().numpy() if torch.is_tensor(a) else a, np.asarray(b), rtol=rtol, atol=atol)
+
+
+def test_distill_golden(golden_dir):
+    G = np.load(os.path.join(golden_dir, "distill.npz"))
+    for c in range(3):
+        pre = "c%d_" % c
+        s = {k: T(G[pre + "s_" + k]).clone().requires_grad_() for k in ("kl", "ce", "sup")}
+        t = {k: T(G[pre + "t_" + k]) for k in ("kl", "sup")}
+        labels = T(G[pre + "labels"])
+        r = O.distill_fc_2_sup_dist(s, t, labels)
+        r["loss"].backward()
+        close(r["loss"], G[pre + "loss"])
+        close(r["soft_loss"], G[pre + "soft"])
+        close(r["hard_loss"], G[pre + "hard"])
+        close(O.kd_loss(s["kl"], t["kl"], 4), G[pre + "kd"])
+        close(O.inter_class_relation(s["sup"], t["sup"]), G[pre + "icr"])
+        for k in ("kl", "ce", "sup"):
+            close(s[k].grad, G[pre + "g_" + k], atol=1e-7)
+        s1 = T(G[pre + "s_kl"]).clone().requires_grad_()
+        r = O.distill_KD(s1, t["kl"], labels)
+        r["loss"].backward()
+        close(r["loss"], G[pre + "KD_loss"])
+        close(s1.grad, G[pre + "KD_g"], atol=1e-7)
+        s2 = T(G[pre + "s_kl"]).clone().requires_grad_()
+        r = O.distill_Dist_KD(s2, t["kl"], labels)
+        r["loss"].backward()
+        close(r["loss"], G[pre + "DistKD_loss"])
+        close(s2.grad, G[pre + "DistKD_g"], atol=1e-7)
+        lg = s["kl"].detach() + s["ce"].detach()
+        assert np.array_equal(torch.argmax(lg, -1).numpy(), G[pre + "argmax"])      # bit-exact indices
+        close(O.aggregate_accuracy(lg, labels), G[pre + "acc"], 0, 0)
+
+
+def test_edist_supportdk_golden(golden_dir):
+    G = np.load(os.path.join(golden_dir, "edist.npz"))
+    for c in range(3):
+        pre = "c%d_" % c
+        ns, nq = int(G[pre + "ns"]), int(G[pre + "nq"])
+        sup, lab, qry = feature_case(int(G[pre + "seed"]), ns, nq, 1.0, bool(G[pre + "shuffle"]))
+        sup.requires_grad_()
+        qry.requires_grad_()
+        r = O.clf_e_dist_1fc_sup(sup, lab, qry, 5, ns // 5)
+        close(r["kl"], G[pre + "kl"])
+        close(r["sup"], G[pre + "sup"], rtol=1e-5, atol=1e-3)
+        w_kl = torch.linspace(-1, 1, nq * 5).reshape(nq, 5)
+        w_sup = torch.linspace(1, -1, 20).reshape(5, 4)
+        ((r["kl"] * w_kl).sum() + (r["sup"] * w_sup).sum() * 1e-3).backward()
+        close(gsum(sup.grad), G[pre + "g_sup_feat"], atol=1e-5)
+        close(gsum(qry.grad), G[pre + "g_qry_feat"], atol=1e-5)
+        close(sup.grad[0, :, :128], G[pre + "g_sup_row0"], atol=1e-6)
+
+
+def test_trx_golden(golden_dir):
+    G = np.load(os.path.join(golden_dir, "trx.npz"))
+    for c in range(3):
+        pre = "c%d_" % c
+        ns, nq = int(G[pre + "ns"]), int(G[pre + "nq"])
+        p, sup1, qry1, sup2, qry2, lab = trx_case_inputs(int(G[pre + "seed"]), ns, nq, bool(G[pre + "shuffle"]))
+        for k in ("k_linear.weight", "k_linear.bias", "v_linear.weight", "v_linear.bias", "norm_k.weight", "norm_k.bias"):
+            p[k].requires_grad_()
+        for x in (sup1, qry1, sup2, qry2):
+            x.requires_grad_()
+        r = O.clf_TRX_2fcsup({"context_features_1": sup1, "context_features_2": sup2}, lab,
+                             {"target_features_1": qry1, "target_features_2": qry2}, p, 5, ns // 5)
+        # logits are O(1e2..1e3) sums of squares
+        close(r["kl"], G[pre + "kl"], rtol=1e-5, atol=1e-3)
+        close(r["ce"], G[pre + "ce"], rtol=1e-5, atol=1e-3)
+        close(r["sup"], G[pre + "sup"], rtol=1e-5, atol=1e-3)
+        w = torch.linspace(-1, 1, nq * 5).reshape(nq, 5)
+        w_sup = torch.linspace(1, -1, 20).reshape(5, 4)
+        ((r["kl"] * w).sum() * 1e-2 + (r["ce"] * w.flip(0)).sum() * 1e-2 + (r["sup"] * w_sup).sum() * 1e-3).backward()
+        close(gsum(sup1.grad), G[pre + "g_sup1"], rtol=1e-4, atol=1e-5)
+        close(gsum(qry1.grad), G[pre + "g_qry1"], rtol=1e-4, atol=1e-5)
+        close(gsum(sup2.grad), G[pre + "g_sup2"], rtol=1e-4, atol=1e-5)
+        close(gsum(qry2.grad), G[pre + "g_qry2"], rtol=1e-4, atol=1e-5)
+        close(p["k_linear.bias"].grad, G[pre + "g_kb"], rtol=1e-4, atol=1e-5)
+        close(p["v_linear.bias"].grad, G[pre + "g_vb"], rtol=1e-4, atol=1e-5)
+        close(p["k_linear.weight"].grad.sum(1), G[pre + "g_kw_sum"], rtol=1e-3, atol=1e-4)
+        close(p["v_linear.weight"].grad.sum(1), G[pre + "g_vw_sum"], rtol=1e-3, atol=1e-4)
+        close(p["norm_k.weight"].grad, G[pre + "g_nkw"], rtol=1e-4, atol=1e-5)
+        close(p["norm_k.bias"].grad, G[pre + "g_nkb"], rtol=1e-4, atol=1e-5)
+        rf = O.clf_TRX_2fcsup_fixed(sup1.detach(), lab, qry1.detach(), p, 5, ns // 5)
+        close(rf["kl"], G[pre + "fixed_kl"], rtol=1e-5, atol=1e-3)
+        close(rf["sup"], G[pre + "fixed_sup"], rtol=1e-5, atol=1e-3)
+
+
+def test_trunk_shapes_and_param_count():
+    shp = O.resnet18_trunk_param_shapes()
+    n = sum(int(np.prod(s)) for k, s in shp.items() if "running" not in k and "num_batches" not in k)
+    assert n == 11176512
+    g = torch.Generator().manual_seed(0)
+    sd = O.init_resnet18_trunk(g)
+    y = O.resnet18_trunk(torch.rand(2, 3, 64, 64, generator=g), sd)
+    assert y.shape == (2, 512, 2, 2)
+    assert int(sd["1.running_mean"].abs().sum() > 0)         # train-mode BN updated running stats
+
+
+def test_mfm_param_count_and_shape():
+    shp = O.mfm_param_shapes()
+    n = sum(int(np.prod(s)) for s in shp.values())
+    assert 5.0e8 < n < 5.8e8                                 # ~541 M
