@@ -1,0 +1,112 @@
+/* lmkd.h — C ABI of liblmkd_hip.so, the MI355X (gfx950) implementation of Lite-MKD's
+ * per-episode hot path.
+ *
+ * The reference (HuiGuanLab/Lite-MKD) is 100 % Python on torch/cuDNN: it has no FFI of its own.
+ * Each entry point below therefore names the reference *call site* whose ATen/cuDNN work it
+ * replaces (file:line under the reference tree).  The Python host layer in lite-mkd_amd/ binds
+ * these with ctypes and exposes the reference's model_select / classifier / Distiller surface.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++ or torch types; every pointer is a DEVICE pointer unless
+ *     marked "host"; tensors are fp32, activations NHWC, all buffers borrowed for the call only;
+ *   - `stream` is a hipStream_t; kernels are enqueued on it and the call returns immediately;
+ *   - return 0 on success, negative on error; lmkd_last_error() gives the message (thread local);
+ *     nothing throws; no entry point allocates, frees or synchronises (hipGraph-capturable).
+ */
+#ifndef LMKD_H
+#define LMKD_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int lmkd_abi_version(void);
+const char* lmkd_last_error(void);
+int lmkd_device_check(int device); /* 0 iff `device` is gfx950 */
+
+/* ---- generic fp32 MFMA GEMM: C = alpha*op(A)*op(B) + beta*C + bias[col] (+relu), strided batched.
+ * layA 'K': A[m*lda+k], 'M': A[k*lda+m];  layB 'K': B[n*ldb+k], 'N': B[k*ldb+n].
+ * replaces nn.Linear fwd/bwd at model/backbone/resnet18_2fc.py:56-64, model/classifiers/TRX_2fcsup.py:97-100,
+ * torch.matmul at TRX_2fcsup.py:121,133 and the nn.TransformerEncoder GEMMs at teacher/code/model.py:1310-1323. */
+int lmkd_gemm_f32(char layA, char layB, int M, int N, int K, float alpha, const float* A, long lda, long sA,
+                  const float* B, long ldb, long sB, float beta, float* C, long ldc, long sC, const float* bias,
+                  int relu, int batch, void* stream);
+
+/* ---- convolution (torchvision ResNet conv layers called at resnet18_2fc.py:41-42) ----
+ * x,y NHWC.  Cs = channels of the NHWC tensor (4 for the channel-padded stem, else multiple of 32). */
+long lmkd_conv2d_packed_weight_elems(int Cout, int Cin, int Cs, int KH, int KW, int mode);
+int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout, int Cin, int Cs, int KH, int KW, int mode /*0 fwd, 1 dgrad*/,
+                             void* stream);
+int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int KH, int KW, int stride, int pad);
+/* stat_partial (nullable): [row_tiles][Cout][2] per-tile (sum, sum of squares) for train-mode BatchNorm */
+int lmkd_conv2d_fwd(const float* x, const float* wp_fwd, float* y, float* stat_partial, int N, int H, int W, int Cs, int Cout,
+                    int KH, int KW, int stride, int pad, void* stream);
+int lmkd_conv2d_bwd_data(const float* dy, const float* wp_dgrad, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                         int stride, int pad, void* stream);
+long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad);
+int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, float* workspace, long ws_bytes, int N, int H, int W,
+                           int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+
+/* ---- layout / BatchNorm / pooling (torchvision bn1/relu/maxpool/BasicBlock, resnet18_2fc.py:33,41-54) ---- */
+int lmkd_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int N, int H, int W, void* stream);
+/* stats: [4][C] = mean, invstd, scale, shift.  scratch: >= 65*2*C doubles */
+int lmkd_bn_finalize(const float* partial, int T, int C, long count, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, float* stats, double* scratch, void* stream);
+int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                       float* stats, void* stream);
+/* y = act(x*scale+shift [+res | +res*rscale+rshift]); res_mode 0 none, 1 plain, 2 affine */
+int lmkd_bn_apply(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows, int C, int relu,
+                  int res_mode, void* stream);
+long lmkd_bn_bwd_workspace(int C);
+/* mask_mode 0 none, 1 (yact>0), 2 (x*scale+shift>0); coef: [3][C] scratch; g_out (nullable) = masked dy */
+int lmkd_bn_backward(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dx,
+                     float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, long rows, int C, int mask_mode,
+                     void* stream);
+int lmkd_relu_backward(const float* dy, const float* y, float* g, long n, void* stream);
+int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, float* y, unsigned char* idx, int N, int H, int W, int C, void* stream);
+int lmkd_maxpool_bwd(const float* dy, const unsigned char* idx, float* g, int N, int H, int W, int C, void* stream);
+/* AdaptiveMaxPool2d((4,4)) + mean over the 16 patches: resnet18_2fc.py:44-54 */
+int lmkd_adaptive_maxpool_mean_fwd(const float* x, float* y, int F, int H, int W, int C, void* stream);
+int lmkd_adaptive_maxpool_mean_bwd(const float* x, const float* dy, float* dx, int F, int H, int W, int C, void* stream);
+long lmkd_colsum_workspace(int C);
+int lmkd_colsum(const float* a, const float* b, float* out, long rows, int C, int accumulate, void* workspace, void* stream);
+
+/* ---- matchers: TemporalCrossTransformer (TRX_2fcsup.py:74-148), SupportDK (:162-189), e_dist (e_dist_fc2.py:52-91) ---- */
+int lmkd_dropout_mask(float* mask, long n, float p, unsigned long long seed, void* stream);
+int lmkd_add_pe(const float* x, const float* pe, const float* mask, float* y, long rows, int D, int L, void* stream); /* :44-48,79-80 */
+int lmkd_mul(const float* a, const float* b, float* out, long n, void* stream);
+int lmkd_axpby(const float* x, float* y, float alpha, float beta, long n, void* stream);
+int lmkd_trx_tuple_ln_fwd(const float* P, const float* bk, const float* bv, const float* gamma, const float* beta, const int* rowmap,
+                          float* Kn, float* Khat, float* V, float* rstd, int NV, int L, int D, float eps, void* stream); /* :85-104 */
+int lmkd_layernorm_bwd_rows(float* dK_inout, const float* Khat, const float* rstd, const float* gamma, long rows, int D, void* stream);
+int lmkd_trx_tuple_bwd_gather(const float* dKraw, const float* dV, const int* rowmap, float* dP, int NV, int L, int D, void* stream);
+/* seg_off/seg_cnt/seg_col are HOST int arrays (<= 16 classes) */
+int lmkd_segment_softmax_fwd(float* S, long rows, long ld, int nseg, const int* seg_off, const int* seg_cnt, void* stream); /* :124-130 */
+int lmkd_segment_softmax_bwd(const float* P, float* dP_inout, long rows, long ld, int nseg, const int* seg_off, const int* seg_cnt,
+                             void* stream);
+int lmkd_trx_dist_fwd(const float* Qv, const float* proto, float* logits, int Nq, int way, int T, int D, int nseg, const int* seg_col,
+                      void* stream); /* :137-144 */
+int lmkd_trx_dist_bwd(const float* Qv, float* proto_inout, const float* g, float* dQv, int Nq, int way, int T, int D, int nseg,
+                      const int* seg_col, void* stream);
+int lmkd_supportdk_fwd(const float* support, float* out, int way, int shot, int seq_len, int D, void* stream);
+int lmkd_supportdk_bwd(const float* support, const float* g, float* dsupport, int way, int shot, int seq_len, int D, void* stream);
+int lmkd_mean_frames(const float* x, float* y, long nv, int L, int D, void* stream);
+int lmkd_mean_frames_bwd(const float* dy, float* dx, long nv, int L, int D, void* stream);
+int lmkd_edist_fwd(const float* qm, const float* sm, const int* sup_class, float* dist, float* logits, int Nq, int Ns, int way, int D,
+                   void* stream);
+int lmkd_edist_bwd(const float* qm, const float* sm, const int* sup_class, const float* dist, const float* g, float* dqm, float* dsm,
+                   int Nq, int Ns, int way, int D, void* stream);
+
+/* ---- D2M loss (distillers.py:7-30, 295-337), accuracy (utils.py:116-121), optimizer (trainwandb.py:101-104,141-143) ---- */
+int lmkd_d2m_loss(const float* s_kl, const float* t_kl, const float* s_ce, const long long* labels, const float* s_sup,
+                  const float* t_sup, int Rq, int C, int Rs, int Cs, float T, float w_kl, float w_sup, float w_ce, float* out4,
+                  float* g_kl, float* g_ce, float* g_sup, void* stream);
+int lmkd_accuracy(const float* l1, const float* l2, const long long* labels, long long* pred, float* acc, int R, int C, void* stream);
+int lmkd_sgd_step(float* param, float* grad, float lr, long n, int zero_grad, void* stream);
+int lmkd_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                   long step, long n, int zero_grad, void* stream);
+int lmkd_fill(float* p, float v, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

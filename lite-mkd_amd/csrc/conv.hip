@@ -1,0 +1,552 @@
+// Implicit-GEMM 2-D convolution on the fp32 MFMA tile engine, NHWC activations.
+//
+//   forward      y[n,oh,ow,co]   = sum_{kh,kw,ci} x[n,oh*s+kh-p,ow*s+kw-p,ci] * W[co,ci,kh,kw]
+//   data grad    dx[n,ih,iw,ci]  = sum_{kh,kw,co} dy[n,(ih+p-kh)/s,(iw+p-kw)/s,co] * W[co,ci,kh,kw]
+//   weight grad  dW[co,ci,kh,kw] = sum_{n,oh,ow}  dy[n,oh,ow,co] * x[n,oh*s+kh-p,ow*s+kw-p,ci]
+//
+// forward and data-grad share one kernel: GEMM rows = output pixels, GEMM cols = output
+// channels, K = (tap, channel) of the gathered tensor; a per-class tap table {dh,dw,kofs}
+// describes which source pixel / packed-weight slice each K-step reads.  Stride-2 data-grad
+// enumerates its rows per input-parity class (4 classes), so every tile only runs the taps
+// that are non-zero for its parity (no wasted MFMAs on the zero-stuffed positions).
+// The 7x7 stem (Cin=3) runs on a channel-padded NHWC4 input: one K-step = one kernel row
+// (8 taps x 4 channels = 32 contiguous floats of the input).
+// Train-mode BatchNorm statistics (sum, sum of squares per channel) are reduced from the
+// accumulators in the forward epilogue into per-row-tile partials (deterministic).
+#include "gemm_core.h"
+
+struct ConvGemmArgs {
+  const float* src;
+  const float* wpk;
+  float* out;
+  float* stat_partial;
+  int N, Hs, Ws, Cs;
+  int Hr, Wr, rows_per_class, tiles_per_class;
+  int sh;
+  int Ho, Wo, Co, omul;
+  int Kp, cps, nclass;
+  FastDiv div_hw, div_w;
+  int ntap[LMKD_MAX_CLASSES];
+  Tap taps[LMKD_MAX_CLASSES][LMKD_MAX_TAPS];
+};
+
+// K-major implicit-im2col loader (rows = output pixels of this tile).
+template <int ROWS, bool SMALLC>
+struct LoaderConvGather {
+  static constexpr int NI = ROWS / 32;
+  static constexpr int LD = ROWS + 1;
+  static constexpr int LDS_FLOATS = LMKD_BK * LD;
+  int base[NI], hw[NI];
+  float4 reg[NI];
+  const float* src;
+  int Hs, Ws, Cs, kc4;
+  __device__ __forceinline__ void init(const float* src_, int Hs_, int Ws_, int Cs_, const int* s_src, const int* s_hw) {
+    const int tid = threadIdx.x;
+    src = src_; Hs = Hs_; Ws = Ws_; Cs = Cs_;
+    kc4 = (tid & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      base[i] = s_src[(tid >> 3) + 32 * i];
+      hw[i] = s_hw[(tid >> 3) + 32 * i];
+    }
+  }
+  // tap: this step's {dh,dw}; coff: channel offset inside the tap (multiple of 32)
+  __device__ __forceinline__ void load(int dh, int dw, int coff) {
+    const int dwe = SMALLC ? dw + (kc4 >> 2) : dw;
+    const int rel = (dh * Ws + dwe) * Cs + (SMALLC ? 0 : coff + kc4);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int h = (hw[i] >> 16) + dh, w = (hw[i] & 0xffff) + dwe;
+      if (hw[i] >= 0 && (unsigned)h < (unsigned)Hs && (unsigned)w < (unsigned)Ws)
+        reg[i] = *reinterpret_cast<const float4*>(src + (long)(base[i] + rel));
+      else
+        reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(float* S) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float* d = S + kc4 * LD + (tid >> 3) + 32 * i;
+      d[0] = reg[i].x;
+      d[LD] = reg[i].y;
+      d[2 * LD] = reg[i].z;
+      d[3 * LD] = reg[i].w;
+    }
+  }
+};
+
+template <class Cfg, bool SMALLC, bool STATS>
+__global__ __launch_bounds__(LMKD_THREADS) void conv_gemm_kernel(ConvGemmArgs a) {
+  using LA = LoaderConvGather<Cfg::BM, SMALLC>;
+  using LB = LoaderKMajorDense<Cfg::BN>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (LA::LDS_FLOATS + LB::LDS_FLOATS)];
+  __shared__ int s_src[Cfg::BM], s_hw[Cfg::BM], s_out[Cfg::BM];
+  __shared__ float s_red[STATS ? Cfg::WM * Cfg::BN * 2 : 1];
+
+  const int tid = threadIdx.x;
+  const int cls = blockIdx.x / a.tiles_per_class;
+  const int tile = blockIdx.x - cls * a.tiles_per_class;
+  const int ph = cls >> 1, pw = cls & 1;
+  const int row0 = tile * Cfg::BM, n0 = blockIdx.y * Cfg::BN;
+  for (int r = tid; r < Cfg::BM; r += LMKD_THREADS) {
+    const int m = row0 + r;
+    if (m < a.rows_per_class) {
+      const int n = fdiv(m, a.div_hw);
+      const int rem = m - n * a.Hr * a.Wr;
+      const int aa = fdiv(rem, a.div_w);
+      const int bb = rem - aa * a.Wr;
+      s_src[r] = ((n * a.Hs + aa * a.sh) * a.Ws + bb * a.sh) * a.Cs;
+      s_hw[r] = ((aa * a.sh) << 16) | (bb * a.sh);
+      s_out[r] = ((n * a.Ho + aa * a.omul + ph) * a.Wo + bb * a.omul + pw) * a.Co;
+    } else {
+      s_src[r] = 0;
+      s_hw[r] = -1;
+      s_out[r] = -1;
+    }
+  }
+  __syncthreads();
+  LA la;
+  LB lb;
+  la.init(a.src, a.Hs, a.Ws, a.Cs, s_src, s_hw);
+  lb.init(a.wpk, a.Kp, n0, a.Co, a.Kp);
+
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  const int nk = a.ntap[cls] * a.cps;
+  {
+    // hand-inlined gemm_mainloop: the two loaders take different per-step arguments
+    constexpr int SA = LA::LDS_FLOATS, SB = LB::LDS_FLOATS;
+    float* As0 = smem;
+    float* Bs0 = smem + 2 * SA;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int a_off = (lane >> 5) * LA::LD + wm * (Cfg::TM * 32) + (lane & 31);
+    const int b_off = (lane >> 5) * LB::LD + wn * (Cfg::TN * 32) + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const Tap* taps = a.taps[cls];
+    auto issue = [&](int t) {
+      const int tp = t / a.cps, cc = t - tp * a.cps;
+      const Tap tap = taps[tp];
+      la.load(tap.dh, tap.dw, cc * LMKD_BK);
+      lb.load(tap.kofs + cc * LMKD_BK);
+    };
+    if (nk > 0) {
+      issue(0);
+      la.store(As0);
+      lb.store(Bs0);
+      __syncthreads();
+      for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) issue(t + 1);
+        mfma_kstep<Cfg, LA::LD, LB::LD>(As0 + cur * SA, Bs0 + cur * SB, a_off, b_off, acc);
+        if (t + 1 < nk) {
+          la.store(As0 + (cur ^ 1) * SA);
+          lb.store(Bs0 + (cur ^ 1) * SB);
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int cl0 = wn * (Cfg::TN * 32) + (lane & 31);
+  float s1[Cfg::TN], s2[Cfg::TN];
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane);
+      const int ob = s_out[rl];
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int col = n0 + cl0 + j * 32;
+        const float v = acc[i][j][e];
+        if (ob >= 0 && col < a.Co) a.out[(long)ob + col] = v;
+        if (STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (lane < 32) {
+        s_red[(wm * Cfg::BN + cl0 + j * 32) * 2 + 0] = t1;
+        s_red[(wm * Cfg::BN + cl0 + j * 32) * 2 + 1] = t2;
+      }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    if (tid < Cfg::BN && n0 + tid < a.Co) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < Cfg::WM; ++w) {
+        s1 += s_red[(w * Cfg::BN + tid) * 2 + 0];
+        s2 += s_red[(w * Cfg::BN + tid) * 2 + 1];
+      }
+      float* p = a.stat_partial + ((long)blockIdx.x * a.Co + n0 + tid) * 2;
+      p[0] = s1;
+      p[1] = s2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// weight gradient: rows = co (dy, K-outer), cols = packed (tap, ci), K = pixels, split-K slabs
+// ---------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* dy;
+  const float* x;
+  float* slab;
+  int N, Hs, Ws, Cs, Ho, Wo, Co;
+  int stride, pad, KH, KW, KWp;
+  int Kp, Mpix, steps_total, steps_per_split;
+  FastDiv div_hw, div_w;
+};
+
+template <int ROWS, bool SMALLC>
+struct LoaderWgradGather {
+  static constexpr int NI = ROWS / 32;
+  static constexpr int LD = ROWS;
+  static constexpr int LDS_FLOATS = LMKD_BK * LD;
+  static constexpr int CPR = ROWS / 4;
+  const float* x;
+  FastDiv div_hw, div_w;
+  int Mpix, HoWo, Wo, Hs, Ws, Cs, stride;
+  float4 reg[NI];
+  int dh, dw, coff, r4;
+  bool tap_ok;
+  __device__ __forceinline__ void init(const WgradArgs& a, int j0) {
+    x = a.x; div_hw = a.div_hw; div_w = a.div_w;
+    Mpix = a.Mpix; HoWo = a.Ho * a.Wo; Wo = a.Wo; Hs = a.Hs; Ws = a.Ws; Cs = a.Cs; stride = a.stride;
+    const int tid = threadIdx.x;
+    r4 = (tid % CPR) * 4;
+    const int col = j0 + r4;
+    if (SMALLC) {  // col -> (kh = col/32, kw = (col%32)/4), 4 channels per tap
+      const int kh = col >> 5, kw = (col & 31) >> 2;
+      dh = kh - a.pad; dw = kw - a.pad; coff = 0;
+      tap_ok = kh < a.KH && kw < a.KW && col < a.Kp;
+    } else {
+      const int tap = col / a.Cs;
+      coff = col - tap * a.Cs;
+      const int kh = tap / a.KWp, kw = tap - kh * a.KWp;
+      dh = kh - a.pad; dw = kw - a.pad;
+      tap_ok = col < a.Kp && kw < a.KW;
+    }
+  }
+  __device__ __forceinline__ void load(int koff) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = koff + tid / CPR + (LMKD_THREADS / CPR) * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tap_ok && p < Mpix) {
+        const int n = fdiv(p, div_hw);
+        const int rem = p - n * HoWo;
+        const int oh = fdiv(rem, div_w);
+        const int ow = rem - oh * Wo;
+        const int h = oh * stride + dh, w = ow * stride + dw;
+        if ((unsigned)h < (unsigned)Hs && (unsigned)w < (unsigned)Ws)
+          v = *reinterpret_cast<const float4*>(x + ((long)(n * Hs + h) * Ws + w) * Cs + coff);
+      }
+      reg[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(float* S) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int k = tid / CPR + (LMKD_THREADS / CPR) * i;
+      *reinterpret_cast<float4*>(S + k * LD + r4) = reg[i];
+    }
+  }
+};
+
+template <class Cfg, bool SMALLC>
+__global__ __launch_bounds__(LMKD_THREADS) void conv_wgrad_kernel(WgradArgs a) {
+  using LA = LoaderMMajorDense<Cfg::BM>;
+  using LB = LoaderWgradGather<Cfg::BN, SMALLC>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (LA::LDS_FLOATS + LB::LDS_FLOATS)];
+  const int m0 = blockIdx.x * Cfg::BM, j0 = blockIdx.y * Cfg::BN, z = blockIdx.z;
+  LA la;
+  LB lb;
+  la.init(a.dy, a.Co, m0, a.Co, a.Mpix);
+  lb.init(a, j0);
+  const int s0 = z * a.steps_per_split;
+  int nk = a.steps_total - s0;
+  if (nk > a.steps_per_split) nk = a.steps_per_split;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  auto koff = [s0](int t) { return (s0 + t) * LMKD_BK; };
+  gemm_mainloop<Cfg>(la, lb, nk, koff, koff, smem, acc);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  float* C = a.slab + (long)z * a.Co * a.Kp;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = j0 + wn * (Cfg::TN * 32) + j * 32 + (lane & 31);
+    if (col >= a.Kp) continue;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane);
+        if (row < a.Co) C[(long)row * a.Kp + col] = acc[i][j][e];
+      }
+  }
+}
+
+// dW (OIHW) = sum over split slabs of slab[z][co][(kh*KWp+kw)*Cs + ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Co, int Cin,
+                                    int Cs, int KH, int KW, int KWp, int Kp) {
+  const long total = (long)Co * KH * KW * Cin;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int ci = idx % Cin;
+    long r = idx / Cin;
+    const int kw = r % KW; r /= KW;
+    const int kh = r % KH;
+    const int co = r / KH;
+    const long so = (long)co * Kp + (long)(kh * KWp + kw) * Cs + ci;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slab[(long)z * Co * Kp + so];
+    dw[(((long)co * Cin + ci) * KH + kh) * KW + kw] = s;
+  }
+}
+
+// mode 0: Wp[co][(kh*KWp+kw)*Cs + ci] = W[co][ci][kh][kw]   (zero for padded kw / ci)
+// mode 1: Wd[ci][(kh*KW+kw)*Co + co] = W[co][ci][kh][kw]
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Cin, int Cs, int KH,
+                                    int KW, int KWp, int mode) {
+  if (mode == 0) {
+    const long total = (long)Co * KH * KWp * Cs;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+      const int ci = idx % Cs;
+      long r = idx / Cs;
+      const int kw = r % KWp; r /= KWp;
+      const int kh = r % KH;
+      const int co = r / KH;
+      wp[idx] = (ci < Cin && kw < KW) ? w[(((long)co * Cin + ci) * KH + kh) * KW + kw] : 0.f;
+    }
+  } else {
+    const long total = (long)Cin * KH * KW * Co;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+      const int co = idx % Co;
+      long r = idx / Co;
+      const int kw = r % KW; r /= KW;
+      const int kh = r % KH;
+      const int ci = r / KH;
+      wp[idx] = w[(((long)co * Cin + ci) * KH + kh) * KW + kw];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+static inline int conv_out(int H, int K, int s, int p) { return (H + 2 * p - K) / s + 1; }
+static inline int kw_padded(int Cs, int KW) { return Cs >= 32 ? KW : ((KW * Cs + 31) / 32) * 32 / Cs; }
+
+extern "C" long lmkd_conv2d_packed_weight_elems(int Cout, int Cin, int Cs, int KH, int KW, int mode) {
+  if (mode == 0) return (long)Cout * KH * kw_padded(Cs, KW) * Cs;
+  return (long)Cin * KH * KW * Cout;
+}
+
+extern "C" int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout, int Cin, int Cs, int KH, int KW,
+                                        int mode, void* stream) {
+  LMKD_REQUIRE(w_oihw && wp, "lmkd_conv2d_pack_weights: null pointer");
+  LMKD_REQUIRE(mode == 0 || mode == 1, "lmkd_conv2d_pack_weights: mode must be 0 (fwd) or 1 (dgrad)");
+  LMKD_REQUIRE(Cs >= Cin && (Cs % 32 == 0 || Cs == 4), "lmkd_conv2d_pack_weights: Cs=%d must be 4 or a multiple of 32", Cs);
+  const long total = lmkd_conv2d_packed_weight_elems(Cout, Cin, Cs, KH, KW, mode);
+  int grid = cdiv(total, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, wp, Cout, Cin, Cs, KH, KW,
+                     kw_padded(Cs, KW), mode);
+  LMKD_CHECK_LAUNCH("lmkd_conv2d_pack_weights");
+  return LMKD_OK;
+}
+
+template <bool SMALLC, bool STATS>
+static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
+  if (ncols <= 64) {
+    using Cfg = TileCfg<128, 64, 2, 2>;
+    dim3 grid(a.nclass * a.tiles_per_class, cdiv(ncols, Cfg::BN));
+    hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS>), grid, dim3(LMKD_THREADS), 0, s, a);
+  } else {
+    using Cfg = TileCfg<128, 128, 2, 2>;
+    dim3 grid(a.nclass * a.tiles_per_class, cdiv(ncols, Cfg::BN));
+    hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS>), grid, dim3(LMKD_THREADS), 0, s, a);
+  }
+  LMKD_CHECK_LAUNCH("conv_gemm_kernel");
+  return LMKD_OK;
+}
+
+// number of row tiles (= rows of the BN partial-statistics buffer) of a forward conv
+extern "C" int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int KH, int KW, int stride, int pad) {
+  const long M = (long)N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad);
+  return cdiv(M, 128);
+}
+
+extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float* stat_partial, int N, int H, int W, int Cs,
+                               int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  LMKD_REQUIRE(x && wp && y, "lmkd_conv2d_fwd: null pointer");
+  LMKD_REQUIRE(aligned16(x) && aligned16(wp), "lmkd_conv2d_fwd: x / packed weights must be 16-byte aligned");
+  LMKD_REQUIRE(Cs % 32 == 0 || Cs == 4, "lmkd_conv2d_fwd: channel count %d must be 4 (padded stem) or a multiple of 32", Cs);
+  LMKD_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0, "lmkd_conv2d_fwd: empty tensor");
+  const bool smallc = Cs == 4;
+  const int KWp = kw_padded(Cs, KW);
+  LMKD_REQUIRE(!smallc || KWp == 8, "lmkd_conv2d_fwd: padded-stem path needs KW <= 8");
+  LMKD_REQUIRE(KH * (smallc ? 1 : KW) <= LMKD_MAX_TAPS, "lmkd_conv2d_fwd: kernel %dx%d has too many taps", KH, KW);
+  LMKD_REQUIRE(H < 32768 && W < 32768, "lmkd_conv2d_fwd: spatial dims too large");
+  ConvGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src = x; a.wpk = wp; a.out = y; a.stat_partial = stat_partial;
+  a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cs;
+  a.Ho = conv_out(H, KH, stride, pad); a.Wo = conv_out(W, KW, stride, pad); a.Co = Cout;
+  LMKD_REQUIRE(a.Ho > 0 && a.Wo > 0, "lmkd_conv2d_fwd: empty output");
+  LMKD_REQUIRE((long)N * H * W * Cs < 2147483647L && (long)N * a.Ho * a.Wo * Cout < 2147483647L,
+               "lmkd_conv2d_fwd: tensor exceeds 2^31 elements");
+  a.Hr = a.Ho; a.Wr = a.Wo; a.rows_per_class = N * a.Ho * a.Wo; a.tiles_per_class = cdiv(a.rows_per_class, 128);
+  a.sh = stride; a.omul = 1; a.nclass = 1;
+  a.Kp = KH * KWp * Cs;
+  a.div_hw = make_fastdiv(a.Hr * a.Wr); a.div_w = make_fastdiv(a.Wr);
+  if (smallc) {
+    a.cps = 1;
+    a.ntap[0] = KH;
+    for (int kh = 0; kh < KH; ++kh) a.taps[0][kh] = Tap{kh - pad, -pad, kh * KWp * Cs};
+  } else {
+    a.cps = Cs / 32;
+    a.ntap[0] = KH * KW;
+    for (int kh = 0; kh < KH; ++kh)
+      for (int kw = 0; kw < KW; ++kw) a.taps[0][kh * KW + kw] = Tap{kh - pad, kw - pad, (kh * KWp + kw) * Cs};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (smallc) return stat_partial ? launch_conv_gemm<true, true>(a, Cout, s) : launch_conv_gemm<true, false>(a, Cout, s);
+  return stat_partial ? launch_conv_gemm<false, true>(a, Cout, s) : launch_conv_gemm<false, false>(a, Cout, s);
+}
+
+// dx[N,H,W,Cin] from dy[N,Ho,Wo,Cout]; wd = weights packed with mode 1
+extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx, int N, int H, int W, int Cin, int Cout,
+                                    int KH, int KW, int stride, int pad, void* stream) {
+  LMKD_REQUIRE(dy && wd && dx, "lmkd_conv2d_bwd_data: null pointer");
+  LMKD_REQUIRE(aligned16(dy) && aligned16(wd), "lmkd_conv2d_bwd_data: operands must be 16-byte aligned");
+  LMKD_REQUIRE(Cout % 32 == 0, "lmkd_conv2d_bwd_data: Cout=%d must be a multiple of 32", Cout);
+  LMKD_REQUIRE(stride == 1 || stride == 2, "lmkd_conv2d_bwd_data: stride %d unsupported", stride);
+  LMKD_REQUIRE(KH * KW <= LMKD_MAX_TAPS, "lmkd_conv2d_bwd_data: kernel too large");
+  const int Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
+  LMKD_REQUIRE(stride == 1 || (H % 2 == 0 && W % 2 == 0), "lmkd_conv2d_bwd_data: stride-2 needs even H, W");
+  LMKD_REQUIRE((long)N * H * W * Cin < 2147483647L && (long)N * Ho * Wo * Cout < 2147483647L,
+               "lmkd_conv2d_bwd_data: tensor exceeds 2^31 elements");
+  ConvGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src = dy; a.wpk = wd; a.out = dx; a.stat_partial = nullptr;
+  a.N = N; a.Hs = Ho; a.Ws = Wo; a.Cs = Cout;
+  a.Ho = H; a.Wo = W; a.Co = Cin;
+  a.Kp = KH * KW * Cout; a.cps = Cout / 32;
+  a.sh = 1;
+  if (stride == 1) {
+    a.nclass = 1; a.omul = 1; a.Hr = H; a.Wr = W;
+    int nt = 0;
+    for (int kh = 0; kh < KH; ++kh)
+      for (int kw = 0; kw < KW; ++kw) a.taps[0][nt++] = Tap{pad - kh, pad - kw, (kh * KW + kw) * Cout};
+    a.ntap[0] = nt;
+  } else {
+    // rows enumerated per input parity (ph,pw): ih = 2a+ph, source oh = (ih + pad - kh)/2 = a + (ph+pad-kh)/2
+    a.nclass = 4; a.omul = 2; a.Hr = H / 2; a.Wr = W / 2;
+    for (int c = 0; c < 4; ++c) {
+      const int ph = c >> 1, pw = c & 1;
+      int nt = 0;
+      for (int kh = 0; kh < KH; ++kh) {
+        if (((ph + pad - kh) & 1) != 0) continue;
+        for (int kw = 0; kw < KW; ++kw) {
+          if (((pw + pad - kw) & 1) != 0) continue;
+          // floor division (numerator may be negative)
+          const int nh = ph + pad - kh, nw = pw + pad - kw;
+          a.taps[c][nt++] = Tap{nh >= 0 ? nh / 2 : -((-nh) / 2), nw >= 0 ? nw / 2 : -((-nw) / 2), (kh * KW + kw) * Cout};
+        }
+      }
+      a.ntap[c] = nt;
+    }
+  }
+  a.rows_per_class = N * a.Hr * a.Wr;
+  a.tiles_per_class = cdiv(a.rows_per_class, 128);
+  a.div_hw = make_fastdiv(a.Hr * a.Wr); a.div_w = make_fastdiv(a.Wr);
+  return launch_conv_gemm<false, false>(a, Cin, (hipStream_t)stream);
+}
+
+static void wgrad_plan(int Mpix, int Cout, int Kp, int* splits, int* steps_per_split, int* bm, int* bn) {
+  *bm = Cout <= 64 ? 64 : 128;
+  *bn = (Kp % 128 == 0 && Kp >= 1024) ? 128 : 64;
+  const int tiles = cdiv(Cout, *bm) * cdiv(Kp, *bn);
+  const int steps = cdiv(Mpix, LMKD_BK);
+  int sp = cdiv(1536, tiles);
+  if (sp > steps / 8) sp = steps / 8;
+  if (sp < 1) sp = 1;
+  *steps_per_split = cdiv(steps, sp);
+  *splits = cdiv(steps, *steps_per_split);
+}
+
+extern "C" long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
+  const int Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
+  const int Kp = KH * kw_padded(Cs, KW) * Cs;
+  int splits, sps, bm, bn;
+  wgrad_plan(N * Ho * Wo, Cout, Kp, &splits, &sps, &bm, &bn);
+  return (long)splits * Cout * Kp * sizeof(float);
+}
+
+// dw_oihw[Cout,Cin,KH,KW] from x[N,H,W,Cs] (Cs >= Cin channel-padded) and dy[N,Ho,Wo,Cout]
+extern "C" int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, float* workspace, long ws_bytes,
+                                      int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                      void* stream) {
+  LMKD_REQUIRE(x && dy && dw_oihw && workspace, "lmkd_conv2d_bwd_weight: null pointer");
+  LMKD_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(workspace), "lmkd_conv2d_bwd_weight: operands must be 16-byte aligned");
+  LMKD_REQUIRE(Cs % 32 == 0 || Cs == 4, "lmkd_conv2d_bwd_weight: channel count %d must be 4 or a multiple of 32", Cs);
+  LMKD_REQUIRE(Cout % 4 == 0, "lmkd_conv2d_bwd_weight: Cout %% 4 != 0");
+  const bool smallc = Cs == 4;
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dy = dy; a.x = x; a.slab = workspace;
+  a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cs;
+  a.Ho = conv_out(H, KH, stride, pad); a.Wo = conv_out(W, KW, stride, pad); a.Co = Cout;
+  a.stride = stride; a.pad = pad; a.KH = KH; a.KW = KW; a.KWp = kw_padded(Cs, KW);
+  a.Kp = KH * a.KWp * Cs;
+  a.Mpix = N * a.Ho * a.Wo;
+  LMKD_REQUIRE((long)N * H * W * Cs < 2147483647L && (long)a.Mpix * Cout < 2147483647L, "lmkd_conv2d_bwd_weight: tensor too large");
+  int splits, bm, bn;
+  wgrad_plan(a.Mpix, Cout, a.Kp, &splits, &a.steps_per_split, &bm, &bn);
+  a.steps_total = cdiv(a.Mpix, LMKD_BK);
+  LMKD_REQUIRE(ws_bytes >= (long)splits * Cout * a.Kp * (long)sizeof(float), "lmkd_conv2d_bwd_weight: workspace too small");
+  a.div_hw = make_fastdiv(a.Ho * a.Wo); a.div_w = make_fastdiv(a.Wo);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(Cout, bm), cdiv(a.Kp, bn), splits);
+  if (smallc) {
+    LMKD_REQUIRE(bm == 64 && bn == 64, "lmkd_conv2d_bwd_weight: padded-stem path expects Cout <= 64");
+    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<64, 64, 2, 2>, true>), grid, dim3(LMKD_THREADS), 0, s, a);
+  } else if (bm == 64 && bn == 64) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<64, 64, 2, 2>, false>), grid, dim3(LMKD_THREADS), 0, s, a);
+  } else if (bm == 128 && bn == 64) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<128, 64, 2, 2>, false>), grid, dim3(LMKD_THREADS), 0, s, a);
+  } else if (bm == 64 && bn == 128) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<64, 128, 2, 2>, false>), grid, dim3(LMKD_THREADS), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<128, 128, 2, 2>, false>), grid, dim3(LMKD_THREADS), 0, s, a);
+  }
+  LMKD_CHECK_LAUNCH("conv_wgrad_kernel");
+  const long total = (long)Cout * KH * KW * Cin;
+  int rg = cdiv(total, 256);
+  if (rg > 4096) rg = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, s, (const float*)workspace, dw_oihw, splits, Cout, Cin, Cs,
+                     KH, KW, a.KWp, a.Kp);
+  LMKD_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return LMKD_OK;
+}

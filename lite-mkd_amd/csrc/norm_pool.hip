@@ -1,0 +1,517 @@
+// HBM-bound kernels around the convolutions: layout change, train-mode BatchNorm
+// (finalize / apply / backward), the stem's BN+ReLU+maxpool, the adaptive-max 4x4 + patch
+// mean head, column reductions (bias / LayerNorm parameter grads).  All NHWC, float4 per
+// lane along the channel dimension, 256-thread workgroups, grid-stride, deterministic
+// two-level reductions (no float atomics).
+#include "common.h"
+
+#define NP_THREADS 256
+static inline int ew_grid(long n_items) {
+  long g = (n_items + NP_THREADS - 1) / NP_THREADS;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------
+// [N,3,H,W] -> [N,H,W,4] (4th channel zero): the stem conv runs on NHWC4
+// ---------------------------------------------------------------------------------
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float4* __restrict__ y, long npix_total, long hw) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix_total; p += (long)gridDim.x * blockDim.x) {
+    const long n = p / hw, r = p - n * hw;
+    const float* b = x + n * 3 * hw + r;
+    y[p] = make_float4(b[0], b[hw], b[2 * hw], 0.f);
+  }
+}
+
+extern "C" int lmkd_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, void* stream) {
+  LMKD_REQUIRE(x && y && N > 0 && H > 0 && W > 0, "lmkd_nchw3_to_nhwc4: bad arguments");
+  LMKD_REQUIRE(aligned16(y), "lmkd_nchw3_to_nhwc4: output must be 16-byte aligned");
+  const long hw = (long)H * W, total = hw * N;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, (float4*)y, total, hw);
+  LMKD_CHECK_LAUNCH("lmkd_nchw3_to_nhwc4");
+  return LMKD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// column reduction of per-tile partials:  in[T][C][V] (float) -> out[C][V] (double)
+// grid = (ceil(C*V/64), TS): stage 1 writes TS x (C*V) doubles, stage 2 (TS==1 grid.y) finishes
+// ---------------------------------------------------------------------------------
+template <typename Tin>
+__global__ void colsum_partials_kernel(const Tin* __restrict__ in, double* __restrict__ out, int T, int CV) {
+  __shared__ double red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int tg = threadIdx.x >> 6;
+  const int per = (T + gridDim.y - 1) / gridDim.y;
+  const int t0 = blockIdx.y * per;
+  int t1 = t0 + per;
+  if (t1 > T) t1 = T;
+  double s = 0.0;
+  if (c < CV)
+    for (int t = t0 + tg; t < t1; t += 4) s += (double)in[(long)t * CV + c];
+  red[tg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (tg == 0 && c < CV) out[(long)blockIdx.y * CV + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// reduce in[T][CV] floats to out[CV] doubles using scratch (>= 64*CV doubles)
+static int colsum_to_double(const float* in, int T, int CV, double* out, double* scratch, hipStream_t s) {
+  const int gx = cdiv(CV, 64);
+  if (T > 256) {
+    const int TS = 64;
+    hipLaunchKernelGGL(colsum_partials_kernel<float>, dim3(gx, TS), dim3(256), 0, s, in, scratch, T, CV);
+    hipLaunchKernelGGL(colsum_partials_kernel<double>, dim3(gx, 1), dim3(256), 0, s, (const double*)scratch, out, TS, CV);
+  } else {
+    hipLaunchKernelGGL(colsum_partials_kernel<float>, dim3(gx, 1), dim3(256), 0, s, in, out, T, CV);
+  }
+  LMKD_CHECK_LAUNCH("colsum_partials_kernel");
+  return LMKD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// BatchNorm finalize: sums -> mean / invstd / fused scale+shift, running-stat update
+//   stats layout out: [4][C] = mean, invstd, scale (= gamma*invstd), shift (= beta - mean*scale)
+// ---------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps, float* __restrict__ stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sums[2 * c] / count;
+  double var = sums[2 * c + 1] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  stats[c] = (float)mean;
+  stats[C + c] = invstd;
+  stats[2 * C + c] = g * invstd;
+  stats[3 * C + c] = b - (float)mean * g * invstd;
+  if (running_mean) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+// eval mode: stats from running estimates
+__global__ void bn_eval_stats_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps,
+                                     float* __restrict__ stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(running_var[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  stats[c] = running_mean[c];
+  stats[C + c] = invstd;
+  stats[2 * C + c] = g * invstd;
+  stats[3 * C + c] = b - running_mean[c] * g * invstd;
+}
+
+// partial: [T][C][2] (sum, sumsq) from the conv epilogue; scratch: >= (64+1)*2*C doubles
+extern "C" int lmkd_bn_finalize(const float* partial, int T, int C, long count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* stats,
+                                double* scratch, void* stream) {
+  LMKD_REQUIRE(partial && stats && scratch && T > 0 && C > 0 && count > 0, "lmkd_bn_finalize: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  double* sums = scratch;
+  int rc = colsum_to_double(partial, T, 2 * C, sums, scratch + 2 * C, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, (const double*)sums, C, (double)count, gamma, beta,
+                     running_mean, running_var, momentum, eps, stats);
+  LMKD_CHECK_LAUNCH("bn_finalize_kernel");
+  return LMKD_OK;
+}
+
+extern "C" int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* stats, void* stream) {
+  LMKD_REQUIRE(running_mean && running_var && stats && C > 0, "lmkd_bn_eval_stats: bad arguments");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, C, gamma, beta, running_mean,
+                     running_var, eps, stats);
+  LMKD_CHECK_LAUNCH("bn_eval_stats_kernel");
+  return LMKD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// BN apply:  y = act( x*scale + shift  [+ r]  [+ r*rscale + rshift] )
+// res_mode: 0 none, 1 plain residual, 2 residual with its own BN affine (downsample branch)
+// ---------------------------------------------------------------------------------
+__global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __restrict__ stats, const float4* __restrict__ res,
+                                const float* __restrict__ rstats, float4* __restrict__ y, long n4, int C, int relu, int res_mode) {
+  const int C4 = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + c);
+    const float4 sh = *reinterpret_cast<const float4*>(stats + 3 * C + c);
+    float4 v = x[i];
+    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+    if (res_mode == 1) {
+      const float4 r = res[i];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    } else if (res_mode == 2) {
+      const float4 r = res[i];
+      const float4 rs = *reinterpret_cast<const float4*>(rstats + 2 * C + c);
+      const float4 rh = *reinterpret_cast<const float4*>(rstats + 3 * C + c);
+      v.x += fmaf(r.x, rs.x, rh.x); v.y += fmaf(r.y, rs.y, rh.y); v.z += fmaf(r.z, rs.z, rh.z); v.w += fmaf(r.w, rs.w, rh.w);
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    y[i] = v;
+  }
+}
+
+extern "C" int lmkd_bn_apply(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows,
+                             int C, int relu, int res_mode, void* stream) {
+  LMKD_REQUIRE(x && stats && y && rows > 0 && C > 0 && C % 4 == 0, "lmkd_bn_apply: bad arguments (C=%d)", C);
+  LMKD_REQUIRE(res_mode == 0 || res, "lmkd_bn_apply: residual pointer missing");
+  LMKD_REQUIRE(res_mode != 2 || rstats, "lmkd_bn_apply: residual stats missing");
+  const long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const float4*)x, stats,
+                     (const float4*)res, rstats, (float4*)y, n4, C, relu, res_mode);
+  LMKD_CHECK_LAUNCH("bn_apply_kernel");
+  return LMKD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// BN backward.  g = dy * mask, mask_mode: 0 none, 1 (yact > 0), 2 (x*scale+shift > 0)
+//   reduce: partial[b][C][2] = (sum g, sum g*xhat)     xhat = (x-mean)*invstd
+//   apply : dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M);  optional g_out = g
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float4 bn_masked_grad(const float4 dy, const float4 xv, const float4* yact, long i, const float* stats,
+                                                 int C, int c, int mask_mode) {
+  float4 g = dy;
+  if (mask_mode == 1) {
+    const float4 yv = yact[i];
+    g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+  } else if (mask_mode == 2) {
+    const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + c);
+    const float4 sh = *reinterpret_cast<const float4*>(stats + 3 * C + c);
+    g.x = fmaf(xv.x, sc.x, sh.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
+    g.z = fmaf(xv.z, sc.z, sh.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sc.w, sh.w) > 0.f ? g.w : 0.f;
+  }
+  return g;
+}
+
+// block: 256 threads = (256/C4) row lanes x C4 channel-quads (C4 = C/4 <= 256, power of two or divisor of 256)
+__global__ void bn_bwd_reduce_kernel(const float4* __restrict__ dy, const float4* __restrict__ x, const float4* __restrict__ yact,
+                                     const float* __restrict__ stats, float* __restrict__ partial, long rows, int C, int mask_mode) {
+  extern __shared__ float sm[];  // [RL][C][2]
+  const int C4 = C >> 2;
+  const int RL = NP_THREADS / C4;
+  const int cq = threadIdx.x % C4, rl = threadIdx.x / C4;
+  const int c = cq * 4;
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+  if (rl < RL) {
+    const float4 mean = *reinterpret_cast<const float4*>(stats + c);
+    const float4 istd = *reinterpret_cast<const float4*>(stats + C + c);
+    for (long r = (long)blockIdx.x * RL + rl; r < rows; r += (long)gridDim.x * RL) {
+      const long i = r * C4 + cq;
+      const float4 xv = x[i];
+      const float4 g = bn_masked_grad(dy[i], xv, yact, i, stats, C, c, mask_mode);
+      s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+      s2.x = fmaf(g.x, (xv.x - mean.x) * istd.x, s2.x); s2.y = fmaf(g.y, (xv.y - mean.y) * istd.y, s2.y);
+      s2.z = fmaf(g.z, (xv.z - mean.z) * istd.z, s2.z); s2.w = fmaf(g.w, (xv.w - mean.w) * istd.w, s2.w);
+    }
+    float* d = sm + ((long)rl * C + c) * 2;
+    d[0] = s1.x; d[1] = s2.x; d[2] = s1.y; d[3] = s2.y; d[4] = s1.z; d[5] = s2.z; d[6] = s1.w; d[7] = s2.w;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * C; j += NP_THREADS) {
+    float s = 0.f;
+    for (int q = 0; q < RL; ++q) s += sm[(long)q * 2 * C + j];
+    partial[(long)blockIdx.x * 2 * C + j] = s;
+  }
+}
+
+__global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ stats, float* __restrict__ coef, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sg = sums[2 * c], sgx = sums[2 * c + 1];
+  const float g = gamma ? gamma[c] : 1.f;
+  const float invstd = stats[C + c];
+  coef[c] = g * invstd;                        // A
+  coef[C + c] = (float)(sg / count);           // mean(g)
+  coef[2 * C + c] = (float)(sgx / count);      // mean(g*xhat)
+  if (dgamma) dgamma[c] = (float)sgx;
+  if (dbeta) dbeta[c] = (float)sg;
+}
+
+__global__ void bn_bwd_apply_kernel(const float4* __restrict__ dy, const float4* __restrict__ x, const float4* __restrict__ yact,
+                                    const float* __restrict__ stats, const float* __restrict__ coef, float4* __restrict__ dx,
+                                    float4* __restrict__ g_out, long n4, int C, int mask_mode) {
+  const int C4 = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const float4 xv = x[i];
+    const float4 g = bn_masked_grad(dy[i], xv, yact, i, stats, C, c, mask_mode);
+    const float4 mean = *reinterpret_cast<const float4*>(stats + c);
+    const float4 istd = *reinterpret_cast<const float4*>(stats + C + c);
+    const float4 A = *reinterpret_cast<const float4*>(coef + c);
+    const float4 mg = *reinterpret_cast<const float4*>(coef + C + c);
+    const float4 mgx = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+    float4 o;
+    o.x = A.x * (g.x - mg.x - (xv.x - mean.x) * istd.x * mgx.x);
+    o.y = A.y * (g.y - mg.y - (xv.y - mean.y) * istd.y * mgx.y);
+    o.z = A.z * (g.z - mg.z - (xv.z - mean.z) * istd.z * mgx.z);
+    o.w = A.w * (g.w - mg.w - (xv.w - mean.w) * istd.w * mgx.w);
+    dx[i] = o;
+    if (g_out) g_out[i] = g;
+  }
+}
+
+extern "C" long lmkd_bn_bwd_workspace(int C) { return (long)(2048 * 2 * C) * sizeof(float) + (long)(66 * 2 * C) * sizeof(double) + 64; }
+
+// dy, x, (yact) : [rows, C];  stats from the forward;  outputs dx (may alias dy), g_out (optional), dgamma, dbeta
+// coef: [3][C] floats scratch;  workspace: lmkd_bn_bwd_workspace(C) bytes
+extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma,
+                                float* dx, float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, long rows,
+                                int C, int mask_mode, void* stream) {
+  LMKD_REQUIRE(dy && x && stats && dx && coef && workspace, "lmkd_bn_backward: null pointer");
+  LMKD_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "lmkd_bn_backward: unsupported channel count %d", C);
+  LMKD_REQUIRE(mask_mode != 1 || yact, "lmkd_bn_backward: mask_mode 1 needs the activation output");
+  hipStream_t s = (hipStream_t)stream;
+  const int RL = NP_THREADS / (C / 4);
+  int nb = cdiv(rows, (long)RL * 8);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  float* partial = (float*)workspace;
+  double* dscr = (double*)((char*)workspace + (((long)2048 * 2 * C * sizeof(float) + 63) / 64) * 64);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(NP_THREADS), (size_t)RL * C * 2 * sizeof(float), s, (const float4*)dy,
+                     (const float4*)x, (const float4*)yact, stats, partial, rows, C, mask_mode);
+  LMKD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+  int rc = colsum_to_double(partial, nb, 2 * C, dscr, dscr + 2 * C, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, (const double*)dscr, C, (double)rows, gamma, stats, coef,
+                     dgamma, dbeta);
+  const long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, (const float4*)dy, (const float4*)x,
+                     (const float4*)yact, stats, (const float*)coef, (float4*)dx, (float4*)g_out, n4, C, mask_mode);
+  LMKD_CHECK_LAUNCH("bn_bwd_apply_kernel");
+  return LMKD_OK;
+}
+
+// plain ReLU backward (eval-mode / no-BN paths): g = dy * (y > 0)
+__global__ void relu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ y, float4* __restrict__ g, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 d = dy[i], v = y[i];
+    g[i] = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
+  }
+}
+extern "C" int lmkd_relu_backward(const float* dy, const float* y, float* g, long n, void* stream) {
+  LMKD_REQUIRE(dy && y && g && n > 0 && n % 4 == 0, "lmkd_relu_backward: bad arguments");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n / 4)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const float4*)dy,
+                     (const float4*)y, (float4*)g, n / 4);
+  LMKD_CHECK_LAUNCH("relu_bwd_kernel");
+  return LMKD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// stem: y = maxpool3x3/s2/p1( relu( x*scale + shift ) ), argmax (0..8, first max in scan order)
+// ---------------------------------------------------------------------------------
+__global__ void bn_relu_maxpool_kernel(const float4* __restrict__ x, const float* __restrict__ stats, float4* __restrict__ y,
+                                       uchar4* __restrict__ idx, int N, int H, int W, int C, int OH, int OW) {
+  const int C4 = C >> 2;
+  const long total = (long)N * OH * OW * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % C4);
+    long r = i / C4;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + cq * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(stats + 3 * C + cq * 4);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uchar4 am = make_uchar4(255, 255, 255, 255);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = oh * 2 - 1 + kh;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = ow * 2 - 1 + kw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float4 v = x[((long)(n * H + h) * W + w) * C4 + cq];
+        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+        const unsigned char t = (unsigned char)(kh * 3 + kw);
+        if (v.x > m.x || am.x == 255) { m.x = v.x; am.x = t; }
+        if (v.y > m.y || am.y == 255) { m.y = v.y; am.y = t; }
+        if (v.z > m.z || am.z == 255) { m.z = v.z; am.z = t; }
+        if (v.w > m.w || am.w == 255) { m.w = v.w; am.w = t; }
+      }
+    }
+    y[i] = m;
+    idx[i] = am;
+  }
+}
+
+extern "C" int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, float* y, unsigned char* idx, int N, int H, int W, int C,
+                                        void* stream) {
+  LMKD_REQUIRE(x && stats && y && idx && C % 4 == 0, "lmkd_bn_relu_maxpool_fwd: bad arguments");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * OH * OW * C / 4;
+  hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const float4*)x, stats,
+                     (float4*)y, (uchar4*)idx, N, H, W, C, OH, OW);
+  LMKD_CHECK_LAUNCH("bn_relu_maxpool_kernel");
+  return LMKD_OK;
+}
+
+// gather form of the maxpool backward: g[n,h,w,c] = sum over the (<=4) windows covering (h,w) whose argmax is (h,w)
+__global__ void maxpool_bwd_kernel(const float4* __restrict__ dy, const uchar4* __restrict__ idx, float4* __restrict__ g, int N, int H,
+                                   int W, int C, int OH, int OW) {
+  const int C4 = C >> 2;
+  const long total = (long)N * H * W * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % C4);
+    long r = i / C4;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // windows oh with 2*oh-1 <= h <= 2*oh+1
+    const int oh_lo = h >> 1, oh_hi = (h + 1) >> 1;
+    const int ow_lo = w >> 1, ow_hi = (w + 1) >> 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      if (oh >= OH) continue;
+      const int kh = h - (2 * oh - 1);
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        if (ow >= OW) continue;
+        const int kw = w - (2 * ow - 1);
+        const unsigned char t = (unsigned char)(kh * 3 + kw);
+        const long o = ((long)(n * OH + oh) * OW + ow) * C4 + cq;
+        const uchar4 am = idx[o];
+        const float4 d = dy[o];
+        if (am.x == t) acc.x += d.x;
+        if (am.y == t) acc.y += d.y;
+        if (am.z == t) acc.z += d.z;
+        if (am.w == t) acc.w += d.w;
+      }
+    }
+    g[i] = acc;
+  }
+}
+
+extern "C" int lmkd_maxpool_bwd(const float* dy, const unsigned char* idx, float* g, int N, int H, int W, int C, void* stream) {
+  LMKD_REQUIRE(dy && idx && g && C % 4 == 0, "lmkd_maxpool_bwd: bad arguments");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * H * W * C / 4;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const float4*)dy,
+                     (const uchar4*)idx, (float4*)g, N, H, W, C, OH, OW);
+  LMKD_CHECK_LAUNCH("maxpool_bwd_kernel");
+  return LMKD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// head: AdaptiveMaxPool2d((4,4)) + mean over the 16 patches.  x [F,H,W,C] -> y [F,C]
+// window i of an axis of length L: [floor(i*L/4), ceil((i+1)*L/4))
+// ---------------------------------------------------------------------------------
+__global__ void adaptive_maxpool_mean_kernel(const float* __restrict__ x, float* __restrict__ y, int F, int H, int W, int C) {
+  const long total = (long)F * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int f = (int)(i / C);
+    const float* b = x + (long)f * H * W * C + c;
+    float s = 0.f;
+    for (int ph = 0; ph < 4; ++ph) {
+      const int h0 = (ph * H) / 4, h1 = ((ph + 1) * H + 3) / 4;
+      for (int pw = 0; pw < 4; ++pw) {
+        const int w0 = (pw * W) / 4, w1 = ((pw + 1) * W + 3) / 4;
+        float m = -INFINITY;
+        for (int h = h0; h < h1; ++h)
+          for (int w = w0; w < w1; ++w) m = fmaxf(m, b[(long)(h * W + w) * C]);
+        s += m;
+      }
+    }
+    y[i] = s * (1.f / 16.f);
+  }
+}
+
+// dx[f,h,w,c] = sum over windows whose (first) argmax is (h,w) of dy[f,c]/16.  H*W <= 64.
+__global__ void adaptive_maxpool_mean_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                 int F, int H, int W, int C) {
+  const long total = (long)F * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int f = (int)(i / C);
+    const float* b = x + (long)f * H * W * C + c;
+    float* d = dx + (long)f * H * W * C + c;
+    const float gv = dy[i] * (1.f / 16.f);
+    unsigned long long cnt_lo = 0, cnt_hi = 0, cnt_4 = 0;   // 3 bit planes: a position is the argmax of at most 4 windows
+    for (int ph = 0; ph < 4; ++ph) {
+      const int h0 = (ph * H) / 4, h1 = ((ph + 1) * H + 3) / 4;
+      for (int pw = 0; pw < 4; ++pw) {
+        const int w0 = (pw * W) / 4, w1 = ((pw + 1) * W + 3) / 4;
+        float m = -INFINITY;
+        int am = h0 * W + w0;
+        for (int h = h0; h < h1; ++h)
+          for (int w = w0; w < w1; ++w) {
+            const float v = b[(long)(h * W + w) * C];
+            if (v > m) { m = v; am = h * W + w; }
+          }
+        // ripple-add 1 into the per-position counter held as bit planes
+        const unsigned long long bit = 1ull << am;
+        const unsigned long long carry = cnt_lo & bit;
+        const unsigned long long carry2 = cnt_hi & carry;
+        cnt_lo ^= bit;
+        cnt_hi ^= carry;
+        cnt_4 ^= carry2;
+      }
+    }
+    for (int p = 0; p < H * W; ++p) {
+      const int k = (int)((cnt_lo >> p) & 1ull) + 2 * (int)((cnt_hi >> p) & 1ull) + 4 * (int)((cnt_4 >> p) & 1ull);
+      d[(long)p * C] = gv * (float)k;
+    }
+  }
+}
+
+extern "C" int lmkd_adaptive_maxpool_mean_fwd(const float* x, float* y, int F, int H, int W, int C, void* stream) {
+  LMKD_REQUIRE(x && y && F > 0 && H >= 4 && W >= 4 && C > 0, "lmkd_adaptive_maxpool_mean_fwd: bad arguments");
+  hipLaunchKernelGGL(adaptive_maxpool_mean_kernel, dim3(ew_grid((long)F * C)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, y, F, H, W, C);
+  LMKD_CHECK_LAUNCH("adaptive_maxpool_mean_kernel");
+  return LMKD_OK;
+}
+extern "C" int lmkd_adaptive_maxpool_mean_bwd(const float* x, const float* dy, float* dx, int F, int H, int W, int C, void* stream) {
+  LMKD_REQUIRE(x && dy && dx && F > 0 && H >= 4 && W >= 4 && H * W <= 64, "lmkd_adaptive_maxpool_mean_bwd: bad arguments (H*W must be <= 64)");
+  LMKD_REQUIRE(H <= 8 && W <= 8, "lmkd_adaptive_maxpool_mean_bwd: H, W must be <= 8 (at most 2 overlapping windows per axis)");
+  hipLaunchKernelGGL(adaptive_maxpool_mean_bwd_kernel, dim3(ew_grid((long)F * C)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, dy, dx, F, H, W, C);
+  LMKD_CHECK_LAUNCH("adaptive_maxpool_mean_bwd_kernel");
+  return LMKD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// column sums of a [rows, C] matrix (Linear bias grads, LayerNorm parameter grads):
+//   out[c] = sum_r a[r,c] * (b ? b[r,c] : 1)
+// ---------------------------------------------------------------------------------
+__global__ void colsum_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partial, long rows, int C) {
+  // grid.x over column chunks of 256, grid.y over row slices
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * per;
+  long r1 = r0 + per;
+  if (r1 > rows) r1 = rows;
+  float s = 0.f;
+  for (long r = r0; r < r1; ++r) s += b ? a[r * C + c] * b[r * C + c] : a[r * C + c];
+  partial[(long)blockIdx.y * C + c] = s;
+}
+__global__ void colsum_finish_kernel(const double* __restrict__ sums, float* __restrict__ out, int C, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) out[c] = (accumulate ? out[c] : 0.f) + (float)sums[c];
+}
+
+extern "C" long lmkd_colsum_workspace(int C) { return (long)64 * C * sizeof(float) + (long)66 * C * sizeof(double) + 64; }
+
+extern "C" int lmkd_colsum(const float* a, const float* b, float* out, long rows, int C, int accumulate, void* workspace, void* stream) {
+  LMKD_REQUIRE(a && out && workspace && rows > 0 && C > 0, "lmkd_colsum: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int slices = (int)(rows < 64 ? rows : 64);
+  float* partial = (float*)workspace;
+  double* dscr = (double*)((char*)workspace + (((long)64 * C * sizeof(float) + 63) / 64) * 64);
+  hipLaunchKernelGGL(colsum_rows_kernel, dim3(cdiv(C, 256), slices), dim3(256), 0, s, a, b, partial, rows, C);
+  LMKD_CHECK_LAUNCH("colsum_rows_kernel");
+  int rc = colsum_to_double(partial, slices, C, dscr, dscr + C, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)dscr, out, C, accumulate);
+  LMKD_CHECK_LAUNCH("colsum_finish_kernel");
+  return LMKD_OK;
+}

@@ -1,0 +1,94 @@
+"""ResNet-18 trunk = torchvision resnet18().children()[:-2] (resnet18_2fc.py:30-33), rebuilt on the
+HIP conv/BN kernels.  Module/parameter names reproduce nn.Sequential's state_dict keys
+(`0.weight`, `1.running_mean`, `4.0.conv1.weight`, `5.0.downsample.1.bias`, ...) so checkpoints
+written by the reference load unchanged (model_select.py:138-153)."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+STAGES = [("4", 64, 64, 1), ("5", 64, 128, 2), ("6", 128, 256, 2), ("7", 256, 512, 2)]
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")   # torchvision ResNet.__init__
+        self.weight = nn.Parameter(w)
+
+
+class _BN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def args(self):
+        return self.weight, self.bias, self.running_mean, self.running_var
+
+
+class _Block(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.stride = stride
+        self.conv1 = _Conv(cin, cout, 3)
+        self.bn1 = _BN(cout)
+        self.conv2 = _Conv(cout, cout, 3)
+        self.bn2 = _BN(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential()
+            self.downsample.add_module("0", _Conv(cin, cout, 1))
+            self.downsample.add_module("1", _BN(cout))
+
+    def forward(self, x):
+        tr = self.training
+        if self.downsample is not None:
+            ds = (self.downsample[0].weight,) + self.downsample[1].args()
+        else:
+            ds = (None, None, None, None, None)
+        y = ops.BasicBlockFn.apply(x, self.stride, tr, self.conv1.weight, *self.bn1.args(),
+                                   self.conv2.weight, *self.bn2.args(), *ds)
+        if tr:
+            self.bn1.num_batches_tracked += 1
+            self.bn2.num_batches_tracked += 1
+            if self.downsample is not None:
+                self.downsample[1].num_batches_tracked += 1
+        return y
+
+
+class ResNet18Trunk(nn.Module):
+    """[F,3,H,W] NCHW frames -> NHWC feature map [F,H/32,W/32,512]."""
+
+    def __init__(self):
+        super().__init__()
+        self.add_module("0", _Conv(3, 64, 7))
+        self.add_module("1", _BN(64))
+        for name, cin, cout, stride in STAGES:
+            stage = nn.Sequential()
+            stage.add_module("0", _Block(cin, cout, stride))
+            stage.add_module("1", _Block(cout, cout, 1))
+            self.add_module(name, stage)
+
+    def forward(self, x):
+        conv, bn = getattr(self, "0"), getattr(self, "1")
+        y = ops.StemFn.apply(x, conv.weight, *bn.args(), self.training)
+        if self.training:
+            bn.num_batches_tracked += 1
+        for name, _, _, _ in STAGES:
+            for blk in getattr(self, name):
+                y = blk(y)
+        return y
+
+
+class Linear(nn.Linear):
+    """nn.Linear parameters/init, forward on the MFMA GEMM."""
+
+    def forward(self, x):
+        return ops.LinearFn.apply(x, self.weight, self.bias)

@@ -1,0 +1,36 @@
+"""resnet18_2fc backbone (reference: model/backbone/resnet18_2fc.py:16-86)."""
+import torch.nn as nn
+
+from ... import ops
+from .resnet import Linear, ResNet18Trunk
+
+
+class resnet18_2fc(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.args.trans_linear_in_dim = 2048          # resnet18_2fc.py:27
+        self.num_patches = 16
+        self.resnet = ResNet18Trunk()
+        self.fc1 = Linear(512, 2048)
+        self.fc2 = Linear(512, 2048)
+
+    def forward(self, context_feature, context_labels, target_feature):
+        # two separate trunk calls = two separate BatchNorm batches (resnet18_2fc.py:41-42)
+        cf = ops.PoolHeadFn.apply(self.resnet(context_feature))        # :44-54
+        tf = ops.PoolHeadFn.apply(self.resnet(target_feature))
+        L, D = self.args.seq_len, self.args.trans_linear_in_dim
+        context_feature_dict = {
+            "context_features_1": self.fc1(cf).reshape(-1, L, D),
+            "context_features_2": self.fc2(cf).reshape(-1, L, D),
+        }
+        target_features_dict = {
+            "target_features_1": self.fc1(tf).reshape(-1, L, D),
+            "target_features_2": self.fc2(tf).reshape(-1, L, D),
+        }
+        return context_feature_dict, target_features_dict
+
+    def distribute_model(self):
+        """The reference wraps self.resnet in nn.DataParallel (resnet18_2fc.py:80-86).  Here multi-GPU is
+        episode-parallel (one process per GPU, see parallel.py), so this is a no-op."""
+        return None

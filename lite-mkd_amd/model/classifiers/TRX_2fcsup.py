@@ -1,0 +1,117 @@
+"""TRX_2fcsup / TRX_2fcsup_fixed classifiers (reference: model/classifiers/TRX_2fcsup.py:24-256).
+
+Differences from the reference that do not change results: logits stay on the device (the
+reference assembles them in CPU tensors, :114,180, and the distiller moves them back); the
+4096-wide tuple Linear is evaluated as two 2048-wide per-frame projections (same sum, 3.5x fewer
+FLOPs); all classes are matched in one pass over class-sorted support tuples."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+
+class PositionalEncoding(nn.Module):
+    """TRX_2fcsup.py:24-48.  Holds the `pe` buffer [1,max_len,d_model]; the add (+dropout) is fused into
+    the TRX op."""
+
+    def __init__(self, d_model, dropout, max_len=5000, pe_scale_factor=0.1):
+        super().__init__()
+        self.p = float(dropout)
+        self.pe_scale_factor = pe_scale_factor
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * -(math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term) * self.pe_scale_factor
+        pe[:, 1::2] = torch.cos(position * div_term) * self.pe_scale_factor
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+
+class TemporalCrossTransformer(nn.Module):
+    """TRX_2fcsup.py:50-160.  Parameters are held by standard nn.Linear / nn.LayerNorm containers so the
+    state_dict keys (k_linear.*, v_linear.*, norm_k.*, norm_v.*, pe.pe) and default init match."""
+
+    def __init__(self, args, temporal_set_size=2):
+        super().__init__()
+        if temporal_set_size != 2:
+            raise NotImplementedError("only frame pairs (temporal_set_size=2) are on the hot path")
+        self.args = args
+        self.temporal_set_size = temporal_set_size
+        max_len = int(self.args.seq_len * 1.5)
+        self.pe = PositionalEncoding(2048, self.args.trans_dropout, max_len=max_len)
+        self.k_linear = nn.Linear(2048 * temporal_set_size, self.args.trans_linear_out_dim)
+        self.v_linear = nn.Linear(2048 * temporal_set_size, self.args.trans_linear_out_dim)
+        self.norm_k = nn.LayerNorm(self.args.trans_linear_out_dim)
+        self.norm_v = nn.LayerNorm(self.args.trans_linear_out_dim)       # unused by forward (:106), as in the reference
+        self.tuples_len = self.args.seq_len * (self.args.seq_len - 1) // 2
+        self._drop_calls = 0
+
+    def _mask(self, n_rows, device):
+        p = self.pe.p
+        if not self.training or p <= 0.0:
+            return None
+        self._drop_calls += 1
+        seed = (torch.initial_seed() * 1000003 + self._drop_calls) & 0x7FFFFFFFFFFFFFFF
+        return ops.dropout_mask((n_rows, 2048), p, seed, device)
+
+    def forward(self, support_set, support_labels, queries):
+        L = self.args.seq_len
+        if support_set.shape[1] != L or support_set.shape[2] != 2048:
+            raise RuntimeError("TemporalCrossTransformer expects [N,%d,2048] features" % L)
+        plan = ops.get_plan(support_labels, self.args.way)
+        pe = self.pe.pe[0, :L].contiguous()
+        mask = self._mask((support_set.shape[0] + queries.shape[0]) * L, support_set.device)
+        a = (self.k_linear.weight, self.k_linear.bias, self.v_linear.weight, self.v_linear.bias,
+             self.norm_k.weight, self.norm_k.bias, pe, mask, plan)
+        if torch.is_grad_enabled() and (support_set.requires_grad or self.k_linear.weight.requires_grad):
+            logits = ops.TRXLogitsFn.apply(support_set, queries, *a)
+        else:
+            logits = ops.trx_logits_nograd(support_set, queries, plan, *a[:8])
+        return {"logits": logits}
+
+
+class SupportDK(nn.Module):
+    """TRX_2fcsup.py:162-189 (== e_dist_fc2.py:17-44).  Ignores the labels and assumes class-sorted
+    support, exactly like the reference; output is [5,4] (way x way-1)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+
+    def forward(self, support_set, support_labels, queries):
+        return {"logits": ops.SupportDKFn.apply(support_set, self.args.way, self.args.shot)}
+
+
+class TRX_2fcsup(nn.Module):
+    """TRX_2fcsup.py:191-224."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.train()
+        self.args = args
+        self.transformers = TemporalCrossTransformer(args, 2)
+        self.supportKD = SupportDK(args)
+
+    def forward(self, context_feature, context_labels, target_feature):
+        l1 = self.transformers(context_feature["context_features_1"], context_labels, target_feature["target_features_1"])["logits"]
+        l2 = self.transformers(context_feature["context_features_2"], context_labels, target_feature["target_features_2"])["logits"]
+        l3 = self.supportKD(context_feature["context_features_2"], context_labels, target_feature["target_features_2"])["logits"]
+        return {"logits": {"kl": l1, "ce": l2, "sup": l3}}
+
+
+class TRX_2fcsup_fixed(nn.Module):
+    """TRX_2fcsup.py:226-256 — the frozen teacher head (no_grad)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.train()
+        self.args = args
+        self.transformers = TemporalCrossTransformer(args, 2)
+        self.supportKD = SupportDK(args)
+
+    def forward(self, context_feature, context_labels, target_feature):
+        with torch.no_grad():
+            l1 = self.transformers(context_feature, context_labels, target_feature)["logits"]
+            l2 = self.supportKD(context_feature, context_labels, target_feature)["logits"]
+        return {"logits": {"kl": l1, "sup": l2}}

@@ -1,0 +1,610 @@
+"""Tensor-level wrappers over the C ABI (include/lmkd.h) and the autograd Functions that tie
+the HIP kernels into torch.autograd.  torch is plumbing here (device memory, stream, autograd
+graph); all arithmetic of the hot path happens in liblmkd_hip.so.
+
+Activations are NHWC fp32.  Every wrapper checks device/dtype/contiguity and raises on misuse."""
+import ctypes
+import math
+
+import torch
+
+from ._lib import lib
+
+
+# ------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("lite-mkd_amd ops need CUDA(HIP) tensors; got a %s tensor — the HIP hot path has no CPU fallback" % t.device)
+        if t.dtype not in (torch.float32, torch.int64, torch.int32, torch.uint8):
+            raise RuntimeError("unsupported dtype %s" % t.dtype)
+        if not t.is_contiguous():
+            raise RuntimeError("non-contiguous tensor passed to a HIP op")
+
+
+def _ints(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _f32(x):
+    return ctypes.c_float(float(x))
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------
+def gemm(layA, layB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, beta=0.0, bias=None, relu=False,
+         batch=1, sA=0, sB=0, sC=0, A_off=0, B_off=0, C_off=0):
+    """C = alpha*op(A)*op(B) + beta*C + bias.  *_off are element offsets into the tensors' storage."""
+    _chk(A, B, C, bias)
+    es = 4
+    lib().call("lmkd_gemm_f32", layA.encode(), layB.encode(), M, N, K, _f32(alpha),
+               ctypes.c_void_p(A.data_ptr() + A_off * es), lda, sA,
+               ctypes.c_void_p(B.data_ptr() + B_off * es), ldb, sB, _f32(beta),
+               ctypes.c_void_p(C.data_ptr() + C_off * es), ldc, sC, _p(bias), int(relu), batch, _stream())
+    return C
+
+
+def linear_fwd(x, w, b):
+    """y[M,N] = x[M,K] w[N,K]^T + b"""
+    M, K = x.shape
+    N = w.shape[0]
+    y = _empty((M, N), x)
+    return gemm("K", "K", M, N, K, x, K, w, K, y, N, bias=b)
+
+
+def colsum(a, b=None, out=None, accumulate=False):
+    rows, C = a.shape
+    if out is None:
+        out = _empty((C,), a)
+        accumulate = False
+    _chk(a, b, out)
+    ws = torch.empty(lib().value("lmkd_colsum_workspace", C), dtype=torch.uint8, device=a.device)
+    lib().call("lmkd_colsum", _p(a), _p(b), _p(out), rows, C, int(accumulate), _p(ws), _stream())
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear (resnet18_2fc.py:56-64 fc1/fc2).  fwd/dgrad/wgrad on the MFMA GEMM, bias grad = column sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return linear_fwd(x, w.contiguous(), b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty((M, K), x)
+            gemm("K", "N", M, K, N, dy, N, w, K, dx, K)          # dx = dy @ W
+        if ctx.needs_input_grad[1]:
+            dw = _empty((N, K), x)
+            gemm("M", "N", N, K, M, dy, N, x, K, dw, K)          # dW = dy^T @ x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy)
+        return dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------
+# convolution pieces
+# ------------------------------------------------------------------------------------------
+def pack_weights(w, Cs, mode):
+    Cout, Cin, KH, KW = w.shape
+    n = lib().value("lmkd_conv2d_packed_weight_elems", Cout, Cin, Cs, KH, KW, mode)
+    wp = _empty((n,), w)
+    _chk(w)
+    lib().call("lmkd_conv2d_pack_weights", _p(w), _p(wp), Cout, Cin, Cs, KH, KW, mode, _stream())
+    return wp
+
+
+def conv_out_size(H, K, s, p):
+    return (H + 2 * p - K) // s + 1
+
+
+def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats):
+    """x NHWC [N,H,W,Cs] -> (y [N,Ho,Wo,Cout], stat partial [T,Cout,2] | None)"""
+    _chk(x, wp)
+    N, H, W, Cs = x.shape
+    Ho, Wo = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
+    y = _empty((N, Ho, Wo, Cout), x)
+    part = None
+    if want_stats:
+        T = lib().value("lmkd_conv2d_fwd_row_tiles", N, H, W, KH, KW, stride, pad)
+        part = _empty((T, Cout, 2), x)
+    lib().call("lmkd_conv2d_fwd", _p(x), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, _stream())
+    return y, part
+
+
+def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None):
+    N, H, W, Cin = x_shape
+    _chk(dy, wd, out)
+    dx = out if out is not None else _empty((N, H, W, Cin), dy)
+    lib().call("lmkd_conv2d_bwd_data", _p(dy), _p(wd), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, _stream())
+    return dx
+
+
+def conv_bwd_weight(x, dy, w_shape, stride, pad):
+    Cout, Cin, KH, KW = w_shape
+    N, H, W, Cs = x.shape
+    _chk(x, dy)
+    nbytes = lib().value("lmkd_conv2d_bwd_weight_workspace", N, H, W, Cs, Cout, KH, KW, stride, pad)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = _empty(w_shape, x)
+    lib().call("lmkd_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, _stream())
+    return dw
+
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def bn_stats_train(part, count, gamma, beta, running_mean, running_var):
+    T, C, _ = part.shape
+    stats = _empty((4, C), part)
+    scratch = torch.empty(66 * 2 * C, dtype=torch.float64, device=part.device)
+    lib().call("lmkd_bn_finalize", _p(part), T, C, count, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+               _f32(BN_MOMENTUM), _f32(BN_EPS), _p(stats), _p(scratch), _stream())
+    return stats
+
+
+def bn_stats_eval(gamma, beta, running_mean, running_var):
+    C = gamma.shape[0]
+    stats = _empty((4, C), gamma)
+    lib().call("lmkd_bn_eval_stats", C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _f32(BN_EPS), _p(stats), _stream())
+    return stats
+
+
+def bn_apply(x, stats, relu, res=None, rstats=None):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    mode = 0 if res is None else (2 if rstats is not None else 1)
+    _chk(x, stats, res, rstats)
+    lib().call("lmkd_bn_apply", _p(x), _p(stats), _p(res), _p(rstats), _p(y), rows, C, int(relu), mode, _stream())
+    return y
+
+
+def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None):
+    """-> dx, g (masked dy) | None, dgamma, dbeta"""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    _chk(dy, x, yact, stats, gamma)
+    dx = dx_out if dx_out is not None else torch.empty_like(x)
+    g = torch.empty_like(x) if want_g else None
+    dgamma, dbeta = _empty((C,), x), _empty((C,), x)
+    coef = _empty((3, C), x)
+    ws = torch.empty(lib().value("lmkd_bn_bwd_workspace", C), dtype=torch.uint8, device=x.device)
+    lib().call("lmkd_bn_backward", _p(dy), _p(x), _p(yact), _p(stats), _p(gamma), _p(dx), _p(g), _p(dgamma), _p(dbeta),
+               _p(coef), _p(ws), rows, C, mask_mode, _stream())
+    return dx, g, dgamma, dbeta
+
+
+def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training):
+    Cout, _, KH, KW = w.shape
+    wp = pack_weights(w, Cs, 0)
+    y, part = conv_fwd(x, wp, Cout, KH, KW, stride, pad, training)
+    if training:
+        stats = bn_stats_train(part, y.numel() // Cout, gamma, beta, rm, rv)
+    else:
+        stats = bn_stats_eval(gamma, beta, rm, rv)
+    return y, stats
+
+
+class StemFn(torch.autograd.Function):
+    """conv7x7/2 + BN + ReLU + maxpool3x3/2 (torchvision resnet children 0-3, resnet18_2fc.py:33).
+    Input NCHW [F,3,H,W] (the reference's frame layout), output NHWC [F,H/4,W/4,64]."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, rm, rv, training):
+        _chk(x, w, gamma, beta, rm, rv)
+        F_, Cin, H, W = x.shape
+        if Cin != 3:
+            raise RuntimeError("stem expects 3-channel frames")
+        x4 = _empty((F_, H, W, 4), x)
+        lib().call("lmkd_nchw3_to_nhwc4", _p(x.contiguous()), _p(x4), F_, H, W, _stream())
+        c, stats = _conv_bn_train_or_eval(x4, w, 4, 2, 3, gamma, beta, rm, rv, training)
+        N, Hc, Wc, C = c.shape
+        Ho, Wo = conv_out_size(Hc, 3, 2, 1), conv_out_size(Wc, 3, 2, 1)
+        y = _empty((N, Ho, Wo, C), x)
+        idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+        lib().call("lmkd_bn_relu_maxpool_fwd", _p(c), _p(stats), _p(y), _p(idx), N, Hc, Wc, C, _stream())
+        if training:
+            ctx.save_for_backward(x4, c, stats, idx, gamma)
+            ctx.w_shape = tuple(w.shape)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
+        x4, c, stats, idx, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, Hc, Wc, C = c.shape
+        g = torch.empty_like(c)
+        lib().call("lmkd_maxpool_bwd", _p(dy), _p(idx), _p(g), N, Hc, Wc, C, _stream())
+        dc, _, dgamma, dbeta = bn_backward(g, c, None, stats, gamma, 2, dx_out=g)
+        dw = conv_bwd_weight(x4, dc, ctx.w_shape, 2, 3)
+        return None, dw, dgamma, dbeta, None, None, None
+
+
+class BasicBlockFn(torch.autograd.Function):
+    """torchvision BasicBlock: conv3x3-BN-ReLU-conv3x3-BN (+1x1/2 conv-BN downsample) + add + ReLU.
+    One autograd node per block; backward is hand-scheduled so that the masked gradient buffer
+    of the residual branch is reused as the block-input gradient accumulator."""
+
+    @staticmethod
+    def forward(ctx, x, stride, training, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, wd, gd, bd, rmd, rvd):
+        _chk(x, w1, w2, wd)
+        Cs = x.shape[-1]
+        c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, stride, 1, g1, b1, rm1, rv1, training)
+        a1 = bn_apply(c1, st1, True)
+        c2, st2 = _conv_bn_train_or_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training)
+        if wd is not None:
+            cd, std = _conv_bn_train_or_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, training)
+            y = bn_apply(c2, st2, True, cd, std)
+        else:
+            cd = std = None
+            y = bn_apply(c2, st2, True, x)
+        ctx.training = training
+        ctx.stride = stride
+        ctx.has_ds = wd is not None
+        if training:
+            ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, y, wd, gd, cd, std)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
+        x, w1, g1, c1, st1, a1, w2, g2, c2, st2, y, wd, gd, cd, std = ctx.saved_tensors
+        dy = dy.contiguous()
+        stride = ctx.stride
+        Cmid = w1.shape[0]
+        # bn2 (+ReLU mask from y); g = masked dy = gradient of both residual branches
+        dc2, g, dg2, db2 = bn_backward(dy, c2, y, st2, g2, 1, want_g=True)
+        wd2 = pack_weights(w2, Cmid, 1)
+        da1 = conv_bwd_data(dc2, wd2, a1.shape, Cmid, 3, 3, 1, 1)
+        dw2 = conv_bwd_weight(a1, dc2, tuple(w2.shape), 1, 1)
+        del dc2
+        dc1, _, dg1, db1 = bn_backward(da1, c1, a1, st1, g1, 1, dx_out=da1)
+        dw1 = conv_bwd_weight(x, dc1, tuple(w1.shape), stride, 1)
+        dwd = dgd = dbd = None
+        need_dx = ctx.needs_input_grad[0]
+        dx = None
+        if ctx.has_ds:
+            dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g)
+            dwd = conv_bwd_weight(x, dcd, tuple(wd.shape), stride, 0)
+            if need_dx:
+                wdd = pack_weights(wd, Cmid, 1)
+                dx = conv_bwd_data(dcd, wdd, x.shape, Cmid, 1, 1, stride, 0)
+        else:
+            dx = g                                    # identity branch
+        if need_dx:
+            wd1 = pack_weights(w1, Cmid, 1)
+            tmp = conv_bwd_data(dc1, wd1, x.shape, Cmid, 3, 3, stride, 1)
+            lib().call("lmkd_axpby", _p(tmp), _p(dx), _f32(1.0), _f32(1.0), dx.numel(), _stream())
+        return (dx if need_dx else None, None, None, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None,
+                dwd, dgd, dbd, None, None)
+
+
+class PoolHeadFn(torch.autograd.Function):
+    """AdaptiveMaxPool2d((4,4)) -> mean over the 16 patches (resnet18_2fc.py:44-54). NHWC in, [F,C] out."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        F_, H, W, C = x.shape
+        y = _empty((F_, C), x)
+        lib().call("lmkd_adaptive_maxpool_mean_fwd", _p(x), _p(y), F_, H, W, C, _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        F_, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        lib().call("lmkd_adaptive_maxpool_mean_bwd", _p(x), _p(dy.contiguous()), _p(dx), F_, H, W, C, _stream())
+        return dx
+
+
+# ------------------------------------------------------------------------------------------
+# matchers
+# ------------------------------------------------------------------------------------------
+class ClassPlan:
+    """Host-side description of the support set's class structure (one small D2H copy of the
+    labels per episode, done before any kernel is queued).  Mirrors torch.unique +
+    _extract_class_indices of the reference (TRX_2fcsup.py:108,118-119)."""
+
+    def __init__(self, support_labels, way):
+        lab = support_labels.detach().to("cpu")
+        vals = [int(v) for v in lab.long().tolist()]
+        self.way = way
+        self.classes = sorted(set(vals))
+        for c in self.classes:
+            if c < 0 or c >= way:
+                raise IndexError("support label %d outside [0,%d)" % (c, way))
+        order, self.counts = [], []
+        for c in self.classes:
+            idx = [i for i, v in enumerate(vals) if v == c]
+            order += idx
+            self.counts.append(len(idx))
+        self.ns = len(vals)
+        pos = [0] * self.ns                       # pos[n] = class-sorted position of support video n
+        for p_, n in enumerate(order):
+            pos[n] = p_
+        dev = support_labels.device
+        self.rowmap = torch.tensor(pos, dtype=torch.int32, device=dev)
+        self.cls = torch.tensor(vals, dtype=torch.int32, device=dev)
+        self.uniform = len(set(self.counts)) == 1
+
+
+def _trx_forward(sup, qry, plan, wk, bk, wv, bv, gamma, beta, pe, mask, want_grad):
+    """Shared by the student heads (with grad) and the frozen teacher head.
+    sup [Ns,L,2048], qry [Nq,L,2048] -> logits [Nq,way] (+ saved tensors)"""
+    Ns, L, Din = sup.shape
+    Nq = qry.shape[0]
+    D = wk.shape[0]
+    T = L * (L - 1) // 2
+    NV = Ns + Nq
+    X = torch.cat([sup.reshape(Ns * L, Din), qry.reshape(Nq * L, Din)], 0).contiguous()
+    Xp = torch.empty_like(X)
+    lib().call("lmkd_add_pe", _p(X), _p(pe), _p(mask), _p(Xp), NV * L, Din, L, _stream())
+    # per-frame projections: P = Xp @ [Wk[:, :Din] | Wk[:, Din:] | Wv[:, :Din] | Wv[:, Din:]]^T
+    P = _empty((NV * L, 4 * D), X)
+    gemm("K", "K", NV * L, D, Din, Xp, Din, wk, 2 * Din, P, 4 * D, batch=2, sB=Din, sC=D)
+    gemm("K", "K", NV * L, D, Din, Xp, Din, wv, 2 * Din, P, 4 * D, batch=2, sB=Din, sC=D, C_off=2 * D)
+    rowmap = torch.cat([plan.rowmap, torch.arange(Ns, NV, dtype=torch.int32, device=X.device)])
+    Kn = _empty((NV * T, D), X)
+    V = _empty((NV * T, D), X)
+    Khat = _empty((NV * T, D), X) if want_grad else None
+    rstd = _empty((NV * T,), X) if want_grad else None
+    lib().call("lmkd_trx_tuple_ln_fwd", _p(P), _p(bk), _p(bv), _p(gamma), _p(beta), _p(rowmap), _p(Kn), _p(Khat), _p(V),
+               _p(rstd), NV, L, D, _f32(1e-5), _stream())
+    Rs, Rq = Ns * T, Nq * T
+    Sk, Sv = Kn[:Rs], V[:Rs]
+    Qk, Qv = Kn[Rs:], V[Rs:]
+    S = _empty((Rq, Rs), X)
+    gemm("K", "K", Rq, Rs, D, Qk, D, Sk, D, S, Rs, alpha=1.0 / math.sqrt(D))
+    nseg = len(plan.classes)
+    seg_cnt = [c * T for c in plan.counts]
+    seg_off = [sum(seg_cnt[:i]) for i in range(nseg)]
+    lib().call("lmkd_segment_softmax_fwd", _p(S), Rq, Rs, nseg, _ints(seg_off), _ints(seg_cnt), _stream())
+    proto = _empty((nseg, Rq, D), X)
+    if plan.uniform:
+        gemm("K", "N", Rq, D, seg_cnt[0], S, Rs, Sv, D, proto, D, batch=nseg, sA=seg_cnt[0], sB=seg_cnt[0] * D, sC=Rq * D)
+    else:
+        for s in range(nseg):
+            gemm("K", "N", Rq, D, seg_cnt[s], S, Rs, Sv, D, proto, D, A_off=seg_off[s], B_off=seg_off[s] * D, C_off=s * Rq * D)
+    logits = torch.zeros((Nq, plan.way), dtype=torch.float32, device=X.device)
+    lib().call("lmkd_trx_dist_fwd", _p(Qv), _p(proto), _p(logits), Nq, plan.way, T, D, nseg, _ints(plan.classes), _stream())
+    saved = (Xp, Kn, V, Khat, rstd, S, proto, rowmap, seg_off, seg_cnt)
+    return logits, saved
+
+
+class TRXLogitsFn(torch.autograd.Function):
+    """TemporalCrossTransformer.forward (TRX_2fcsup.py:74-148) for one head."""
+
+    @staticmethod
+    def forward(ctx, sup, qry, wk, bk, wv, bv, gamma, beta, pe, mask, plan):
+        _chk(sup, qry, wk, bk, wv, bv, gamma, beta, pe, mask)
+        logits, saved = _trx_forward(sup.contiguous(), qry.contiguous(), plan, wk, bk, wv, bv, gamma, beta, pe, mask, True)
+        Xp, Kn, V, Khat, rstd, S, proto, rowmap, seg_off, seg_cnt = saved
+        ctx.save_for_backward(Xp, Kn, V, Khat, rstd, S, proto, rowmap, wk, wv, gamma, mask)
+        ctx.plan, ctx.seg_off, ctx.seg_cnt = plan, seg_off, seg_cnt
+        ctx.shapes = (sup.shape, qry.shape)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        Xp, Kn, V, Khat, rstd, S, proto, rowmap, wk, wv, gamma, mask = ctx.saved_tensors
+        plan, seg_off, seg_cnt = ctx.plan, ctx.seg_off, ctx.seg_cnt
+        (Ns, L, Din), (Nq, _, _) = ctx.shapes
+        D = wk.shape[0]
+        T = L * (L - 1) // 2
+        NV, Rs, Rq = Ns + Nq, Ns * T, Nq * T
+        nseg = len(plan.classes)
+        g = g.contiguous()
+        Sk, Sv, Qk, Qv = Kn[:Rs], V[:Rs], Kn[Rs:], V[Rs:]
+        dKn = _empty((NV * T, D), Xp)
+        dV = _empty((NV * T, D), Xp)
+        dSk, dSv, dQk, dQv = dKn[:Rs], dV[:Rs], dKn[Rs:], dV[Rs:]
+        # proto <- dproto ; dQv = -sum_c dproto_c
+        lib().call("lmkd_trx_dist_bwd", _p(Qv), _p(proto), _p(g), _p(dQv), Nq, plan.way, T, D, nseg, _ints(plan.classes), _stream())
+        dS = _empty((Rq, Rs), Xp)
+        if plan.uniform:
+            c = seg_cnt[0]
+            gemm("K", "K", Rq, c, D, proto, D, Sv, D, dS, Rs, batch=nseg, sA=Rq * D, sB=c * D, sC=c)        # dP = dproto @ Vc^T
+            gemm("M", "N", c, D, Rq, S, Rs, proto, D, dSv, D, batch=nseg, sA=c, sB=Rq * D, sC=c * D)       # dVc = P^T @ dproto
+        else:
+            for s in range(nseg):
+                c, o = seg_cnt[s], seg_off[s]
+                gemm("K", "K", Rq, c, D, proto, D, Sv, D, dS, Rs, A_off=s * Rq * D, B_off=o * D, C_off=o)
+                gemm("M", "N", c, D, Rq, S, Rs, proto, D, dSv, D, A_off=o, B_off=s * Rq * D, C_off=o * D)
+        lib().call("lmkd_segment_softmax_bwd", _p(S), _p(dS), Rq, Rs, nseg, _ints(seg_off), _ints(seg_cnt), _stream())
+        sc = 1.0 / math.sqrt(D)
+        gemm("K", "N", Rq, D, Rs, dS, Rs, Sk, D, dQk, D, alpha=sc)                                        # dQk = sc * dS @ Sk
+        gemm("M", "N", Rs, D, Rq, dS, Rs, Qk, D, dSk, D, alpha=sc)                                        # dSk = sc * dS^T @ Qk
+        # LayerNorm parameter grads, then dKn -> dKraw in place
+        dgamma = colsum(dKn, Khat)
+        dbeta = colsum(dKn)
+        lib().call("lmkd_layernorm_bwd_rows", _p(dKn), _p(Khat), _p(rstd), _p(gamma), NV * T, D, _stream())
+        dbk = colsum(dKn)
+        dbv = colsum(dV)
+        dP = _empty((NV * L, 4 * D), Xp)
+        lib().call("lmkd_trx_tuple_bwd_gather", _p(dKn), _p(dV), _p(rowmap), _p(dP), NV, L, D, _stream())
+        # weight grads: dW[:, half] = dP[:, blk]^T @ Xp
+        dwk = _empty((D, 2 * Din), Xp)
+        dwv = _empty((D, 2 * Din), Xp)
+        gemm("M", "N", D, Din, NV * L, dP, 4 * D, Xp, Din, dwk, 2 * Din, batch=2, sA=D, sC=Din)
+        gemm("M", "N", D, Din, NV * L, dP, 4 * D, Xp, Din, dwv, 2 * Din, batch=2, sA=D, sC=Din, A_off=2 * D)
+        # input grads: dXp = sum_blk dP[:, blk] @ W[:, half]
+        dX = _empty((NV * L, Din), Xp)
+        gemm("K", "N", NV * L, Din, D, dP, 4 * D, wk, 2 * Din, dX, Din)
+        gemm("K", "N", NV * L, Din, D, dP, 4 * D, wk, 2 * Din, dX, Din, beta=1.0, A_off=D, B_off=Din)
+        gemm("K", "N", NV * L, Din, D, dP, 4 * D, wv, 2 * Din, dX, Din, beta=1.0, A_off=2 * D)
+        gemm("K", "N", NV * L, Din, D, dP, 4 * D, wv, 2 * Din, dX, Din, beta=1.0, A_off=3 * D, B_off=Din)
+        if mask is not None:
+            lib().call("lmkd_mul", _p(dX), _p(mask), _p(dX), dX.numel(), _stream())
+        dsup = dX[:Ns * L].reshape(Ns, L, Din)
+        dqry = dX[Ns * L:].reshape(Nq, L, Din)
+        return dsup, dqry, dwk, dbk, dwv, dbv, dgamma, dbeta, None, None, None
+
+
+def trx_logits_nograd(sup, qry, plan, wk, bk, wv, bv, gamma, beta, pe, mask=None):
+    _chk(sup, qry, wk, bk, wv, bv, gamma, beta, pe, mask)
+    return _trx_forward(sup.contiguous(), qry.contiguous(), plan, wk, bk, wv, bv, gamma, beta, pe, mask, False)[0]
+
+
+def dropout_mask(shape, p, seed, device):
+    m = torch.empty(shape, dtype=torch.float32, device=device)
+    lib().call("lmkd_dropout_mask", _p(m), m.numel(), _f32(p), ctypes.c_ulonglong(seed), _stream())
+    return m
+
+
+class SupportDKFn(torch.autograd.Function):
+    """SupportDK.forward (TRX_2fcsup.py:162-189): labels ignored, class-sorted support assumed."""
+
+    @staticmethod
+    def forward(ctx, sup, way, shot):
+        sup = sup.contiguous()
+        _chk(sup)
+        Ns, L, D = sup.shape
+        if Ns != way * shot:
+            raise RuntimeError("shape '[%d, %d, %d, %d]' is invalid for input of size %d" % (way, shot, L, D, sup.numel()))
+        out = _empty((way, way - 1), sup)
+        lib().call("lmkd_supportdk_fwd", _p(sup), _p(out), way, shot, L, D, _stream())
+        ctx.save_for_backward(sup)
+        ctx.ws = (way, shot)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (sup,) = ctx.saved_tensors
+        way, shot = ctx.ws
+        Ns, L, D = sup.shape
+        d = torch.empty_like(sup)
+        lib().call("lmkd_supportdk_bwd", _p(sup), _p(g.contiguous()), _p(d), way, shot, L, D, _stream())
+        return d, None, None
+
+
+class EDistFn(torch.autograd.Function):
+    """e_dist.forward (e_dist_fc2.py:52-91)."""
+
+    @staticmethod
+    def forward(ctx, sup, qry, plan):
+        sup, qry = sup.contiguous(), qry.contiguous()
+        _chk(sup, qry)
+        Ns, L, D = sup.shape
+        Nq = qry.shape[0]
+        sm, qm = _empty((Ns, D), sup), _empty((Nq, D), sup)
+        lib().call("lmkd_mean_frames", _p(sup), _p(sm), Ns, L, D, _stream())
+        lib().call("lmkd_mean_frames", _p(qry), _p(qm), Nq, L, D, _stream())
+        dist = _empty((Nq, Ns), sup)
+        logits = _empty((Nq, plan.way), sup)
+        lib().call("lmkd_edist_fwd", _p(qm), _p(sm), _p(plan.cls), _p(dist), _p(logits), Nq, Ns, plan.way, D, _stream())
+        ctx.save_for_backward(sm, qm, dist)
+        ctx.plan, ctx.L = plan, L
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        sm, qm, dist = ctx.saved_tensors
+        plan, L = ctx.plan, ctx.L
+        Ns, D = sm.shape
+        Nq = qm.shape[0]
+        dqm, dsm = torch.empty_like(qm), torch.empty_like(sm)
+        lib().call("lmkd_edist_bwd", _p(qm), _p(sm), _p(plan.cls), _p(dist), _p(g.contiguous()), _p(dqm), _p(dsm), Nq, Ns, plan.way, D, _stream())
+        dsup, dqry = _empty((Ns, L, D), sm), _empty((Nq, L, D), sm)
+        lib().call("lmkd_mean_frames_bwd", _p(dsm), _p(dsup), Ns, L, D, _stream())
+        lib().call("lmkd_mean_frames_bwd", _p(dqm), _p(dqry), Nq, L, D, _stream())
+        return dsup, dqry, None
+
+
+# ------------------------------------------------------------------------------------------
+# loss / accuracy
+# ------------------------------------------------------------------------------------------
+class D2MLossFn(torch.autograd.Function):
+    """w_kl*kd_loss + w_sup*inter_class_relation + w_ce*cross_entropy (distillers.py:7-30,295-337),
+    values and logits gradients in one launch.  Returns a [4] tensor: total, kl, sup, ce."""
+
+    @staticmethod
+    def forward(ctx, s_kl, t_kl, s_ce, labels, s_sup, t_sup, T, w_kl, w_sup, w_ce):
+        ts = [t.contiguous() if t is not None else None for t in (s_kl, t_kl, s_ce, labels, s_sup, t_sup)]
+        s_kl, t_kl, s_ce, labels, s_sup, t_sup = ts
+        _chk(*ts)
+        ref = s_kl if s_kl is not None else (s_ce if s_ce is not None else s_sup)
+        if labels is not None and labels.dtype != torch.int64:
+            raise RuntimeError("labels must be int64 (the reference casts with .type(torch.LongTensor), trainwandb.py:441)")
+        out = _empty((4,), ref)
+        g_kl = torch.empty_like(s_kl) if s_kl is not None else None
+        g_ce = torch.empty_like(s_ce) if s_ce is not None else None
+        g_sup = torch.empty_like(s_sup) if s_sup is not None else None
+        q = s_kl if s_kl is not None else s_ce
+        Rq, C = (q.shape if q is not None else (0, 0))
+        Rs, Cs = (s_sup.shape if s_sup is not None else (0, 0))
+        lib().call("lmkd_d2m_loss", _p(s_kl), _p(t_kl), _p(s_ce), _p(labels), _p(s_sup), _p(t_sup), Rq, C, Rs, Cs, _f32(T),
+                   _f32(w_kl), _f32(w_sup), _f32(w_ce), _p(out), _p(g_kl), _p(g_ce), _p(g_sup), _stream())
+        ctx.grads = (g_kl, g_ce, g_sup)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        g_kl, g_ce, g_sup = ctx.grads
+        s = gout[0]                                # only the total carries gradient
+
+        def sc(t):
+            return None if t is None else t * s
+        return sc(g_kl), None, sc(g_ce), None, sc(g_sup), None, None, None, None, None
+
+
+def accuracy(l1, l2, labels):
+    """aggregate_accuracy (utils.py:116-121) on l1 (+ l2): -> (acc 0-dim tensor, predictions int64)"""
+    l1 = l1.contiguous()
+    l2 = l2.contiguous() if l2 is not None else None
+    labels = labels.contiguous()
+    _chk(l1, l2, labels)
+    R, C = l1.shape
+    pred = torch.empty((R,), dtype=torch.int64, device=l1.device)
+    acc = _empty((1,), l1)
+    lib().call("lmkd_accuracy", _p(l1), _p(l2), _p(labels), _p(pred), _p(acc), R, C, _stream())
+    return acc[0], pred
+
+
+_plan_cache = [None, None, None]
+
+
+def get_plan(support_labels, way):
+    """ClassPlan for this label tensor; cached on tensor identity so Student.forward can build it (one
+    tiny D2H copy) BEFORE the backbone kernels are queued and the classifier reuses it."""
+    if _plan_cache[0] is support_labels and _plan_cache[1] == way:
+        return _plan_cache[2]
+    plan = ClassPlan(support_labels, way)
+    _plan_cache[0], _plan_cache[1], _plan_cache[2] = support_labels, way, plan
+    return plan

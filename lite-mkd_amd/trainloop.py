@@ -1,0 +1,186 @@
+"""The per-episode training loop of the reference (trainwandb.py:111-188 train, :190-287 train_task,
+:359-417 test, :419-443 prepare_task) with its quirks kept:
+  * `iteration` is incremented before use and the optimizer fires when (iteration+1) % tasks_per_batch == 0,
+    so the first step comes after tasks_per_batch-1 episodes (:125,141-143);
+  * scheduler.step() runs every episode (:145) — milestones are in episodes;
+  * only the CE term carries the 1/16 accumulation scaling (distillers.py:326-335).
+wandb / checkpoint-file side effects are replaced by an optional `log` callback."""
+import numpy as np
+import torch
+
+from . import ops
+from .parallel import FlatParams, world_size
+from ._lib import lib
+import ctypes
+
+
+class FusedOptimizer:
+    """SGD (no momentum; trainwandb.py:103-104, options.py:72-73) or Adam over the flat buffers."""
+
+    def __init__(self, module, opt="sgd", lr=1e-4):
+        self.bucket = FlatParams(module)
+        self.opt, self.lr, self.steps = opt, float(lr), 0
+        if opt == "adam":
+            self.m = torch.zeros_like(self.bucket.flat)
+            self.v = torch.zeros_like(self.bucket.flat)
+        elif opt != "sgd":
+            raise KeyError(opt)
+
+    def zero_grad(self):
+        self.bucket.zero_grad()
+
+    def step(self):
+        b = self.bucket
+        b.allreduce_grads()
+        self.steps += 1
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+        if self.opt == "sgd":
+            lib().call("lmkd_sgd_step", P(b.flat), P(b.grad), ctypes.c_float(self.lr), b.numel, 0, s)
+        else:
+            lib().call("lmkd_adam_step", P(b.flat), P(b.grad), P(self.m), P(self.v), ctypes.c_float(self.lr),
+                       ctypes.c_float(0.9), ctypes.c_float(0.999), ctypes.c_float(1e-8), self.steps, b.numel, 0, s)
+
+
+class MultiStepLR:
+    """torch.optim.lr_scheduler.MultiStepLR(milestones, gamma=0.1) on FusedOptimizer.lr."""
+
+    def __init__(self, optimizer, milestones, gamma=0.1):
+        self.opt, self.milestones, self.gamma, self.n = optimizer, sorted(milestones), gamma, 0
+        self.base = optimizer.lr
+
+    def step(self):
+        self.n += 1
+        self.opt.lr = self.base * self.gamma ** sum(1 for m in self.milestones if m <= self.n)
+
+
+def prepare_task(task_dict, device, images_to_device=True):
+    """trainwandb.py:419-443"""
+    context_images, context_labels = task_dict["support_set"][0], task_dict["support_labels"][0]
+    target_images, target_labels = task_dict["target_set"][0], task_dict["target_labels"][0]
+    context_teacher_feature = task_dict["support_set_feature_teacher"][0]
+    target_teacher_feature = task_dict["target_set_feature_teacher"][0]
+    real_target_labels = task_dict.get("real_target_labels", [None])[0]
+    batch_class_list = task_dict.get("batch_class_list", [None])[0]
+    if images_to_device:
+        context_images = context_images.to(device)
+        target_images = target_images.to(device)
+        context_teacher_feature = context_teacher_feature.to(device)
+        target_teacher_feature = target_teacher_feature.to(device)
+    context_labels = context_labels.to(device)
+    target_labels = target_labels.long().to(device)
+    return (context_images, target_images, context_teacher_feature, target_teacher_feature, context_labels,
+            target_labels, real_target_labels, batch_class_list)
+
+
+def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
+    """trainwandb.py:190-287 for the logits-based distillers."""
+    (context_images, target_images, context_teacher_feature, target_teacher_feature, context_labels,
+     target_labels, _, _) = prepare_task(task_dict, config.device)
+    model_dict = student(context_images, context_labels, target_images)
+    teacher_model_dict = teacher(context_teacher_feature, context_labels, target_teacher_feature)
+    target_logits = model_dict["logits"]
+    teacher_logits = teacher_model_dict["logits"]
+    loss = getattr(distiller, config.distill_name)(target_logits, teacher_logits, target_labels)
+    task_loss = loss["loss"]
+    if isinstance(target_logits, dict) and "kl" in target_logits and "ce" in target_logits:
+        task_accuracy, _ = ops.accuracy(target_logits["kl"], target_logits["ce"], target_labels)     # :247-257,278
+    elif isinstance(target_logits, dict):
+        task_accuracy = accuracy_fn(target_logits["kl"], target_labels)
+    else:
+        task_accuracy = accuracy_fn(target_logits, target_labels)
+    task_loss.backward(retain_graph=False)
+    return task_loss.detach(), task_accuracy, {"accuracy": task_accuracy}
+
+
+def train(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log=None):
+    """trainwandb.py:111-188.  Returns (losses, accuracies) as python floats."""
+    losses, accuracies = [], []
+    total_iterations = config.training_iterations
+    every = max(1, config.tasks_per_batch // world_size())
+    iteration = 0
+    for task_dict in video_loader:
+        if iteration >= total_iterations:
+            break
+        iteration += 1
+        torch.set_grad_enabled(True)
+        task_loss, task_accuracy, _ = train_task(task_dict, student, teacher, distiller, accuracy_fn, config)
+        losses.append(task_loss)
+        accuracies.append(task_accuracy)
+        if ((iteration + 1) % every == 0) or (iteration == (total_iterations - 1)):
+            optimizer.step()
+            optimizer.zero_grad()
+        scheduler.step()
+        if log is not None and (iteration + 1) % config.print_freq == 0:
+            log(iteration, float(torch.stack(losses[-config.print_freq:]).mean()),
+                float(torch.stack(accuracies[-config.print_freq:]).mean()))
+    return [float(x) for x in losses], [float(x) for x in accuracies]
+
+
+def test_task(task_dict, model, accuracy_fn, config):
+    """trainwandb.py:289-357 (student branch)."""
+    (context_images, target_images, _, _, context_labels, target_labels, _, _) = prepare_task(task_dict, config.device)
+    logits = model(context_images, context_labels, target_images)["logits"]
+    if isinstance(logits, dict) and "kl" in logits and "ce" in logits:
+        acc, _ = ops.accuracy(logits["kl"], logits["ce"], target_labels)
+    elif isinstance(logits, dict):
+        acc = accuracy_fn(logits["kl"], target_labels)
+    else:
+        acc = accuracy_fn(logits, target_labels)
+    return {"test_accuracy": acc}
+
+
+def test(model, video_loader, accuracy_fn, config):
+    """trainwandb.py:359-417: eval mode, no_grad, mean accuracy x100 and 95 % CI = 196*std/sqrt(n)."""
+    model.eval()
+    accuracies = []
+    with torch.no_grad():
+        if hasattr(video_loader, "dataset"):
+            video_loader.dataset.train = False
+        iteration = 0
+        for task_dict in video_loader:
+            if iteration >= config.num_test_tasks:
+                break
+            iteration += 1
+            accuracies.append(test_task(task_dict, model, accuracy_fn, config)["test_accuracy"].item())
+        if hasattr(video_loader, "dataset"):
+            video_loader.dataset.train = True
+    model.train()
+    accuracy = np.array(accuracies).mean() * 100.0
+    confidence = (196.0 * np.array(accuracies).std()) / np.sqrt(len(accuracies))
+    return {config.dataset: {"accuracy": accuracy, "confidence": confidence}}
+
+
+class SyntheticEpisodes:
+    """Stand-in for VideoDataset + DataLoader(batch_size=1) (video_reader.py:398-485): yields task_dicts with
+    the same keys/shapes/dtypes, frames ~ U[0,1), teacher features ~ N(0,1), shuffled float labels.
+    Episode e of rank r uses seed base + r*10**6 + e."""
+
+    def __init__(self, config, base_seed=0, rank=0, device="cpu", length=10 ** 9, train=True):
+        self.c, self.base, self.rank, self.device, self.length = config, base_seed, rank, device, length
+        self.train = train
+        self.dataset = self
+
+    def episode(self, e):
+        c = self.c
+        g = torch.Generator(device="cpu").manual_seed(self.base + self.rank * 10 ** 6 + e)
+        q = c.query_per_class if self.train else c.query_per_class_test
+        ns, nq, L, S = c.way * c.shot, c.way * q, c.seq_len, c.img_size
+        sl = torch.arange(c.way).repeat_interleave(c.shot)[torch.randperm(ns, generator=g)].float()
+        tl = torch.arange(c.way).repeat_interleave(q)[torch.randperm(nq, generator=g)].float()
+        if str(self.device) != "cpu":
+            gd = torch.Generator(device=self.device).manual_seed(self.base + self.rank * 10 ** 6 + e)
+            rnd = lambda *s: torch.rand(*s, generator=gd, device=self.device)          # noqa: E731
+            nrm = lambda *s: torch.randn(*s, generator=gd, device=self.device)         # noqa: E731
+        else:
+            rnd = lambda *s: torch.rand(*s, generator=g)                               # noqa: E731
+            nrm = lambda *s: torch.randn(*s, generator=g)                              # noqa: E731
+        d = {"support_set": rnd(ns * L, 3, S, S), "target_set": rnd(nq * L, 3, S, S),
+             "support_set_feature_teacher": nrm(ns, L, 2048), "target_set_feature_teacher": nrm(nq, L, 2048),
+             "support_labels": sl, "target_labels": tl, "real_target_labels": tl.clone(),
+             "batch_class_list": torch.arange(c.way).float()}
+        return {k: v.unsqueeze(0) for k, v in d.items()}
+
+    def __iter__(self):
+        for e in range(self.length):
+            yield self.episode(e)

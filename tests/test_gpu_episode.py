@@ -1,0 +1,119 @@
+"""GPU: whole-episode parity (student + teacher + D2M loss + backward) against the CPU oracle on the same
+seeded episode and weights; loop semantics on the real modules; size-independent properties at the
+benchmark size."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("shot,query,img,clf,dist", [(1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist"),
+                                                     (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist")])
+def test_episode_matches_oracle(dev, shot, query, img, clf, dist):
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd import ops
+    from oracle import ref_cpu as O
+    args = default_args(shot=shot, query_per_class=query, img_size=img, trans_dropout=0.0, device=dev, model_classifier=clf)
+    torch.manual_seed(1)
+    student, teacher = Student(args).to(dev), Teacher(args).to(dev)
+    ep = O.make_episode(900 + shot, 5, shot, query, img=img)
+    sp = {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
+    tp = {k[len("classifier.transformers."):]: v.detach().cpu().clone() for k, v in teacher.state_dict().items()
+          if k.startswith("classifier.transformers.")}
+    labels = ep["target_labels"].long()
+    out = student(ep["support_set"].to(dev), ep["support_labels"].to(dev), ep["target_set"].to(dev))
+    tl = teacher(ep["support_set_feature_teacher"].to(dev), ep["support_labels"].to(dev), ep["target_set_feature_teacher"].to(dev))["logits"]
+    loss = getattr(Distiller(dist, args.cfg, dev), dist)(out["logits"], tl, labels.to(dev))["loss"]
+    loss.backward()
+    acc, pred = ops.accuracy(out["logits"]["kl"], out["logits"]["ce"], labels.to(dev))
+    for v in sp.values():
+        if v.is_floating_point():
+            v.requires_grad_()
+    o = O.student_forward(ep, sp, 5, shot, classifier=clf)
+    ot = O.clf_TRX_2fcsup_fixed(ep["support_set_feature_teacher"], ep["support_labels"], ep["target_set_feature_teacher"], tp, 5, shot)
+    ol = O.distill_fc_2_sup_dist(o["logits"], ot, labels)["loss"]
+    ol.backward()
+    # features: rel 2e-3 of max; logits O(1e2..1e3): abs 2e-2 + rel 2e-3; loss rel 1e-3 (fp32, different summation order)
+    for k in ("context_features_1", "context_features_2"):
+        assert _rel(out["context_features"][k], o["context_features"][k]) < 2e-3, k
+    for k in ("kl", "ce", "sup"):
+        a, b = out["logits"][k].detach().cpu(), o["logits"][k].detach()
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-2), (k, float((a - b).abs().max()))
+        assert torch.allclose(tl[k].cpu(), ot[k], rtol=1e-4, atol=2e-2) if k != "ce" else True
+    assert abs(loss.item() - ol.item()) < 1e-3 * max(1.0, abs(ol.item()))
+    # argmax bit-exact wherever the oracle's top-2 margin exceeds the logit tolerance
+    lg = o["logits"]["kl"].detach() + o["logits"]["ce"].detach()
+    srt = torch.sort(lg, -1).values
+    clear = (srt[:, -1] - srt[:, -2]) > 5e-2
+    assert torch.equal(pred.cpu()[clear], torch.argmax(lg, -1)[clear])
+    # gradients of every parameter: max error relative to the tensor's max |grad| < 3e-2
+    worst = ("", 0.0)
+    for k, p in student.named_parameters():
+        ref = sp[k].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        e = _rel(p.grad, ref)
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 3e-2, worst
+    print("worst grad:", worst, "loss", loss.item(), ol.item())
+
+
+def test_train_loop_runs_and_steps(dev):
+    """real modules through trainloop.train: SGD step every (iteration+1)%tasks_per_batch, weights change only then"""
+    from litemkd_amd import trainloop as TL
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd.utils import aggregate_accuracy
+    cfg = default_args(shot=1, query_per_class=1, img_size=64, device=dev, training_iterations=5, tasks_per_batch=3,
+                       learning_rate=1e-2, print_freq=100)
+    torch.manual_seed(2)
+    student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
+    opt = TL.FusedOptimizer(student, "sgd", cfg.learning_rate)
+    sch = TL.MultiStepLR(opt, cfg.sch)
+    w0 = opt.bucket.flat.clone()
+    src = TL.SyntheticEpisodes(cfg, base_seed=5, device=dev)
+    losses, accs = TL.train(student, teacher, src, Distiller(cfg.distill_name, cfg.cfg, dev), opt, sch, aggregate_accuracy, cfg)
+    assert len(losses) == 5 and all(l == l for l in losses)          # finite
+    assert opt.steps == 3                                            # iterations 2 and 5 ((it+1)%3==0) and 4 (= total-1)
+    assert float((opt.bucket.flat - w0).abs().max()) > 0
+    assert float(opt.bucket.grad.abs().max()) == 0.0 or opt.steps >= 2
+    # eval path: running statistics, no grad
+    acc = TL.test(student, TL.SyntheticEpisodes(cfg, base_seed=9, device=dev, train=False), aggregate_accuracy,
+                  default_args(**{**vars(cfg), "num_test_tasks": 2}))
+    assert 0.0 <= acc[cfg.dataset]["accuracy"] <= 100.0
+
+
+def test_full_size_properties(dev):
+    """BASELINE size (5-way 5-shot, 8x224^2): properties that need no oracle —
+    BN batch independence of the two trunk calls, permutation equivariance over frames, determinism."""
+    from litemkd_amd.model.backbone.resnet import ResNet18Trunk
+    from litemkd_amd import ops
+    torch.manual_seed(3)
+    trunk = ResNet18Trunk().to(dev).train()
+    x = torch.rand(200, 3, 224, 224, device=dev)
+    with torch.no_grad():
+        f1 = ops.PoolHeadFn.apply(trunk(x))
+        f2 = ops.PoolHeadFn.apply(trunk(x))
+        perm = torch.randperm(200, device=dev)
+        f3 = ops.PoolHeadFn.apply(trunk(x[perm].contiguous()))
+    assert torch.equal(f1, f2)                                        # deterministic (no float atomics)
+    # batch statistics are permutation invariant up to fp32 summation order
+    assert float((f3 - f1[perm]).abs().max()) < 1e-3 * float(f1.abs().max())
+    assert torch.isfinite(f1).all()

@@ -1,0 +1,358 @@
+"""GPU parity tests of every HIP op against the CPU oracle (torch CPU fp32 / oracle.ref_cpu).
+All calls go through the C ABI (lite-mkd_amd/_lib.py -> liblmkd_hip.so).  Tolerances are fp32:
+different summation order vs the CPU library, stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import litemkd_amd
+    litemkd_amd.lib().call("lmkd_device_check", 0)
+    return torch.device("cuda", 0)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, rtol, atol, msg=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bad.any(), "%s: %d/%d elements differ, max abs err %.3e (ref max %.3e)" % (
+        msg, int(bad.sum()), bad.numel(), float(err.max()), float(b.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layA,layB", [("K", "K"), ("K", "N"), ("M", "K"), ("M", "N")])
+@pytest.mark.parametrize("M,N,K", [(400, 4608, 2048), (700, 700, 1152), (28, 36, 140), (132, 260, 64)])
+def test_gemm(dev, layA, layB, M, N, K):
+    from litemkd_amd import ops
+    A = rnd(M, K, seed=1)
+    B = rnd(K, N, seed=2)
+    bias = rnd(N, seed=3)
+    ref = 0.5 * (A.double() @ B.double()).float() + bias
+    Ad = (A if layA == "K" else A.t()).contiguous().to(dev)
+    Bd = (B.t() if layB == "K" else B).contiguous().to(dev)
+    C = torch.empty(M, N, device=dev)
+    ops.gemm(layA, layB, M, N, K, Ad, Ad.shape[1], Bd, Bd.shape[1], C, N, alpha=0.5, bias=bias.to(dev))
+    close(C, ref, 1e-4, 1e-4 * math.sqrt(K), "gemm %s%s" % (layA, layB))
+
+
+def test_gemm_batched_beta_relu(dev):
+    from litemkd_amd import ops
+    A = rnd(3, 64, 96, seed=4)
+    B = rnd(3, 80, 96, seed=5)
+    C0 = rnd(3, 64, 80, seed=6)
+    ref = torch.relu(torch.einsum("bmk,bnk->bmn", A, B) + 2.0 * C0)
+    C = C0.clone().to(dev)
+    ops.gemm("K", "K", 64, 80, 96, A.to(dev), 96, B.to(dev), 96, C, 80, beta=2.0, relu=True, batch=3,
+             sA=64 * 96, sB=80 * 96, sC=64 * 80)
+    close(C, ref, 1e-4, 1e-3, "batched gemm")
+
+
+def test_gemm_rejects_bad_alignment(dev):
+    from litemkd_amd import ops
+    A = torch.zeros(8, 6, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.gemm("K", "K", 8, 8, 6, A, 6, A, 6, torch.zeros(8, 8, device=dev), 8)
+
+
+# ------------------------------------------------------------------------------------------
+CONVS = [  # N, Cin, H, W, Cout, K, stride, pad
+    (3, 3, 64, 64, 64, 7, 2, 3),       # stem (NHWC4 path)
+    (2, 64, 28, 28, 64, 3, 1, 1),      # layer1
+    (2, 64, 28, 28, 128, 3, 2, 1),     # layerN.0.conv1
+    (2, 128, 14, 14, 128, 3, 1, 1),
+    (2, 64, 28, 28, 128, 1, 2, 0),     # downsample
+    (5, 256, 7, 7, 512, 3, 1, 1),      # ragged row tile (M = 245)
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_fwd_bwd(dev, cfg):
+    from litemkd_amd import ops
+    N, Cin, H, W, Cout, K, s, p = cfg
+    x = rnd(N, Cin, H, W, seed=10).requires_grad_()
+    w = (rnd(Cout, Cin, K, K, seed=11) * math.sqrt(2.0 / (Cout * K * K))).requires_grad_()
+    y = F.conv2d(x, w, None, s, p)
+    gy = rnd(*y.shape, seed=12)
+    y.backward(gy)
+    Cs = 4 if Cin == 3 else Cin
+    xd = torch.zeros(N, H, W, Cs)
+    xd[..., :Cin] = nhwc(x.detach())
+    xd, wdv = xd.to(dev), w.detach().to(dev)
+    wp = ops.pack_weights(wdv, Cs, 0)
+    yd, part = ops.conv_fwd(xd, wp, Cout, K, K, s, p, True)
+    tol = 2e-5 * math.sqrt(Cin * K * K)
+    close(nchw(yd), y, 1e-4, tol, "conv fwd")
+    # fused BN statistics: per-channel sum and sum of squares
+    sums = part.double().sum(0).cpu()
+    close(sums[:, 0], y.detach().double().sum((0, 2, 3)), 1e-4, 1e-2, "bn sum")
+    close(sums[:, 1], (y.detach().double() ** 2).sum((0, 2, 3)), 1e-4, 1e-2, "bn sumsq")
+    gyd = nhwc(gy).to(dev)
+    dw = ops.conv_bwd_weight(xd, gyd, tuple(w.shape), s, p)
+    close(dw, w.grad, 1e-3, 2e-5 * math.sqrt(N * y.shape[2] * y.shape[3]) * 3, "conv wgrad")
+    if Cin != 3:
+        wd = ops.pack_weights(wdv, Cin, 1)
+        dx = ops.conv_bwd_data(gyd, wd, (N, H, W, Cin), Cout, K, K, s, p)
+        close(nchw(dx), x.grad, 1e-4, 2e-5 * math.sqrt(Cout * K * K), "conv dgrad")
+
+
+def test_bn_train_apply_backward(dev):
+    from litemkd_amd import ops
+    N, C, H, W = 4, 64, 14, 14
+    x = (rnd(N, C, H, W, seed=20) * 2 + 0.5).requires_grad_()
+    res = rnd(N, C, H, W, seed=21).requires_grad_()
+    gamma = (1 + 0.1 * rnd(C, seed=22)).requires_grad_()
+    beta = (0.1 * rnd(C, seed=23)).requires_grad_()
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.relu(F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5) + res)
+    gy = rnd(N, C, H, W, seed=24)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(dev)
+    # statistics from the (sum, sumsq) partial layout the conv epilogue produces
+    flat = xd.reshape(-1, C)
+    T = 7
+    chunks = flat.reshape(T, -1, C)
+    part = torch.stack([chunks.sum(1), (chunks ** 2).sum(1)], -1).contiguous()
+    rmd, rvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    st = ops.bn_stats_train(part, flat.shape[0], gamma.detach().to(dev), beta.detach().to(dev), rmd, rvd)
+    close(rmd, rm, 1e-4, 1e-5, "running_mean")
+    close(rvd, rv, 1e-4, 1e-5, "running_var")
+    yd = ops.bn_apply(xd, st, True, nhwc(res.detach()).to(dev))
+    close(nchw(yd), y, 1e-4, 1e-4, "bn apply")
+    dx, g, dg, db = ops.bn_backward(nhwc(gy).to(dev), xd, yd, st, gamma.detach().to(dev), 1, want_g=True)
+    close(nchw(dx), x.grad, 1e-3, 2e-5, "bn dx")
+    close(nchw(g), res.grad, 1e-5, 1e-6, "residual grad")
+    close(dg, gamma.grad, 1e-3, 1e-3, "dgamma")
+    close(db, beta.grad, 1e-3, 1e-3, "dbeta")
+
+
+def _trunk_params(seed):
+    from oracle import ref_cpu as O
+    g = torch.Generator().manual_seed(seed)
+    sd = O.init_resnet18_trunk(g)
+    # non-trivial BN affine so gamma/beta paths are exercised
+    for k in list(sd):
+        if k.endswith(".weight") and sd[k].dim() == 1:
+            sd[k] = 1 + 0.1 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith(".bias"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+    return sd
+
+
+def test_trunk_forward_backward(dev):
+    """whole ResNet-18 trunk (stem + 8 BasicBlocks + pooled head) fwd + bwd vs the oracle, 6 frames 64x64"""
+    from litemkd_amd import ops
+    from litemkd_amd.model.backbone.resnet import ResNet18Trunk
+    from oracle import ref_cpu as O
+    sd = _trunk_params(5)
+    trunk = ResNet18Trunk()
+    trunk.load_state_dict(sd)
+    trunk = trunk.to(dev).train()
+    x = torch.rand(6, 3, 64, 64, generator=torch.Generator().manual_seed(6))
+    osd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    taps = {}
+    fm = O.resnet18_trunk(x, osd, True, True, taps)
+    feat = O.pooled_frame_features(fm)
+    gfeat = rnd(*feat.shape, seed=7)
+    feat.backward(gfeat)
+    y = trunk(x.to(dev))
+    close(nchw(y), fm, 2e-3, 2e-3, "trunk feature map")
+    f = ops.PoolHeadFn.apply(y)
+    close(f, feat, 2e-3, 2e-3, "pooled features")
+    f.backward(gfeat.to(dev))
+    close(trunk.state_dict()["1.running_var"], osd["1.running_var"], 1e-3, 1e-4, "stem running_var")
+    close(trunk.state_dict()["7.1.bn2.running_mean"], osd["7.1.bn2.running_mean"], 1e-3, 1e-4, "last running_mean")
+    named = dict(trunk.named_parameters())
+    worst = 0.0
+    for k, p in named.items():
+        ref = osd[k].grad
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((p.grad.cpu() - ref).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 2e-2, "grad %s: rel-to-max err %.3e" % (k, err)
+    print("trunk worst grad err (rel to max):", worst)
+
+
+def test_pool_head(dev):
+    from litemkd_amd import ops
+    x = rnd(5, 512, 7, 7, seed=30).requires_grad_()
+    from oracle import ref_cpu as O
+    y = O.pooled_frame_features(x)
+    gy = rnd(*y.shape, seed=31)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(dev).requires_grad_()
+    yd = ops.PoolHeadFn.apply(xd)
+    close(yd, y, 1e-6, 1e-6, "adaptive max+mean")
+    yd.backward(gy.to(dev))
+    close(nchw(xd.grad), x.grad, 1e-6, 1e-7, "adaptive max+mean bwd")
+
+
+def test_linear(dev):
+    from litemkd_amd import ops
+    x = rnd(200, 512, seed=40).requires_grad_()
+    w = (rnd(2048, 512, seed=41) * 0.05).requires_grad_()
+    b = rnd(2048, seed=42).requires_grad_()
+    y = F.linear(x, w, b)
+    gy = rnd(200, 2048, seed=43)
+    y.backward(gy)
+    xd, wd, bd = (t.detach().to(dev).requires_grad_() for t in (x, w, b))
+    yd = ops.LinearFn.apply(xd, wd, bd)
+    yd.backward(gy.to(dev))
+    close(yd, y, 1e-4, 1e-4, "linear")
+    close(xd.grad, x.grad, 1e-4, 1e-4, "linear dx")
+    close(wd.grad, w.grad, 1e-4, 1e-3, "linear dw")
+    close(bd.grad, b.grad, 1e-4, 1e-3, "linear db")
+
+
+# ------------------------------------------------------------------------------------------
+def _args(dev, **kw):
+    from litemkd_amd.options import default_args
+    return default_args(device=dev, trans_dropout=0.0, **kw)
+
+
+def _gsum(g):
+    return g.reshape(g.shape[0], 8, 32, 64).sum(-1)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_trx_golden(dev, golden_dir, case):
+    """TRX_2fcsup / TRX_2fcsup_fixed vs the fixtures produced by the reference's own module."""
+    import os
+    from litemkd_amd.model import classifiers as C
+    from oracle.gen_golden import trx_case_inputs
+    G = np.load(os.path.join(golden_dir, "trx.npz"))
+    pre = "c%d_" % case
+    ns, nq = int(G[pre + "ns"]), int(G[pre + "nq"])
+    p, sup1, qry1, sup2, qry2, lab = trx_case_inputs(int(G[pre + "seed"]), ns, nq, bool(G[pre + "shuffle"]))
+    args = _args(dev, shot=ns // 5)
+    clf = C.TRX_2fcsup(args)
+    sd = clf.state_dict()
+    for k, v in p.items():
+        sd["transformers." + k].copy_(v)
+    clf = clf.to(dev)
+    t = [x.to(dev).requires_grad_() for x in (sup1, qry1, sup2, qry2)]
+    r = clf({"context_features_1": t[0], "context_features_2": t[2]}, lab.to(dev),
+            {"target_features_1": t[1], "target_features_2": t[3]})["logits"]
+    for k in ("kl", "ce", "sup"):
+        close(r[k], torch.from_numpy(G[pre + k]), 1e-4, 2e-2, "trx " + k)
+    w = torch.linspace(-1, 1, nq * 5).reshape(nq, 5).to(dev)
+    w_sup = torch.linspace(1, -1, 20).reshape(5, 4).to(dev)
+    ((r["kl"] * w).sum() * 1e-2 + (r["ce"] * w.flip(0)).sum() * 1e-2 + (r["sup"] * w_sup).sum() * 1e-3).backward()
+    for name, x in zip(("g_sup1", "g_qry1", "g_sup2", "g_qry2"), t):
+        ref = torch.from_numpy(G[pre + name])
+        close(_gsum(x.grad), ref, 2e-3, 2e-3 * float(ref.abs().max()), name)
+    close(t[0].grad[0, :, :128], torch.from_numpy(G[pre + "g_sup1_row0"]), 2e-3, 1e-5, "g_sup1 row0")
+    tr = clf.transformers
+    for name, gt in (("g_kb", tr.k_linear.bias.grad), ("g_vb", tr.v_linear.bias.grad), ("g_nkw", tr.norm_k.weight.grad),
+                     ("g_nkb", tr.norm_k.bias.grad), ("g_kw_sum", tr.k_linear.weight.grad.sum(1)),
+                     ("g_vw_sum", tr.v_linear.weight.grad.sum(1))):
+        ref = torch.from_numpy(G[pre + name])
+        close(gt, ref, 5e-3, 5e-3 * float(ref.abs().max()), name)
+    fx = C.TRX_2fcsup_fixed(args)
+    fsd = fx.state_dict()
+    for k, v in p.items():
+        fsd["transformers." + k].copy_(v)
+    fx = fx.to(dev)
+    rf = fx(sup1.to(dev), lab.to(dev), qry1.to(dev))["logits"]
+    close(rf["kl"], torch.from_numpy(G[pre + "fixed_kl"]), 1e-4, 2e-2, "fixed kl")
+    close(rf["sup"], torch.from_numpy(G[pre + "fixed_sup"]), 1e-4, 2e-2, "fixed sup")
+
+
+def test_trx_ragged_classes(dev):
+    """unequal shots per class + a missing class (column stays 0, like torch.zeros in the reference)"""
+    from litemkd_amd import ops
+    from oracle import ref_cpu as O
+    g = torch.Generator().manual_seed(77)
+    p = O.make_trx_params(g)
+    lab = torch.tensor([0., 0., 0., 2., 2., 3., 3., 3., 3., 4.])
+    sup = torch.randn(10, 8, 2048, generator=g) * 0.5
+    qry = torch.randn(6, 8, 2048, generator=g) * 0.5
+    ref = O.trx_logits(sup, lab, qry, p, way=5)
+    plan = ops.ClassPlan(lab.to(dev), 5)
+    pd = {k: v.to(dev) for k, v in p.items()}
+    out = ops.trx_logits_nograd(sup.to(dev), qry.to(dev), plan, pd["k_linear.weight"], pd["k_linear.bias"], pd["v_linear.weight"],
+                                pd["v_linear.bias"], pd["norm_k.weight"], pd["norm_k.bias"], pd["pe.pe"][0, :8].contiguous())
+    close(out, ref, 1e-4, 2e-2, "ragged trx")
+    assert float(out[:, 1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_edist_golden(dev, golden_dir, case):
+    import os
+    from litemkd_amd.model import classifiers as C
+    from oracle.gen_golden import feature_case
+    G = np.load(os.path.join(golden_dir, "edist.npz"))
+    pre = "c%d_" % case
+    ns, nq = int(G[pre + "ns"]), int(G[pre + "nq"])
+    sup, lab, qry = feature_case(int(G[pre + "seed"]), ns, nq, 1.0, bool(G[pre + "shuffle"]))
+    args = _args(dev, shot=ns // 5)
+    clf = C.e_dist_1fc_sup(args)
+    s, q = sup.to(dev).requires_grad_(), qry.to(dev).requires_grad_()
+    r = clf(s, lab.to(dev), q)["logits"]
+    close(r["kl"], torch.from_numpy(G[pre + "kl"]), 1e-5, 1e-4, "edist kl")
+    close(r["sup"], torch.from_numpy(G[pre + "sup"]), 1e-5, 1e-2, "supportdk")
+    w_kl = torch.linspace(-1, 1, nq * 5).reshape(nq, 5).to(dev)
+    w_sup = torch.linspace(1, -1, 20).reshape(5, 4).to(dev)
+    ((r["kl"] * w_kl).sum() + (r["sup"] * w_sup).sum() * 1e-3).backward()
+    close(_gsum(s.grad), torch.from_numpy(G[pre + "g_sup_feat"]), 1e-3, 1e-4, "edist dsup")
+    close(_gsum(q.grad), torch.from_numpy(G[pre + "g_qry_feat"]), 1e-3, 1e-4, "edist dqry")
+    close(s.grad[0, :, :128], torch.from_numpy(G[pre + "g_sup_row0"]), 1e-3, 1e-6, "edist dsup row0")
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_distill_golden(dev, golden_dir, case):
+    import os
+    from litemkd_amd import distillers as D
+    from litemkd_amd import ops
+    from litemkd_amd.options import DEFAULT_CFG
+    G = np.load(os.path.join(golden_dir, "distill.npz"))
+    pre = "c%d_" % case
+    T = lambda k: torch.from_numpy(G[pre + k]).to(dev)          # noqa: E731
+    s = {k: T("s_" + k).clone().requires_grad_() for k in ("kl", "ce", "sup")}
+    t = {k: T("t_" + k) for k in ("kl", "sup")}
+    labels = T("labels")
+    dist = D.Distiller("fc_2_sup_dist", dict(DEFAULT_CFG), dev)
+    r = dist.fc_2_sup_dist(s, t, labels)
+    r["loss"].backward()
+    close(r["loss"], T("loss"), 1e-5, 1e-5, "loss")
+    close(r["soft_loss"], T("soft"), 1e-5, 1e-5, "soft")
+    close(r["hard_loss"], T("hard"), 1e-5, 1e-5, "hard")
+    for k in ("kl", "ce", "sup"):
+        close(s[k].grad, T("g_" + k), 1e-4, 1e-7, "grad " + k)
+    close(D.kd_loss(s["kl"].detach(), t["kl"], 4), T("kd"), 1e-5, 1e-5, "kd_loss")
+    close(D.inter_class_relation(s["sup"].detach(), t["sup"]), T("icr"), 1e-5, 1e-5, "icr")
+    s1 = T("s_kl").clone().requires_grad_()
+    r = dist.KD(s1, t["kl"], labels)
+    r["loss"].backward()
+    close(r["loss"], T("KD_loss"), 1e-5, 1e-5, "KD")
+    close(s1.grad, T("KD_g"), 1e-4, 1e-7, "KD grad")
+    s2 = T("s_kl").clone().requires_grad_()
+    r = dist.Dist_KD(s2, t["kl"], labels)
+    r["loss"].backward()
+    close(r["loss"], T("DistKD_loss"), 1e-5, 1e-5, "Dist_KD")
+    close(s2.grad, T("DistKD_g"), 1e-4, 1e-7, "Dist_KD grad")
+    acc, pred = ops.accuracy(s["kl"].detach(), s["ce"].detach(), labels)
+    assert np.array_equal(pred.cpu().numpy(), G[pre + "argmax"])            # bit-exact class indices
+    assert float(acc) == float(G[pre + "acc"])
