@@ -1,0 +1,149 @@
+#!/usr/bin/env python
+"""Benchmark of the Lite-MKD hot path on MI355X: episodes/sec, 5-way 5-shot, 8 x 224^2 frames, fp32
+(BASELINE.json configs[1]).  One "step" = one training episode exactly as trainwandb.py:190-287 runs it:
+student forward over 400 frames (two 200-frame BatchNorm batches), frozen TRX teacher head on the teacher
+features, D2M loss fc_2_sup_dist, backward; plus the SGD step (and, for N>1, one RCCL all-reduce of the flat
+gradient bucket) every tasks_per_batch/N episodes, as in trainwandb.py:141-143.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line (rank 0) with `roofline` (conv MFMA kernel, HIP-event timed inside the timed region)
+and `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+FWD_GFLOP_PER_FRAME = 3.627            # SURVEY.md 8d (ResNet-18 trunk, 224x224)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--shot", type=int, default=5)
+    ap.add_argument("--pool", type=int, default=2, help="distinct resident synthetic episodes to cycle through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.1, help="TRX dropout (reference default 0.1, active in train mode)")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    import litemkd_amd  # noqa: F401
+    from litemkd_amd import ops, trainloop as TL
+    from litemkd_amd.parallel import init_distributed
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd.utils import aggregate_accuracy
+
+    rank, world, dev = init_distributed()
+    assert dev.type == "cuda", "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
+    litemkd_amd.lib().call("lmkd_device_check", dev.index)
+    cfg = default_args(shot=a.shot, device=dev, trans_dropout=a.dropout, training_iterations=10 ** 9, print_freq=10 ** 9)
+    torch.manual_seed(1234)                                  # identical initial weights on every rank
+    student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
+    opt = TL.FusedOptimizer(student, cfg.opt, cfg.learning_rate)
+    opt.bucket.broadcast_params(0)
+    sch = TL.MultiStepLR(opt, cfg.sch)
+    distiller = Distiller(cfg.distill_name, cfg.cfg, dev)
+    src = TL.SyntheticEpisodes(cfg, base_seed=2024, rank=rank, device=dev)
+    pool = [src.episode(e) for e in range(a.pool)]           # resident in HBM before the timed region
+    every = max(1, cfg.tasks_per_batch // world)
+
+    def run(n, it0):
+        it = it0
+        for i in range(n):
+            it += 1
+            TL.train_task(pool[i % len(pool)], student, teacher, distiller, aggregate_accuracy, cfg)
+            if (it + 1) % every == 0:
+                opt.step()
+                opt.zero_grad()
+            sch.step()
+        return it
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = run(a.warmup, 0)
+    fence()
+    ops.CONV_TIMING = []
+    t0 = time.perf_counter()
+    it = run(a.steps, it)
+    fence()
+    dt = time.perf_counter() - t0
+    timing, ops.CONV_TIMING = ops.CONV_TIMING, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # roofline of the dominant kernel family (implicit-GEMM conv fwd + dgrad, one template): algorithmic FLOPs / HIP-event time
+    fam = {}
+    for name, flops, e0, e1 in timing:
+        f = fam.setdefault(name, [0.0, 0.0, 0])
+        f[0] += flops
+        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[2] += 1
+    cg = fam.get("conv_gemm_kernel", [0.0, 1.0, 1])
+    wg = fam.get("conv_wgrad_kernel", [0.0, 1.0, 1])
+    achieved = cg[0] / cg[1] / 1e12
+    frames = 8 * 5 * (a.shot + cfg.query_per_class)
+    step_tflop = 3 * FWD_GFLOP_PER_FRAME * frames / 1e3
+    out = {
+        "metric": "episodes/sec (5-way %d-shot, 8x224^2 frames)" % a.shot, "value": world * a.steps / dt, "unit": "episodes/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "HMDB-shape 5-way %d-shot ResNet-18 + TRX_2fcsup + D2M fc_2_sup_dist training episode, fp32" % a.shot,
+                   "frames_per_episode": frames, "img": 224, "tasks_per_batch": cfg.tasks_per_batch, "optimizer": cfg.opt,
+                   "episodes_per_optimizer_step_per_rank": every, "parallelism": "episode-parallel dp%d" % world,
+                   "trans_dropout": a.dropout},
+        "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad, v_mfma_f32_32x32x2_f32)",
+                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                     "traffic": None, "launches": cg[2], "avg_launch_ms": cg[1] / max(cg[2], 1) * 1e3,
+                     "wgrad_kernel_tflops": wg[0] / wg[1] / 1e12, "wgrad_avg_launch_ms": wg[1] / max(wg[2], 1) * 1e3,
+                     "conv_time_frac_of_step": (cg[1] + wg[1]) / dt,
+                     "episode_model_tflops": step_tflop * world * a.steps / dt},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.shot)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(shot):
+    """The CPU oracle (oracle/ref_cpu.py: torch-CPU fp32 restatement of the same episode) on this box's host cores.
+    Bounded sample: ONE full training episode of the same workload (no warm-up), all cores."""
+    from oracle import ref_cpu as O
+    n = os.cpu_count() or 1
+    n = min(n, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else n
+    torch.set_num_threads(n)
+    ep = O.make_episode(7, 5, shot, 5)
+    params = O.make_student_params(11)
+    for k, v in params.items():
+        if v.is_floating_point() and "running" not in k and not k.endswith("pe.pe"):
+            v.requires_grad_()
+    tp = O.make_trx_params(torch.Generator().manual_seed(12))
+    t0 = time.perf_counter()
+    O.train_episode(ep, params, tp, 5, shot)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "episodes/s", "cores": n, "kind": "port",
+            "sample": "1 full 5-way %d-shot 224^2 training episode (fwd+loss+bwd), torch-CPU fp32 oracle, %.1f s" % (shot, dt)}
+
+
+if __name__ == "__main__":
+    main()

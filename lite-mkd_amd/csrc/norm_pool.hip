@@ -465,14 +465,14 @@ __global__ void adaptive_maxpool_mean_bwd_kernel(const float* __restrict__ x, co
 }
 
 extern "C" int lmkd_adaptive_maxpool_mean_fwd(const float* x, float* y, int F, int H, int W, int C, void* stream) {
-  LMKD_REQUIRE(x && y && F > 0 && H >= 4 && W >= 4 && C > 0, "lmkd_adaptive_maxpool_mean_fwd: bad arguments");
+  LMKD_REQUIRE(x && y && F > 0 && H >= 1 && W >= 1 && C > 0, "lmkd_adaptive_maxpool_mean_fwd: bad arguments");
   hipLaunchKernelGGL(adaptive_maxpool_mean_kernel, dim3(ew_grid((long)F * C)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, y, F, H, W, C);
   LMKD_CHECK_LAUNCH("adaptive_maxpool_mean_kernel");
   return LMKD_OK;
 }
 extern "C" int lmkd_adaptive_maxpool_mean_bwd(const float* x, const float* dy, float* dx, int F, int H, int W, int C, void* stream) {
-  LMKD_REQUIRE(x && dy && dx && F > 0 && H >= 4 && W >= 4 && H * W <= 64, "lmkd_adaptive_maxpool_mean_bwd: bad arguments (H*W must be <= 64)");
-  LMKD_REQUIRE(H <= 8 && W <= 8, "lmkd_adaptive_maxpool_mean_bwd: H, W must be <= 8 (at most 2 overlapping windows per axis)");
+  LMKD_REQUIRE(x && dy && dx && F > 0 && H * W <= 64, "lmkd_adaptive_maxpool_mean_bwd: bad arguments (H*W must be <= 64)");
+  LMKD_REQUIRE(H >= 2 && W >= 2 && H <= 8 && W <= 8, "lmkd_adaptive_maxpool_mean_bwd: H, W must be in [2,8] (at most 2 overlapping windows per axis)");
   hipLaunchKernelGGL(adaptive_maxpool_mean_bwd_kernel, dim3(ew_grid((long)F * C)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, dy, dx, F, H, W, C);
   LMKD_CHECK_LAUNCH("adaptive_maxpool_mean_bwd_kernel");
   return LMKD_OK;

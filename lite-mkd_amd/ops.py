@@ -126,6 +126,27 @@ def conv_out_size(H, K, s, p):
     return (H + 2 * p - K) // s + 1
 
 
+# Optional per-launch timing of the conv kernels with HIP events on the launch stream (bench.py roofline):
+# set ops.CONV_TIMING = [] to collect (kernel family, algorithmic FLOPs, start event, end event).
+CONV_TIMING = None
+
+
+class _timed:
+    def __init__(self, family, flops):
+        self.on = CONV_TIMING is not None
+        if self.on:
+            self.rec = (family, flops, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def __enter__(self):
+        if self.on:
+            self.rec[2].record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.rec[3].record()
+            CONV_TIMING.append(self.rec)
+
+
 def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats):
     """x NHWC [N,H,W,Cs] -> (y [N,Ho,Wo,Cout], stat partial [T,Cout,2] | None)"""
     _chk(x, wp)
@@ -136,7 +157,9 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats):
     if want_stats:
         T = lib().value("lmkd_conv2d_fwd_row_tiles", N, H, W, KH, KW, stride, pad)
         part = _empty((T, Cout, 2), x)
-    lib().call("lmkd_conv2d_fwd", _p(x), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, _stream())
+    cin = 3 if Cs == 4 else Cs
+    with _timed("conv_gemm_kernel", 2.0 * N * Ho * Wo * Cout * cin * KH * KW):
+        lib().call("lmkd_conv2d_fwd", _p(x), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, _stream())
     return y, part
 
 
@@ -144,7 +167,8 @@ def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None):
     N, H, W, Cin = x_shape
     _chk(dy, wd, out)
     dx = out if out is not None else _empty((N, H, W, Cin), dy)
-    lib().call("lmkd_conv2d_bwd_data", _p(dy), _p(wd), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, _stream())
+    with _timed("conv_gemm_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW):
+        lib().call("lmkd_conv2d_bwd_data", _p(dy), _p(wd), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, _stream())
     return dx
 
 
@@ -155,7 +179,8 @@ def conv_bwd_weight(x, dy, w_shape, stride, pad):
     nbytes = lib().value("lmkd_conv2d_bwd_weight_workspace", N, H, W, Cs, Cout, KH, KW, stride, pad)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     dw = _empty(w_shape, x)
-    lib().call("lmkd_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, _stream())
+    with _timed("conv_wgrad_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW):
+        lib().call("lmkd_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, _stream())
     return dw
 
 

@@ -40,8 +40,8 @@ def test_episode_matches_oracle(dev, shot, query, img, clf, dist):
     loss = getattr(Distiller(dist, args.cfg, dev), dist)(out["logits"], tl, labels.to(dev))["loss"]
     loss.backward()
     acc, pred = ops.accuracy(out["logits"]["kl"], out["logits"]["ce"], labels.to(dev))
-    for v in sp.values():
-        if v.is_floating_point():
+    for k, v in sp.items():
+        if v.is_floating_point() and "running" not in k and not k.endswith("pe.pe"):
             v.requires_grad_()
     o = O.student_forward(ep, sp, 5, shot, classifier=clf)
     ot = O.clf_TRX_2fcsup_fixed(ep["support_set_feature_teacher"], ep["support_labels"], ep["target_set_feature_teacher"], tp, 5, shot)
@@ -60,14 +60,17 @@ def test_episode_matches_oracle(dev, shot, query, img, clf, dist):
     srt = torch.sort(lg, -1).values
     clear = (srt[:, -1] - srt[:, -2]) > 5e-2
     assert torch.equal(pred.cpu()[clear], torch.argmax(lg, -1)[clear])
-    # gradients of every parameter: max error relative to the tensor's max |grad| < 3e-2
+    # gradients of every parameter: max abs error < 3e-2 * max|grad of that tensor| + 1e-5 * max|grad| over the model
+    # (the floor covers gradients that are exactly 0 in exact arithmetic, e.g. biases that cancel in q - s differences)
+    gmax = max(float(v.grad.abs().max()) for v in sp.values() if v.grad is not None)
     worst = ("", 0.0)
     for k, p in student.named_parameters():
         ref = sp[k].grad
         if ref is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
-        e = _rel(p.grad, ref)
+        err = float((p.grad.detach().cpu() - ref).abs().max())
+        e = err / (float(ref.abs().max()) + 3e-4 * gmax)
         if e > worst[1]:
             worst = (k, e)
     assert worst[1] < 3e-2, worst

@@ -269,7 +269,8 @@ def test_trx_golden(dev, golden_dir, case):
                      ("g_nkb", tr.norm_k.bias.grad), ("g_kw_sum", tr.k_linear.weight.grad.sum(1)),
                      ("g_vw_sum", tr.v_linear.weight.grad.sum(1))):
         ref = torch.from_numpy(G[pre + name])
-        close(gt, ref, 5e-3, 5e-3 * float(ref.abs().max()), name)
+        # (the v-bias gradient is exactly 0 in exact arithmetic: softmax rows sum to 1 — compare against an absolute floor)
+        close(gt, ref, 5e-3, 5e-3 * max(float(ref.abs().max()), 1e-4), name)
     fx = C.TRX_2fcsup_fixed(args)
     fsd = fx.state_dict()
     for k, v in p.items():
