@@ -184,15 +184,45 @@ def test_trunk_forward_backward(dev):
     f.backward(gfeat.to(dev))
     close(trunk.state_dict()["1.running_var"], osd["1.running_var"], 1e-3, 1e-4, "stem running_var")
     close(trunk.state_dict()["7.1.bn2.running_mean"], osd["7.1.bn2.running_mean"], 1e-3, 1e-4, "last running_mean")
-    named = dict(trunk.named_parameters())
+    # A whole-trunk gradient is only as reproducible as its ReLU masks: a pre-activation within fp32 rounding of 0
+    # flips (y = 0 on one side, 5e-6 on the other) and with few samples per channel one flip moves that channel's
+    # gradient by percents.  So: relative L2 per tensor here, tight elementwise bounds in test_block_isolated below.
     worst = 0.0
-    for k, p in named.items():
-        ref = osd[k].grad
-        scale = float(ref.abs().max()) + 1e-12
-        err = float((p.grad.cpu() - ref).abs().max()) / scale
+    for k, p in trunk.named_parameters():
+        ref = osd[k].grad.double()
+        err = float((p.grad.cpu().double() - ref).norm() / (ref.norm() + 1e-30))
         worst = max(worst, err)
-        assert err < 2e-2, "grad %s: rel-to-max err %.3e" % (k, err)
-    print("trunk worst grad err (rel to max):", worst)
+        assert err < 5e-2, "grad %s: rel-L2 err %.3e" % (k, err)
+    print("trunk worst grad rel-L2 err:", worst)
+
+
+@pytest.mark.parametrize("N,cin,cout,H,stride", [(6, 256, 512, 6, 2), (6, 512, 512, 3, 1), (6, 64, 128, 24, 2), (6, 64, 64, 24, 1)])
+def test_block_isolated(dev, N, cin, cout, H, stride):
+    """one BasicBlock (with / without downsample) fwd + bwd on identical inputs: elementwise fp32 agreement"""
+    from litemkd_amd.model.backbone import resnet as R
+    torch.manual_seed(0)
+    blk = R._Block(cin, cout, stride)
+    x = torch.relu(torch.randn(N, cin, H, H)).requires_grad_()
+    ref = {k: v.detach().clone().requires_grad_() for k, v in blk.named_parameters()}
+
+    def bn(t, pre):
+        return F.batch_norm(t, torch.zeros(cout), torch.ones(cout), ref[pre + ".weight"], ref[pre + ".bias"], True, 0.1, 1e-5)
+    out = F.relu(bn(F.conv2d(x, ref["conv1.weight"], None, stride, 1), "bn1"))
+    out = bn(F.conv2d(out, ref["conv2.weight"], None, 1, 1), "bn2")
+    idn = x
+    if blk.downsample is not None:
+        idn = bn(F.conv2d(x, ref["downsample.0.weight"], None, stride, 0), "downsample.1")
+    y = F.relu(out + idn)
+    gy = torch.randn(y.shape)
+    y.backward(gy)
+    blk = blk.to(dev).train()
+    xd = nhwc(x.detach()).to(dev).requires_grad_()
+    yd = blk(xd)
+    yd.backward(nhwc(gy).to(dev))
+    close(nchw(yd), y, 1e-4, 1e-4, "block y")
+    close(nchw(xd.grad), x.grad, 1e-3, 1e-4 * float(x.grad.abs().max()), "block dx")
+    for k, v in blk.named_parameters():
+        close(v.grad, ref[k].grad, 1e-3, 1e-4 * float(ref[k].grad.abs().max()), "block " + k)
 
 
 def test_pool_head(dev):
