@@ -36,7 +36,8 @@ int lmkd_gemm_f32(char layA, char layB, int M, int N, int K, float alpha, const 
 long lmkd_conv2d_packed_weight_elems(int Cout, int Cin, int Cs, int KH, int KW, int mode);
 int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout, int Cin, int Cs, int KH, int KW, int mode /*0 fwd, 1 dgrad*/,
                              void* stream);
-int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int KH, int KW, int stride, int pad);
+int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, int KW, int stride, int pad);
+int lmkd_conv_set_tile(int id); /* tuning: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 64x128 */
 /* stat_partial (nullable): [row_tiles][Cout][2] per-tile (sum, sum of squares) for train-mode BatchNorm */
 int lmkd_conv2d_fwd(const float* x, const float* wp_fwd, float* y, float* stat_partial, int N, int H, int W, int Cs, int Cout,
                     int KH, int KW, int stride, int pad, void* stream);
@@ -48,9 +49,11 @@ int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, floa
 
 /* ---- layout / BatchNorm / pooling (torchvision bn1/relu/maxpool/BasicBlock, resnet18_2fc.py:33,41-54) ---- */
 int lmkd_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int N, int H, int W, void* stream);
-/* stats: [4][C] = mean, invstd, scale, shift.  scratch: >= 65*2*C doubles */
+/* stats: [5][C] = mean, invstd, scale, shift, unbiased batch variance.  scratch: >= 65*2*C doubles.
+ * running_mean/var may be NULL (update deferred to lmkd_bn_running_update) */
 int lmkd_bn_finalize(const float* partial, int T, int C, long count, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float momentum, float eps, float* stats, double* scratch, void* stream);
+int lmkd_bn_running_update(float* running_mean, float* running_var, const float* stats, int C, float momentum, void* stream);
 int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                        float* stats, void* stream);
 /* y = act(x*scale+shift [+res | +res*rscale+rshift]); res_mode 0 none, 1 plain, 2 affine */
@@ -95,6 +98,12 @@ int lmkd_edist_fwd(const float* qm, const float* sm, const int* sup_class, float
                    void* stream);
 int lmkd_edist_bwd(const float* qm, const float* sm, const int* sup_class, const float* dist, const float* g, float* dqm, float* dsm,
                    int Nq, int Ns, int way, int D, void* stream);
+
+/* ---- MFM teacher fusion (teacher/code/model.py:1135-1151,1300-1331,1361-1392,1648-1664), inference:
+ * LayerNorm(x (+res[r mod res_rows])) written at row stride ldy, and the 8-token self-attention of nn.TransformerEncoderLayer ---- */
+int lmkd_layernorm_fwd(const float* x, const float* res, long res_rows, const float* gamma, const float* beta, float* y, long ldy,
+                       long rows, int D, float eps, void* stream);
+int lmkd_mha_small(const float* qkv, float* out, int B, int L, int D, int H, void* stream);
 
 /* ---- D2M loss (distillers.py:7-30, 295-337), accuracy (utils.py:116-121), optimizer (trainwandb.py:101-104,141-143) ---- */
 int lmkd_d2m_loss(const float* s_kl, const float* t_kl, const float* s_ce, const long long* labels, const float* s_sup,

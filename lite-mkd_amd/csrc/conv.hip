@@ -79,7 +79,7 @@ struct LoaderConvGather {
 template <class Cfg, bool SMALLC, bool STATS>
 __global__ __launch_bounds__(LMKD_THREADS) void conv_gemm_kernel(ConvGemmArgs a) {
   using LA = LoaderConvGather<Cfg::BM, SMALLC>;
-  using LB = LoaderKMajorDense<Cfg::BN>;
+  using LB = LoaderMMajorDense<Cfg::BN>;   // packed weights are K-outer: Wp[k][col]
   __shared__ __attribute__((aligned(16))) float smem[2 * (LA::LDS_FLOATS + LB::LDS_FLOATS)];
   __shared__ int s_src[Cfg::BM], s_hw[Cfg::BM], s_out[Cfg::BM];
   __shared__ float s_red[STATS ? Cfg::WM * Cfg::BN * 2 : 1];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(LMKD_THREADS) void conv_gemm_kernel(ConvGemmArgs a)
   LA la;
   LB lb;
   la.init(a.src, a.Hs, a.Ws, a.Cs, s_src, s_hw);
-  lb.init(a.wpk, a.Kp, n0, a.Co, a.Kp);
+  lb.init(a.wpk, a.Co, n0, a.Co, a.Kp);
 
   f32x16 acc[Cfg::TM][Cfg::TN];
   const int nk = a.ntap[cls] * a.cps;
@@ -324,28 +324,29 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
-// mode 0: Wp[co][(kh*KWp+kw)*Cs + ci] = W[co][ci][kh][kw]   (zero for padded kw / ci)
-// mode 1: Wd[ci][(kh*KW+kw)*Co + co] = W[co][ci][kh][kw]
+// K-outer packed weights (the GEMM's B operand, row k contiguous over the output columns):
+// mode 0 (forward): Wp[(kh*KWp+kw)*Cs + ci][co] = W[co][ci][kh][kw]   (zero for padded kw / ci)
+// mode 1 (dgrad)  : Wd[(kh*KW+kw)*Co + co][ci] = W[co][ci][kh][kw]
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Cin, int Cs, int KH,
                                     int KW, int KWp, int mode) {
   if (mode == 0) {
     const long total = (long)Co * KH * KWp * Cs;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-      const int ci = idx % Cs;
-      long r = idx / Cs;
-      const int kw = r % KWp; r /= KWp;
-      const int kh = r % KH;
-      const int co = r / KH;
+      const int co = idx % Co;
+      long r = idx / Co;
+      const int ci = r % Cs; r /= Cs;
+      const int kw = r % KWp;
+      const int kh = r / KWp;
       wp[idx] = (ci < Cin && kw < KW) ? w[(((long)co * Cin + ci) * KH + kh) * KW + kw] : 0.f;
     }
   } else {
     const long total = (long)Cin * KH * KW * Co;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-      const int co = idx % Co;
-      long r = idx / Co;
-      const int kw = r % KW; r /= KW;
-      const int kh = r % KH;
-      const int ci = r / KH;
+      const int ci = idx % Cin;
+      long r = idx / Cin;
+      const int co = r % Co; r /= Co;
+      const int kw = r % KW;
+      const int kh = r / KW;
       wp[idx] = w[(((long)co * Cin + ci) * KH + kh) * KW + kw];
     }
   }
@@ -376,25 +377,61 @@ extern "C" int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout
   return LMKD_OK;
 }
 
+// ---- tile configuration -------------------------------------------------------------------------
+// id: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 (rows x cols).  Workgroups per CU by LDS: 2 / 3 / 4 / 3.
+static int g_tile_override = 0;
+extern "C" int lmkd_conv_set_tile(int id) {
+  LMKD_REQUIRE(id >= 0 && id <= 4, "lmkd_conv_set_tile: id must be 0 (auto) .. 4");
+  g_tile_override = id;
+  return LMKD_OK;
+}
+static inline int cfg_bm(int id) { return id <= 2 ? 128 : 64; }
+static inline int cfg_bn(int id) { return (id == 1 || id == 4) ? 128 : 64; }
+static inline int cfg_wg_per_cu(int id) { return id == 1 ? 2 : (id == 3 ? 4 : 3); }
+
+// Pick the tile that minimises ceil(tiles / 256 CUs) * work per tile: at 64 cycles per fp32 MFMA every configuration is
+// matrix-pipe bound, so what differs is how evenly the launch's tiles divide over the CUs (the tail).
+static int pick_conv_cfg(long rows_per_class, int nclass, int ncols) {
+  if (g_tile_override) return (ncols <= 64 && cfg_bn(g_tile_override) == 128) ? (cfg_bm(g_tile_override) == 128 ? 2 : 3) : g_tile_override;
+  int best = 0;
+  double best_cost = 1e30;
+  const int cand[4] = {1, 2, 4, 3};
+  for (int c = 0; c < 4; ++c) {
+    const int id = cand[c];
+    if (ncols <= 64 && cfg_bn(id) == 128) continue;
+    const long tiles = (long)nclass * cdiv(rows_per_class, cfg_bm(id)) * cdiv(ncols, cfg_bn(id));
+    // matrix-pipe-bound model: a CU's time is the MFMA work of the tiles it receives, whatever their concurrency;
+    // smaller tiles pay ~3-5 % for extra staging, barriers and epilogues (measured per layer, profiles/)
+    double cost = (double)cdiv(tiles, 256) * cfg_bm(id) * cfg_bn(id);
+    cost *= (id == 1 ? 1.00 : (id == 3 ? 1.05 : 1.03));
+    if (cost < best_cost) { best_cost = cost; best = id; }
+  }
+  return best;
+}
+
+template <class Cfg, bool SMALLC, bool STATS>
+static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
+  a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
+  dim3 grid(a.nclass * a.tiles_per_class, cdiv(ncols, Cfg::BN));
+  hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS>), grid, dim3(LMKD_THREADS), 0, s, a);
+}
+
 template <bool SMALLC, bool STATS>
 static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
-  if (ncols <= 64) {
-    using Cfg = TileCfg<128, 64, 2, 2>;
-    dim3 grid(a.nclass * a.tiles_per_class, cdiv(ncols, Cfg::BN));
-    hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS>), grid, dim3(LMKD_THREADS), 0, s, a);
-  } else {
-    using Cfg = TileCfg<128, 128, 2, 2>;
-    dim3 grid(a.nclass * a.tiles_per_class, cdiv(ncols, Cfg::BN));
-    hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS>), grid, dim3(LMKD_THREADS), 0, s, a);
+  switch (pick_conv_cfg(a.rows_per_class, a.nclass, ncols)) {
+    case 1: launch_conv_cfg<TileCfg<128, 128, 2, 2>, SMALLC, STATS>(a, ncols, s); break;
+    case 2: launch_conv_cfg<TileCfg<128, 64, 2, 2>, SMALLC, STATS>(a, ncols, s); break;
+    case 3: launch_conv_cfg<TileCfg<64, 64, 2, 2>, SMALLC, STATS>(a, ncols, s); break;
+    default: launch_conv_cfg<TileCfg<64, 128, 2, 2>, SMALLC, STATS>(a, ncols, s); break;
   }
   LMKD_CHECK_LAUNCH("conv_gemm_kernel");
   return LMKD_OK;
 }
 
 // number of row tiles (= rows of the BN partial-statistics buffer) of a forward conv
-extern "C" int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int KH, int KW, int stride, int pad) {
+extern "C" int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   const long M = (long)N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad);
-  return cdiv(M, 128);
+  return cdiv(M, cfg_bm(pick_conv_cfg(M, 1, Cout)));
 }
 
 extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float* stat_partial, int N, int H, int W, int Cs,
@@ -484,15 +521,30 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
   return launch_conv_gemm<false, false>(a, Cin, (hipStream_t)stream);
 }
 
+// Split-K plan of the weight gradient.  Output tiles are few (Cout x 9*Cin is small) and the reduction is long, so the
+// pixel range is split over gridDim.z.  The split count is chosen so that the launch is (just under) a whole number of
+// rounds of resident workgroups: an arbitrary count leaves a 1.5-round launch that runs as long as a 2-round one.
 static void wgrad_plan(int Mpix, int Cout, int Kp, int* splits, int* steps_per_split, int* bm, int* bn) {
   *bm = Cout <= 64 ? 64 : 128;
   *bn = (Kp % 128 == 0 && Kp >= 1024) ? 128 : 64;
   const int tiles = cdiv(Cout, *bm) * cdiv(Kp, *bn);
   const int steps = cdiv(Mpix, LMKD_BK);
-  int sp = cdiv(1536, tiles);
-  if (sp > steps / 8) sp = steps / 8;
-  if (sp < 1) sp = 1;
-  *steps_per_split = cdiv(steps, sp);
+  const int per_cu = (*bm == 128 && *bn == 128) ? 2 : ((*bm == 64 && *bn == 64) ? 4 : 3);
+  const int slots = 256 * per_cu;
+  int best_sp = 1;
+  double best_cost = 1e30;
+  for (int r = 1; r <= 3; ++r) {
+    int sp = (slots * r) / tiles;
+    if (sp > steps / 4) sp = steps / 4;
+    if (sp < 1) sp = 1;
+    const int sps = cdiv(steps, sp);
+    sp = cdiv(steps, sps);
+    const double rounds = (double)cdiv((long)tiles * sp, slots);
+    // cost: K-steps executed per slot, plus the slab write + reduce traffic expressed in K-step units (~1 step per split)
+    const double cost = rounds * sps + 1.0 * sp / 8.0;
+    if (cost < best_cost) { best_cost = cost; best_sp = sp; }
+  }
+  *steps_per_split = cdiv(steps, best_sp);
   *splits = cdiv(steps, *steps_per_split);
 }
 

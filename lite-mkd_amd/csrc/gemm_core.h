@@ -121,21 +121,34 @@ struct LoaderMMajorDense {
 // ---------------------------------------------------------------------------------
 // MFMA main loop
 // ---------------------------------------------------------------------------------
+// One K-step (BK/2 k-pairs) of MFMAs from the LDS tiles.  The fragments of k-pair kk+1 are read from LDS BEFORE the
+// MFMAs of k-pair kk are issued (two register sets, fully unrolled), so the ~100-cycle ds_read latency hides behind the
+// 4 x 64-cycle MFMAs of the previous pair; hipcc otherwise emits read -> wait lgkmcnt(0) -> 4 MFMAs per pair and the
+// matrix pipe idles at every pair.
 template <class Cfg, int LDA, int LDB>
 __device__ __forceinline__ void mfma_kstep(const float* __restrict__ As, const float* __restrict__ Bs,
                                            int a_off, int b_off, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  constexpr int NK = LMKD_BK / 2;
+  float a[2][Cfg::TM], b[2][Cfg::TN];
 #pragma unroll
-  for (int kk = 0; kk < LMKD_BK / 2; ++kk) {
-    float a[Cfg::TM], b[Cfg::TN];
+  for (int i = 0; i < Cfg::TM; ++i) a[0][i] = As[a_off + 32 * i];
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i) a[i] = As[a_off + 2 * kk * LDA + 32 * i];
+  for (int j = 0; j < Cfg::TN; ++j) b[0][j] = Bs[b_off + 32 * j];
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) b[j] = Bs[b_off + 2 * kk * LDB + 32 * j];
+  for (int kk = 0; kk < NK; ++kk) {
+    const int cur = kk & 1, nxt = cur ^ 1;
+    if (kk + 1 < NK) {
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) a[nxt][i] = As[a_off + 2 * (kk + 1) * LDA + 32 * i];
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) b[nxt][j] = Bs[b_off + 2 * (kk + 1) * LDB + 32 * j];
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this pair's MFMAs (hipcc would sink it)
+    }
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
   }
 }
 

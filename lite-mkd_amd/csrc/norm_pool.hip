@@ -70,7 +70,7 @@ static int colsum_to_double(const float* in, int T, int CV, double* out, double*
 
 // ---------------------------------------------------------------------------------
 // BatchNorm finalize: sums -> mean / invstd / fused scale+shift, running-stat update
-//   stats layout out: [4][C] = mean, invstd, scale (= gamma*invstd), shift (= beta - mean*scale)
+//   stats layout out: [5][C] = mean, invstd, scale (= gamma*invstd), shift (= beta - mean*scale), unbiased variance
 // ---------------------------------------------------------------------------------
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ running_mean,
@@ -86,11 +86,30 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, doubl
   stats[C + c] = invstd;
   stats[2 * C + c] = g * invstd;
   stats[3 * C + c] = b - (float)mean * g * invstd;
+  const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+  stats[4 * C + c] = (float)unb;
   if (running_mean) {
-    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
   }
+}
+
+// deferred running-statistics update (two trunk calls overlapped on two streams update in program order afterwards):
+//   running = (1-m)*running + m*batch  with batch mean = stats[0], unbiased variance = stats[4]
+__global__ void bn_running_update_kernel(float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         const float* __restrict__ stats, int C, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * stats[c];
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * stats[4 * C + c];
+}
+extern "C" int lmkd_bn_running_update(float* running_mean, float* running_var, const float* stats, int C, float momentum,
+                                      void* stream) {
+  LMKD_REQUIRE(running_mean && running_var && stats && C > 0, "lmkd_bn_running_update: bad arguments");
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, running_mean, running_var,
+                     stats, C, momentum);
+  LMKD_CHECK_LAUNCH("bn_running_update_kernel");
+  return LMKD_OK;
 }
 
 // eval mode: stats from running estimates
@@ -105,6 +124,7 @@ __global__ void bn_eval_stats_kernel(int C, const float* __restrict__ gamma, con
   stats[C + c] = invstd;
   stats[2 * C + c] = g * invstd;
   stats[3 * C + c] = b - running_mean[c] * g * invstd;
+  stats[4 * C + c] = running_var[c];
 }
 
 // partial: [T][C][2] (sum, sumsq) from the conv epilogue; scratch: >= (64+1)*2*C doubles

@@ -3,8 +3,10 @@ method names; each method is resolved by `getattr(distiller, config.distill_name
 and returns a dict with at least 'loss' (0-dim tensor carrying grad).
 
 All methods built from the three primitives kd_loss / inter_class_relation / cross_entropy run as ONE
-fused HIP launch (values + logits gradients).  Methods of the reference that need other plugins
-(strm*, KL_feature, wsl focal weighting) raise NotImplementedError."""
+fused HIP launch (values + logits gradients).  All 22 logits-only methods of the reference are provided; `support_sim`
+and `KL_feature` (they need classifier outputs no in-scope plugin produces) raise NotImplementedError."""
+import torch
+
 from . import ops
 
 
@@ -83,6 +85,115 @@ class Distiller(object):
                       T=self.distill_dict["temperature"], w_kl=1.0, w_sup=0.5, w_ce=1.0 / 16.0)[0]
         return {"loss": loss}
 
+    # ---- the remaining logits-only methods of the reference: each is a linear combination of the three primitives.
+    # They take the generic route (one launch per term, 0-dim tensors combined by autograd); the focal weights of the
+    # *wsl family are computed from detached CE values exactly as in the reference.
+    def _kd(self, s, t):
+        return kd_loss(self._to(s), self._to(t), self.distill_dict["temperature"])
+
+    def _icr(self, s, t):
+        return inter_class_relation(self._to(s), self._to(t))
+
+    def _ce16(self, s, labels):
+        return cross_entropy(self._to(s), labels) / 16
+
+    def _focal(self, ce_s, ce_t):
+        fw = ce_s.detach() / (ce_t.detach() + 1e-8)
+        return 1 - torch.exp(-torch.clamp(fw, min=0))
+
+    def wsl(self, s, t, labels):
+        """distillers.py:76-98"""
+        d = self.distill_dict
+        fw = self._focal(cross_entropy(self._to(s), labels), cross_entropy(self._to(t), labels))
+        soft, hard = fw * self._kd(s, t), self._ce16(s, labels)
+        return {"soft_loss": d["soft_loss_weight"] * soft, "hard_loss": d["hard_loss_weight"] * hard,
+                "loss": d["soft_loss_weight"] * soft + d["hard_loss_weight"] * hard}
+
+    def fc_2_wsl(self, s, t, labels):
+        """distillers.py:163-201"""
+        fw = self._focal(cross_entropy(self._to(s["fc_1"]), labels), cross_entropy(self._to(s["fc_2"]), labels))
+        soft, hard = (1 + fw) * self._kd(s["fc_2"], t), (2 - fw) * self._ce16(s["fc_1"], labels)
+        self.distill_dict["fcwsl_aerfa"] = fw
+        return {"hard_loss": hard, "soft_loss": soft, "loss": soft + hard, "aerfa": fw}
+
+    def strm(self, s, t, labels):
+        """distillers.py:203-213"""
+        pat, fr = self._ce16(s["pat"], labels), self._ce16(s["fr"], labels)
+        return {"pat_loss": pat, "fr_loss": fr, "loss": 0.1 * pat + fr}
+
+    def strm_KD(self, s, t, labels):
+        """distillers.py:215-227"""
+        kl = self.distill_dict["soft_loss_weight"] * self._kd(s["fr"], t)
+        pat, fr = self._ce16(s["pat"], labels), self._ce16(s["fr"], labels)
+        return {"pat_loss": pat, "fr_loss": fr, "softloss": kl, "loss": 0.1 * pat + fr + kl}
+
+    def fc_2_sup(self, s, t, labels):
+        """distillers.py:229-284"""
+        fw = self._focal(cross_entropy(self._to(s["ce"]), labels), cross_entropy(self._to(s["kl"]), labels))
+        kl, sup, ce = self._kd(s["kl"], t["kl"]), self._kd(s["sup"], t["sup"]) / 16, self._ce16(s["ce"], labels)
+        return {"soft_loss": kl, "hard_loss": 0.01 * sup + ce, "loss": (1 + fw) * kl + (2 - fw) * (0.1 * sup + ce)}
+
+    def fc_2_sup_kl(self, s, t, labels):
+        """distillers.py:339-383"""
+        kl, sup, ce = self._kd(s["kl"], t["kl"]), self._kd(s["sup"], t["sup"]), self._ce16(s["ce"], labels)
+        return {"soft_loss": kl, "hard_loss": 0.5 * sup + ce, "loss": kl + 0.5 * sup + ce}
+
+    def fc_2_sup_dist_cece(self, s, t, labels):
+        """distillers.py:385-429"""
+        kl, sup = self._kd(s["kl"], t["kl"]), self._icr(s["sup"], t["sup"])
+        ce, klce = self._ce16(s["ce"], labels), self._ce16(s["kl"], labels)
+        return {"soft_loss": kl, "hard_loss": 0.5 * sup + ce, "loss": kl + klce + 0.5 * sup + ce}
+
+    def fc_2_sup_klklcece(self, s, t, labels):
+        """distillers.py:431-475"""
+        kl, sup = self._kd(s["kl"], t["kl"]), self._kd(s["sup"], t["sup"])
+        ce, klce = self._ce16(s["ce"], labels), self._ce16(s["kl"], labels)
+        return {"soft_loss": kl, "hard_loss": 0.5 * sup + ce, "loss": kl + klce + 0.5 * sup + ce}
+
+    def fc_2_sup_distdistcece(self, s, t, labels):
+        """distillers.py:477-499"""
+        kl, sup = self._icr(s["kl"], t["kl"]), self._icr(s["sup"], t["sup"])
+        ce, klce = self._ce16(s["ce"], labels), self._ce16(s["kl"], labels)
+        return {"soft_loss": kl, "hard_loss": 0.5 * sup + ce, "loss": kl + klce + 0.5 * sup + ce}
+
+    def fc_2_sup_2(self, s, t, labels):
+        """distillers.py:501-547"""
+        kl, ce = self._kd(s["kl"], t["kl"]), self._ce16(s["ce"], labels)
+        sup_ce, sup_kl = self._icr(s["sup_ce"], t["sup"]), self._icr(s["sup_kl"], t["sup"])
+        return {"soft_loss": kl + 0.5 * sup_kl, "hard_loss": ce + 0.5 * sup_ce, "loss": (kl + sup_kl) + ce + sup_ce}
+
+    def fc_2_sup_disver(self, s, t, labels):
+        """distillers.py:549-572"""
+        kl_sup, sup_q = self._kd(s["sup"], t["sup"]), self._icr(s["kl"], t["kl"])
+        ce_kl, ce_sup = self._ce16(s["kl"], labels), self._ce16(s["ce"], labels)
+        return {"soft_loss": kl_sup, "hard_loss": sup_q + ce_sup, "loss": 0.5 * kl_sup + sup_q + ce_sup + ce_kl}
+
+    def fc_2_sup_dist_wsl(self, s, t, labels):
+        """distillers.py:574-624"""
+        fw = self._focal(cross_entropy(self._to(s["ce"]), labels), cross_entropy(self._to(s["kl"]), labels))
+        kl, sup, ce = self._kd(s["kl"], t["kl"]), self._icr(s["sup"], t["sup"]), self._ce16(s["ce"], labels)
+        return {"soft_loss": kl, "hard_loss": 0.5 * sup + ce, "loss": (0.5 + fw) * kl + (1.5 - fw) * (0.5 * sup + ce)}
+
+    def strm_fc_2_sup_dist(self, s, t, labels):
+        """distillers.py:626-653"""
+        loss = (self._kd(s["fr1"], t["kl"]) + 0.5 * self._icr(s["sup"], t["sup"]) + self._ce16(s["fr2"], labels)
+                + 0.1 * (self._kd(s["pat"], t["kl"]) + self._ce16(s["pat"], labels)))
+        return {"loss": loss}
+
+    def strm_1fc_sup(self, s, t, labels):
+        """distillers.py:655-681"""
+        loss = (self._kd(s["fr"], t["kl"]) + 0.5 * self._icr(s["sup"], t["sup"]) + self._ce16(s["fr"], labels)
+                + 0.1 * (self._kd(s["pat"], t["kl"]) + self._ce16(s["pat"], labels)))
+        return {"loss": loss}
+
+    def fc_1_sup(self, s, t, labels):
+        """distillers.py:683-696"""
+        return {"loss": self._ce16(s["kl"], labels) + self._kd(s["kl"], t["kl"]) + 0.5 * self._icr(s["sup"], t["sup"])}
+
+    def fc_sup(self, s, t, labels):
+        """distillers.py:698-711"""
+        return {"loss": self._ce16(s["kl"], labels) + 0.5 * self._icr(s["sup"], t["sup"])}
+
     def __getattr__(self, name):
         if name in _OUT_OF_SCOPE:
             def _missing(*a, **k):
@@ -91,6 +202,5 @@ class Distiller(object):
         raise AttributeError(name)
 
 
-_OUT_OF_SCOPE = {"wsl", "support_sim", "KL_feature", "fc_2_wsl", "strm", "strm_KD", "fc_2_sup", "fc_2_sup_kl",
-                 "fc_2_sup_dist_cece", "fc_2_sup_klklcece", "fc_2_sup_distdistcece", "fc_2_sup_2", "fc_2_sup_disver",
-                 "fc_2_sup_dist_wsl", "strm_fc_2_sup_dist", "strm_1fc_sup", "fc_1_sup", "fc_sup"}
+# need per-support-sample similarity logits / raw features that no in-scope classifier produces (distillers.py:110-150)
+_OUT_OF_SCOPE = {"support_sim", "KL_feature"}

@@ -53,14 +53,8 @@ class _Block(nn.Module):
             ds = (self.downsample[0].weight,) + self.downsample[1].args()
         else:
             ds = (None, None, None, None, None)
-        y = ops.BasicBlockFn.apply(x, self.stride, tr, self.conv1.weight, *self.bn1.args(),
-                                   self.conv2.weight, *self.bn2.args(), *ds)
-        if tr:
-            self.bn1.num_batches_tracked += 1
-            self.bn2.num_batches_tracked += 1
-            if self.downsample is not None:
-                self.downsample[1].num_batches_tracked += 1
-        return y
+        return ops.BasicBlockFn.apply(x, self.stride, tr, self.conv1.weight, *self.bn1.args(),
+                                      self.conv2.weight, *self.bn2.args(), *ds)
 
 
 class ResNet18Trunk(nn.Module):
@@ -79,12 +73,62 @@ class ResNet18Trunk(nn.Module):
     def forward(self, x):
         conv, bn = getattr(self, "0"), getattr(self, "1")
         y = ops.StemFn.apply(x, conv.weight, *bn.args(), self.training)
-        if self.training:
-            bn.num_batches_tracked += 1
         for name, _, _, _ in STAGES:
             for blk in getattr(self, name):
                 y = blk(y)
+        if self.training and not ops.deferring():
+            self.bump_counters(1)
         return y
+
+    def bump_counters(self, n):
+        """num_batches_tracked += n for every BatchNorm (one fused launch)"""
+        bufs = [m.num_batches_tracked for m in self.modules() if isinstance(m, _BN)]
+        torch._foreach_add_(bufs, n)
+
+
+# The two trunk calls of an episode (support frames, query frames: resnet18_2fc.py:41-42) are independent: they are
+# queued on two HIP streams so that their kernels interleave on the GPU (the MFMA-bound convolutions of one call fill the
+# workgroup-quantisation tails of the other and overlap its HBM-bound BatchNorm passes).  Each call still normalises with
+# its OWN batch statistics; the running-statistics updates are deferred and applied in the reference's order
+# (support, then query).  autograd runs each call's backward on the stream of its forward, so the backward overlaps too.
+OVERLAP_TRUNK_CALLS = True
+
+
+def two_trunk_calls(trunk, head, context_frames, target_frames):
+    """-> (head(trunk(context_frames)), head(trunk(target_frames))).  The two calls are enqueued layer by layer,
+    alternating between the two streams, so both queues stay fed (and autograd, which walks the graph in reverse creation
+    order, alternates between them in the backward as well)."""
+    if not (OVERLAP_TRUNK_CALLS and context_frames.is_cuda):
+        return head(trunk(context_frames)), head(trunk(target_frames))
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    main = torch.cuda.current_stream()
+    side = ops.side_stream(context_frames.device)
+    side.wait_stream(main)
+    target_frames.record_stream(side)
+    q_upd, s_upd = [], []
+    defer = trunk.training
+    layers = [lambda t: ops.StemFn.apply(t, getattr(trunk, "0").weight, *getattr(trunk, "1").args(), trunk.training)]
+    for name, _, _, _ in STAGES:
+        layers += list(getattr(trunk, name))
+    layers.append(head)
+    cf, tf = context_frames, target_frames
+    try:
+        for layer in layers:
+            if defer:
+                ops.set_defer(s_upd)
+            cf = layer(cf)
+            with torch.cuda.stream(side):
+                if defer:
+                    ops.set_defer(q_upd)
+                tf = layer(tf)
+    finally:
+        ops.set_defer(None)
+    main.wait_stream(side)
+    tf.record_stream(main)
+    if defer:
+        ops.apply_deferred(s_upd + q_upd)
+        trunk.bump_counters(2)
+    return cf, tf
 
 
 class Linear(nn.Linear):

@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from ... import ops
-from .resnet import Linear, ResNet18Trunk
+from .resnet import Linear, ResNet18Trunk, two_trunk_calls
 
 
 class resnet18_2fc(nn.Module):
@@ -17,8 +17,7 @@ class resnet18_2fc(nn.Module):
 
     def forward(self, context_feature, context_labels, target_feature):
         # two separate trunk calls = two separate BatchNorm batches (resnet18_2fc.py:41-42)
-        cf = ops.PoolHeadFn.apply(self.resnet(context_feature))        # :44-54
-        tf = ops.PoolHeadFn.apply(self.resnet(target_feature))
+        cf, tf = two_trunk_calls(self.resnet, ops.PoolHeadFn.apply, context_feature, target_feature)     # :41-54
         L, D = self.args.seq_len, self.args.trans_linear_in_dim
         context_feature_dict = {
             "context_features_1": self.fc1(cf).reshape(-1, L, D),

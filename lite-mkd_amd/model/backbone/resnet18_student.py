@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from ... import ops
-from .resnet import Linear, ResNet18Trunk
+from .resnet import Linear, ResNet18Trunk, two_trunk_calls
 
 
 class resnet18_student(nn.Module):
@@ -15,8 +15,7 @@ class resnet18_student(nn.Module):
         self.res18_2048 = Linear(512, 2048)
 
     def forward(self, context_feature, context_labels, target_feature):
-        cf = ops.PoolHeadFn.apply(self.resnet(context_feature))
-        tf = ops.PoolHeadFn.apply(self.resnet(target_feature))
+        cf, tf = two_trunk_calls(self.resnet, ops.PoolHeadFn.apply, context_feature, target_feature)
         L, D = self.args.seq_len, self.args.trans_linear_in_dim
         return self.res18_2048(cf).reshape(-1, L, D), self.res18_2048(tf).reshape(-1, L, D)
 

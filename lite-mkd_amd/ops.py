@@ -155,7 +155,7 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats):
     y = _empty((N, Ho, Wo, Cout), x)
     part = None
     if want_stats:
-        T = lib().value("lmkd_conv2d_fwd_row_tiles", N, H, W, KH, KW, stride, pad)
+        T = lib().value("lmkd_conv2d_fwd_row_tiles", N, H, W, Cout, KH, KW, stride, pad)
         part = _empty((T, Cout, 2), x)
     cin = 3 if Cs == 4 else Cs
     with _timed("conv_gemm_kernel", 2.0 * N * Ho * Wo * Cout * cin * KH * KW):
@@ -190,7 +190,7 @@ BN_MOMENTUM = 0.1
 
 def bn_stats_train(part, count, gamma, beta, running_mean, running_var):
     T, C, _ = part.shape
-    stats = _empty((4, C), part)
+    stats = _empty((5, C), part)
     scratch = torch.empty(66 * 2 * C, dtype=torch.float64, device=part.device)
     lib().call("lmkd_bn_finalize", _p(part), T, C, count, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                _f32(BN_MOMENTUM), _f32(BN_EPS), _p(stats), _p(scratch), _stream())
@@ -199,7 +199,7 @@ def bn_stats_train(part, count, gamma, beta, running_mean, running_var):
 
 def bn_stats_eval(gamma, beta, running_mean, running_var):
     C = gamma.shape[0]
-    stats = _empty((4, C), gamma)
+    stats = _empty((5, C), gamma)
     lib().call("lmkd_bn_eval_stats", C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _f32(BN_EPS), _p(stats), _stream())
     return stats
 
@@ -229,12 +229,46 @@ def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None)
     return dx, g, dgamma, dbeta
 
 
+# When the two trunk calls of an episode run on two HIP streams (backbone: overlap_trunk_calls), the running-statistics
+# updates are deferred and applied afterwards in program order (support call first, then query call), so the result is
+# identical to the serial reference order.  _DEFER is the list collecting (running_mean, running_var, stats).
+_DEFER = None
+
+
+def set_defer(lst):
+    global _DEFER
+    _DEFER = lst
+
+
+def deferring():
+    return _DEFER is not None
+
+
+def apply_deferred(entries):
+    for rm, rv, stats in entries:
+        lib().call("lmkd_bn_running_update", _p(rm), _p(rv), _p(stats), rm.shape[0], _f32(BN_MOMENTUM), _stream())
+
+
+_side_streams = {}
+
+
+def side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training):
     Cout, _, KH, KW = w.shape
     wp = pack_weights(w, Cs, 0)
     y, part = conv_fwd(x, wp, Cout, KH, KW, stride, pad, training)
     if training:
-        stats = bn_stats_train(part, y.numel() // Cout, gamma, beta, rm, rv)
+        if _DEFER is not None:
+            stats = bn_stats_train(part, y.numel() // Cout, gamma, beta, None, None)
+            _DEFER.append((rm, rv, stats))
+        else:
+            stats = bn_stats_train(part, y.numel() // Cout, gamma, beta, rm, rv)
     else:
         stats = bn_stats_eval(gamma, beta, rm, rv)
     return y, stats
@@ -367,8 +401,8 @@ class ClassPlan:
     labels per episode, done before any kernel is queued).  Mirrors torch.unique +
     _extract_class_indices of the reference (TRX_2fcsup.py:108,118-119)."""
 
-    def __init__(self, support_labels, way):
-        lab = support_labels.detach().to("cpu")
+    def __init__(self, support_labels, way, cpu_copy=None):
+        lab = cpu_copy if cpu_copy is not None else support_labels.detach().to("cpu")
         vals = [int(v) for v in lab.long().tolist()]
         self.way = way
         self.classes = sorted(set(vals))
@@ -623,13 +657,21 @@ def accuracy(l1, l2, labels):
 
 
 _plan_cache = [None, None, None]
+_cpu_labels = [None, None]
+
+
+def note_cpu_labels(device_labels, cpu_labels):
+    """prepare_task moves the (CPU) support labels to the device; remembering the CPU copy lets get_plan build the class
+    plan without a device->host copy, i.e. without draining the stream between episodes."""
+    _cpu_labels[0], _cpu_labels[1] = device_labels, cpu_labels
 
 
 def get_plan(support_labels, way):
-    """ClassPlan for this label tensor; cached on tensor identity so Student.forward can build it (one
-    tiny D2H copy) BEFORE the backbone kernels are queued and the classifier reuses it."""
+    """ClassPlan for this label tensor; cached on tensor identity so Student.forward can build it BEFORE the backbone
+    kernels are queued and the classifier reuses it."""
     if _plan_cache[0] is support_labels and _plan_cache[1] == way:
         return _plan_cache[2]
-    plan = ClassPlan(support_labels, way)
+    src = _cpu_labels[1] if _cpu_labels[0] is support_labels else None
+    plan = ClassPlan(support_labels, way, src)
     _plan_cache[0], _plan_cache[1], _plan_cache[2] = support_labels, way, plan
     return plan

@@ -67,7 +67,10 @@ def prepare_task(task_dict, device, images_to_device=True):
         target_images = target_images.to(device)
         context_teacher_feature = context_teacher_feature.to(device)
         target_teacher_feature = target_teacher_feature.to(device)
+    cpu_labels = context_labels if context_labels.device.type == "cpu" else None
     context_labels = context_labels.to(device)
+    if cpu_labels is not None and context_labels is not cpu_labels:
+        ops.note_cpu_labels(context_labels, cpu_labels)
     target_labels = target_labels.long().to(device)
     return (context_images, target_images, context_teacher_feature, target_teacher_feature, context_labels,
             target_labels, real_target_labels, batch_class_list)

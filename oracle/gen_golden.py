@@ -110,6 +110,27 @@ def gen_distill(mods):
     return out
 
 
+def gen_distill_methods(mods):
+    """every logits-only Distiller method of the reference: loss value + gradient of every student logit tensor"""
+    D = mods["distillers"]
+    out = {}
+    for i, name in enumerate(sorted(O.DISTILL_SIGNATURES)):
+        s, t, labels = O.distill_inputs(name, 500 + i)
+        leaves = [s] if torch.is_tensor(s) else list(s.values())
+        for v in leaves:
+            v.requires_grad_()
+        dist = D.Distiller(name, dict(O.DEFAULT_CFG), torch.device("cpu"))
+        r = getattr(dist, name)(s, t, labels)
+        r["loss"].sum().backward()
+        out[name + "__loss"] = r["loss"].detach().reshape(())
+        if torch.is_tensor(s):
+            out[name + "__g"] = s.grad
+        else:
+            for k, v in s.items():
+                out[name + "__g_" + k] = v.grad if v.grad is not None else torch.zeros_like(v)
+    return out
+
+
 def feature_case(seed, ns=25, nq=25, scale=1.0, shuffle=True):
     g = torch.Generator().manual_seed(seed)
     sup = torch.randn(ns, 8, 2048, generator=g) * scale
@@ -207,7 +228,7 @@ def main():
     torch.manual_seed(0)
     mods = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    for name, fn in (("distill", gen_distill), ("edist", gen_edist), ("trx", gen_trx)):
+    for name, fn in (("distill", gen_distill), ("distill_methods", gen_distill_methods), ("edist", gen_edist), ("trx", gen_trx)):
         data = t2n(fn(mods))
         path = os.path.join(GOLD, name + ".npz")
         if a.check_only:

@@ -305,6 +305,101 @@ def distill_Dist_KD(s, t, labels, cfg=DEFAULT_CFG):
     return {"soft_loss": d, "hard_loss": ce, "loss": ce + d}
 
 
+def _focal(ce_s, ce_t):
+    """1 - exp(-max(ce_s/(ce_t+1e-8), 0)) on detached values (distillers.py:84-88 and siblings)"""
+    fw = ce_s.detach() / (ce_t.detach() + 1e-8)
+    return 1 - torch.exp(-torch.clamp(fw, min=0))
+
+
+def _ce16(s, labels):
+    return F.cross_entropy(s, labels) / 16
+
+
+# the remaining Distiller methods (distillers.py:76-733) that are compositions of kd_loss / inter_class_relation / CE
+def distill_method(name, s, t, labels, cfg=DEFAULT_CFG):
+    T = cfg["temperature"]
+    hw, sw = cfg["hard_loss_weight"], cfg["soft_loss_weight"]
+    if name == "KD":
+        return distill_KD(s, t, labels, cfg)["loss"]
+    if name == "Dist_KD":
+        return distill_Dist_KD(s, t, labels, cfg)["loss"]
+    if name == "fc_2_sup_dist":
+        return distill_fc_2_sup_dist(s, t, labels, cfg)["loss"]
+    if name == "ce":                                                    # :100-108
+        return _ce16(s, labels)
+    if name == "wsl":                                                   # :76-98
+        fw = _focal(F.cross_entropy(s, labels), F.cross_entropy(t, labels))
+        return sw * fw * kd_loss(s, t, T) + hw * _ce16(s, labels)
+    if name == "fc_2":                                                  # :152-161
+        return hw * _ce16(s["fc_1"], labels) + sw * kd_loss(s["fc_2"], t, T)
+    if name == "fc_2_wsl":                                              # :163-201
+        fw = _focal(F.cross_entropy(s["fc_1"], labels), F.cross_entropy(s["fc_2"], labels))
+        return (1 + fw) * kd_loss(s["fc_2"], t, T) + (2 - fw) * _ce16(s["fc_1"], labels)
+    if name == "strm":                                                  # :203-213
+        return 0.1 * _ce16(s["pat"], labels) + _ce16(s["fr"], labels)
+    if name == "strm_KD":                                               # :215-227
+        return 0.1 * _ce16(s["pat"], labels) + _ce16(s["fr"], labels) + sw * kd_loss(s["fr"], t, T)
+    if name == "fc_2_sup":                                              # :229-284
+        fw = _focal(F.cross_entropy(s["ce"], labels), F.cross_entropy(s["kl"], labels))
+        return (1 + fw) * kd_loss(s["kl"], t["kl"], T) + (2 - fw) * (0.1 * kd_loss(s["sup"], t["sup"], T) / 16 + _ce16(s["ce"], labels))
+    if name == "fc_2_sup_kl":                                           # :339-383
+        return kd_loss(s["kl"], t["kl"], T) + 0.5 * kd_loss(s["sup"], t["sup"], T) + _ce16(s["ce"], labels)
+    if name == "fc_2_sup_dist_cece":                                    # :385-429
+        return kd_loss(s["kl"], t["kl"], T) + _ce16(s["kl"], labels) + 0.5 * inter_class_relation(s["sup"], t["sup"]) + _ce16(s["ce"], labels)
+    if name == "fc_2_sup_klklcece":                                     # :431-475
+        return kd_loss(s["kl"], t["kl"], T) + _ce16(s["kl"], labels) + 0.5 * kd_loss(s["sup"], t["sup"], T) + _ce16(s["ce"], labels)
+    if name == "fc_2_sup_distdistcece":                                 # :477-499
+        return inter_class_relation(s["kl"], t["kl"]) + _ce16(s["kl"], labels) + 0.5 * inter_class_relation(s["sup"], t["sup"]) + _ce16(s["ce"], labels)
+    if name == "fc_2_sup_2":                                            # :501-547
+        return (kd_loss(s["kl"], t["kl"], T) + inter_class_relation(s["sup_kl"], t["sup"])) + _ce16(s["ce"], labels) + inter_class_relation(s["sup_ce"], t["sup"])
+    if name == "fc_2_sup_disver":                                       # :549-572
+        return 0.5 * kd_loss(s["sup"], t["sup"], T) + inter_class_relation(s["kl"], t["kl"]) + _ce16(s["ce"], labels) + _ce16(s["kl"], labels)
+    if name == "fc_2_sup_dist_wsl":                                     # :574-624
+        fw = _focal(F.cross_entropy(s["ce"], labels), F.cross_entropy(s["kl"], labels))
+        return (0.5 + fw) * kd_loss(s["kl"], t["kl"], T) + (1.5 - fw) * (0.5 * inter_class_relation(s["sup"], t["sup"]) + _ce16(s["ce"], labels))
+    if name == "strm_fc_2_sup_dist":                                    # :626-653
+        return (kd_loss(s["fr1"], t["kl"], T) + 0.5 * inter_class_relation(s["sup"], t["sup"]) + _ce16(s["fr2"], labels)
+                + 0.1 * (kd_loss(s["pat"], t["kl"], T) + _ce16(s["pat"], labels)))
+    if name == "strm_1fc_sup":                                          # :655-681
+        return (kd_loss(s["fr"], t["kl"], T) + 0.5 * inter_class_relation(s["sup"], t["sup"]) + _ce16(s["fr"], labels)
+                + 0.1 * (kd_loss(s["pat"], t["kl"], T) + _ce16(s["pat"], labels)))
+    if name == "fc_1_sup" or name == "e_dist_1fc_sup":                  # :683-696, :713-733
+        return _ce16(s["kl"], labels) + kd_loss(s["kl"], t["kl"], T) + 0.5 * inter_class_relation(s["sup"], t["sup"])
+    if name == "fc_sup":                                                # :698-711
+        return _ce16(s["kl"], labels) + 0.5 * inter_class_relation(s["sup"], t["sup"])
+    raise KeyError(name)
+
+
+# name -> (student keys or None for a plain tensor, teacher keys or None)
+DISTILL_SIGNATURES = {
+    "KD": (None, None), "Dist_KD": (None, None), "ce": (None, None), "wsl": (None, None),
+    "fc_2": (("fc_1", "fc_2"), None), "fc_2_wsl": (("fc_1", "fc_2"), None),
+    "strm": (("pat", "fr"), None), "strm_KD": (("pat", "fr"), None),
+    "fc_2_sup_dist": (("kl", "ce", "sup"), ("kl", "sup")), "fc_2_sup": (("kl", "ce", "sup"), ("kl", "sup")),
+    "fc_2_sup_kl": (("kl", "ce", "sup"), ("kl", "sup")), "fc_2_sup_dist_cece": (("kl", "ce", "sup"), ("kl", "sup")),
+    "fc_2_sup_klklcece": (("kl", "ce", "sup"), ("kl", "sup")), "fc_2_sup_distdistcece": (("kl", "ce", "sup"), ("kl", "sup")),
+    "fc_2_sup_2": (("kl", "ce", "sup_ce", "sup_kl"), ("kl", "sup")), "fc_2_sup_disver": (("kl", "ce", "sup"), ("kl", "sup")),
+    "fc_2_sup_dist_wsl": (("kl", "ce", "sup"), ("kl", "sup")),
+    "strm_fc_2_sup_dist": (("fr1", "fr2", "pat", "sup"), ("kl", "sup")), "strm_1fc_sup": (("fr", "pat", "sup"), ("kl", "sup")),
+    "fc_1_sup": (("kl", "sup"), ("kl", "sup")), "fc_sup": (("kl", "sup"), ("kl", "sup")), "e_dist_1fc_sup": (("kl", "sup"), ("kl", "sup")),
+}
+
+
+def distill_inputs(name, seed, nq=25):
+    """seeded logits for a method: -> (student, teacher, labels); 'sup*' keys are [5,4], the rest [nq,5]"""
+    g = torch.Generator().manual_seed(seed)
+    sk, tk = DISTILL_SIGNATURES[name]
+
+    def mk(k):
+        if k.startswith("sup"):
+            return torch.randn(5, 4, generator=g) * 20 - 100
+        return torch.randn(nq, 5, generator=g) * 30 - 300
+    s = mk("x") if sk is None else {k: mk(k) for k in sk}
+    t = mk("x") if tk is None else {k: mk(k) for k in tk}
+    labels = torch.randint(0, 5, (nq,), generator=g)
+    return s, t, labels
+
+
 # A14 ------------------------------------------------------------------------
 def aggregate_accuracy(logits, labels):
     """utils.py:116-121."""

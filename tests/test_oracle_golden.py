@@ -118,3 +118,44 @@ def test_mfm_param_count_and_shape():
     shp = O.mfm_param_shapes()
     n = sum(int(np.prod(s)) for s in shp.values())
     assert 5.0e8 < n < 5.8e8                                 # ~541 M
+
+
+def test_distill_methods_golden(golden_dir):
+    """all 22 logits-only Distiller methods of the reference (distillers.py:42-733): value + student-logit gradients"""
+    G = np.load(os.path.join(golden_dir, "distill_methods.npz"))
+    for i, name in enumerate(sorted(O.DISTILL_SIGNATURES)):
+        s, t, labels = O.distill_inputs(name, 500 + i)
+        leaves = {"": s} if torch.is_tensor(s) else s
+        for v in leaves.values():
+            v.requires_grad_()
+        loss = O.distill_method(name, s, t, labels)
+        loss.backward()
+        close(loss, G[name + "__loss"], 1e-5, 1e-5)
+        for k, v in leaves.items():
+            key = name + ("__g" if k == "" else "__g_" + k)
+            close(v.grad if v.grad is not None else torch.zeros_like(v), G[key], 1e-4, 1e-7)
+
+
+def test_mfm_oracle_matches_torch_transformer_encoder():
+    """the MFM restatement vs torch's own nn.TransformerEncoder / nn.Embedding / nn.LayerNorm modules (the building
+    blocks the reference instantiates at teacher/code/model.py:1300-1331,1361-1392), reduced width"""
+    import torch.nn as nn
+    d, L, N = 64, 8, 3
+    torch.manual_seed(0)
+    pes = [(nn.Embedding(L, d), nn.LayerNorm(d)) for _ in range(3)]
+    enc = nn.TransformerEncoder(nn.TransformerEncoderLayer(d_model=3 * d, nhead=3, batch_first=True), num_layers=2).eval()
+    f1 = nn.Linear(3 * d, d)
+    p = {}
+    for i, (e, ln) in enumerate(pes):
+        p["three_fusion.positionEncoding%d.position_embeddings.weight" % (i + 1)] = e.weight.detach()
+        p["three_fusion.positionEncoding%d.LayerNorm.weight" % (i + 1)] = ln.weight.detach()
+        p["three_fusion.positionEncoding%d.LayerNorm.bias" % (i + 1)] = ln.bias.detach()
+    for k, v in enc.state_dict().items():
+        p["three_fusion.transformer_encoder." + k] = v
+    p["three_fusion.f1.weight"], p["three_fusion.f1.bias"] = f1.weight.detach(), f1.bias.detach()
+    xs = [torch.randn(N, L, d) for _ in range(3)]
+    with torch.no_grad():
+        h = torch.cat([ln(x + e.weight[:L]) for x, (e, ln) in zip(xs, pes)], -1)
+        ref = f1(enc(h))
+        out = O.mfm_three_fusion(xs[0], xs[1], xs[2], p)
+    close(out, ref, 1e-4, 1e-5)
