@@ -33,9 +33,10 @@ struct ConvGemmArgs {
 // K-major implicit-im2col loader (rows = output pixels of this tile).
 template <int ROWS, bool SMALLC>
 struct LoaderConvGather {
+  static constexpr bool ROWK = true;
   static constexpr int NI = ROWS / 32;
-  static constexpr int LD = ROWS + 1;
-  static constexpr int LDS_FLOATS = LMKD_BK * LD;
+  static constexpr int LD = LMKD_LDK;
+  static constexpr int LDS_FLOATS = ROWS * LMKD_LDK;
   int base[NI], hw[NI];
   float4 reg[NI];
   const float* src;
@@ -66,20 +67,14 @@ struct LoaderConvGather {
   __device__ __forceinline__ void store(float* S) const {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      float* d = S + kc4 * LD + (tid >> 3) + 32 * i;
-      d[0] = reg[i].x;
-      d[LD] = reg[i].y;
-      d[2 * LD] = reg[i].z;
-      d[3 * LD] = reg[i].w;
-    }
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(S + ((tid >> 3) + 32 * i) * LMKD_LDK + kc4) = reg[i];
   }
 };
 
 template <class Cfg, bool SMALLC, bool STATS>
 __global__ __launch_bounds__(LMKD_THREADS) void conv_gemm_kernel(ConvGemmArgs a) {
   using LA = LoaderConvGather<Cfg::BM, SMALLC>;
-  using LB = LoaderMMajorDense<Cfg::BN>;   // packed weights are K-outer: Wp[k][col]
+  using LB = LoaderKMajorDense<Cfg::BN>;   // packed weights are K-major: Wp[col][k]
   __shared__ __attribute__((aligned(16))) float smem[2 * (LA::LDS_FLOATS + LB::LDS_FLOATS)];
   __shared__ int s_src[Cfg::BM], s_hw[Cfg::BM], s_out[Cfg::BM];
   __shared__ float s_red[STATS ? Cfg::WM * Cfg::BN * 2 : 1];
@@ -109,7 +104,7 @@ __global__ __launch_bounds__(LMKD_THREADS) void conv_gemm_kernel(ConvGemmArgs a)
   LA la;
   LB lb;
   la.init(a.src, a.Hs, a.Ws, a.Cs, s_src, s_hw);
-  lb.init(a.wpk, a.Co, n0, a.Co, a.Kp);
+  lb.init(a.wpk, a.Kp, n0, a.Co, a.Kp);
 
   f32x16 acc[Cfg::TM][Cfg::TN];
   const int nk = a.ntap[cls] * a.cps;
@@ -120,8 +115,9 @@ __global__ __launch_bounds__(LMKD_THREADS) void conv_gemm_kernel(ConvGemmArgs a)
     float* Bs0 = smem + 2 * SA;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-    const int a_off = (lane >> 5) * LA::LD + wm * (Cfg::TM * 32) + (lane & 31);
-    const int b_off = (lane >> 5) * LB::LD + wn * (Cfg::TN * 32) + (lane & 31);
+    const int h = lane >> 5;
+    const int a_row = wm * (Cfg::TM * 32) + (lane & 31);
+    const int b_row = wn * (Cfg::TN * 32) + (lane & 31);
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -143,7 +139,7 @@ __global__ __launch_bounds__(LMKD_THREADS) void conv_gemm_kernel(ConvGemmArgs a)
       for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) issue(t + 1);
-        mfma_kstep<Cfg, LA::LD, LB::LD>(As0 + cur * SA, Bs0 + cur * SB, a_off, b_off, acc);
+        mfma_kstep<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
         if (t + 1 < nk) {
           la.store(As0 + (cur ^ 1) * SA);
           lb.store(Bs0 + (cur ^ 1) * SB);
@@ -217,6 +213,7 @@ struct WgradArgs {
 
 template <int ROWS, bool SMALLC>
 struct LoaderWgradGather {
+  static constexpr bool ROWK = false;
   static constexpr int NI = ROWS / 32;
   static constexpr int LD = ROWS;
   static constexpr int LDS_FLOATS = LMKD_BK * LD;
@@ -324,29 +321,29 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
-// K-outer packed weights (the GEMM's B operand, row k contiguous over the output columns):
-// mode 0 (forward): Wp[(kh*KWp+kw)*Cs + ci][co] = W[co][ci][kh][kw]   (zero for padded kw / ci)
-// mode 1 (dgrad)  : Wd[(kh*KW+kw)*Co + co][ci] = W[co][ci][kh][kw]
+// K-major packed weights (the GEMM's B operand: one row of K per output column):
+// mode 0 (forward): Wp[co][(kh*KWp+kw)*Cs + ci] = W[co][ci][kh][kw]   (zero for padded kw / ci)
+// mode 1 (dgrad)  : Wd[ci][(kh*KW+kw)*Co + co] = W[co][ci][kh][kw]
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Cin, int Cs, int KH,
                                     int KW, int KWp, int mode) {
   if (mode == 0) {
     const long total = (long)Co * KH * KWp * Cs;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-      const int co = idx % Co;
-      long r = idx / Co;
-      const int ci = r % Cs; r /= Cs;
-      const int kw = r % KWp;
-      const int kh = r / KWp;
+      const int ci = idx % Cs;
+      long r = idx / Cs;
+      const int kw = r % KWp; r /= KWp;
+      const int kh = r % KH;
+      const int co = r / KH;
       wp[idx] = (ci < Cin && kw < KW) ? w[(((long)co * Cin + ci) * KH + kh) * KW + kw] : 0.f;
     }
   } else {
     const long total = (long)Cin * KH * KW * Co;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-      const int ci = idx % Cin;
-      long r = idx / Cin;
-      const int co = r % Co; r /= Co;
-      const int kw = r % KW;
-      const int kh = r / KW;
+      const int co = idx % Co;
+      long r = idx / Co;
+      const int kw = r % KW; r /= KW;
+      const int kh = r % KH;
+      const int ci = r / KH;
       wp[idx] = w[(((long)co * Cin + ci) * KH + kh) * KW + kw];
     }
   }
@@ -400,10 +397,11 @@ static int pick_conv_cfg(long rows_per_class, int nclass, int ncols) {
     const int id = cand[c];
     if (ncols <= 64 && cfg_bn(id) == 128) continue;
     const long tiles = (long)nclass * cdiv(rows_per_class, cfg_bm(id)) * cdiv(ncols, cfg_bn(id));
-    // matrix-pipe-bound model: a CU's time is the MFMA work of the tiles it receives, whatever their concurrency;
-    // smaller tiles pay ~3-5 % for extra staging, barriers and epilogues (measured per layer, profiles/)
+    // matrix-pipe-bound model: a CU's time is the MFMA work of the tiles it receives, whatever their concurrency.
+    // Measured per layer (profiles/): with 4 workgroups (= 4 waves per SIMD) resident the 64x64 tile sustains 104-110
+    // TFLOP/s, the 128-wide tiles (2-3 workgroups per CU) 92-103, so occupancy outweighs operand reuse here.
     double cost = (double)cdiv(tiles, 256) * cfg_bm(id) * cfg_bn(id);
-    cost *= (id == 1 ? 1.00 : (id == 3 ? 1.05 : 1.03));
+    cost *= (id == 1 ? 1.12 : (id == 3 ? 1.00 : 1.07));
     if (cost < best_cost) { best_cost = cost; best = id; }
   }
   return best;
@@ -525,6 +523,8 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
 // pixel range is split over gridDim.z.  The split count is chosen so that the launch is (just under) a whole number of
 // rounds of resident workgroups: an arbitrary count leaves a 1.5-round launch that runs as long as a 2-round one.
 static void wgrad_plan(int Mpix, int Cout, int Kp, int* splits, int* steps_per_split, int* bm, int* bn) {
+  // both operands are K-outer here (b32 fragment reads): the 128-wide tiles (1 read per MFMA) beat 64x64 (2 per MFMA):
+  // measured 91.6 vs 74.8 TFLOP/s over the trunk's weight gradients
   *bm = Cout <= 64 ? 64 : 128;
   *bn = (Kp % 128 == 0 && Kp >= 1024) ? 128 : 64;
   const int tiles = cdiv(Cout, *bm) * cdiv(Kp, *bn);
@@ -533,14 +533,14 @@ static void wgrad_plan(int Mpix, int Cout, int Kp, int* splits, int* steps_per_s
   const int slots = 256 * per_cu;
   int best_sp = 1;
   double best_cost = 1e30;
-  for (int r = 1; r <= 3; ++r) {
+  for (int r = 1; r <= 3; ++r) {            // (just under) r whole rounds of resident workgroups
     int sp = (slots * r) / tiles;
     if (sp > steps / 4) sp = steps / 4;
     if (sp < 1) sp = 1;
     const int sps = cdiv(steps, sp);
     sp = cdiv(steps, sps);
     const double rounds = (double)cdiv((long)tiles * sp, slots);
-    // cost: K-steps executed per slot, plus the slab write + reduce traffic expressed in K-step units (~1 step per split)
+    // cost: K-steps executed per slot, plus the slab write + reduce traffic expressed in K-step units
     const double cost = rounds * sps + 1.0 * sp / 8.0;
     if (cost < best_cost) { best_cost = cost; best_sp = sp; }
   }

@@ -1,12 +1,18 @@
 // fp32 MFMA tile engine for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, 64 cycles/SIMD).
 //
-// One 256-thread workgroup (4 waves, one per SIMD) owns a BM x BN output tile.  Both
-// operand tiles live in LDS in "K-outer" form  S[k][row]  (row = M index for A, N index
-// for B), double buffered, BK = 32.  A wave's MFMA fragments are then single ds_read_b32
-// per operand per k-pair: lane (r = lane&31, h = lane>>5) reads S[2*kk + h][row0 + r]
-// (32 consecutive floats per half wave -> conflict free).  At 64 cycles per MFMA the LDS
-// and VALU pipes have ~10x slack, so the engine is MFMA-issue bound by construction; the
-// loaders only have to keep HBM/L2 requests 128-B coalesced.
+// One 256-thread workgroup (4 waves, one per SIMD) owns a BM x BN output tile; both operand tiles are double
+// buffered in LDS, BK = 32.  Two LDS tile forms, chosen by how the operand lies in memory:
+//   RowK   S[row][36]  (K contiguous in memory: x[M,K], W[N,K], NHWC im2col rows).  Filled with one ds_write_b128 per
+//          16-B global chunk; a lane (r = lane&31, h = lane>>5) reads its fragments with ONE ds_read_b128 per 8 k:
+//          S[row0+r][8t+4h .. 8t+4h+3].  Row stride 36 floats = 9 x 16 B and 9 is odd, so the 16 rows of a b128 lane
+//          group cover all 64 banks: conflict free.
+//   KOuter S[k][rows]  (K-outer in memory: dy[pix][C], W[N,K] read as B[k=N][K]).  Filled with ds_write_b128 along the
+//          row index; fragments are ds_read_b32 of 32 consecutive floats per half wave.
+// An MFMA 32x32x2 consumes k = {k0, k1} on lane halves h = 0/1; any assignment of the 32 k of a K-step to (MFMA, half)
+// works as long as A and B use the same one.  Here MFMA (t, j) of a K-step takes k = 8t + 4h + j, which is what the
+// b128 RowK read delivers in its 4 components.
+// At 64 cycles per MFMA the LDS and VALU pipes have large slack; the fragment reads of group t+1 are issued before
+// the MFMAs of group t so their latency hides behind 16 x 64 MFMA cycles.
 //
 // Loaders (global -> registers -> LDS, software prefetch of the next K-step while the
 // MFMAs of the current one run):
@@ -38,13 +44,15 @@ struct TileCfg {
 // ---------------------------------------------------------------------------------
 // loaders
 // ---------------------------------------------------------------------------------
-// K-major dense: elem(row, k) = base[row*ld + k].  LDS tile S[k][row], LD = ROWS+1 (odd:
-// the transposing ds_write_b32 of a half wave then hits 32 distinct banks).
+#define LMKD_LDK 36   // RowK row stride in floats
+
+// K-major dense: elem(row, k) = base[row*ld + k].  LDS tile RowK.
 template <int ROWS>
 struct LoaderKMajorDense {
+  static constexpr bool ROWK = true;
   static constexpr int NI = ROWS / 32;
-  static constexpr int LD = ROWS + 1;
-  static constexpr int LDS_FLOATS = LMKD_BK * LD;
+  static constexpr int LD = LMKD_LDK;
+  static constexpr int LDS_FLOATS = ROWS * LMKD_LDK;
   const float* p[NI];
   float4 reg[NI];
   int kc4, K;
@@ -69,19 +77,14 @@ struct LoaderKMajorDense {
   __device__ __forceinline__ void store(float* S) const {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      float* d = S + kc4 * LD + (tid >> 3) + 32 * i;
-      d[0] = reg[i].x;
-      d[LD] = reg[i].y;
-      d[2 * LD] = reg[i].z;
-      d[3 * LD] = reg[i].w;
-    }
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(S + ((tid >> 3) + 32 * i) * LMKD_LDK + kc4) = reg[i];
   }
 };
 
-// K-outer dense: elem(k, row) = base[k*ld + row].  LDS tile S[k][row], LD = ROWS.
+// K-outer dense: elem(k, row) = base[k*ld + row].  LDS tile KOuter, LD = ROWS.
 template <int ROWS>
 struct LoaderMMajorDense {
+  static constexpr bool ROWK = false;
   static constexpr int NI = ROWS / 32;
   static constexpr int LD = ROWS;
   static constexpr int LDS_FLOATS = LMKD_BK * LD;
@@ -121,34 +124,46 @@ struct LoaderMMajorDense {
 // ---------------------------------------------------------------------------------
 // MFMA main loop
 // ---------------------------------------------------------------------------------
-// One K-step (BK/2 k-pairs) of MFMAs from the LDS tiles.  The fragments of k-pair kk+1 are read from LDS BEFORE the
-// MFMAs of k-pair kk are issued (two register sets, fully unrolled), so the ~100-cycle ds_read latency hides behind the
-// 4 x 64-cycle MFMAs of the previous pair; hipcc otherwise emits read -> wait lgkmcnt(0) -> 4 MFMAs per pair and the
-// matrix pipe idles at every pair.
-template <class Cfg, int LDA, int LDB>
-__device__ __forceinline__ void mfma_kstep(const float* __restrict__ As, const float* __restrict__ Bs,
-                                           int a_off, int b_off, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
-  constexpr int NK = LMKD_BK / 2;
-  float a[2][Cfg::TM], b[2][Cfg::TN];
+// Fragments of k-group t (8 k: MFMA j takes k = 8t + 4h + j) of one operand: N tiles of 32 rows starting at `row`.
+template <bool ROWK, int LD, int N>
+__device__ __forceinline__ void read_frags(const float* __restrict__ S, int row, int h, int t, float (&f)[N][4]) {
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i) a[0][i] = As[a_off + 32 * i];
+  for (int i = 0; i < N; ++i) {
+    if (ROWK) {
+      const float4 q = *reinterpret_cast<const float4*>(S + (row + 32 * i) * LD + 8 * t + 4 * h);
+      f[i][0] = q.x; f[i][1] = q.y; f[i][2] = q.z; f[i][3] = q.w;
+    } else {
 #pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) b[0][j] = Bs[b_off + 32 * j];
+      for (int j = 0; j < 4; ++j) f[i][j] = S[(8 * t + 4 * h + j) * LD + row + 32 * i];
+    }
+  }
+}
+
+// One K-step (BK = 32 = 4 groups of 8 k, 4 MFMAs per output tile per group) from the LDS tiles.  The fragments of group
+// t+1 are read BEFORE the MFMAs of group t are issued (two register sets, fully unrolled; the sched_barrier keeps hipcc
+// from sinking the reads next to their use), so the LDS latency hides behind the MFMAs.
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void mfma_kstep(const float* __restrict__ As, const float* __restrict__ Bs, int a_row, int b_row,
+                                           int h, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  constexpr int NG = LMKD_BK / 8;
+  float a[2][Cfg::TM][4], b[2][Cfg::TN][4];
+  read_frags<LA::ROWK, LA::LD, Cfg::TM>(As, a_row, h, 0, a[0]);
+  read_frags<LB::ROWK, LB::LD, Cfg::TN>(Bs, b_row, h, 0, b[0]);
 #pragma unroll
-  for (int kk = 0; kk < NK; ++kk) {
-    const int cur = kk & 1, nxt = cur ^ 1;
-    if (kk + 1 < NK) {
-#pragma unroll
-      for (int i = 0; i < Cfg::TM; ++i) a[nxt][i] = As[a_off + 2 * (kk + 1) * LDA + 32 * i];
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) b[nxt][j] = Bs[b_off + 2 * (kk + 1) * LDB + 32 * j];
-      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this pair's MFMAs (hipcc would sink it)
+  for (int t = 0; t < NG; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    if (t + 1 < NG) {
+      read_frags<LA::ROWK, LA::LD, Cfg::TM>(As, a_row, h, t + 1, a[nxt]);
+      read_frags<LB::ROWK, LB::LD, Cfg::TN>(Bs, b_row, h, t + 1, b[nxt]);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < Cfg::TN; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][j], b[cur][jj][j], acc[i][jj], 0, 0, 0);
   }
 }
 
@@ -161,9 +176,9 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nk, FA koffA, 
   float* Bs0 = smem + 2 * SA;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-  const int r = lane & 31, h = lane >> 5;
-  const int a_off = h * LA::LD + wm * (Cfg::TM * 32) + r;
-  const int b_off = h * LB::LD + wn * (Cfg::TN * 32) + r;
+  const int h = lane >> 5;
+  const int a_row = wm * (Cfg::TM * 32) + (lane & 31);
+  const int b_row = wn * (Cfg::TN * 32) + (lane & 31);
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -182,7 +197,7 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nk, FA koffA, 
       la.load(koffA(t + 1));
       lb.load(koffB(t + 1));
     }
-    mfma_kstep<Cfg, LA::LD, LB::LD>(As0 + cur * SA, Bs0 + cur * SB, a_off, b_off, acc);
+    mfma_kstep<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
     if (t + 1 < nk) {
       la.store(As0 + (cur ^ 1) * SA);
       lb.store(Bs0 + (cur ^ 1) * SB);
