@@ -41,8 +41,9 @@ int lmkd_conv_set_tile(int id); /* tuning: 0 auto, 1 128x128, 2 128x64, 3 64x64,
 /* stat_partial (nullable): [row_tiles][Cout][2] per-tile (sum, sum of squares) for train-mode BatchNorm */
 int lmkd_conv2d_fwd(const float* x, const float* wp_fwd, float* y, float* stat_partial, int N, int H, int W, int Cs, int Cout,
                     int KH, int KW, int stride, int pad, void* stream);
+/* accumulate != 0: dx += ... (the block's residual-branch gradient is already in dx) */
 int lmkd_conv2d_bwd_data(const float* dy, const float* wp_dgrad, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                         int stride, int pad, void* stream);
+                         int stride, int pad, int accumulate, void* stream);
 long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad);
 int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, float* workspace, long ws_bytes, int N, int H, int W,
                            int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);

@@ -25,6 +25,7 @@ struct ConvGemmArgs {
   int sh;
   int Ho, Wo, Co, omul;
   int Kp, cps, nclass;
+  int accum;   // epilogue: out = acc + out (residual-branch gradient already sits in the output buffer)
   FastDiv div_hw, div_w;
   int ntap[LMKD_MAX_CLASSES];
   Tap taps[LMKD_MAX_CLASSES][LMKD_MAX_TAPS];
@@ -165,7 +166,10 @@ __global__ __launch_bounds__(LMKD_THREADS) void conv_gemm_kernel(ConvGemmArgs a)
       for (int j = 0; j < Cfg::TN; ++j) {
         const int col = n0 + cl0 + j * 32;
         const float v = acc[i][j][e];
-        if (ob >= 0 && col < a.Co) a.out[(long)ob + col] = v;
+        if (ob >= 0 && col < a.Co) {
+          float* o = a.out + (long)ob + col;
+          *o = a.accum ? v + *o : v;
+        }
         if (STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
       }
     }
@@ -470,9 +474,9 @@ extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float*
   return stat_partial ? launch_conv_gemm<false, true>(a, Cout, s) : launch_conv_gemm<false, false>(a, Cout, s);
 }
 
-// dx[N,H,W,Cin] from dy[N,Ho,Wo,Cout]; wd = weights packed with mode 1
+// dx[N,H,W,Cin] (+= when accumulate) from dy[N,Ho,Wo,Cout]; wd = weights packed with mode 1
 extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx, int N, int H, int W, int Cin, int Cout,
-                                    int KH, int KW, int stride, int pad, void* stream) {
+                                    int KH, int KW, int stride, int pad, int accumulate, void* stream) {
   LMKD_REQUIRE(dy && wd && dx, "lmkd_conv2d_bwd_data: null pointer");
   LMKD_REQUIRE(aligned16(dy) && aligned16(wd), "lmkd_conv2d_bwd_data: operands must be 16-byte aligned");
   LMKD_REQUIRE(Cout % 32 == 0, "lmkd_conv2d_bwd_data: Cout=%d must be a multiple of 32", Cout);
@@ -484,7 +488,7 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
                "lmkd_conv2d_bwd_data: tensor exceeds 2^31 elements");
   ConvGemmArgs a;
   memset(&a, 0, sizeof(a));
-  a.src = dy; a.wpk = wd; a.out = dx; a.stat_partial = nullptr;
+  a.src = dy; a.wpk = wd; a.out = dx; a.stat_partial = nullptr; a.accum = accumulate;
   a.N = N; a.Hs = Ho; a.Ws = Wo; a.Cs = Cout;
   a.Ho = H; a.Wo = W; a.Co = Cin;
   a.Kp = KH * KW * Cout; a.cps = Cout / 32;

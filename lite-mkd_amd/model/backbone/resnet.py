@@ -49,7 +49,10 @@ class _Block(nn.Module):
 
     def forward(self, x):
         tr = self.training
+        ops.mark_cacheable(self.conv1.weight)
+        ops.mark_cacheable(self.conv2.weight)
         if self.downsample is not None:
+            ops.mark_cacheable(self.downsample[0].weight)
             ds = (self.downsample[0].weight,) + self.downsample[1].args()
         else:
             ds = (None, None, None, None, None)
@@ -72,6 +75,7 @@ class ResNet18Trunk(nn.Module):
 
     def forward(self, x):
         conv, bn = getattr(self, "0"), getattr(self, "1")
+        ops.mark_cacheable(conv.weight)
         y = ops.StemFn.apply(x, conv.weight, *bn.args(), self.training)
         for name, _, _, _ in STAGES:
             for blk in getattr(self, name):
@@ -107,6 +111,7 @@ def two_trunk_calls(trunk, head, context_frames, target_frames):
     target_frames.record_stream(side)
     q_upd, s_upd = [], []
     defer = trunk.training
+    ops.mark_cacheable(getattr(trunk, "0").weight)
     layers = [lambda t: ops.StemFn.apply(t, getattr(trunk, "0").weight, *getattr(trunk, "1").args(), trunk.training)]
     for name, _, _, _ in STAGES:
         layers += list(getattr(trunk, name))

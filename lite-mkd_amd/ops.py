@@ -113,7 +113,44 @@ class LinearFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------
 # convolution pieces
 # ------------------------------------------------------------------------------------------
+# Packed weights of module parameters are cached: the two trunk calls of an episode and all episodes between two optimizer
+# steps reuse them.  Only parameters that a module has registered with mark_cacheable() are cached (identity is checked
+# through a weak reference, so a recycled device address can never return another tensor's pack); the cache entry is
+# validated by the parameter's in-place `_version` (torch optimizers, load_state_dict) and by WEIGHT_EPOCH, which the
+# fused HIP optimizer bumps because it updates the flat buffer through raw pointers.
+import weakref
+
+WEIGHT_EPOCH = [0]
+_pack_cache = {}
+
+
+def mark_cacheable(param):
+    ptr = param.data_ptr()
+    e = _pack_cache.get(ptr)
+    if e is None or e["ref"]() is not param:
+        _pack_cache[ptr] = {"ref": weakref.ref(param), "packs": {}}
+
+
 def pack_weights(w, Cs, mode):
+    e = _pack_cache.get(w.data_ptr())
+    owner = e["ref"]() if e is not None else None
+    if owner is None or owner.data_ptr() != w.data_ptr() or owner.shape != w.shape:
+        return _pack_weights(w, Cs, mode)
+    tag = (owner._version, WEIGHT_EPOCH[0])
+    cur = torch.cuda.current_stream()
+    hit = e["packs"].get((Cs, mode))
+    if hit is not None and hit[0] == tag:
+        if hit[3] != cur.cuda_stream:
+            cur.wait_event(hit[2])            # packed on the other stream: order this stream behind the pack kernel
+        return hit[1]
+    wp = _pack_weights(w, Cs, mode)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    e["packs"][(Cs, mode)] = (tag, wp, ev, cur.cuda_stream)
+    return wp
+
+
+def _pack_weights(w, Cs, mode):
     Cout, Cin, KH, KW = w.shape
     n = lib().value("lmkd_conv2d_packed_weight_elems", Cout, Cin, Cs, KH, KW, mode)
     wp = _empty((n,), w)
@@ -163,12 +200,14 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats):
     return y, part
 
 
-def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None):
+def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumulate=False):
     N, H, W, Cin = x_shape
     _chk(dy, wd, out)
+    if accumulate and out is None:
+        raise ValueError("accumulate needs an output buffer")
     dx = out if out is not None else _empty((N, H, W, Cin), dy)
     with _timed("conv_gemm_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW):
-        lib().call("lmkd_conv2d_bwd_data", _p(dy), _p(wd), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, _stream())
+        lib().call("lmkd_conv2d_bwd_data", _p(dy), _p(wd), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, int(accumulate), _stream())
     return dx
 
 
@@ -351,7 +390,7 @@ class BasicBlockFn(torch.autograd.Function):
         da1 = conv_bwd_data(dc2, wd2, a1.shape, Cmid, 3, 3, 1, 1)
         dw2 = conv_bwd_weight(a1, dc2, tuple(w2.shape), 1, 1)
         del dc2
-        dc1, _, dg1, db1 = bn_backward(da1, c1, a1, st1, g1, 1, dx_out=da1)
+        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)    # mask from c1*scale+shift > 0
         dw1 = conv_bwd_weight(x, dc1, tuple(w1.shape), stride, 1)
         dwd = dgd = dbd = None
         need_dx = ctx.needs_input_grad[0]
@@ -366,8 +405,7 @@ class BasicBlockFn(torch.autograd.Function):
             dx = g                                    # identity branch
         if need_dx:
             wd1 = pack_weights(w1, Cmid, 1)
-            tmp = conv_bwd_data(dc1, wd1, x.shape, Cmid, 3, 3, stride, 1)
-            lib().call("lmkd_axpby", _p(tmp), _p(dx), _f32(1.0), _f32(1.0), dx.numel(), _stream())
+            conv_bwd_data(dc1, wd1, x.shape, Cmid, 3, 3, stride, 1, out=dx, accumulate=True)   # dx += dgrad(conv1)
         return (dx if need_dx else None, None, None, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None,
                 dwd, dgd, dbd, None, None)
 

@@ -33,6 +33,7 @@ class FusedOptimizer:
         b = self.bucket
         b.allreduce_grads()
         self.steps += 1
+        ops.WEIGHT_EPOCH[0] += 1            # invalidates the packed-weight cache (raw-pointer update below)
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
         if self.opt == "sgd":

@@ -124,3 +124,31 @@ def test_full_size_properties(dev):
     # batch statistics are permutation invariant up to fp32 summation order
     assert float((f3 - f1[perm]).abs().max()) < 1e-3 * float(f1.abs().max())
     assert torch.isfinite(f1).all()
+
+
+def test_packed_weight_cache_follows_optimizer(dev):
+    """the packed conv weights are cached between optimizer steps; after a fused SGD step (raw-pointer update) and after
+    an in-place torch update the next forward must see the new weights"""
+    from litemkd_amd import trainloop as TL
+    from litemkd_amd.model.backbone.resnet import ResNet18Trunk
+    torch.manual_seed(5)
+    trunk = ResNet18Trunk().to(dev).train()
+    x = torch.rand(4, 3, 64, 64, device=dev)
+    opt = TL.FusedOptimizer(trunk, "sgd", 0.05)
+    y0 = trunk(x)
+    y0.sum().backward()
+    opt.step()                                   # weights change through the flat buffer
+    y1 = trunk(x)
+    fresh = ResNet18Trunk().to(dev).train()
+    fresh.load_state_dict(trunk.state_dict())    # same weights, no cached packs
+    for m in fresh.modules():
+        if hasattr(m, "running_mean"):
+            pass
+    # running statistics do not enter train-mode outputs, so the two forwards must agree exactly
+    y2 = fresh(x)
+    assert float((y1 - y0).abs().max()) > 0
+    assert torch.equal(y1, y2)
+    with torch.no_grad():
+        getattr(trunk, "4")[0].conv1.weight.mul_(1.5)      # in-place torch update bumps _version
+    fresh.load_state_dict(trunk.state_dict())
+    assert torch.equal(trunk(x), fresh(x))
