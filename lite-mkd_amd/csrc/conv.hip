@@ -25,6 +25,7 @@ struct ConvGemmArgs {
   int sh;
   int Ho, Wo, Co, omul;
   int Kp, cps, nclass;
+  int n_rt, n_ct;   // row tiles (all classes) and column tiles of this launch (XCD-aware 1-D grid, see xcd_decode)
   int accum;   // epilogue: out = acc + out (residual-branch gradient already sits in the output buffer)
   FastDiv div_hw, div_w;
   int ntap[LMKD_MAX_CLASSES];
@@ -32,10 +33,11 @@ struct ConvGemmArgs {
 };
 
 // K-major implicit-im2col loader (rows = output pixels of this tile).
-template <int ROWS, bool SMALLC>
+template <int ROWS, bool SMALLC, int THREADS = LMKD_THREADS>
 struct LoaderConvGather {
   static constexpr bool ROWK = true;
-  static constexpr int NI = ROWS / 32;
+  static constexpr int RPP = THREADS / 8;
+  static constexpr int NI = ROWS / RPP;
   static constexpr int LD = LMKD_LDK;
   static constexpr int LDS_FLOATS = ROWS * LMKD_LDK;
   int base[NI], hw[NI];
@@ -48,8 +50,8 @@ struct LoaderConvGather {
     kc4 = (tid & 7) * 4;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      base[i] = s_src[(tid >> 3) + 32 * i];
-      hw[i] = s_hw[(tid >> 3) + 32 * i];
+      base[i] = s_src[(tid >> 3) + RPP * i];
+      hw[i] = s_hw[(tid >> 3) + RPP * i];
     }
   }
   // tap: this step's {dh,dw}; coff: channel offset inside the tap (multiple of 32)
@@ -68,24 +70,54 @@ struct LoaderConvGather {
   __device__ __forceinline__ void store(float* S) const {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(S + ((tid >> 3) + 32 * i) * LMKD_LDK + kc4) = reg[i];
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(S + ((tid >> 3) + RPP * i) * LMKD_LDK + kc4) = reg[i];
   }
 };
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2) in linear id order.  Tiles that share a
+// weight column slice are therefore given ids that are congruent mod 8, so one XCD keeps re-reading the SAME slice of the
+// packed weights from its own L2 (layer 4: 9.4 MB of weights, 1.2 MB per 64-column slice) instead of every XCD streaming
+// all of them through the Infinity Cache.  Pure speed hint: any placement computes the same tiles.
+__device__ __forceinline__ bool xcd_decode(int L, int n_rt, int n_ct, int& rt, int& ct) {
+  const int x = L & 7, j = L >> 3;
+  if (n_ct >= 8 && (n_ct & 7) == 0) {
+    ct = x + 8 * (j / n_rt);
+    rt = j - (j / n_rt) * n_rt;
+    return ct < n_ct;
+  }
+  if (n_ct == 1 || n_ct == 2 || n_ct == 4) {
+    const int g = 8 / n_ct;               // XCDs sharing one column tile
+    ct = x % n_ct;
+    rt = j * g + x / n_ct;
+    return rt < n_rt;
+  }
+  const int t = L;                        // generic fallback: row-major
+  ct = t / n_rt;
+  rt = t - ct * n_rt;
+  return ct < n_ct;
+}
+static inline int xcd_grid(int n_rt, int n_ct) {
+  if (n_ct >= 8 && (n_ct & 7) == 0) return n_rt * n_ct;
+  if (n_ct == 1 || n_ct == 2 || n_ct == 4) return 8 * cdiv(n_rt, 8 / n_ct);
+  return n_rt * n_ct;
+}
+
 template <class Cfg, bool SMALLC, bool STATS>
-__global__ __launch_bounds__(LMKD_THREADS) void conv_gemm_kernel(ConvGemmArgs a) {
-  using LA = LoaderConvGather<Cfg::BM, SMALLC>;
-  using LB = LoaderKMajorDense<Cfg::BN>;   // packed weights are K-major: Wp[col][k]
+__global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a) {
+  using LA = LoaderConvGather<Cfg::BM, SMALLC, Cfg::THREADS>;
+  using LB = LoaderKMajorDense<Cfg::BN, Cfg::THREADS>;   // packed weights are K-major: Wp[col][k]
   __shared__ __attribute__((aligned(16))) float smem[2 * (LA::LDS_FLOATS + LB::LDS_FLOATS)];
   __shared__ int s_src[Cfg::BM], s_hw[Cfg::BM], s_out[Cfg::BM];
   __shared__ float s_red[STATS ? Cfg::WM * Cfg::BN * 2 : 1];
 
   const int tid = threadIdx.x;
-  const int cls = blockIdx.x / a.tiles_per_class;
-  const int tile = blockIdx.x - cls * a.tiles_per_class;
+  int rt, ct;
+  if (!xcd_decode(blockIdx.x, a.n_rt, a.n_ct, rt, ct)) return;
+  const int cls = rt / a.tiles_per_class;
+  const int tile = rt - cls * a.tiles_per_class;
   const int ph = cls >> 1, pw = cls & 1;
-  const int row0 = tile * Cfg::BM, n0 = blockIdx.y * Cfg::BN;
-  for (int r = tid; r < Cfg::BM; r += LMKD_THREADS) {
+  const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
+  for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
     const int m = row0 + r;
     if (m < a.rows_per_class) {
       const int n = fdiv(m, a.div_hw);
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(LMKD_THREADS) void conv_gemm_kernel(ConvGemmArgs a)
         s1 += s_red[(w * Cfg::BN + tid) * 2 + 0];
         s2 += s_red[(w * Cfg::BN + tid) * 2 + 1];
       }
-      float* p = a.stat_partial + ((long)blockIdx.x * a.Co + n0 + tid) * 2;
+      float* p = a.stat_partial + ((long)rt * a.Co + n0 + tid) * 2;
       p[0] = s1;
       p[1] = s2;
     }
@@ -379,33 +411,38 @@ extern "C" int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout
 }
 
 // ---- tile configuration -------------------------------------------------------------------------
-// id: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 (rows x cols).  Workgroups per CU by LDS: 2 / 3 / 4 / 3.
+// id: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 (rows x cols, 4 waves), 5 = 128x128 and 6 = 128x64 with 8 waves (2 per SIMD).
+// Workgroups per CU by LDS: 2 / 2 / 4 / 2 / 2.
 static int g_tile_override = 0;
 extern "C" int lmkd_conv_set_tile(int id) {
-  LMKD_REQUIRE(id >= 0 && id <= 4, "lmkd_conv_set_tile: id must be 0 (auto) .. 4");
+  LMKD_REQUIRE(id >= 0 && id <= 6, "lmkd_conv_set_tile: id must be 0 (auto) .. 6");
   g_tile_override = id;
   return LMKD_OK;
 }
-static inline int cfg_bm(int id) { return id <= 2 ? 128 : 64; }
-static inline int cfg_bn(int id) { return (id == 1 || id == 4) ? 128 : 64; }
+static inline int cfg_bm(int id) { return (id <= 2 || id >= 5) ? 128 : 64; }
+static inline int cfg_bn(int id) { return (id == 1 || id == 4 || id == 5) ? 128 : 64; }
 static inline int cfg_wg_per_cu(int id) { return id == 1 ? 2 : (id == 3 ? 4 : 3); }
 
 // Pick the tile that minimises ceil(tiles / 256 CUs) * work per tile: at 64 cycles per fp32 MFMA every configuration is
 // matrix-pipe bound, so what differs is how evenly the launch's tiles divide over the CUs (the tail).
 static int pick_conv_cfg(long rows_per_class, int nclass, int ncols) {
-  if (g_tile_override) return (ncols <= 64 && cfg_bn(g_tile_override) == 128) ? (cfg_bm(g_tile_override) == 128 ? 2 : 3) : g_tile_override;
+  if (g_tile_override) {
+    if (ncols <= 64 && cfg_bn(g_tile_override) == 128) return g_tile_override == 5 ? 6 : (cfg_bm(g_tile_override) == 128 ? 2 : 3);
+    return g_tile_override;
+  }
   int best = 0;
   double best_cost = 1e30;
-  const int cand[4] = {1, 2, 4, 3};
+  const int cand[4] = {5, 2, 4, 3};
   for (int c = 0; c < 4; ++c) {
     const int id = cand[c];
     if (ncols <= 64 && cfg_bn(id) == 128) continue;
     const long tiles = (long)nclass * cdiv(rows_per_class, cfg_bm(id)) * cdiv(ncols, cfg_bn(id));
     // matrix-pipe-bound model: a CU's time is the MFMA work of the tiles it receives, whatever their concurrency.
-    // Measured per layer (profiles/): with 4 workgroups (= 4 waves per SIMD) resident the 64x64 tile sustains 104-110
-    // TFLOP/s, the 128-wide tiles (2-3 workgroups per CU) 92-103, so occupancy outweighs operand reuse here.
+    // Measured per layer (profiles/): what matters is 4 waves per SIMD.  128x128 with 8 waves (2 workgroups per CU)
+    // sustains 115-119 TFLOP/s when the launch has many tiles, 64x64 with 4 waves (4 per CU) 104-110, the 4-wave 128-wide
+    // tiles (2 waves per SIMD) 92-103.
     double cost = (double)cdiv(tiles, 256) * cfg_bm(id) * cfg_bn(id);
-    cost *= (id == 1 ? 1.12 : (id == 3 ? 1.00 : 1.07));
+    cost *= (id == 5 ? 0.92 : (id == 3 ? 1.00 : 1.07));
     if (cost < best_cost) { best_cost = cost; best = id; }
   }
   return best;
@@ -414,8 +451,9 @@ static int pick_conv_cfg(long rows_per_class, int nclass, int ncols) {
 template <class Cfg, bool SMALLC, bool STATS>
 static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
   a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
-  dim3 grid(a.nclass * a.tiles_per_class, cdiv(ncols, Cfg::BN));
-  hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS>), grid, dim3(LMKD_THREADS), 0, s, a);
+  a.n_rt = a.nclass * a.tiles_per_class;
+  a.n_ct = cdiv(ncols, Cfg::BN);
+  hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS>), dim3(xcd_grid(a.n_rt, a.n_ct)), dim3(Cfg::THREADS), 0, s, a);
 }
 
 template <bool SMALLC, bool STATS>
@@ -424,6 +462,8 @@ static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
     case 1: launch_conv_cfg<TileCfg<128, 128, 2, 2>, SMALLC, STATS>(a, ncols, s); break;
     case 2: launch_conv_cfg<TileCfg<128, 64, 2, 2>, SMALLC, STATS>(a, ncols, s); break;
     case 3: launch_conv_cfg<TileCfg<64, 64, 2, 2>, SMALLC, STATS>(a, ncols, s); break;
+    case 5: launch_conv_cfg<TileCfg<128, 128, 2, 4>, SMALLC, STATS>(a, ncols, s); break;
+    case 6: launch_conv_cfg<TileCfg<128, 64, 4, 2>, SMALLC, STATS>(a, ncols, s); break;
     default: launch_conv_cfg<TileCfg<64, 128, 2, 2>, SMALLC, STATS>(a, ncols, s); break;
   }
   LMKD_CHECK_LAUNCH("conv_gemm_kernel");

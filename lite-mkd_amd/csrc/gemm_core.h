@@ -37,7 +37,8 @@ template <int BM_, int BN_, int WM_, int WN_>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
   static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static_assert(WM * WN == 4, "4 waves");
+  static constexpr int THREADS = 64 * WM * WN;     // 4 waves (one per SIMD) or 8 waves (two per SIMD)
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   static_assert(TM >= 1 && TN >= 1, "wave tile");
 };
 
@@ -47,10 +48,12 @@ struct TileCfg {
 #define LMKD_LDK 36   // RowK row stride in floats
 
 // K-major dense: elem(row, k) = base[row*ld + k].  LDS tile RowK.
-template <int ROWS>
+template <int ROWS, int THREADS = LMKD_THREADS>
 struct LoaderKMajorDense {
   static constexpr bool ROWK = true;
-  static constexpr int NI = ROWS / 32;
+  static constexpr int RPP = THREADS / 8;          // rows per pass (8 lanes x 16 B cover one 32-float row)
+  static constexpr int NI = ROWS / RPP;
+  static_assert(ROWS % RPP == 0, "tile rows vs threads");
   static constexpr int LD = LMKD_LDK;
   static constexpr int LDS_FLOATS = ROWS * LMKD_LDK;
   const float* p[NI];
@@ -62,7 +65,7 @@ struct LoaderKMajorDense {
     K = K_;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      int r = row0 + (tid >> 3) + 32 * i;
+      int r = row0 + (tid >> 3) + RPP * i;
       p[i] = (r < nrows) ? base + (long)r * ld + kc4 : nullptr;
     }
   }
@@ -77,18 +80,20 @@ struct LoaderKMajorDense {
   __device__ __forceinline__ void store(float* S) const {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(S + ((tid >> 3) + 32 * i) * LMKD_LDK + kc4) = reg[i];
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(S + ((tid >> 3) + RPP * i) * LMKD_LDK + kc4) = reg[i];
   }
 };
 
 // K-outer dense: elem(k, row) = base[k*ld + row].  LDS tile KOuter, LD = ROWS.
-template <int ROWS>
+template <int ROWS, int THREADS = LMKD_THREADS>
 struct LoaderMMajorDense {
   static constexpr bool ROWK = false;
-  static constexpr int NI = ROWS / 32;
   static constexpr int LD = ROWS;
   static constexpr int LDS_FLOATS = LMKD_BK * LD;
   static constexpr int CPR = ROWS / 4;  // float4 chunks per k row
+  static constexpr int KPP = THREADS / CPR;         // k rows per pass
+  static constexpr int NI = LMKD_BK / KPP;
+  static_assert(THREADS % CPR == 0 && LMKD_BK % KPP == 0, "tile rows vs threads");
   const float* base;
   long ld;
   float4 reg[NI];
@@ -106,7 +111,7 @@ struct LoaderMMajorDense {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      int k = koff + tid / CPR + (LMKD_THREADS / CPR) * i;
+      int k = koff + tid / CPR + KPP * i;
       if (rin && k < K) reg[i] = *reinterpret_cast<const float4*>(base + (long)k * ld);
       else reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -115,7 +120,7 @@ struct LoaderMMajorDense {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      int k = tid / CPR + (LMKD_THREADS / CPR) * i;
+      int k = tid / CPR + KPP * i;
       *reinterpret_cast<float4*>(S + k * LD + r4) = reg[i];
     }
   }

@@ -8,7 +8,7 @@
 #define NP_THREADS 256
 static inline int ew_grid(long n_items) {
   long g = (n_items + NP_THREADS - 1) / NP_THREADS;
-  if (g > 256 * 8) g = 256 * 8;
+  if (g > 256 * 4) g = 256 * 4;   // 4 workgroups (16 waves) per CU saturate HBM and leave the other 16 wave slots to a co-running MFMA kernel
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -292,7 +292,7 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
   hipStream_t s = (hipStream_t)stream;
   const int RL = NP_THREADS / (C / 4);
   int nb = cdiv(rows, (long)RL * 8);
-  if (nb > 2048) nb = 2048;
+  if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   float* partial = (float*)workspace;
   double* dscr = (double*)((char*)workspace + (((long)2048 * 2 * C * sizeof(float) + 63) / 64) * 64);
