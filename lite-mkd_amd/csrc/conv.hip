@@ -25,7 +25,7 @@ struct ConvGemmArgs {
   int sh;
   int Ho, Wo, Co, omul;
   int Kp, cps, nclass;
-  int n_rt, n_ct;   // row tiles (all classes) and column tiles of this launch (XCD-aware 1-D grid, see xcd_decode)
+  int n_rt, n_ct, xcd_mode;   // row tiles (all classes), column tiles, tile order (XCD-aware 1-D grid, see xcd_decode)
   int accum;   // epilogue: out = acc + out (residual-branch gradient already sits in the output buffer)
   FastDiv div_hw, div_w;
   int ntap[LMKD_MAX_CLASSES];
@@ -74,32 +74,32 @@ struct LoaderConvGather {
   }
 };
 
-// Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2) in linear id order.  Tiles that share a
-// weight column slice are therefore given ids that are congruent mod 8, so one XCD keeps re-reading the SAME slice of the
-// packed weights from its own L2 (layer 4: 9.4 MB of weights, 1.2 MB per 64-column slice) instead of every XCD streaming
-// all of them through the Infinity Cache.  Pure speed hint: any placement computes the same tiles.
-__device__ __forceinline__ bool xcd_decode(int L, int n_rt, int n_ct, int& rt, int& ct) {
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2) in linear id order.  The tile order is
+// chosen so that what one XCD touches at a time fits its L2 (PMC: the naive order re-fetched every input row ~6x):
+//   mode 0 (row bands): XCD x owns a contiguous band of row tiles and walks it in order, column tiles fastest.  The 3x3
+//          halo rows shared by neighbouring row tiles and the A tile shared by the column tiles are then L2 hits.
+//   mode 1 (column slices, n_ct a multiple of 8): XCD x owns column tiles x, x+8, ...: it keeps re-reading ONE slice of
+//          the packed weights (layer 4: 9.4 MB of weights, 1.2 MB per 64-column slice) while streaming the small A.
+// Pure speed hint: any placement computes the same tiles.
+static int g_xcd_mode = -1;   // -1 auto
+extern "C" int lmkd_conv_set_xcd_mode(int m) { g_xcd_mode = m; return LMKD_OK; }
+
+__device__ __forceinline__ bool xcd_decode(int L, int n_rt, int n_ct, int mode, int& rt, int& ct) {
   const int x = L & 7, j = L >> 3;
-  if (n_ct >= 8 && (n_ct & 7) == 0) {
+  if (mode == 1) {
     ct = x + 8 * (j / n_rt);
     rt = j - (j / n_rt) * n_rt;
     return ct < n_ct;
   }
-  if (n_ct == 1 || n_ct == 2 || n_ct == 4) {
-    const int g = 8 / n_ct;               // XCDs sharing one column tile
-    ct = x % n_ct;
-    rt = j * g + x / n_ct;
-    return rt < n_rt;
-  }
-  const int t = L;                        // generic fallback: row-major
-  ct = t / n_rt;
-  rt = t - ct * n_rt;
-  return ct < n_ct;
+  const int chunk = (n_rt + 7) >> 3;
+  ct = j % n_ct;
+  const int rl = j / n_ct;
+  rt = x * chunk + rl;
+  return rl < chunk && rt < n_rt;
 }
-static inline int xcd_grid(int n_rt, int n_ct) {
-  if (n_ct >= 8 && (n_ct & 7) == 0) return n_rt * n_ct;
-  if (n_ct == 1 || n_ct == 2 || n_ct == 4) return 8 * cdiv(n_rt, 8 / n_ct);
-  return n_rt * n_ct;
+static inline int xcd_grid(int n_rt, int n_ct, int mode) {
+  if (mode == 1) return n_rt * n_ct;
+  return 8 * cdiv(n_rt, 8) * n_ct;
 }
 
 template <class Cfg, bool SMALLC, bool STATS>
@@ -112,9 +112,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
 
   const int tid = threadIdx.x;
   int rt, ct;
-  if (!xcd_decode(blockIdx.x, a.n_rt, a.n_ct, rt, ct)) return;
-  const int cls = rt / a.tiles_per_class;
-  const int tile = rt - cls * a.tiles_per_class;
+  if (!xcd_decode(blockIdx.x, a.n_rt, a.n_ct, a.xcd_mode, rt, ct)) return;
+  // parity classes interleaved (stride-2 data gradient: the classes run 1, 2, 2 and 4 taps): every XCD band and every
+  // stretch of the dispatch order then carries the same mix of light and heavy tiles
+  const int tile = rt / a.nclass;
+  const int cls = rt - tile * a.nclass;
   const int ph = cls >> 1, pw = cls & 1;
   const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
   for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
@@ -244,6 +246,7 @@ struct WgradArgs {
   int N, Hs, Ws, Cs, Ho, Wo, Co;
   int stride, pad, KH, KW, KWp;
   int Kp, Mpix, steps_total, steps_per_split;
+  int n_mt, n_jt, splits, xcd_mode;   // 1-D grid decode (xcd_mode 1: all tiles of pixel split z run on XCD z % 8)
   FastDiv div_hw, div_w;
 };
 
@@ -311,7 +314,21 @@ __global__ __launch_bounds__(LMKD_THREADS) void conv_wgrad_kernel(WgradArgs a) {
   using LA = LoaderMMajorDense<Cfg::BM>;
   using LB = LoaderWgradGather<Cfg::BN, SMALLC>;
   __shared__ __attribute__((aligned(16))) float smem[2 * (LA::LDS_FLOATS + LB::LDS_FLOATS)];
-  const int m0 = blockIdx.x * Cfg::BM, j0 = blockIdx.y * Cfg::BN, z = blockIdx.z;
+  // Tile order.  The 9 column tiles (taps) of one pixel split read the same x rows and the same dy rows; in plain order
+  // they land on different XCDs and every XCD fetches those rows again (PMC: 2.6-3.1 GB per launch on the 160 MB layers).
+  // With many splits, all tiles of split z are given ids congruent mod 8 so that one XCD's L2 serves them.
+  int z, tz;
+  const int tiles_per_z = a.n_mt * a.n_jt;
+  if (a.xcd_mode) {
+    const int xj = blockIdx.x >> 3;
+    z = (blockIdx.x & 7) + 8 * (xj / tiles_per_z);
+    if (z >= a.splits) return;
+    tz = xj - (xj / tiles_per_z) * tiles_per_z;
+  } else {
+    z = blockIdx.x / tiles_per_z;
+    tz = blockIdx.x - z * tiles_per_z;
+  }
+  const int m0 = (tz % a.n_mt) * Cfg::BM, j0 = (tz / a.n_mt) * Cfg::BN;
   LA la;
   LB lb;
   la.init(a.dy, a.Co, m0, a.Co, a.Mpix);
@@ -453,7 +470,9 @@ static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
   a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
   a.n_rt = a.nclass * a.tiles_per_class;
   a.n_ct = cdiv(ncols, Cfg::BN);
-  hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS>), dim3(xcd_grid(a.n_rt, a.n_ct)), dim3(Cfg::THREADS), 0, s, a);
+  a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
+  if (g_xcd_mode == 0) a.xcd_mode = 0;
+  hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS>), dim3(xcd_grid(a.n_rt, a.n_ct, a.xcd_mode)), dim3(Cfg::THREADS), 0, s, a);
 }
 
 template <bool SMALLC, bool STATS>
@@ -624,7 +643,11 @@ extern "C" int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw
   LMKD_REQUIRE(ws_bytes >= (long)splits * Cout * a.Kp * (long)sizeof(float), "lmkd_conv2d_bwd_weight: workspace too small");
   a.div_hw = make_fastdiv(a.Ho * a.Wo); a.div_w = make_fastdiv(a.Wo);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(cdiv(Cout, bm), cdiv(a.Kp, bn), splits);
+  a.n_mt = cdiv(Cout, bm); a.n_jt = cdiv(a.Kp, bn); a.splits = splits;
+  // measured: cuts FETCH_SIZE 3-10x on the 160 MB layers but runs 5-20 % slower (84 vs 93 TFLOP/s on layer 1), so it is
+  // off by default; lmkd_conv_set_xcd_mode(2) turns it on for launches with >= 32 splits
+  a.xcd_mode = (g_xcd_mode == 2 && splits >= 32) ? 1 : 0;
+  dim3 grid((a.xcd_mode ? 8 * cdiv(splits, 8) : splits) * a.n_mt * a.n_jt);
   if (smallc) {
     LMKD_REQUIRE(bm == 64 && bn == 64, "lmkd_conv2d_bwd_weight: padded-stem path expects Cout <= 64");
     hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<64, 64, 2, 2>, true>), grid, dim3(LMKD_THREADS), 0, s, a);
