@@ -169,10 +169,10 @@ CONV_TIMING = None
 
 
 class _timed:
-    def __init__(self, family, flops):
+    def __init__(self, family, flops, nbytes=0):
         self.on = CONV_TIMING is not None
         if self.on:
-            self.rec = (family, flops, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.rec = (family, flops, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), nbytes)
 
     def __enter__(self):
         if self.on:
@@ -195,7 +195,7 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats):
         T = lib().value("lmkd_conv2d_fwd_row_tiles", N, H, W, Cout, KH, KW, stride, pad)
         part = _empty((T, Cout, 2), x)
     cin = 3 if Cs == 4 else Cs
-    with _timed("conv_gemm_kernel", 2.0 * N * Ho * Wo * Cout * cin * KH * KW):
+    with _timed("conv_gemm_kernel", 2.0 * N * Ho * Wo * Cout * cin * KH * KW, 4 * (x.numel() + y.numel() + wp.numel())):
         lib().call("lmkd_conv2d_fwd", _p(x), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, _stream())
     return y, part
 
@@ -206,7 +206,8 @@ def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumula
     if accumulate and out is None:
         raise ValueError("accumulate needs an output buffer")
     dx = out if out is not None else _empty((N, H, W, Cin), dy)
-    with _timed("conv_gemm_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW):
+    with _timed("conv_gemm_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
+                4 * (dy.numel() + dx.numel() * (2 if accumulate else 1) + wd.numel())):
         lib().call("lmkd_conv2d_bwd_data", _p(dy), _p(wd), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, int(accumulate), _stream())
     return dx
 
@@ -218,7 +219,8 @@ def conv_bwd_weight(x, dy, w_shape, stride, pad):
     nbytes = lib().value("lmkd_conv2d_bwd_weight_workspace", N, H, W, Cs, Cout, KH, KW, stride, pad)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     dw = _empty(w_shape, x)
-    with _timed("conv_wgrad_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW):
+    with _timed("conv_wgrad_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
+                4 * (x.numel() + dy.numel() + dw.numel())):
         lib().call("lmkd_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, _stream())
     return dw
 
