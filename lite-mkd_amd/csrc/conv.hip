@@ -250,13 +250,14 @@ struct WgradArgs {
   FastDiv div_hw, div_w;
 };
 
-template <int ROWS, bool SMALLC>
+template <int ROWS, bool SMALLC, int THREADS = LMKD_THREADS>
 struct LoaderWgradGather {
   static constexpr bool ROWK = false;
-  static constexpr int NI = ROWS / 32;
   static constexpr int LD = ROWS;
   static constexpr int LDS_FLOATS = LMKD_BK * LD;
   static constexpr int CPR = ROWS / 4;
+  static constexpr int KPP = THREADS / CPR;
+  static constexpr int NI = LMKD_BK / KPP;
   const float* x;
   FastDiv div_hw, div_w;
   int Mpix, HoWo, Wo, Hs, Ws, Cs, stride;
@@ -285,7 +286,7 @@ struct LoaderWgradGather {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int p = koff + tid / CPR + (LMKD_THREADS / CPR) * i;
+      const int p = koff + tid / CPR + KPP * i;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tap_ok && p < Mpix) {
         const int n = fdiv(p, div_hw);
@@ -303,16 +304,16 @@ struct LoaderWgradGather {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      int k = tid / CPR + (LMKD_THREADS / CPR) * i;
+      int k = tid / CPR + KPP * i;
       *reinterpret_cast<float4*>(S + k * LD + r4) = reg[i];
     }
   }
 };
 
 template <class Cfg, bool SMALLC>
-__global__ __launch_bounds__(LMKD_THREADS) void conv_wgrad_kernel(WgradArgs a) {
-  using LA = LoaderMMajorDense<Cfg::BM>;
-  using LB = LoaderWgradGather<Cfg::BN, SMALLC>;
+__global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgradArgs a) {
+  using LA = LoaderMMajorDense<Cfg::BM, Cfg::THREADS>;
+  using LB = LoaderWgradGather<Cfg::BN, SMALLC, Cfg::THREADS>;
   __shared__ __attribute__((aligned(16))) float smem[2 * (LA::LDS_FLOATS + LB::LDS_FLOATS)];
   // Tile order.  The 9 column tiles (taps) of one pixel split read the same x rows and the same dy rows; in plain order
   // they land on different XCDs and every XCD fetches those rows again (PMC: 2.6-3.1 GB per launch on the 160 MB layers).
@@ -658,7 +659,7 @@ extern "C" int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw
   } else if (bm == 64 && bn == 128) {
     hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<64, 128, 2, 2>, false>), grid, dim3(LMKD_THREADS), 0, s, a);
   } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<128, 128, 2, 2>, false>), grid, dim3(LMKD_THREADS), 0, s, a);
+    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<128, 128, 2, 4>, false>), grid, dim3(512), 0, s, a);   // 8 waves: 4 per SIMD at 2 workgroups per CU
   }
   LMKD_CHECK_LAUNCH("conv_wgrad_kernel");
   const long total = (long)Cout * KH * KW * Cin;
