@@ -210,34 +210,36 @@ __device__ __forceinline__ float4 bn_masked_grad(const float4 dy, const float4 x
   return g;
 }
 
-// block: 256 threads = (256/C4) row lanes x C4 channel-quads (C4 = C/4 <= 256, power of two or divisor of 256)
+// block: 256 threads = RL row lanes x CC4 channel-quads of one channel chunk (chunk = min(C, 1024) channels, blockIdx.y)
 __global__ void bn_bwd_reduce_kernel(const float4* __restrict__ dy, const float4* __restrict__ x, const float4* __restrict__ yact,
-                                     const float* __restrict__ stats, float* __restrict__ partial, long rows, int C, int mask_mode) {
-  extern __shared__ float sm[];  // [RL][C][2]
-  const int C4 = C >> 2;
-  const int RL = NP_THREADS / C4;
-  const int cq = threadIdx.x % C4, rl = threadIdx.x / C4;
-  const int c = cq * 4;
+                                     const float* __restrict__ stats, float* __restrict__ partial, long rows, int C, int CC,
+                                     int mask_mode) {
+  extern __shared__ float sm[];  // [RL][CC][2]
+  const int C4 = C >> 2, CC4 = CC >> 2;
+  const int RL = NP_THREADS / CC4;
+  const int cq = threadIdx.x % CC4, rl = threadIdx.x / CC4;
+  const int c0 = blockIdx.y * CC;
+  const int c = c0 + cq * 4;
   float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-  if (rl < RL) {
+  {
     const float4 mean = *reinterpret_cast<const float4*>(stats + c);
     const float4 istd = *reinterpret_cast<const float4*>(stats + C + c);
     for (long r = (long)blockIdx.x * RL + rl; r < rows; r += (long)gridDim.x * RL) {
-      const long i = r * C4 + cq;
+      const long i = r * C4 + (c >> 2);
       const float4 xv = x[i];
       const float4 g = bn_masked_grad(dy[i], xv, yact, i, stats, C, c, mask_mode);
       s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
       s2.x = fmaf(g.x, (xv.x - mean.x) * istd.x, s2.x); s2.y = fmaf(g.y, (xv.y - mean.y) * istd.y, s2.y);
       s2.z = fmaf(g.z, (xv.z - mean.z) * istd.z, s2.z); s2.w = fmaf(g.w, (xv.w - mean.w) * istd.w, s2.w);
     }
-    float* d = sm + ((long)rl * C + c) * 2;
+    float* d = sm + ((long)rl * CC + cq * 4) * 2;
     d[0] = s1.x; d[1] = s2.x; d[2] = s1.y; d[3] = s2.y; d[4] = s1.z; d[5] = s2.z; d[6] = s1.w; d[7] = s2.w;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < 2 * C; j += NP_THREADS) {
+  for (int j = threadIdx.x; j < 2 * CC; j += NP_THREADS) {
     float s = 0.f;
-    for (int q = 0; q < RL; ++q) s += sm[(long)q * 2 * C + j];
-    partial[(long)blockIdx.x * 2 * C + j] = s;
+    for (int q = 0; q < RL; ++q) s += sm[(long)q * 2 * CC + j];
+    partial[(long)blockIdx.x * 2 * C + 2 * c0 + j] = s;
   }
 }
 
@@ -287,17 +289,18 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
                                 float* dx, float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, long rows,
                                 int C, int mask_mode, void* stream) {
   LMKD_REQUIRE(dy && x && stats && dx && coef && workspace, "lmkd_bn_backward: null pointer");
-  LMKD_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "lmkd_bn_backward: unsupported channel count %d", C);
+  const int CC = C > 1024 ? 1024 : C;   // channel chunk handled by one workgroup column
+  LMKD_REQUIRE(C % 4 == 0 && C % CC == 0 && 256 % (CC / 4) == 0, "lmkd_bn_backward: unsupported channel count %d", C);
   LMKD_REQUIRE(mask_mode != 1 || yact, "lmkd_bn_backward: mask_mode 1 needs the activation output");
   hipStream_t s = (hipStream_t)stream;
-  const int RL = NP_THREADS / (C / 4);
+  const int RL = NP_THREADS / (CC / 4);
   int nb = cdiv(rows, (long)RL * 8);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   float* partial = (float*)workspace;
   double* dscr = (double*)((char*)workspace + (((long)2048 * 2 * C * sizeof(float) + 63) / 64) * 64);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(NP_THREADS), (size_t)RL * C * 2 * sizeof(float), s, (const float4*)dy,
-                     (const float4*)x, (const float4*)yact, stats, partial, rows, C, mask_mode);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, C / CC), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s,
+                     (const float4*)dy, (const float4*)x, (const float4*)yact, stats, partial, rows, C, CC, mask_mode);
   LMKD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
   int rc = colsum_to_double(partial, nb, 2 * C, dscr, dscr + 2 * C, s);
   if (rc) return rc;

@@ -60,6 +60,37 @@ class _Block(nn.Module):
                                       self.conv2.weight, *self.bn2.args(), *ds)
 
 
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, width, stride):
+        super().__init__()
+        self.stride = stride
+        cout = width * 4
+        self.conv1 = _Conv(cin, width, 1)
+        self.bn1 = _BN(width)
+        self.conv2 = _Conv(width, width, 3)
+        self.bn2 = _BN(width)
+        self.conv3 = _Conv(width, cout, 1)
+        self.bn3 = _BN(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential()
+            self.downsample.add_module("0", _Conv(cin, cout, 1))
+            self.downsample.add_module("1", _BN(cout))
+
+    def forward(self, x):
+        for c in (self.conv1, self.conv2, self.conv3):
+            ops.mark_cacheable(c.weight)
+        if self.downsample is not None:
+            ops.mark_cacheable(self.downsample[0].weight)
+            ds = (self.downsample[0].weight,) + self.downsample[1].args()
+        else:
+            ds = (None, None, None, None, None)
+        return ops.BottleneckFn.apply(x, self.stride, self.training, self.conv1.weight, *self.bn1.args(),
+                                      self.conv2.weight, *self.bn2.args(), self.conv3.weight, *self.bn3.args(), *ds)
+
+
 class ResNet18Trunk(nn.Module):
     """[F,3,H,W] NCHW frames -> NHWC feature map [F,H/32,W/32,512]."""
 
@@ -67,6 +98,9 @@ class ResNet18Trunk(nn.Module):
         super().__init__()
         self.add_module("0", _Conv(3, 64, 7))
         self.add_module("1", _BN(64))
+        self._build_stages()
+
+    def _build_stages(self):
         for name, cin, cout, stride in STAGES:
             stage = nn.Sequential()
             stage.add_module("0", _Block(cin, cout, stride))
@@ -88,6 +122,20 @@ class ResNet18Trunk(nn.Module):
         """num_batches_tracked += n for every BatchNorm (one fused launch)"""
         bufs = [m.num_batches_tracked for m in self.modules() if isinstance(m, _BN)]
         torch._foreach_add_(bufs, n)
+
+
+class ResNet50Trunk(ResNet18Trunk):
+    """torchvision resnet50().children()[:-2] (resnet50_2fc.py:29-32): Bottleneck stages [3, 4, 6, 3], widths 64..512,
+    output [F,H/32,W/32,2048]; 23 508 032 parameters."""
+
+    def _build_stages(self):
+        cin = 64
+        for name, width, n, stride in (("4", 64, 3, 1), ("5", 128, 4, 2), ("6", 256, 6, 2), ("7", 512, 3, 2)):
+            stage = nn.Sequential()
+            for i in range(n):
+                stage.add_module(str(i), _Bottleneck(cin, width, stride if i == 0 else 1))
+                cin = width * 4
+            self.add_module(name, stage)
 
 
 # The two trunk calls of an episode (support frames, query frames: resnet18_2fc.py:41-42) are independent: they are

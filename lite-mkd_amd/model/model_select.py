@@ -7,15 +7,15 @@ import torch.nn as nn
 
 from .. import ops
 from . import classifiers
-from .backbone import resnet18_2fc, resnet18_student
+from .backbone import resnet18_2fc, resnet18_student, resnet50_2fc, resnet50_stduent
 
 # every key of the reference's name2backbone (model_select.py:167-180); None = plugin outside the hot path
 name2backbone = {
     "resnet18_student": resnet18_student,
-    "resnet50_student": None,
+    "resnet50_student": resnet50_stduent,
     "strm18_student": None,
     "resnet18_2fc": resnet18_2fc,
-    "resnet50_2fc": None,
+    "resnet50_2fc": resnet50_2fc,
     "strmbackbone": None,
     "meta_baseline": None,
     "meta_baseline_fc2": None,

@@ -412,6 +412,66 @@ class BasicBlockFn(torch.autograd.Function):
                 dwd, dgd, dbd, None, None)
 
 
+class BottleneckFn(torch.autograd.Function):
+    """torchvision Bottleneck (ResNet-50, v1.5: the stride sits on the 3x3 conv): conv1x1-BN-ReLU-conv3x3/s-BN-ReLU-
+    conv1x1-BN (+ conv1x1/s-BN downsample) + add + ReLU.  Same hand-scheduled backward as BasicBlockFn."""
+
+    @staticmethod
+    def forward(ctx, x, stride, training, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3,
+                wd, gd, bd, rmd, rvd):
+        _chk(x, w1, w2, w3, wd)
+        Cs = x.shape[-1]
+        Cm = w1.shape[0]
+        c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, 1, 0, g1, b1, rm1, rv1, training)
+        a1 = bn_apply(c1, st1, True)
+        c2, st2 = _conv_bn_train_or_eval(a1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training)
+        a2 = bn_apply(c2, st2, True)
+        c3, st3 = _conv_bn_train_or_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, training)
+        if wd is not None:
+            cd, std = _conv_bn_train_or_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, training)
+            y = bn_apply(c3, st3, True, cd, std)
+        else:
+            cd = std = None
+            y = bn_apply(c3, st3, True, x)
+        ctx.training, ctx.stride, ctx.has_ds = training, stride, wd is not None
+        if training:
+            ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, a2, w3, g3, c3, st3, y, wd, gd, cd, std)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
+        x, w1, g1, c1, st1, a1, w2, g2, c2, st2, a2, w3, g3, c3, st3, y, wd, gd, cd, std = ctx.saved_tensors
+        dy = dy.contiguous()
+        stride = ctx.stride
+        Cm, Co = w1.shape[0], w3.shape[0]
+        dc3, g, dg3, db3 = bn_backward(dy, c3, y, st3, g3, 1, want_g=True)
+        da2 = conv_bwd_data(dc3, pack_weights(w3, Cm, 1), a2.shape, Co, 1, 1, 1, 0)
+        dw3 = conv_bwd_weight(a2, dc3, tuple(w3.shape), 1, 0)
+        del dc3
+        dc2, _, dg2, db2 = bn_backward(da2, c2, None, st2, g2, 2, dx_out=da2)
+        da1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), a1.shape, Cm, 3, 3, stride, 1)
+        dw2 = conv_bwd_weight(a1, dc2, tuple(w2.shape), stride, 1)
+        del dc2, da2
+        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)
+        dw1 = conv_bwd_weight(x, dc1, tuple(w1.shape), 1, 0)
+        dwd = dgd = dbd = None
+        need_dx = ctx.needs_input_grad[0]
+        dx = None
+        if ctx.has_ds:
+            dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g)
+            dwd = conv_bwd_weight(x, dcd, tuple(wd.shape), stride, 0)
+            if need_dx:
+                dx = conv_bwd_data(dcd, pack_weights(wd, x.shape[-1], 1), x.shape, Co, 1, 1, stride, 0)
+        else:
+            dx = g
+        if need_dx:
+            conv_bwd_data(dc1, pack_weights(w1, x.shape[-1], 1), x.shape, Cm, 1, 1, 1, 0, out=dx, accumulate=True)
+        return (dx if need_dx else None, None, None, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None,
+                dw3, dg3, db3, None, None, dwd, dgd, dbd, None, None)
+
+
 class PoolHeadFn(torch.autograd.Function):
     """AdaptiveMaxPool2d((4,4)) -> mean over the 16 patches (resnet18_2fc.py:44-54). NHWC in, [F,C] out."""
 

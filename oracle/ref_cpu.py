@@ -120,6 +120,74 @@ def resnet18_trunk(x, sd, training=True, update_running=True, taps=None):
     return x
 
 
+# ResNet-50 trunk (torchvision resnet50().children()[:-2], resnet50_2fc.py:29-32; v1.5: stride on conv2)
+RESNET50_STAGES = [(4, 64, 3, 1), (5, 128, 4, 2), (6, 256, 6, 2), (7, 512, 3, 2)]
+
+
+def resnet50_trunk_param_shapes():
+    shapes = {"0.weight": (64, 3, 7, 7)}
+
+    def bn(prefix, c):
+        shapes[prefix + ".weight"] = (c,)
+        shapes[prefix + ".bias"] = (c,)
+        shapes[prefix + ".running_mean"] = (c,)
+        shapes[prefix + ".running_var"] = (c,)
+        shapes[prefix + ".num_batches_tracked"] = ()
+
+    bn("1", 64)
+    cin = 64
+    for idx, width, n, stride in RESNET50_STAGES:
+        for b in range(n):
+            p = "%d.%d" % (idx, b)
+            shapes[p + ".conv1.weight"] = (width, cin, 1, 1)
+            bn(p + ".bn1", width)
+            shapes[p + ".conv2.weight"] = (width, width, 3, 3)
+            bn(p + ".bn2", width)
+            shapes[p + ".conv3.weight"] = (width * 4, width, 1, 1)
+            bn(p + ".bn3", width * 4)
+            if b == 0:
+                shapes[p + ".downsample.0.weight"] = (width * 4, cin, 1, 1)
+                bn(p + ".downsample.1", width * 4)
+            cin = width * 4
+    return shapes
+
+
+def init_trunk_from_shapes(shapes, gen):
+    sd = {}
+    for k, shp in shapes.items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_mean"):
+            sd[k] = torch.zeros(shp)
+        elif k.endswith("running_var"):
+            sd[k] = torch.ones(shp)
+        elif len(shp) == 4:
+            sd[k] = torch.randn(shp, generator=gen) * math.sqrt(2.0 / (shp[0] * shp[2] * shp[3]))
+        elif k.endswith(".weight"):
+            sd[k] = torch.ones(shp)
+        else:
+            sd[k] = torch.zeros(shp)
+    return sd
+
+
+def resnet50_trunk(x, sd, training=True, update_running=True):
+    x = F.conv2d(x, sd["0.weight"], None, 2, 3)
+    x = F.relu(_bn(x, sd, "1", training, update_running))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for idx, width, n, stride in RESNET50_STAGES:
+        for b in range(n):
+            p = "%d.%d" % (idx, b)
+            s = stride if b == 0 else 1
+            idn = x
+            out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"]), sd, p + ".bn1", training, update_running))
+            out = F.relu(_bn(F.conv2d(out, sd[p + ".conv2.weight"], None, s, 1), sd, p + ".bn2", training, update_running))
+            out = _bn(F.conv2d(out, sd[p + ".conv3.weight"]), sd, p + ".bn3", training, update_running)
+            if (p + ".downsample.0.weight") in sd:
+                idn = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], None, s, 0), sd, p + ".downsample.1", training, update_running)
+            x = F.relu(out + idn)
+    return x
+
+
 # ----------------------------------------------------------------------------
 # A3  pooled head (model/backbone/resnet18_2fc.py:44-77, resnet18_student.py:41-60)
 # ----------------------------------------------------------------------------
@@ -136,6 +204,19 @@ def backbone_resnet18_2fc(ctx_imgs, tgt_imgs, params, seq_len=8, training=True, 
     sd = {k[len("resnet."):]: v for k, v in params.items() if k.startswith("resnet.")}
     cf = pooled_frame_features(resnet18_trunk(ctx_imgs, sd, training, update_running))
     tf = pooled_frame_features(resnet18_trunk(tgt_imgs, sd, training, update_running))
+    out_c, out_t = {}, {}
+    for h in (1, 2):
+        w, b = params["fc%d.weight" % h], params["fc%d.bias" % h]
+        out_c["context_features_%d" % h] = F.linear(cf, w, b).reshape(-1, seq_len, 2048)
+        out_t["target_features_%d" % h] = F.linear(tf, w, b).reshape(-1, seq_len, 2048)
+    return out_c, out_t
+
+
+def backbone_resnet50_2fc(ctx_imgs, tgt_imgs, params, seq_len=8, training=True, update_running=True):
+    """resnet50_2fc.forward (resnet50_2fc.py:38-78): ResNet-50 trunk, pooled 2048-d frame features, two 2048->2048 heads."""
+    sd = {k[len("resnet."):]: v for k, v in params.items() if k.startswith("resnet.")}
+    cf = pooled_frame_features(resnet50_trunk(ctx_imgs, sd, training, update_running))
+    tf = pooled_frame_features(resnet50_trunk(tgt_imgs, sd, training, update_running))
     out_c, out_t = {}, {}
     for h in (1, 2):
         w, b = params["fc%d.weight" % h], params["fc%d.bias" % h]
@@ -557,6 +638,8 @@ def student_forward(ep, params, way=5, shot=5, classifier="TRX_2fcsup", backbone
           if k.startswith("classifier.transformers.")}
     if backbone == "resnet18_2fc":
         ctx, tgt = backbone_resnet18_2fc(ep["support_set"], ep["target_set"], bp, 8, training, update_running)
+    elif backbone == "resnet50_2fc":
+        ctx, tgt = backbone_resnet50_2fc(ep["support_set"], ep["target_set"], bp, 8, training, update_running)
     else:
         ctx, tgt = backbone_resnet18_student(ep["support_set"], ep["target_set"], bp, 8, training, update_running)
     if classifier == "TRX_2fcsup":

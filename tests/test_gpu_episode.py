@@ -21,15 +21,17 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-@pytest.mark.parametrize("shot,query,img,clf,dist", [(1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist"),
-                                                     (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist")])
-def test_episode_matches_oracle(dev, shot, query, img, clf, dist):
+@pytest.mark.parametrize("shot,query,img,clf,dist,bb", [(1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc"),
+                                                        (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc"),
+                                                        (1, 1, 64, "TRX_2fcsup", "fc_2_sup_dist", "resnet50_2fc")])
+def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb):
     from litemkd_amd.model.model_select import Student, Teacher
     from litemkd_amd.distillers import Distiller
     from litemkd_amd.options import default_args
     from litemkd_amd import ops
     from oracle import ref_cpu as O
-    args = default_args(shot=shot, query_per_class=query, img_size=img, trans_dropout=0.0, device=dev, model_classifier=clf)
+    args = default_args(shot=shot, query_per_class=query, img_size=img, trans_dropout=0.0, device=dev, model_classifier=clf,
+                        model_backbone=bb)
     torch.manual_seed(1)
     student, teacher = Student(args).to(dev), Teacher(args).to(dev)
     ep = O.make_episode(900 + shot, 5, shot, query, img=img)
@@ -45,7 +47,7 @@ def test_episode_matches_oracle(dev, shot, query, img, clf, dist):
     for k, v in sp.items():
         if v.is_floating_point() and "running" not in k and not k.endswith("pe.pe"):
             v.requires_grad_()
-    o = O.student_forward(ep, sp, 5, shot, classifier=clf)
+    o = O.student_forward(ep, sp, 5, shot, classifier=clf, backbone=bb)
     ot = O.clf_TRX_2fcsup_fixed(ep["support_set_feature_teacher"], ep["support_labels"], ep["target_set_feature_teacher"], tp, 5, shot)
     ol = O.distill_fc_2_sup_dist(o["logits"], ot, labels)["loss"]
     ol.backward()

@@ -445,3 +445,36 @@ def test_all_distiller_methods_golden(dev, golden_dir):
             ref = torch.from_numpy(G[name + ("__g" if k == "" else "__g_" + k)])
             got = v.grad if v.grad is not None else torch.zeros_like(v)
             close(got, ref, 1e-4, 1e-7, name + " grad " + k)
+
+
+def test_resnet50_trunk_forward_backward(dev):
+    """ResNet-50 trunk (Bottleneck blocks, BatchNorm over up to 2048 channels) fwd + bwd vs the oracle, 6 frames 96x96"""
+    from litemkd_amd import ops
+    from litemkd_amd.model.backbone.resnet import ResNet50Trunk
+    from oracle import ref_cpu as O
+    g = torch.Generator().manual_seed(8)
+    shapes = O.resnet50_trunk_param_shapes()
+    n = sum(int(np.prod(s)) for k, s in shapes.items() if "running" not in k and "num_batches" not in k)
+    assert n == 23508032                                  # torchvision resnet50 minus the 2048x1000 fc
+    sd = O.init_trunk_from_shapes(shapes, g)
+    trunk = ResNet50Trunk()
+    trunk.load_state_dict(sd)
+    trunk = trunk.to(dev).train()
+    x = torch.rand(6, 3, 96, 96, generator=g)
+    osd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    fm = O.resnet50_trunk(x, osd, True, True)
+    feat = O.pooled_frame_features(fm)
+    gfeat = rnd(*feat.shape, seed=9)
+    feat.backward(gfeat)
+    y = trunk(x.to(dev))
+    close(nchw(y), fm, 2e-3, 2e-3 * float(fm.abs().max()), "resnet50 feature map")
+    f = ops.PoolHeadFn.apply(y)
+    f.backward(gfeat.to(dev))
+    close(trunk.state_dict()["7.2.bn3.running_var"], osd["7.2.bn3.running_var"], 1e-3, 1e-4, "running_var")
+    worst = 0.0
+    for k, p in trunk.named_parameters():
+        ref = osd[k].grad.double()
+        err = float((p.grad.cpu().double() - ref).norm() / (ref.norm() + 1e-30))
+        worst = max(worst, err)
+        assert err < 5e-2, "grad %s: rel-L2 err %.3e" % (k, err)
+    print("resnet50 worst grad rel-L2 err:", worst)

@@ -65,7 +65,7 @@ def test_registry_and_state_dict_keys():
     # DataParallel prefix stripping (model_select.py:143-150)
     out = ms.strip_dataparallel_prefix({"backbone.resnet.module.0.weight": 1, "backbone.fc1.weight": 2})
     assert set(out) == {"backbone.resnet.0.weight", "backbone.fc1.weight"}
-    for name in ("resnet18_student", "resnet18_2fc"):
+    for name in ("resnet18_student", "resnet18_2fc", "resnet50_2fc", "resnet50_student"):
         assert ms.name2backbone[name] is not None
     from litemkd_amd.distillers import Distiller
     d = Distiller("fc_2_sup_dist", a.cfg, "cpu")
