@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--serial", action="store_true", help="queue the two trunk calls on ONE stream (no kernel overlap); use this "
                     "mode under rocprofv3 so per-kernel durations are not inflated by concurrent kernels")
     ap.add_argument("--roofline-episodes", type=int, default=2)
+    ap.add_argument("--backbone", default="resnet18_2fc", help="resnet18_2fc (headline) or resnet50_2fc (BASELINE configs[4])")
+    ap.add_argument("--live-mfm", action="store_true", help="fuse rgb/depth/flow teacher features with the MFM transformer "
+                    "inside every episode (BASELINE configs[4]) instead of using precomputed fused features")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -53,7 +56,8 @@ def main():
     assert dev.type == "cuda", "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
     litemkd_amd.lib().call("lmkd_device_check", dev.index)
-    cfg = default_args(shot=a.shot, device=dev, trans_dropout=a.dropout, training_iterations=10 ** 9, print_freq=10 ** 9)
+    cfg = default_args(shot=a.shot, device=dev, trans_dropout=a.dropout, training_iterations=10 ** 9, print_freq=10 ** 9,
+                       model_backbone=a.backbone)
     torch.manual_seed(1234)                                  # identical initial weights on every rank
     student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
     opt = TL.FusedOptimizer(student, cfg.opt, cfg.learning_rate)
@@ -62,13 +66,27 @@ def main():
     distiller = Distiller(cfg.distill_name, cfg.cfg, dev)
     src = TL.SyntheticEpisodes(cfg, base_seed=2024, rank=rank, device=dev)
     pool = [src.episode(e) for e in range(a.pool)]           # resident in HBM before the timed region
+    mfm = None
+    if a.live_mfm:
+        import argparse as _ap
+        from litemkd_amd.teacher import ThreeTRXShiftLoopTime
+        mfm = ThreeTRXShiftLoopTime(_ap.Namespace(seq_len=cfg.seq_len, trans_num=2, shirt_num=1)).eval().to(dev)
+        g = torch.Generator(device=dev).manual_seed(99 + rank)
+        nv = cfg.way * (cfg.shot + cfg.query_per_class)
+        mods = [{k: torch.randn(nv, cfg.seq_len, 2048, generator=g, device=dev).abs() for k in ("rgb", "depth", "flow")}
+                for _ in range(a.pool)]
     every = max(1, cfg.tasks_per_batch // world)
 
     def run(n, it0):
         it = it0
         for i in range(n):
             it += 1
-            TL.train_task(pool[i % len(pool)], student, teacher, distiller, aggregate_accuracy, cfg)
+            ep = pool[i % len(pool)]
+            if mfm is not None:      # live fusion: the teacher features of this episode come out of the MFM transformer
+                fused = mfm.extract_feature(mods[i % len(pool)])
+                ns = cfg.way * cfg.shot
+                ep = dict(ep, support_set_feature_teacher=fused[:ns].unsqueeze(0), target_set_feature_teacher=fused[ns:].unsqueeze(0))
+            TL.train_task(ep, student, teacher, distiller, aggregate_accuracy, cfg)
             if (it + 1) % every == 0:
                 opt.step()
                 opt.zero_grad()
@@ -136,7 +154,8 @@ def main():
         "metric": "episodes/sec (5-way %d-shot, 8x224^2 frames)" % a.shot, "value": world * a.steps / dt, "unit": "episodes/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "HMDB-shape 5-way %d-shot ResNet-18 + TRX_2fcsup + D2M fc_2_sup_dist training episode, fp32" % a.shot,
+        "config": {"workload": "HMDB-shape 5-way %d-shot %s + TRX_2fcsup + D2M fc_2_sup_dist training episode%s, fp32"
+                               % (a.shot, a.backbone, " + live MFM fusion" if a.live_mfm else ""),
                    "frames_per_episode": frames, "img": 224, "tasks_per_batch": cfg.tasks_per_batch, "optimizer": cfg.opt,
                    "episodes_per_optimizer_step_per_rank": every, "parallelism": "episode-parallel dp%d" % world,
                    "trans_dropout": a.dropout, "trunk_calls_overlapped_on_two_streams": not a.serial},

@@ -1,3 +1,5 @@
+// Ceiling probe: v_mfma_f32_32x32x2_f32 issued from registers (mode 0) vs with operands re-read from LDS (mode 1), 1-4
+// waves per SIMD, with the in-kernel clock.  hipcc --offload-arch=gfx950 -O3 tools/mfma_peak2.hip -o /tmp/mfma_peak2
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -1,3 +1,5 @@
+"""Co-execution experiment: 40 convolutions and 40 BatchNorm-backward launches alone, and on two streams at once
+(TILE=<id> selects the conv tile).  Result recorded in DESIGN.md section 5."""
 import sys, os, time, torch
 sys.path.insert(0, os.getcwd())
 import litemkd_amd
