@@ -17,12 +17,14 @@ def init_distributed(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
     if use_cuda:
+        local = local % torch.cuda.device_count()      # rehearsals may run several ranks on one card (gloo only)
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+        backend = backend or os.environ.get("LMKD_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
 
