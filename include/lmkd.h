@@ -37,6 +37,7 @@ long lmkd_conv2d_packed_weight_elems(int Cout, int Cin, int Cs, int KH, int KW, 
 int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout, int Cin, int Cs, int KH, int KW, int mode /*0 fwd, 1 dgrad*/,
                              void* stream);
 int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, int KW, int stride, int pad);
+int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound kernels, workgroups per CU (default 4) */
 int lmkd_conv_set_xcd_mode(int mode); /* tuning: -1 auto, 0 force row-band tile order, 2 auto + XCD-grouped weight-gradient splits */
 int lmkd_conv_set_tile(int id); /* tuning: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 64x128 */
 /* stat_partial (nullable): [row_tiles][Cout][2] per-tile (sum, sum of squares) for train-mode BatchNorm */

@@ -6,9 +6,15 @@
 #include "common.h"
 
 #define NP_THREADS 256
+static int g_ew_wg_per_cu = 4;
+extern "C" int lmkd_set_elementwise_wg_per_cu(int n) {
+  if (n < 1 || n > 8) return LMKD_EINVAL;
+  g_ew_wg_per_cu = n;
+  return LMKD_OK;
+}
 static inline int ew_grid(long n_items) {
   long g = (n_items + NP_THREADS - 1) / NP_THREADS;
-  if (g > 256 * 4) g = 256 * 4;   // 4 workgroups (16 waves) per CU saturate HBM and leave the other 16 wave slots to a co-running MFMA kernel
+  if (g > 256 * g_ew_wg_per_cu) g = 256 * g_ew_wg_per_cu;   // default 4: 4 workgroups (16 waves) per CU saturate HBM and leave the other 16 wave slots to a co-running MFMA kernel
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -295,7 +301,7 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
   hipStream_t s = (hipStream_t)stream;
   const int RL = NP_THREADS / (CC / 4);
   int nb = cdiv(rows, (long)RL * 8);
-  if (nb > 1024) nb = 1024;
+  if (nb > 256 * g_ew_wg_per_cu) nb = 256 * g_ew_wg_per_cu;
   if (nb < 1) nb = 1;
   float* partial = (float*)workspace;
   double* dscr = (double*)((char*)workspace + (((long)2048 * 2 * C * sizeof(float) + 63) / 64) * 64);

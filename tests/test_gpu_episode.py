@@ -154,3 +154,44 @@ def test_packed_weight_cache_follows_optimizer(dev):
         getattr(trunk, "4")[0].conv1.weight.mul_(1.5)      # in-place torch update bumps _version
     fresh.load_state_dict(trunk.state_dict())
     assert torch.equal(trunk(x), fresh(x))
+
+
+def test_full_size_episode_matches_oracle(dev):
+    """BASELINE configs[1] at full size (5-way 5-shot, 5 queries/class, 400 frames of 224x224): logits, loss and class
+    predictions of the HIP path against the CPU oracle on the same episode and weights (~10 s of oracle time)."""
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd import ops
+    from oracle import ref_cpu as O
+    args = default_args(trans_dropout=0.0, device=dev)
+    torch.manual_seed(11)
+    student, teacher = Student(args).to(dev), Teacher(args).to(dev)
+    ep = O.make_episode(4242, 5, 5, 5)
+    sp = {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
+    tp = {k[len("classifier.transformers."):]: v.detach().cpu().clone() for k, v in teacher.state_dict().items()
+          if k.startswith("classifier.transformers.")}
+    labels = ep["target_labels"].long()
+    with torch.no_grad():
+        out = student(ep["support_set"].to(dev), ep["support_labels"].to(dev), ep["target_set"].to(dev))
+        tl = teacher(ep["support_set_feature_teacher"].to(dev), ep["support_labels"].to(dev), ep["target_set_feature_teacher"].to(dev))["logits"]
+        loss = Distiller("fc_2_sup_dist", args.cfg, dev).fc_2_sup_dist(out["logits"], tl, labels.to(dev))["loss"]
+        acc, pred = ops.accuracy(out["logits"]["kl"], out["logits"]["ce"], labels.to(dev))
+        o = O.student_forward(ep, sp, 5, 5)
+        ot = O.clf_TRX_2fcsup_fixed(ep["support_set_feature_teacher"], ep["support_labels"], ep["target_set_feature_teacher"], tp, 5, 5)
+        ol = O.distill_fc_2_sup_dist(o["logits"], ot, labels)["loss"]
+    for k in ("context_features_1", "context_features_2"):
+        assert _rel(out["context_features"][k], o["context_features"][k]) < 2e-3, k
+    for k in ("kl", "ce", "sup"):
+        a, b = out["logits"][k].cpu(), o["logits"][k]
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-2), (k, float((a - b).abs().max()))
+    assert abs(loss.item() - ol.item()) < 1e-3 * max(1.0, abs(ol.item()))
+    lg = o["logits"]["kl"] + o["logits"]["ce"]
+    srt = torch.sort(lg, -1).values
+    clear = (srt[:, -1] - srt[:, -2]) > 5e-2
+    assert int(clear.sum()) >= 20                                       # the margin guard must not hide the test
+    assert torch.equal(pred.cpu()[clear], torch.argmax(lg, -1)[clear])   # bit-exact class indices
+    assert abs(float(acc) - float(O.aggregate_accuracy(lg, labels))) < 1e-6 or not bool(clear.all())
+    # running statistics after the two deferred updates (support first, then query) equal the serial reference order
+    assert _rel(student.state_dict()["backbone.resnet.1.running_mean"], sp["backbone.resnet.1.running_mean"]) < 1e-3
+    assert _rel(student.state_dict()["backbone.resnet.7.1.bn2.running_var"], sp["backbone.resnet.7.1.bn2.running_var"]) < 1e-3

@@ -26,6 +26,7 @@ def timed(fa, fb):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) * 1e3
 from litemkd_amd._lib import lib
 lib().call("lmkd_conv_set_tile", int(os.environ.get("TILE", "0")))
+lib().call("lmkd_set_elementwise_wg_per_cu", int(os.environ.get("EW", "4")))
 convs(3); bns(3); torch.cuda.synchronize()
 for _ in range(2):
     a = timed(lambda: convs(40), None); b = timed(lambda: bns(40), None)
