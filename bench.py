@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="queue the two trunk calls on ONE stream (no kernel overlap); use this "
                     "mode under rocprofv3 so per-kernel durations are not inflated by concurrent kernels")
     ap.add_argument("--roofline-episodes", type=int, default=2)
+    ap.add_argument("--tile", type=int, default=0, help="tuning: force a conv tile configuration (lmkd_conv_set_tile), 0 = auto")
     ap.add_argument("--backbone", default="resnet18_2fc", help="resnet18_2fc (headline) or resnet50_2fc (BASELINE configs[4])")
     ap.add_argument("--live-mfm", action="store_true", help="fuse rgb/depth/flow teacher features with the MFM transformer "
                     "inside every episode (BASELINE configs[4]) instead of using precomputed fused features")
@@ -56,6 +57,7 @@ def main():
     assert dev.type == "cuda", "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
     litemkd_amd.lib().call("lmkd_device_check", dev.index)
+    litemkd_amd.lib().call("lmkd_conv_set_tile", a.tile)
     cfg = default_args(shot=a.shot, device=dev, trans_dropout=a.dropout, training_iterations=10 ** 9, print_freq=10 ** 9,
                        model_backbone=a.backbone)
     torch.manual_seed(1234)                                  # identical initial weights on every rank

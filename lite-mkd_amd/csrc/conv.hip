@@ -121,11 +121,17 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
   const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
   for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
     const int m = row0 + r;
-    if (m < a.rows_per_class) {
-      const int n = fdiv(m, a.div_hw);
+    bool ok = m < a.rows_per_class;
+    int n = 0, aa = 0, bb = 0;
+    if (ok) {
+      n = fdiv(m, a.div_hw);
       const int rem = m - n * a.Hr * a.Wr;
-      const int aa = fdiv(rem, a.div_w);
-      const int bb = rem - aa * a.Wr;
+      aa = fdiv(rem, a.div_w);
+      bb = rem - aa * a.Wr;
+      // odd H or W in the stride-2 data gradient: the odd-parity classes have one row/column fewer
+      ok = (aa * a.omul + ph) < a.Ho && (bb * a.omul + pw) < a.Wo;
+    }
+    if (ok) {
       s_src[r] = ((n * a.Hs + aa * a.sh) * a.Ws + bb * a.sh) * a.Cs;
       s_hw[r] = ((aa * a.sh) << 16) | (bb * a.sh);
       s_out[r] = ((n * a.Ho + aa * a.omul + ph) * a.Wo + bb * a.omul + pw) * a.Co;
@@ -543,7 +549,6 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
   LMKD_REQUIRE(stride == 1 || stride == 2, "lmkd_conv2d_bwd_data: stride %d unsupported", stride);
   LMKD_REQUIRE(KH * KW <= LMKD_MAX_TAPS, "lmkd_conv2d_bwd_data: kernel too large");
   const int Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
-  LMKD_REQUIRE(stride == 1 || (H % 2 == 0 && W % 2 == 0), "lmkd_conv2d_bwd_data: stride-2 needs even H, W");
   LMKD_REQUIRE((long)N * H * W * Cin < 2147483647L && (long)N * Ho * Wo * Cout < 2147483647L,
                "lmkd_conv2d_bwd_data: tensor exceeds 2^31 elements");
   ConvGemmArgs a;
@@ -561,7 +566,7 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
     a.ntap[0] = nt;
   } else {
     // rows enumerated per input parity (ph,pw): ih = 2a+ph, source oh = (ih + pad - kh)/2 = a + (ph+pad-kh)/2
-    a.nclass = 4; a.omul = 2; a.Hr = H / 2; a.Wr = W / 2;
+    a.nclass = 4; a.omul = 2; a.Hr = (H + 1) / 2; a.Wr = (W + 1) / 2;
     for (int c = 0; c < 4; ++c) {
       const int ph = c >> 1, pw = c & 1;
       int nt = 0;

@@ -92,6 +92,8 @@ CONVS = [  # N, Cin, H, W, Cout, K, stride, pad
     (2, 128, 14, 14, 128, 3, 1, 1),
     (2, 64, 28, 28, 128, 1, 2, 0),     # downsample
     (5, 256, 7, 7, 512, 3, 1, 1),      # ragged row tile (M = 245)
+    (3, 64, 7, 7, 128, 3, 2, 1),       # stride 2 on an odd map (7 -> 4): parity classes of unequal size
+    (3, 64, 9, 5, 64, 1, 2, 0),        # 1x1 stride 2, odd H and W
 ]
 
 
