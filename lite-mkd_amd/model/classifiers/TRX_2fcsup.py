@@ -115,3 +115,48 @@ class TRX_2fcsup_fixed(nn.Module):
             l1 = self.transformers(context_feature, context_labels, target_feature)["logits"]
             l2 = self.supportKD(context_feature, context_labels, target_feature)["logits"]
         return {"logits": {"kl": l1, "sup": l2}}
+
+
+class TRX(nn.Module):
+    """model/classifiers/TRX.py:167-183 — one TemporalCrossTransformer head, returns {'logits': [Nq, way]}."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.train()
+        self.args = args
+        self.transformers = TemporalCrossTransformer(args, 2)
+
+    def forward(self, context_feature, context_labels, target_feature):
+        return self.transformers(context_feature, context_labels, target_feature)
+
+
+class TRX_fixed(nn.Module):
+    """model/classifiers/TRX.py:186-211 — frozen single-head teacher (weights come from load_teacher)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.train()
+        self.args = args
+        self.transformers = TemporalCrossTransformer(args, 2)
+
+    def forward(self, context_feature, context_labels, target_feature):
+        with torch.no_grad():
+            L, D = self.args.seq_len, self.args.trans_linear_in_dim
+            c = context_feature.reshape(-1, L, D)
+            t = target_feature.reshape(-1, L, D)
+            return {"logits": self.transformers(c, context_labels, t)["logits"]}
+
+
+class TRX_2fc(nn.Module):
+    """model/classifiers/TRX_2fc.py:163-192 — the two fc heads through the shared transformer, {'fc_1','fc_2'}."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.train()
+        self.args = args
+        self.transformers = TemporalCrossTransformer(args, 2)
+
+    def forward(self, context_feature, context_labels, target_feature):
+        l1 = self.transformers(context_feature["context_features_1"], context_labels, target_feature["target_features_1"])["logits"]
+        l2 = self.transformers(context_feature["context_features_2"], context_labels, target_feature["target_features_2"])["logits"]
+        return {"logits": {"fc_1": l1, "fc_2": l2}}

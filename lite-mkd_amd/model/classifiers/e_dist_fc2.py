@@ -77,3 +77,11 @@ class e_dist_fc2_sup_fixed(nn.Module):
         l1 = self.e_dict(context_feature, context_labels, target_feature)["logits"]
         l2 = self.supportKD(context_feature, context_labels, target_feature)["logits"]
         return {"logits": {"kl": l1, "sup": l2}}
+
+
+class CosDistance(e_dist):
+    """model/classifiers/COS.py:23-62: despite the name the same Euclidean matcher, but it returns the bare [Nq, way] tensor
+    (so, as in the reference, it cannot be used through Student, which indexes ['logits'])."""
+
+    def forward(self, support_set, support_labels, queries):
+        return super().forward(support_set, support_labels, queries)["logits"]

@@ -195,3 +195,32 @@ def test_full_size_episode_matches_oracle(dev):
     # running statistics after the two deferred updates (support first, then query) equal the serial reference order
     assert _rel(student.state_dict()["backbone.resnet.1.running_mean"], sp["backbone.resnet.1.running_mean"]) < 1e-3
     assert _rel(student.state_dict()["backbone.resnet.7.1.bn2.running_var"], sp["backbone.resnet.7.1.bn2.running_var"]) < 1e-3
+
+
+@pytest.mark.parametrize("clf,dist,teacher", [("TRX", "KD", "train_teacher"), ("TRX_2fc", "fc_2", "train_teacher"),
+                                             ("e_dist_1fc_sup", "e_dist_1fc_sup", "e_dist_fc2_sup")])
+def test_other_plugin_combinations_run(dev, clf, dist, teacher):
+    """registry combinations from the reference's scripts other than the default: forward + loss + backward produce
+    finite values, and the single-head TRX path equals the 'kl' head of TRX_2fcsup on the same features"""
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from oracle import ref_cpu as O
+    bb = "resnet18_student" if clf in ("TRX", "e_dist_1fc_sup") else "resnet18_2fc"
+    args = default_args(shot=1, query_per_class=1, img_size=64, trans_dropout=0.0, device=dev, model_classifier=clf,
+                        model_backbone=bb, model_teacher=teacher, distill_name=dist)
+    torch.manual_seed(3)
+    student, tch = Student(args).to(dev), Teacher(args).to(dev)
+    ep = O.make_episode(77, 5, 1, 1, img=64)
+    out = student(ep["support_set"].to(dev), ep["support_labels"].to(dev), ep["target_set"].to(dev))
+    tl = tch(ep["support_set_feature_teacher"].to(dev), ep["support_labels"].to(dev), ep["target_set_feature_teacher"].to(dev))["logits"]
+    loss = getattr(Distiller(dist, args.cfg, dev), dist)(out["logits"], tl, ep["target_labels"].long().to(dev))["loss"]
+    loss.backward()
+    assert torch.isfinite(loss)
+    g = [p.grad for p in student.parameters() if p.grad is not None]
+    assert len(g) > 60 and all(torch.isfinite(x).all() for x in g)
+    if clf == "TRX":
+        sp = {k: v.detach().cpu() for k, v in student.state_dict().items()}
+        cp = {k[len("classifier.transformers."):]: v for k, v in sp.items() if k.startswith("classifier.transformers.")}
+        ref = O.trx_logits(out["context_features"].detach().cpu(), ep["support_labels"], out["target_features"].detach().cpu(), cp)
+        assert torch.allclose(out["logits"].detach().cpu(), ref, rtol=1e-4, atol=2e-2)
