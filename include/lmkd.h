@@ -51,6 +51,9 @@ int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, floa
                            int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
 
 /* ---- layout / BatchNorm / pooling (torchvision bn1/relu/maxpool/BasicBlock, resnet18_2fc.py:33,41-54) ---- */
+/* crop + horizontal flip + ToTensor of uint8 HWC frames into NHWC4 (video_reader.py:92-112 after Resize); crop/flip per video */
+int lmkd_frames_u8_to_nhwc4(const unsigned char* src, float* dst, const int* crop_y, const int* crop_x, const int* flip, int F, int Hs,
+                            int Ws, int H, int W, int frames_per_video, void* stream);
 int lmkd_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int N, int H, int W, void* stream);
 /* stats: [5][C] = mean, invstd, scale, shift, unbiased batch variance.  scratch: >= 65*2*C doubles.
  * running_mean/var may be NULL (update deferred to lmkd_bn_running_update) */

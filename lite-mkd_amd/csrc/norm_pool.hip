@@ -40,6 +40,38 @@ extern "C" int lmkd_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W
 }
 
 // ---------------------------------------------------------------------------------
+// GPU side of the frame transform (video_reader.py:92-112 after the PIL Resize): per-video crop + horizontal flip +
+// ToTensor (/255) of uint8 HWC frames, written straight in the stem's NHWC4 layout.
+//   src [F, Hs, Ws, 3] uint8 ; crop_y/crop_x/flip: one entry per video (frames_per_video consecutive frames share it)
+// ---------------------------------------------------------------------------------
+__global__ void frames_u8_to_nhwc4_kernel(const unsigned char* __restrict__ src, float4* __restrict__ dst, const int* __restrict__ crop_y,
+                                          const int* __restrict__ crop_x, const int* __restrict__ flip, long total, int Hs, int Ws,
+                                          int H, int W, int frames_per_video) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(p % W);
+    long r = p / W;
+    const int h = (int)(r % H);
+    const int f = (int)(r / H);
+    const int v = f / frames_per_video;
+    const int sx = crop_x[v] + (flip[v] ? (W - 1 - w) : w);
+    const int sy = crop_y[v] + h;
+    const unsigned char* s = src + (((long)f * Hs + sy) * Ws + sx) * 3;
+    dst[p] = make_float4((float)s[0] / 255.f, (float)s[1] / 255.f, (float)s[2] / 255.f, 0.f);   // ToTensor: x.div(255)
+  }
+}
+
+extern "C" int lmkd_frames_u8_to_nhwc4(const unsigned char* src, float* dst, const int* crop_y, const int* crop_x, const int* flip,
+                                       int F, int Hs, int Ws, int H, int W, int frames_per_video, void* stream) {
+  LMKD_REQUIRE(src && dst && crop_y && crop_x && flip && F > 0 && H > 0 && W > 0 && H <= Hs && W <= Ws && frames_per_video > 0,
+               "lmkd_frames_u8_to_nhwc4: bad arguments");
+  const long total = (long)F * H * W;
+  hipLaunchKernelGGL(frames_u8_to_nhwc4_kernel, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, src, (float4*)dst, crop_y,
+                     crop_x, flip, total, Hs, Ws, H, W, frames_per_video);
+  LMKD_CHECK_LAUNCH("frames_u8_to_nhwc4_kernel");
+  return LMKD_OK;
+}
+
+// ---------------------------------------------------------------------------------
 // column reduction of per-tile partials:  in[T][C][V] (float) -> out[C][V] (double)
 // grid = (ceil(C*V/64), TS): stage 1 writes TS x (C*V) doubles, stage 2 (TS==1 grid.y) finishes
 // ---------------------------------------------------------------------------------

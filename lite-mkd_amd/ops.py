@@ -322,11 +322,15 @@ class StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, gamma, beta, rm, rv, training):
         _chk(x, w, gamma, beta, rm, rv)
-        F_, Cin, H, W = x.shape
-        if Cin != 3:
-            raise RuntimeError("stem expects 3-channel frames")
-        x4 = _empty((F_, H, W, 4), x)
-        lib().call("lmkd_nchw3_to_nhwc4", _p(x.contiguous()), _p(x4), F_, H, W, _stream())
+        if x.dim() == 4 and x.shape[-1] == 4 and x.shape[1] != 3:
+            x4 = x.contiguous()                      # already NHWC4 (frames_u8_to_nhwc4)
+            F_, H, W, _ = x4.shape
+        else:
+            F_, Cin, H, W = x.shape
+            if Cin != 3:
+                raise RuntimeError("stem expects 3-channel frames")
+            x4 = _empty((F_, H, W, 4), x)
+            lib().call("lmkd_nchw3_to_nhwc4", _p(x.contiguous()), _p(x4), F_, H, W, _stream())
         c, stats = _conv_bn_train_or_eval(x4, w, 4, 2, 3, gamma, beta, rm, rv, training)
         N, Hc, Wc, C = c.shape
         Ho, Wo = conv_out_size(Hc, 3, 2, 1), conv_out_size(Wc, 3, 2, 1)
@@ -351,6 +355,23 @@ class StemFn(torch.autograd.Function):
         dc, _, dgamma, dbeta = bn_backward(g, c, None, stats, gamma, 2, dx_out=g)
         dw = conv_bwd_weight(x4, dc, ctx.w_shape, 2, 3)
         return None, dw, dgamma, dbeta, None, None, None
+
+
+def frames_u8_to_nhwc4(frames_u8, crop_y, crop_x, flip, size, frames_per_video=8):
+    """uint8 frames [F,Hs,Ws,3] (after the host Resize) -> float NHWC4 [F,size,size,4] in [0,1]: per-video crop offsets and
+    horizontal-flip flags (int32 device tensors, one entry per video), ToTensor scaling.  The result can be passed to the
+    backbones in place of the float NCHW frames (the stem recognises the layout)."""
+    _chk(frames_u8, crop_y, crop_x, flip)
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
+        raise RuntimeError("frames_u8_to_nhwc4 expects uint8 [F,H,W,3] frames")
+    F_, Hs, Ws, _ = frames_u8.shape
+    nv = F_ // frames_per_video
+    if nv * frames_per_video != F_ or crop_y.numel() != nv or crop_x.numel() != nv or flip.numel() != nv:
+        raise RuntimeError("one crop/flip entry per video of %d frames expected" % frames_per_video)
+    out = torch.empty((F_, size, size, 4), dtype=torch.float32, device=frames_u8.device)
+    lib().call("lmkd_frames_u8_to_nhwc4", _p(frames_u8), _p(out), _p(crop_y), _p(crop_x), _p(flip), F_, Hs, Ws, size, size,
+               frames_per_video, _stream())
+    return out
 
 
 class BasicBlockFn(torch.autograd.Function):

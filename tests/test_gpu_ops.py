@@ -480,3 +480,30 @@ def test_resnet50_trunk_forward_backward(dev):
         worst = max(worst, err)
         assert err < 5e-2, "grad %s: rel-L2 err %.3e" % (k, err)
     print("resnet50 worst grad rel-L2 err:", worst)
+
+
+def test_frames_u8_transform(dev):
+    """GPU crop + flip + ToTensor of uint8 frames == the reference's transform order (flip, then crop, then ToTensor:
+    video_reader.py:92-112) and the stem accepts the NHWC4 result"""
+    from litemkd_amd import ops
+    from litemkd_amd.model.backbone.resnet import ResNet18Trunk
+    g = torch.Generator().manual_seed(3)
+    F_, Hs, Ws, S = 16, 72, 80, 64
+    u8 = torch.randint(0, 256, (F_, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    cy = torch.tensor([3, 8], dtype=torch.int32)
+    cx = torch.tensor([10, 0], dtype=torch.int32)
+    fl = torch.tensor([1, 0], dtype=torch.int32)
+    ref = torch.empty(F_, 3, S, S)
+    for f in range(F_):
+        v = f // 8
+        img = u8[f].float() / 255.0                      # ToTensor commutes with crop / flip
+        img = img[int(cy[v]):int(cy[v]) + S, int(cx[v]):int(cx[v]) + S]
+        if int(fl[v]):
+            img = img.flip(1)
+        ref[f] = img.permute(2, 0, 1)
+    out = ops.frames_u8_to_nhwc4(u8.to(dev), cy.to(dev), cx.to(dev), fl.to(dev), S)
+    assert torch.equal(out[..., :3].cpu(), ref.permute(0, 2, 3, 1)) and float(out[..., 3].abs().max()) == 0.0
+    torch.manual_seed(1)
+    trunk = ResNet18Trunk().to(dev).eval()
+    with torch.no_grad():
+        assert torch.equal(trunk(out), trunk(ref.to(dev)))
