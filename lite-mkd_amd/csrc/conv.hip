@@ -364,20 +364,28 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// dW (OIHW) = sum over split slabs of slab[z][co][(kh*KWp+kw)*Cs + ci]
+// dW (OIHW) = sum over split slabs of slab[z][co][(kh*KWp+kw)*Cs + ci]  (coalesced slab reads, 8 loads in flight per
+// thread; the scattered 4-byte OIHW writes are ~11 M floats per trunk call in total)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Co, int Cin,
                                     int Cs, int KH, int KW, int KWp, int Kp) {
   const long total = (long)Co * KH * KW * Cin;
+  const long zs = (long)Co * Kp;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int ci = idx % Cin;
     long r = idx / Cin;
     const int kw = r % KW; r /= KW;
     const int kh = r % KH;
     const int co = r / KH;
-    const long so = (long)co * Kp + (long)(kh * KWp + kw) * Cs + ci;
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slab[(long)z * Co * Kp + so];
-    dw[(((long)co * Cin + ci) * KH + kh) * KW + kw] = s;
+    const float* p = slab + (long)co * Kp + (long)(kh * KWp + kw) * Cs + ci;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 8 <= splits; z += 8) {
+      const float a0 = p[(z + 0) * zs], a1 = p[(z + 1) * zs], a2 = p[(z + 2) * zs], a3 = p[(z + 3) * zs];
+      const float a4 = p[(z + 4) * zs], a5 = p[(z + 5) * zs], a6 = p[(z + 6) * zs], a7 = p[(z + 7) * zs];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3; s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+    }
+    for (; z < splits; ++z) s0 += p[z * zs];
+    dw[(((long)co * Cin + ci) * KH + kh) * KW + kw] = (s0 + s1) + (s2 + s3);
   }
 }
 

@@ -92,6 +92,25 @@ __global__ void colsum_partials_kernel(const Tin* __restrict__ in, double* __res
   if (tg == 0 && c < CV) out[(long)blockIdx.y * CV + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// sum of column `col` over T rows of in[T][CV] (4 independent accumulators: the loads of a thread are in flight together)
+template <typename Tin>
+__device__ __forceinline__ double colsum_inline(const Tin* __restrict__ in, int T, int CV, int col) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int t = 0;
+  for (; t + 4 <= T; t += 4) {
+    s0 += (double)in[(long)(t + 0) * CV + col];
+    s1 += (double)in[(long)(t + 1) * CV + col];
+    s2 += (double)in[(long)(t + 2) * CV + col];
+    s3 += (double)in[(long)(t + 3) * CV + col];
+  }
+  for (; t < T; ++t) s0 += (double)in[(long)t * CV + col];
+  return (s0 + s1) + (s2 + s3);
+}
+
+// Stage 1 of a tall reduction (T > 256 rows): in[T][CV] floats -> scratch[64][CV] doubles.  The consumer kernel (finalize /
+// coef) sums the remaining <= 256 rows itself, so a BatchNorm forward costs 1-2 launches and a backward 3-4.
+static int colsum_stage1(const float* in, int T, int CV, double* scratch, hipStream_t s);
+
 // reduce in[T][CV] floats to out[CV] doubles using scratch (>= 64*CV doubles)
 static int colsum_to_double(const float* in, int T, int CV, double* out, double* scratch, hipStream_t s) {
   const int gx = cdiv(CV, 64);
@@ -105,18 +124,26 @@ static int colsum_to_double(const float* in, int T, int CV, double* out, double*
   LMKD_CHECK_LAUNCH("colsum_partials_kernel");
   return LMKD_OK;
 }
+static int colsum_stage1(const float* in, int T, int CV, double* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_partials_kernel<float>, dim3(cdiv(CV, 64), 64), dim3(256), 0, s, in, scratch, T, CV);
+  LMKD_CHECK_LAUNCH("colsum_partials_kernel");
+  return LMKD_OK;
+}
 
 // ---------------------------------------------------------------------------------
 // BatchNorm finalize: sums -> mean / invstd / fused scale+shift, running-stat update
 //   stats layout out: [5][C] = mean, invstd, scale (= gamma*invstd), shift (= beta - mean*scale), unbiased variance
 // ---------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float momentum, float eps, float* __restrict__ stats) {
+__global__ void bn_finalize_kernel(const float* __restrict__ pf, const double* __restrict__ pd, int T, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                   float* __restrict__ stats) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mean = sums[2 * c] / count;
-  double var = sums[2 * c + 1] / count - mean * mean;
+  const double s1 = pf ? colsum_inline(pf, T, 2 * C, 2 * c) : colsum_inline(pd, T, 2 * C, 2 * c);
+  const double s2 = pf ? colsum_inline(pf, T, 2 * C, 2 * c + 1) : colsum_inline(pd, T, 2 * C, 2 * c + 1);
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -171,10 +198,14 @@ extern "C" int lmkd_bn_finalize(const float* partial, int T, int C, long count, 
                                 double* scratch, void* stream) {
   LMKD_REQUIRE(partial && stats && scratch && T > 0 && C > 0 && count > 0, "lmkd_bn_finalize: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  double* sums = scratch;
-  int rc = colsum_to_double(partial, T, 2 * C, sums, scratch + 2 * C, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, (const double*)sums, C, (double)count, gamma, beta,
+  const float* pf = partial;
+  const double* pd = nullptr;
+  if (T > 256) {
+    int rc = colsum_stage1(partial, T, 2 * C, scratch, s);
+    if (rc) return rc;
+    pf = nullptr; pd = scratch; T = 64;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, pf, pd, T, C, (double)count, gamma, beta,
                      running_mean, running_var, momentum, eps, stats);
   LMKD_CHECK_LAUNCH("bn_finalize_kernel");
   return LMKD_OK;
@@ -281,12 +312,13 @@ __global__ void bn_bwd_reduce_kernel(const float4* __restrict__ dy, const float4
   }
 }
 
-__global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ stats, float* __restrict__ coef, float* __restrict__ dgamma,
-                                   float* __restrict__ dbeta) {
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ pf, const double* __restrict__ pd, int T, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ stats, float* __restrict__ coef,
+                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double sg = sums[2 * c], sgx = sums[2 * c + 1];
+  const double sg = pf ? colsum_inline(pf, T, 2 * C, 2 * c) : colsum_inline(pd, T, 2 * C, 2 * c);
+  const double sgx = pf ? colsum_inline(pf, T, 2 * C, 2 * c + 1) : colsum_inline(pd, T, 2 * C, 2 * c + 1);
   const float g = gamma ? gamma[c] : 1.f;
   const float invstd = stats[C + c];
   coef[c] = g * invstd;                        // A
@@ -340,10 +372,16 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, C / CC), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s,
                      (const float4*)dy, (const float4*)x, (const float4*)yact, stats, partial, rows, C, CC, mask_mode);
   LMKD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-  int rc = colsum_to_double(partial, nb, 2 * C, dscr, dscr + 2 * C, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, (const double*)dscr, C, (double)rows, gamma, stats, coef,
-                     dgamma, dbeta);
+  const float* pf = partial;
+  const double* pd = nullptr;
+  int T = nb;
+  if (T > 256) {
+    int rc = colsum_stage1(partial, T, 2 * C, dscr, s);
+    if (rc) return rc;
+    pf = nullptr; pd = dscr; T = 64;
+  }
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, pf, pd, T, C, (double)rows, gamma, stats, coef, dgamma,
+                     dbeta);
   const long n4 = rows * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, (const float4*)dy, (const float4*)x,
                      (const float4*)yact, stats, (const float*)coef, (float4*)dx, (float4*)g_out, n4, C, mask_mode);
