@@ -38,6 +38,9 @@ int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout, int Cin, 
                              void* stream);
 int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, int KW, int stride, int pad);
 int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound kernels, workgroups per CU (default 4) */
+/* compute dtype of the convolutions: 0 = exact fp32 MFMA (default), 1 = bf16 MFMA inputs + fp32 accumulation (BASELINE configs[2]) */
+int lmkd_conv_set_compute_dtype(int bf16);
+int lmkd_conv_get_compute_dtype(void);
 int lmkd_conv_set_xcd_mode(int mode); /* tuning: -1 auto, 0 force row-band tile order, 2 auto + XCD-grouped weight-gradient splits */
 int lmkd_conv_set_tile(int id); /* tuning: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 64x128 */
 /* stat_partial (nullable): [row_tiles][Cout][2] per-tile (sum, sum of squares) for train-mode BatchNorm */

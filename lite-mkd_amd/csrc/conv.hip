@@ -102,7 +102,7 @@ static inline int xcd_grid(int n_rt, int n_ct, int mode) {
   return 8 * cdiv(n_rt, 8) * n_ct;
 }
 
-template <class Cfg, bool SMALLC, bool STATS>
+template <class Cfg, bool SMALLC, bool STATS, bool BF16>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a) {
   using LA = LoaderConvGather<Cfg::BM, SMALLC, Cfg::THREADS>;
   using LB = LoaderKMajorDense<Cfg::BN, Cfg::THREADS>;   // packed weights are K-major: Wp[col][k]
@@ -180,7 +180,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
       for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) issue(t + 1);
-        mfma_kstep<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
+        if (BF16) mfma_kstep_bf16<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
+        else mfma_kstep<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
         if (t + 1 < nk) {
           la.store(As0 + (cur ^ 1) * SA);
           lb.store(Bs0 + (cur ^ 1) * SB);
@@ -316,7 +317,7 @@ struct LoaderWgradGather {
   }
 };
 
-template <class Cfg, bool SMALLC>
+template <class Cfg, bool SMALLC, bool BF16>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgradArgs a) {
   using LA = LoaderMMajorDense<Cfg::BM, Cfg::THREADS>;
   using LB = LoaderWgradGather<Cfg::BN, SMALLC, Cfg::THREADS>;
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgradArgs a) {
   if (nk > a.steps_per_split) nk = a.steps_per_split;
   f32x16 acc[Cfg::TM][Cfg::TN];
   auto koff = [s0](int t) { return (s0 + t) * LMKD_BK; };
-  gemm_mainloop<Cfg>(la, lb, nk, koff, koff, smem, acc);
+  gemm_mainloop<Cfg, LA, LB, decltype(koff), decltype(koff), BF16>(la, lb, nk, koff, koff, smem, acc);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -442,6 +443,14 @@ extern "C" int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout
   return LMKD_OK;
 }
 
+// ---- compute dtype of the convolutions: 0 = exact fp32 MFMA (default), 1 = bf16 MFMA inputs with fp32 accumulation ----
+static int g_conv_bf16 = 0;
+extern "C" int lmkd_conv_set_compute_dtype(int bf16) {
+  g_conv_bf16 = bf16 ? 1 : 0;
+  return LMKD_OK;
+}
+extern "C" int lmkd_conv_get_compute_dtype(void) { return g_conv_bf16; }
+
 // ---- tile configuration -------------------------------------------------------------------------
 // id: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 (rows x cols, 4 waves), 5 = 128x128 and 6 = 128x64 with 8 waves (2 per SIMD).
 // Workgroups per CU by LDS: 2 / 2 / 4 / 2 / 2.
@@ -458,6 +467,7 @@ static inline int cfg_wg_per_cu(int id) { return id == 1 ? 2 : (id == 3 ? 4 : 3)
 // Pick the tile that minimises ceil(tiles / 256 CUs) * work per tile: at 64 cycles per fp32 MFMA every configuration is
 // matrix-pipe bound, so what differs is how evenly the launch's tiles divide over the CUs (the tail).
 static int pick_conv_cfg(long rows_per_class, int nclass, int ncols) {
+  if (g_conv_bf16) return ncols > 64 ? 5 : 3;
   if (g_tile_override) {
     if (ncols <= 64 && cfg_bn(g_tile_override) == 128) return g_tile_override == 5 ? 6 : (cfg_bm(g_tile_override) == 128 ? 2 : 3);
     return g_tile_override;
@@ -480,18 +490,24 @@ static int pick_conv_cfg(long rows_per_class, int nclass, int ncols) {
   return best;
 }
 
-template <class Cfg, bool SMALLC, bool STATS>
+template <class Cfg, bool SMALLC, bool STATS, bool BF16 = false>
 static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
   a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
   a.n_rt = a.nclass * a.tiles_per_class;
   a.n_ct = cdiv(ncols, Cfg::BN);
   a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
   if (g_xcd_mode == 0) a.xcd_mode = 0;
-  hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS>), dim3(xcd_grid(a.n_rt, a.n_ct, a.xcd_mode)), dim3(Cfg::THREADS), 0, s, a);
+  hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS, BF16>), dim3(xcd_grid(a.n_rt, a.n_ct, a.xcd_mode)), dim3(Cfg::THREADS), 0, s, a);
 }
 
 template <bool SMALLC, bool STATS>
 static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
+  if (g_conv_bf16) {   // bf16: load/LDS bound, the big tile reuses operands most; 64-column launches use 64x64
+    if (ncols > 64) launch_conv_cfg<TileCfg<128, 128, 2, 4>, SMALLC, STATS, true>(a, ncols, s);
+    else launch_conv_cfg<TileCfg<64, 64, 2, 2>, SMALLC, STATS, true>(a, ncols, s);
+    LMKD_CHECK_LAUNCH("conv_gemm_kernel<bf16>");
+    return LMKD_OK;
+  }
   switch (pick_conv_cfg(a.rows_per_class, a.nclass, ncols)) {
     case 1: launch_conv_cfg<TileCfg<128, 128, 2, 2>, SMALLC, STATS>(a, ncols, s); break;
     case 2: launch_conv_cfg<TileCfg<128, 64, 2, 2>, SMALLC, STATS>(a, ncols, s); break;
@@ -662,17 +678,26 @@ extern "C" int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw
   // off by default; lmkd_conv_set_xcd_mode(2) turns it on for launches with >= 32 splits
   a.xcd_mode = (g_xcd_mode == 2 && splits >= 32) ? 1 : 0;
   dim3 grid((a.xcd_mode ? 8 * cdiv(splits, 8) : splits) * a.n_mt * a.n_jt);
+#define LMKD_WGRAD_LAUNCH(CFG, SM, THR)                                                                       \
+  do {                                                                                                          \
+    if (g_conv_bf16) hipLaunchKernelGGL((conv_wgrad_kernel<CFG, SM, true>), grid, dim3(THR), 0, s, a);          \
+    else hipLaunchKernelGGL((conv_wgrad_kernel<CFG, SM, false>), grid, dim3(THR), 0, s, a);                     \
+  } while (0)
+  using C64 = TileCfg<64, 64, 2, 2>;
+  using C128x64 = TileCfg<128, 64, 2, 2>;
+  using C64x128 = TileCfg<64, 128, 2, 2>;
+  using C128 = TileCfg<128, 128, 2, 4>;     // 8 waves: 4 per SIMD at 2 workgroups per CU
   if (smallc) {
     LMKD_REQUIRE(bm == 64 && bn == 64, "lmkd_conv2d_bwd_weight: padded-stem path expects Cout <= 64");
-    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<64, 64, 2, 2>, true>), grid, dim3(LMKD_THREADS), 0, s, a);
+    LMKD_WGRAD_LAUNCH(C64, true, LMKD_THREADS);
   } else if (bm == 64 && bn == 64) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<64, 64, 2, 2>, false>), grid, dim3(LMKD_THREADS), 0, s, a);
+    LMKD_WGRAD_LAUNCH(C64, false, LMKD_THREADS);
   } else if (bm == 128 && bn == 64) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<128, 64, 2, 2>, false>), grid, dim3(LMKD_THREADS), 0, s, a);
+    LMKD_WGRAD_LAUNCH(C128x64, false, LMKD_THREADS);
   } else if (bm == 64 && bn == 128) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<64, 128, 2, 2>, false>), grid, dim3(LMKD_THREADS), 0, s, a);
+    LMKD_WGRAD_LAUNCH(C64x128, false, LMKD_THREADS);
   } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<TileCfg<128, 128, 2, 4>, false>), grid, dim3(512), 0, s, a);   // 8 waves: 4 per SIMD at 2 workgroups per CU
+    LMKD_WGRAD_LAUNCH(C128, false, 512);
   }
   LMKD_CHECK_LAUNCH("conv_wgrad_kernel");
   const long total = (long)Cout * KH * KW * Cin;

@@ -172,8 +172,55 @@ __device__ __forceinline__ void mfma_kstep(const float* __restrict__ As, const f
   }
 }
 
+// ---- bf16 MFMA variant (BASELINE configs[2]) -------------------------------------------------------------------------
+// Same loaders and the same fp32 LDS tiles; the fragments are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when they are read
+// and fed to v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  MFMA (m) of a K-step takes k = 16m + 8h + j (j = 0..7) on
+// lane half h for both operands: 8 consecutive k of a RowK row (two ds_read_b128) or 8 rows of a KOuter tile (8 ds_read_b32).
+// The matrix pipe is 16x faster than in fp32, so these kernels are bound by the LDS reads and the global loads instead.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <bool ROWK, int LD, int N>
+__device__ __forceinline__ void read_frags_bf16(const float* __restrict__ S, int row, int h, int m, bf16x8 (&f)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float v[8];
+    if (ROWK) {
+      const float4 q0 = *reinterpret_cast<const float4*>(S + (row + 32 * i) * LD + 16 * m + 8 * h);
+      const float4 q1 = *reinterpret_cast<const float4*>(S + (row + 32 * i) * LD + 16 * m + 8 * h + 4);
+      v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = S[(16 * m + 8 * h + j) * LD + row + 32 * i];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[i][j] = (__bf16)v[j];
+  }
+}
+
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void mfma_kstep_bf16(const float* __restrict__ As, const float* __restrict__ Bs, int a_row, int b_row,
+                                                int h, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  constexpr int NM = LMKD_BK / 16;
+  bf16x8 a[2][Cfg::TM], b[2][Cfg::TN];
+  read_frags_bf16<LA::ROWK, LA::LD, Cfg::TM>(As, a_row, h, 0, a[0]);
+  read_frags_bf16<LB::ROWK, LB::LD, Cfg::TN>(Bs, b_row, h, 0, b[0]);
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int cur = m & 1, nxt = cur ^ 1;
+    if (m + 1 < NM) {
+      read_frags_bf16<LA::ROWK, LA::LD, Cfg::TM>(As, a_row, h, m + 1, a[nxt]);
+      read_frags_bf16<LB::ROWK, LB::LD, Cfg::TN>(Bs, b_row, h, m + 1, b[nxt]);
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int jj = 0; jj < Cfg::TN; ++jj)
+        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][jj], acc[i][jj], 0, 0, 0);
+  }
+}
+
 // Runs nk K-steps.  koffA(t)/koffB(t) give each loader its K offset for step t.
-template <class Cfg, class LA, class LB, class FA, class FB>
+template <class Cfg, class LA, class LB, class FA, class FB, bool BF16 = false>
 __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nk, FA koffA, FB koffB, float* smem,
                                               f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
   constexpr int SA = LA::LDS_FLOATS, SB = LB::LDS_FLOATS;
@@ -202,7 +249,8 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nk, FA koffA, 
       la.load(koffA(t + 1));
       lb.load(koffB(t + 1));
     }
-    mfma_kstep<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
+    if (BF16) mfma_kstep_bf16<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
+    else mfma_kstep<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
     if (t + 1 < nk) {
       la.store(As0 + (cur ^ 1) * SA);
       lb.store(Bs0 + (cur ^ 1) * SB);

@@ -159,6 +159,18 @@ def _pack_weights(w, Cs, mode):
     return wp
 
 
+def set_conv_compute_dtype(dtype):
+    """'fp32' (default): exact-fp32 MFMA.  'bf16' (BASELINE configs[2]): the convolutions round their operands to bf16 when
+    the MFMA fragments are read and accumulate in fp32; everything else (activations in HBM, BatchNorm, loss) stays fp32."""
+    if dtype not in ("fp32", "bf16"):
+        raise ValueError(dtype)
+    lib().call("lmkd_conv_set_compute_dtype", 1 if dtype == "bf16" else 0)
+
+
+def get_conv_compute_dtype():
+    return "bf16" if lib().value("lmkd_conv_get_compute_dtype") else "fp32"
+
+
 def conv_out_size(H, K, s, p):
     return (H + 2 * p - K) // s + 1
 

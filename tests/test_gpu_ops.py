@@ -507,3 +507,79 @@ def test_frames_u8_transform(dev):
     trunk = ResNet18Trunk().to(dev).eval()
     with torch.no_grad():
         assert torch.equal(trunk(out), trunk(ref.to(dev)))
+
+
+@pytest.fixture
+def bf16_convs():
+    from litemkd_amd import ops
+    ops.set_conv_compute_dtype("bf16")
+    yield
+    ops.set_conv_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("cfg", [(3, 3, 64, 64, 64, 7, 2, 3), (2, 64, 28, 28, 64, 3, 1, 1), (2, 64, 28, 28, 128, 3, 2, 1),
+                                 (2, 128, 14, 14, 128, 3, 1, 1), (5, 256, 7, 7, 512, 3, 1, 1), (2, 64, 28, 28, 128, 1, 2, 0)])
+def test_conv_bf16_mode(dev, bf16_convs, cfg):
+    """BASELINE configs[2] arithmetic: operands rounded to bf16 (RNE), fp32 accumulation.  Oracle = the fp32 convolution of
+    the bf16-rounded tensors, so only the summation order differs (same tolerance as the fp32 test)."""
+    from litemkd_amd import ops
+    N, Cin, H, W, Cout, K, s, p = cfg
+    bf = lambda t: t.bfloat16().float()            # noqa: E731
+    x = bf(rnd(N, Cin, H, W, seed=10)).requires_grad_()
+    w = bf(rnd(Cout, Cin, K, K, seed=11) * math.sqrt(2.0 / (Cout * K * K))).requires_grad_()
+    y = F.conv2d(x, w, None, s, p)
+    gy = bf(rnd(*y.shape, seed=12))
+    y.backward(gy)
+    Cs = 4 if Cin == 3 else Cin
+    xd = torch.zeros(N, H, W, Cs)
+    xd[..., :Cin] = nhwc(x.detach())
+    xd, wdv = xd.to(dev), w.detach().to(dev)
+    yd, part = ops.conv_fwd(xd, ops._pack_weights(wdv, Cs, 0), Cout, K, K, s, p, True)
+    close(nchw(yd), y, 1e-4, 2e-5 * math.sqrt(Cin * K * K), "bf16 conv fwd")
+    close(part.double().sum(0).cpu()[:, 0], y.detach().double().sum((0, 2, 3)), 1e-4, 1e-2, "bn sum")
+    gyd = nhwc(gy).to(dev)
+    dw = ops.conv_bwd_weight(xd, gyd, tuple(w.shape), s, p)
+    close(dw, w.grad, 1e-3, 2e-5 * math.sqrt(N * y.shape[2] * y.shape[3]) * 3, "bf16 conv wgrad")
+    if Cin != 3:
+        dx = ops.conv_bwd_data(gyd, ops._pack_weights(wdv, Cin, 1), (N, H, W, Cin), Cout, K, K, s, p)
+        close(nchw(dx), x.grad, 1e-4, 2e-5 * math.sqrt(Cout * K * K), "bf16 conv dgrad")
+    # and the mode really rounds: an operand that is NOT bf16-representable gives a different result than fp32 mode
+    x2 = xd + 1e-3
+    y_b, _ = ops.conv_fwd(x2, ops._pack_weights(wdv, Cs, 0), Cout, K, K, s, p, False)
+    ops.set_conv_compute_dtype("fp32")
+    y_f, _ = ops.conv_fwd(x2, ops._pack_weights(wdv, Cs, 0), Cout, K, K, s, p, False)
+    ops.set_conv_compute_dtype("bf16")
+    assert float((y_b - y_f).abs().max()) > 0
+
+
+def test_episode_bf16_close_to_fp32(dev, bf16_convs):
+    """whole training episode with bf16 convolutions vs the same episode in fp32 on the GPU: features within 3 % of their
+    max (bf16 has an 8-bit mantissa), loss within 2 %, finite gradients.  Tolerance of BASELINE configs[2]."""
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd import ops
+    from oracle import ref_cpu as O
+    args = default_args(shot=1, query_per_class=1, img_size=96, trans_dropout=0.0, device=dev)
+    torch.manual_seed(1)
+    student, teacher = Student(args).to(dev), Teacher(args).to(dev)
+    ep = O.make_episode(901, 5, 1, 1, img=96)
+    labels = ep["target_labels"].long().to(dev)
+
+    def run():
+        student.zero_grad()
+        out = student(ep["support_set"].to(dev), ep["support_labels"].to(dev), ep["target_set"].to(dev))
+        tl = teacher(ep["support_set_feature_teacher"].to(dev), ep["support_labels"].to(dev), ep["target_set_feature_teacher"].to(dev))["logits"]
+        loss = Distiller("fc_2_sup_dist", args.cfg, dev).fc_2_sup_dist(out["logits"], tl, labels)["loss"]
+        loss.backward()
+        return out, loss.item(), [p.grad.clone() for p in student.parameters() if p.grad is not None]
+    out_b, loss_b, g_b = run()
+    ops.set_conv_compute_dtype("fp32")
+    out_f, loss_f, g_f = run()
+    ops.set_conv_compute_dtype("bf16")
+    for k in ("context_features_1", "context_features_2"):
+        a, b = out_b["context_features"][k], out_f["context_features"][k]
+        assert float((a - b).abs().max()) < 3e-2 * float(b.abs().max()), k
+        assert float((a - b).abs().max()) > 0
+    assert abs(loss_b - loss_f) < 2e-2 * abs(loss_f)
+    assert all(torch.isfinite(g).all() for g in g_b) and len(g_b) == len(g_f)
