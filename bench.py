@@ -36,8 +36,10 @@ def main():
     ap.add_argument("--serial", action="store_true", help="queue the two trunk calls on ONE stream (no kernel overlap); use this "
                     "mode under rocprofv3 so per-kernel durations are not inflated by concurrent kernels")
     ap.add_argument("--roofline-episodes", type=int, default=2)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="f32 (headline, BASELINE configs[1]) or bf16: "
-                    "convolution operands rounded to bf16 for the MFMA, fp32 accumulation, everything else fp32 (configs[2])")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f32x3"], default="f32", help="f32 (headline, BASELINE configs[1]: fp32 "
+                    "MFMA); bf16: convolution operands rounded to bf16 for the MFMA, fp32 accumulation, everything else fp32 "
+                    "(configs[2]); f32x3: fp32 convolutions computed on the bf16 matrix pipe from an exact 3-way bf16 split of "
+                    "both operands, 6 products per fp32 product, fp32 accumulation (csrc/conv_x3.h; forward + data gradient)")
     ap.add_argument("--tile", type=int, default=0, help="tuning: force a conv tile configuration (lmkd_conv_set_tile), 0 = auto")
     ap.add_argument("--backbone", default="resnet18_2fc", help="resnet18_2fc (headline) or resnet50_2fc (BASELINE configs[4])")
     ap.add_argument("--live-mfm", action="store_true", help="fuse rgb/depth/flow teacher features with the MFM transformer "
@@ -60,7 +62,7 @@ def main():
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
     litemkd_amd.lib().call("lmkd_device_check", dev.index)
     litemkd_amd.lib().call("lmkd_conv_set_tile", a.tile)
-    ops.set_conv_compute_dtype("bf16" if a.dtype == "bf16" else "fp32")
+    ops.set_conv_compute_dtype({"f32": "fp32", "bf16": "bf16", "f32x3": "fp32x3"}[a.dtype])
     cfg = default_args(shot=a.shot, device=dev, trans_dropout=a.dropout, training_iterations=10 ** 9, print_freq=10 ** 9,
                        model_backbone=a.backbone)
     torch.manual_seed(1234)                                  # identical initial weights on every rank
@@ -146,7 +148,8 @@ def main():
     cg = fam.get("conv_gemm_kernel", [0.0, 1.0, 1, 0.0])
     wg = fam.get("conv_wgrad_kernel", [0.0, 1.0, 1, 0.0])
     achieved = cg[0] / cg[1] / 1e12
-    peak = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+    # dense MFMA peaks (MI355X_MICROARCH.md); f32x3 issues 6 bf16 MFMA flops per algorithmic fp32 flop
+    peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": 2500.0, "f32x3": 2500.0 / 6}[a.dtype]
     # HBM-side traffic of the same kernel family: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950) of `bench.py --serial`,
     # committed under profiles/ — counters cannot be read from inside this process.
@@ -162,12 +165,14 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "HMDB-shape 5-way %d-shot %s + TRX_2fcsup + D2M fc_2_sup_dist training episode%s, %s"
                                % (a.shot, a.backbone, " + live MFM fusion" if a.live_mfm else "",
-                                  "fp32" if a.dtype == "f32" else "bf16 conv operands / fp32 accumulate"),
+                                  {"f32": "fp32", "bf16": "bf16 conv operands / fp32 accumulate",
+                                   "f32x3": "fp32 conv operands as 3 bf16 planes, 6 bf16 MFMA products, fp32 accumulate"}[a.dtype]),
                    "frames_per_episode": frames, "img": 224, "tasks_per_batch": cfg.tasks_per_batch, "optimizer": cfg.opt,
                    "episodes_per_optimizer_step_per_rank": every, "parallelism": "episode-parallel dp%d" % world,
                    "trans_dropout": a.dropout, "trunk_calls_overlapped_on_two_streams": not a.serial},
         "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad, %s)"
-                               % ("v_mfma_f32_32x32x2_f32" if a.dtype == "f32" else "v_mfma_f32_32x32x16_bf16"),
+                               % ("v_mfma_f32_32x32x2_f32" if a.dtype == "f32" else "v_mfma_f32_32x32x16_bf16"
+                                  + (" x6 per fp32 product; peak = bf16 peak / 6" if a.dtype == "f32x3" else "")),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_hbm_traffic.json)",
                      "algorithmic_bytes_per_launch": cg[3] / max(cg[2], 1),

@@ -243,6 +243,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
   }
 }
 
+#include "conv_x3.h"
+
 // ---------------------------------------------------------------------------------
 // weight gradient: rows = co (dy, K-outer), cols = packed (tap, ci), K = pixels, split-K slabs
 // ---------------------------------------------------------------------------------
@@ -445,28 +447,49 @@ extern "C" int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout
 
 // ---- compute dtype of the convolutions: 0 = exact fp32 MFMA (default), 1 = bf16 MFMA inputs with fp32 accumulation ----
 static int g_conv_bf16 = 0;
-extern "C" int lmkd_conv_set_compute_dtype(int bf16) {
-  g_conv_bf16 = bf16 ? 1 : 0;
+static int g_conv_x3 = 0;   // 0 | 6 | 9 bf16 MFMA products per fp32 product (conv_x3.h)
+extern "C" int lmkd_conv_set_compute_dtype(int mode) {
+  LMKD_REQUIRE(mode >= 0 && mode <= 3, "lmkd_conv_set_compute_dtype: 0 fp32 MFMA, 1 bf16, 2 fp32 as 3xbf16 (6 products), 3 (9 products)");
+  g_conv_bf16 = mode == 1;
+  g_conv_x3 = mode == 2 ? 6 : (mode == 3 ? 9 : 0);
   return LMKD_OK;
 }
-extern "C" int lmkd_conv_get_compute_dtype(void) { return g_conv_bf16; }
+extern "C" int lmkd_conv_get_compute_dtype(void) { return g_conv_bf16 ? 1 : (g_conv_x3 == 6 ? 2 : (g_conv_x3 == 9 ? 3 : 0)); }
+
+extern "C" int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, int Kp, void* stream) {
+  LMKD_REQUIRE(wp && wf, "lmkd_conv2d_split_weights: null pointer");
+  LMKD_REQUIRE(ncols > 0 && ncols % 32 == 0 && Kp > 0 && Kp % 32 == 0, "lmkd_conv2d_split_weights: ncols=%d and Kp=%d must be multiples of 32", ncols, Kp);
+  LMKD_REQUIRE((long)ncols * Kp * 6 < 0xffffffe0L, "lmkd_conv2d_split_weights: weights exceed the 4 GiB buffer range");
+  int grid = cdiv((long)ncols * Kp, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(split_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wp, (unsigned short*)wf, ncols, Kp);
+  LMKD_CHECK_LAUNCH("split_weights_kernel");
+  return LMKD_OK;
+}
 
 // ---- tile configuration -------------------------------------------------------------------------
 // id: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 (rows x cols, 4 waves), 5 = 128x128 and 6 = 128x64 with 8 waves (2 per SIMD).
 // Workgroups per CU by LDS: 2 / 2 / 4 / 2 / 2.
 static int g_tile_override = 0;
 extern "C" int lmkd_conv_set_tile(int id) {
-  LMKD_REQUIRE(id >= 0 && id <= 6, "lmkd_conv_set_tile: id must be 0 (auto) .. 6");
+  LMKD_REQUIRE(id >= 0 && id <= 9, "lmkd_conv_set_tile: id must be 0 (auto) .. 9");
   g_tile_override = id;
   return LMKD_OK;
 }
-static inline int cfg_bm(int id) { return (id <= 2 || id >= 5) ? 128 : 64; }
-static inline int cfg_bn(int id) { return (id == 1 || id == 4 || id == 5) ? 128 : 64; }
+// 7..9: the 3xbf16 kernels (conv_x3.h), 8 waves: 7 = 256x64, 8 = 128x128, 9 = 128x64
+static inline int cfg_bm(int id) { return id == 7 ? 256 : ((id <= 2 || id >= 5) ? 128 : 64); }
+static inline int cfg_bn(int id) { return (id == 1 || id == 4 || id == 5 || id == 8) ? 128 : 64; }
 static inline int cfg_wg_per_cu(int id) { return id == 1 ? 2 : (id == 3 ? 4 : 3); }
 
 // Pick the tile that minimises ceil(tiles / 256 CUs) * work per tile: at 64 cycles per fp32 MFMA every configuration is
 // matrix-pipe bound, so what differs is how evenly the launch's tiles divide over the CUs (the tail).
 static int pick_conv_cfg(long rows_per_class, int nclass, int ncols) {
+  if (g_conv_x3) {
+    if (g_tile_override >= 7) return (ncols <= 64 && g_tile_override == 8) ? 9 : g_tile_override;
+    if (ncols <= 64) return 9;
+    // measured (tools/conv_bench_x3.py): 128x128 (one workgroup per CU) wins once the launch has a tile per CU
+    return (long)nclass * cdiv(rows_per_class, 128) * cdiv(ncols, 128) >= 256 ? 8 : 9;
+  }
   if (g_conv_bf16) return ncols > 64 ? 5 : 3;
   if (g_tile_override) {
     if (ncols <= 64 && cfg_bn(g_tile_override) == 128) return g_tile_override == 5 ? 6 : (cfg_bm(g_tile_override) == 128 ? 2 : 3);
@@ -500,8 +523,29 @@ static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
   hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS, BF16>), dim3(xcd_grid(a.n_rt, a.n_ct, a.xcd_mode)), dim3(Cfg::THREADS), 0, s, a);
 }
 
+template <class Cfg, bool SMALLC, bool STATS>
+static void launch_conv_x3(ConvGemmArgs a, int ncols, hipStream_t s) {
+  a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
+  a.n_rt = a.nclass * a.tiles_per_class;
+  a.n_ct = cdiv(ncols, Cfg::BN);
+  a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
+  if (g_xcd_mode == 0) a.xcd_mode = 0;
+  const dim3 grid(xcd_grid(a.n_rt, a.n_ct, a.xcd_mode));
+  if (g_conv_x3 == 9) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, SMALLC, STATS, 9>), grid, dim3(Cfg::THREADS), 0, s, a);
+  else hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, SMALLC, STATS, 6>), grid, dim3(Cfg::THREADS), 0, s, a);
+}
+
 template <bool SMALLC, bool STATS>
 static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
+  if (g_conv_x3) {
+    switch (pick_conv_cfg(a.rows_per_class, a.nclass, ncols)) {
+      case 7: launch_conv_x3<X3Cfg<256, 64, 4, 2>, SMALLC, STATS>(a, ncols, s); break;
+      case 8: launch_conv_x3<X3Cfg<128, 128, 2, 4>, SMALLC, STATS>(a, ncols, s); break;
+      default: launch_conv_x3<X3Cfg<128, 64, 4, 2>, SMALLC, STATS>(a, ncols, s); break;
+    }
+    LMKD_CHECK_LAUNCH("conv_gemm_x3_kernel");
+    return LMKD_OK;
+  }
   if (g_conv_bf16) {   // bf16: load/LDS bound, the big tile reuses operands most; 64-column launches use 64x64
     if (ncols > 64) launch_conv_cfg<TileCfg<128, 128, 2, 4>, SMALLC, STATS, true>(a, ncols, s);
     else launch_conv_cfg<TileCfg<64, 64, 2, 2>, SMALLC, STATS, true>(a, ncols, s);

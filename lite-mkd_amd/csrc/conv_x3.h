@@ -1,0 +1,382 @@
+// fp32 convolution on the bf16 matrix pipe: exact 3-way operand split ("x3").
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate.  Every fp32 number is EXACTLY the sum of three bf16 numbers
+// (24 significand bits = 8 + 8 + 8, same exponent range):  x = x0 + x1 + x2,  x0 = trunc_bf16(x), x1 = trunc_bf16(x - x0),
+// x2 = x - x0 - x1 (both subtractions exact in fp32).  A product a*b is then the sum of nine bf16 x bf16 products, each
+// exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  Dropping the three products of order 2^-24 and below
+// (a1*b2, a2*b1, a2*b2) leaves six MFMAs per fp32-equivalent MFMA of 8x the K depth: 6 x 32 cycles for what takes
+// 8 x 64 cycles on the fp32 pipe, with the same class of error as one fp32 rounding per product (measured against an
+// fp64 reference in tests/test_gpu_ops.py: not larger than the native fp32 MFMA kernels').  NPROD = 9 keeps all nine.
+//
+// Operand tiles live in LDS as three bf16 planes  S[plane][row][32 k + 8 pad]  (80-byte rows: an odd multiple of 16 B, so
+// the 16 rows of each ds_read_b128 lane group cover all 64 banks).  A lane's MFMA operand (8 consecutive k of one row) is ONE
+// ds_read_b128 per plane.  The activation operand is split when it is stored to LDS (4 VALU + 1.5 v_perm per element, once
+// per element per workgroup); the weight operand is split once per optimizer step by lmkd_conv2d_split_weights.
+// Eight waves per workgroup, two per SIMD (waves w and w+4 share one), both operand tiles double buffered in LDS, one
+// barrier per K-step of 32.  Within a K-step a wave has two independent jobs: the MFMAs of step t (LDS buffer t&1) and the
+// split + store of step t+1's tile (other buffer) followed by the global loads of step t+2.  Waves 0-3 run them in the
+// order MFMA, store; waves 4-7 store, MFMA: on every SIMD one wave feeds the matrix pipe while its partner uses the VALU,
+// LDS-write and memory pipes.
+#pragma once
+
+#define X3_LD 40   // bf16 elements per LDS row
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct X3Cfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static constexpr int THREADS = 64 * WM * WN;
+  static constexpr int A_BYTES = 3 * BM * X3_LD * 2, B_BYTES = 3 * BN * X3_LD * 2;
+  static_assert(TM >= 1 && TN >= 1, "wave tile");
+};
+
+__device__ __forceinline__ unsigned x3_hi2(unsigned x1, unsigned x0) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); }
+
+// 4 consecutive k of one row -> the three planes' packed bf16 quads
+__device__ __forceinline__ void x3_split4(const float4& v, uint2& p0, uint2& p1, uint2& p2) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned b0[4], b1[4], b2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    b0[j] = __float_as_uint(x[j]);
+    const float r1 = x[j] - __uint_as_float(b0[j] & 0xffff0000u);
+    b1[j] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(b1[j] & 0xffff0000u);
+    b2[j] = __float_as_uint(r2);
+  }
+  p0 = make_uint2(x3_hi2(b0[1], b0[0]), x3_hi2(b0[3], b0[2]));
+  p1 = make_uint2(x3_hi2(b1[1], b1[0]), x3_hi2(b1[3], b1[2]));
+  p2 = make_uint2(x3_hi2(b2[1], b2[0]), x3_hi2(b2[3], b2[2]));
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define X3_OOB 0xfffffff0u   // byte offset past every buffer: the range check of a buffer load returns zeros
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const void* base, long bytes) {
+  const unsigned long a = (unsigned long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const unsigned n = __builtin_amdgcn_readfirstlane((unsigned)(bytes > 0xffffffe0L ? 0xffffffe0L : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long)hi << 32) | lo), 0, n, 0x00020000);
+}
+
+// Weight operand: split once per optimizer step into MFMA FRAGMENT order (lmkd_conv2d_split_weights)
+//   Wf[n-tile = col/32][k-group = k/16][plane][lane = col%32 + 32*h][8]  holds plane(W[col][16*kgroup + 8*h + j]), j = 0..7,
+// so the B fragments of one K-step (2 k-groups x 3 planes) of one 32-column tile are 6 KiB contiguous and each lane's 16 bytes
+// are exactly its MFMA operand: a wave loads them straight into registers (L1/L2 resident), no LDS and no barrier involved.
+template <int TN>
+struct X3FragB {
+  static constexpr int NR = TN * 6;
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned off[TN];     // byte offset of (n-tile, k-group 0, plane 0, this lane)
+  __device__ __forceinline__ void init(const void* wf, int ncols, int Kp, int col0 /* of this wave */, int lane) {
+    rs = x3_rsrc(wf, (long)ncols * Kp * 6);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nt = (col0 >> 5) + j;
+      off[j] = (nt * 32 < ncols) ? (unsigned)(((long)nt * (Kp >> 4) * 3 * 64 + lane) * 16) : X3_OOB;
+    }
+  }
+  // koff: first k of the K-step (multiple of 32)
+  __device__ __forceinline__ void load(int koff, u32x4 (&reg)[NR]) const {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 6; ++q)   // q = group * 3 + plane
+        reg[j * 6 + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j] == X3_OOB ? X3_OOB : off[j] + (unsigned)(((koff >> 4) * 3 + q) * 1024), 0, 0);
+  }
+};
+
+// implicit-im2col rows (output pixels) x 32 k of one tap: per row a byte offset and one validity bit per tap, so a
+// K-step's loads are  offset = valid ? base + tap shift : out of range  (no branches, no 64-bit address arithmetic)
+template <int ROWS, bool SMALLC, int THREADS>
+struct X3GatherA {
+  static constexpr int RPP = THREADS / 8;
+  static constexpr int NI = ROWS / RPP;
+  static_assert(ROWS % RPP == 0, "tile rows vs threads");
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned base[NI], mask[NI];
+  int kc4;
+  __device__ __forceinline__ void init(const float* src, long elems, int Hs, int Ws, const int* s_src, const int* s_hw,
+                                       const Tap* taps, int ntap) {
+    rs = x3_rsrc(src, elems * 4);
+    const int tid = threadIdx.x;
+    kc4 = (tid & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = (tid >> 3) + RPP * i;
+      const int hw = s_hw[row];
+      base[i] = (unsigned)(s_src[row] + kc4) * 4u;   // padded stem (Cs = 4): kc4 floats = kw tap kc4/4, so the same formula
+      unsigned m = 0;
+      for (int tp = 0; tp < ntap; ++tp) {
+        const int h = (hw >> 16) + taps[tp].dh, w = (hw & 0xffff) + taps[tp].dw + (SMALLC ? (kc4 >> 2) : 0);
+        if (hw >= 0 && (unsigned)h < (unsigned)Hs && (unsigned)w < (unsigned)Ws) m |= 1u << tp;
+      }
+      mask[i] = m;
+    }
+  }
+  // rel: byte offset of this K-step's tap and channel chunk relative to the row's own pixel
+  __device__ __forceinline__ void load(int tp, int rel, float4 (&reg)[NI]) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const unsigned o = ((mask[i] >> tp) & 1u) ? base[i] + (unsigned)rel : X3_OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+      reg[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* S, const float4 (&reg)[NI]) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      uint2 p0, p1, p2;
+      x3_split4(reg[i], p0, p1, p2);
+      unsigned char* d = S + (((tid >> 3) + RPP * i) * X3_LD + kc4) * 2;
+      *reinterpret_cast<uint2*>(d) = p0;
+      *reinterpret_cast<uint2*>(d + ROWS * X3_LD * 2) = p1;
+      *reinterpret_cast<uint2*>(d + 2 * ROWS * X3_LD * 2) = p2;
+    }
+  }
+};
+
+// All MFMAs of one K-step (two groups of 16 k) of a wave's TM x TN tiles: A fragments from the plane tiles in LDS (group 1
+// is read before the MFMAs of group 0 are issued), B fragments from registers.
+template <class Cfg>
+__device__ __forceinline__ void x3_read_group(const unsigned char* __restrict__ ap, int g, bf16x8 (&a)[3][Cfg::TM]) {
+  constexpr int PA = Cfg::BM * X3_LD * 2;
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) a[p][i] = *reinterpret_cast<const bf16x8*>(ap + p * PA + i * (32 * X3_LD * 2) + g * 32);
+}
+
+template <int N>
+__device__ __forceinline__ void x3_landed(float4 (&r)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i].x), "+v"(r[i].y), "+v"(r[i].z), "+v"(r[i].w));
+}
+template <int N>
+__device__ __forceinline__ void x3_landed(u32x4 (&r)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
+}
+
+__device__ __forceinline__ bf16x8 x3_as_bf16(const u32x4& v) {
+  union { u32x4 u; bf16x8 b; } c;
+  c.u = v;
+  return c.b;
+}
+
+template <class Cfg, int NPROD>
+__device__ __forceinline__ void x3_kstep(const unsigned char* __restrict__ As, int a_row, int h, const u32x4 (&rb)[Cfg::TN * 6],
+                                         f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  const unsigned char* ap = As + (a_row * X3_LD + 8 * h) * 2;
+  bf16x8 a[2][3][Cfg::TM];
+  x3_read_group<Cfg>(ap, 0, a[0]);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    if (g == 0) {
+      x3_read_group<Cfg>(ap, 1, a[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const bf16x8 b0 = x3_as_bf16(rb[j * 6 + g * 3 + 0]), b1 = x3_as_bf16(rb[j * 6 + g * 3 + 1]), b2 = x3_as_bf16(rb[j * 6 + g * 3 + 2]);
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        f32x16 c = acc[i][j];
+        if (NPROD == 9) {
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][2][i], b2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][1][i], b2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][2][i], b1, c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][1][i], b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][0][i], b2, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][2][i], b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][0][i], b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][1][i], b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][0][i], b0, c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    }
+  }
+}
+
+template <class Cfg, bool SMALLC, bool STATS, int NPROD>
+__global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs a) {
+  using LA = X3GatherA<Cfg::BM, SMALLC, Cfg::THREADS>;
+  using LB = X3FragB<Cfg::TN>;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Cfg::A_BYTES];
+  __shared__ int s_src[Cfg::BM], s_hw[Cfg::BM], s_out[Cfg::BM];
+  __shared__ float s_red[STATS ? Cfg::WM * Cfg::BN * 2 : 1];
+  const int tid = threadIdx.x;
+  int rt, ct;
+  if (!xcd_decode(blockIdx.x, a.n_rt, a.n_ct, a.xcd_mode, rt, ct)) return;
+  const int tile = rt / a.nclass;
+  const int cls = rt - tile * a.nclass;
+  const int ph = cls >> 1, pw = cls & 1;
+  const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
+  for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
+    const int m = row0 + r;
+    bool ok = m < a.rows_per_class;
+    int n = 0, aa = 0, bb = 0;
+    if (ok) {
+      n = fdiv(m, a.div_hw);
+      const int rem = m - n * a.Hr * a.Wr;
+      aa = fdiv(rem, a.div_w);
+      bb = rem - aa * a.Wr;
+      ok = (aa * a.omul + ph) < a.Ho && (bb * a.omul + pw) < a.Wo;
+    }
+    if (ok) {
+      s_src[r] = ((n * a.Hs + aa * a.sh) * a.Ws + bb * a.sh) * a.Cs;
+      s_hw[r] = ((aa * a.sh) << 16) | (bb * a.sh);
+      s_out[r] = ((n * a.Ho + aa * a.omul + ph) * a.Wo + bb * a.omul + pw) * a.Co;
+    } else {
+      s_src[r] = 0; s_hw[r] = -1; s_out[r] = -1;
+    }
+  }
+  __syncthreads();
+  const int nk = a.ntap[cls] * a.cps;
+  const Tap* taps = a.taps[cls];
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int h = lane >> 5;
+  const int a_row = wm * (Cfg::TM * 32) + (lane & 31);
+  LA la;
+  LB lb;
+  la.init(a.src, (long)a.N * a.Hs * a.Ws * a.Cs, a.Hs, a.Ws, s_src, s_hw, taps, a.ntap[cls]);
+  lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane);
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // Register prefetch.  A: two sets, the loads of K-step t+3 are issued while those of t+2 are in flight.  B: two sets of
+  // fragments.  hipcc places its own s_waitcnt and, across the loop back-edge, falls back to vmcnt(0) - which would also wait
+  // for loads issued a moment ago.  So every set is "landed" (x3_landed: an empty asm that consumes and redefines the
+  // registers) at ONE point per K-step, right before the split/store, when every outstanding load is at least one MFMA
+  // phase old; loads issued after that point never stand between a value and its use.
+  float4 ra0[LA::NI], ra1[LA::NI];
+  u32x4 rb0[LB::NR], rb1[LB::NR];
+  auto tap_of = [&](int t, int& tp, int& cc) { tp = t / a.cps; cc = t - tp * a.cps; };
+  auto issue_a = [&](int t, float4 (&ra)[LA::NI]) {
+    int tp, cc;
+    tap_of(t, tp, cc);
+    const Tap tap = taps[tp];
+    la.load(tp, ((tap.dh * a.Ws + tap.dw) * a.Cs + (SMALLC ? 0 : cc * LMKD_BK)) * 4, ra);
+  };
+  auto issue_b = [&](int t, u32x4 (&rb)[LB::NR]) {
+    int tp, cc;
+    tap_of(t, tp, cc);
+    lb.load(taps[tp].kofs + cc * LMKD_BK, rb);
+  };
+  const bool store_first = __builtin_amdgcn_readfirstlane(wave) >= Cfg::WM * Cfg::WN / 2;
+  // K-step t: MFMAs on LDS buffer t&1 with the B fragments in `rb`; the A set `ra` (step t+1) goes to the other buffer and
+  // is refilled with step t+3.  Waves 4-7 (store first) fetch B(t+1) into `rbn` before their MFMAs; waves 0-3 (MFMAs first)
+  // land B(t+1) in `rbn` after theirs and refill `rb` with B(t+2).
+  auto step = [&](int t, float4 (&ra)[LA::NI], u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR]) {
+    const unsigned char* cur = smem + (t & 1) * Cfg::A_BYTES;
+    unsigned char* nxt = smem + ((t + 1) & 1) * Cfg::A_BYTES;
+    if (store_first) {
+      x3_landed(ra);
+      x3_landed(rb);
+      if (t + 1 < nk) {
+        la.store(nxt, ra);
+        if (t + 3 < nk) issue_a(t + 3, ra);
+        issue_b(t + 1, rbn);
+      }
+    }
+    x3_kstep<Cfg, NPROD>(cur, a_row, h, rb, acc);
+    if (!store_first && t + 1 < nk) {
+      x3_landed(ra);
+      x3_landed(rbn);
+      la.store(nxt, ra);
+      if (t + 3 < nk) issue_a(t + 3, ra);
+      if (t + 2 < nk) issue_b(t + 2, rb);
+    }
+    __syncthreads();
+  };
+  if (nk > 0) {
+    issue_a(0, ra0);
+    issue_b(0, rb0);
+    if (nk > 1) issue_a(1, ra1);
+    x3_landed(ra0);
+    la.store(smem, ra0);
+    if (nk > 2) issue_a(2, ra0);
+    if (!store_first) {
+      x3_landed(rb0);
+      if (nk > 1) issue_b(1, rb1);
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; t += 2) {
+      step(t, ra1, rb0, rb1);
+      if (t + 1 < nk) step(t + 1, ra0, rb1, rb0);
+    }
+  }
+
+  const int cl0 = wn * (Cfg::TN * 32) + (lane & 31);
+  float s1[Cfg::TN], s2[Cfg::TN];
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane);
+      const int ob = s_out[rl];
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int col = n0 + cl0 + j * 32;
+        const float v = acc[i][j][e];
+        if (ob >= 0 && col < a.Co) {
+          float* o = a.out + (long)ob + col;
+          *o = a.accum ? v + *o : v;
+        }
+        if (STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (lane < 32) {
+        s_red[(wm * Cfg::BN + cl0 + j * 32) * 2 + 0] = t1;
+        s_red[(wm * Cfg::BN + cl0 + j * 32) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < Cfg::BN && n0 + tid < a.Co) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < Cfg::WM; ++w) {
+        t1 += s_red[(w * Cfg::BN + tid) * 2 + 0];
+        t2 += s_red[(w * Cfg::BN + tid) * 2 + 1];
+      }
+      float* p = a.stat_partial + ((long)rt * a.Co + n0 + tid) * 2;
+      p[0] = t1;
+      p[1] = t2;
+    }
+  }
+}
+
+// fp32 K-major packed weights Wp[col][Kp] -> fragment-order bf16 planes (layout: X3FragB)
+__global__ void split_weights_kernel(const float* __restrict__ wp, unsigned short* __restrict__ wf, int ncols, int Kp) {
+  const long total = (long)ncols * Kp;
+  const int G = Kp >> 4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx / Kp), k = (int)(idx - (long)col * Kp);
+    const float x = wp[idx];
+    const unsigned b0 = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(b0 & 0xffff0000u);
+    const unsigned b1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
+    const int lane = (col & 31) + 32 * ((k >> 3) & 1);
+    const long o = ((((long)(col >> 5) * G + (k >> 4)) * 3) * 64 + lane) * 8 + (k & 7);
+    wf[o] = (unsigned short)(b0 >> 16);
+    wf[o + 512] = (unsigned short)(b1 >> 16);
+    wf[o + 1024] = (unsigned short)(__float_as_uint(r2) >> 16);
+  }
+}

@@ -30,7 +30,7 @@ def _chk(*tensors):
             continue
         if not t.is_cuda:
             raise RuntimeError("lite-mkd_amd ops need CUDA(HIP) tensors; got a %s tensor — the HIP hot path has no CPU fallback" % t.device)
-        if t.dtype not in (torch.float32, torch.int64, torch.int32, torch.uint8):
+        if t.dtype not in (torch.float32, torch.int64, torch.int32, torch.uint8, torch.int16):
             raise RuntimeError("unsupported dtype %s" % t.dtype)
         if not t.is_contiguous():
             raise RuntimeError("non-contiguous tensor passed to a HIP op")
@@ -156,19 +156,26 @@ def _pack_weights(w, Cs, mode):
     wp = _empty((n,), w)
     _chk(w)
     lib().call("lmkd_conv2d_pack_weights", _p(w), _p(wp), Cout, Cin, Cs, KH, KW, mode, _stream())
+    if lib().value("lmkd_conv_get_compute_dtype") >= 2:      # fp32-as-3xbf16: the conv kernels read the three bf16 planes
+        ncols = Cout if mode == 0 else Cin
+        planes = torch.empty((3 * n,), dtype=torch.int16, device=w.device)
+        lib().call("lmkd_conv2d_split_weights", _p(wp), planes.data_ptr(), ncols, n // ncols, _stream())
+        return planes
     return wp
 
 
 def set_conv_compute_dtype(dtype):
     """'fp32' (default): exact-fp32 MFMA.  'bf16' (BASELINE configs[2]): the convolutions round their operands to bf16 when
     the MFMA fragments are read and accumulate in fp32; everything else (activations in HBM, BatchNorm, loss) stays fp32."""
-    if dtype not in ("fp32", "bf16"):
+    modes = {"fp32": 0, "bf16": 1, "fp32x3": 2, "fp32x3_9": 3}
+    if dtype not in modes:
         raise ValueError(dtype)
-    lib().call("lmkd_conv_set_compute_dtype", 1 if dtype == "bf16" else 0)
+    WEIGHT_EPOCH[0] += 1                                     # packed-weight caches hold the other mode's layout
+    lib().call("lmkd_conv_set_compute_dtype", modes[dtype])
 
 
 def get_conv_compute_dtype():
-    return "bf16" if lib().value("lmkd_conv_get_compute_dtype") else "fp32"
+    return ("fp32", "bf16", "fp32x3", "fp32x3_9")[lib().value("lmkd_conv_get_compute_dtype")]
 
 
 def conv_out_size(H, K, s, p):

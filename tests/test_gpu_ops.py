@@ -583,3 +583,88 @@ def test_episode_bf16_close_to_fp32(dev, bf16_convs):
         assert float((a - b).abs().max()) > 0
     assert abs(loss_b - loss_f) < 2e-2 * abs(loss_f)
     assert all(torch.isfinite(g).all() for g in g_b) and len(g_b) == len(g_f)
+
+
+@pytest.fixture
+def x3_convs():
+    from litemkd_amd import ops
+    ops.set_conv_compute_dtype("fp32x3")
+    yield
+    ops.set_conv_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("cfg", [(3, 3, 64, 64, 64, 7, 2, 3), (2, 64, 28, 28, 64, 3, 1, 1), (2, 64, 28, 28, 128, 3, 2, 1),
+                                 (2, 64, 27, 29, 128, 3, 2, 1), (9, 128, 14, 14, 128, 3, 1, 1), (5, 256, 7, 7, 512, 3, 1, 1),
+                                 (2, 64, 28, 28, 128, 1, 2, 0), (40, 128, 28, 28, 256, 3, 1, 1)])
+@pytest.mark.parametrize("mode", ["fp32x3", "fp32x3_9"])
+def test_conv_x3_mode(dev, cfg, mode):
+    """fp32 convolution on the bf16 matrix pipe (exact 3-way bf16 split of both operands, 6 or 9 products, fp32 accumulate,
+    csrc/conv_x3.h).  Same tolerance as the native fp32 test, and measured against an fp64 convolution its relative-L2 error
+    stays within 2x of the native fp32 MFMA kernel's (measured 0.7x - 1.4x; both are a few 1e-7): fp32-class arithmetic,
+    not reduced precision."""
+    from litemkd_amd import ops
+    N, Cin, H, W, Cout, K, s, p = cfg
+    x = rnd(N, Cin, H, W, seed=20).relu().double().requires_grad_()
+    w = (rnd(Cout, Cin, K, K, seed=21) * math.sqrt(2.0 / (Cout * K * K))).double().requires_grad_()
+    y = F.conv2d(x, w, None, s, p)
+    gy = rnd(*y.shape, seed=22).double()
+    y.backward(gy)
+    Cs = 4 if Cin == 3 else Cin
+    xd = torch.zeros(N, H, W, Cs)
+    xd[..., :Cin] = nhwc(x.detach().float())
+    xd, wdv, gyd = xd.to(dev), w.detach().float().to(dev), nhwc(gy.float()).to(dev)
+    res = {}
+    try:
+        for m in ("fp32", mode):
+            ops.set_conv_compute_dtype(m)
+            yd, part = ops.conv_fwd(xd, ops._pack_weights(wdv, Cs, 0), Cout, K, K, s, p, True)
+            dx = None if Cin == 3 else ops.conv_bwd_data(gyd, ops._pack_weights(wdv, Cin, 1), (N, H, W, Cin), Cout, K, K, s, p)
+            res[m] = (yd, part, dx)
+    finally:
+        ops.set_conv_compute_dtype("fp32")
+    yd, part, dx = res[mode]
+    close(nchw(yd), y.float(), 1e-4, 2e-5 * math.sqrt(Cin * K * K), "x3 conv fwd")
+    close(part.double().sum(0).cpu()[:, 0], y.detach().sum((0, 2, 3)), 1e-4, 1e-2, "bn sum")
+    close(part.double().sum(0).cpu()[:, 1], (y.detach() ** 2).sum((0, 2, 3)), 1e-4, 1e-2, "bn sum of squares")
+    err = lambda a, b: float((a.double().cpu() - b).norm() / b.norm())        # noqa: E731
+    e_nat, e_x3 = err(nchw(res["fp32"][0]), y.detach()), err(nchw(yd), y.detach())
+    assert e_x3 <= 2.0 * e_nat + 1e-8, (e_x3, e_nat)
+    if dx is not None:
+        close(nchw(dx), x.grad.float(), 1e-4, 2e-5 * math.sqrt(Cout * K * K), "x3 conv dgrad")
+        e_nat, e_x3 = err(nchw(res["fp32"][2]), x.grad), err(nchw(dx), x.grad)
+        assert e_x3 <= 2.0 * e_nat + 1e-8, (e_x3, e_nat)
+
+
+def test_episode_x3_matches_fp32(dev, x3_convs):
+    """whole training episode with the 3xbf16 convolutions vs the same episode with the fp32 MFMA convolutions: same loss
+    to 1e-5 relative, features to 1e-4 of their max, gradients to 2e-2 relative L2 (ReLU-mask flips, as between any two fp32
+    implementations; see test_block_isolated)."""
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd import ops
+    from oracle import ref_cpu as O
+    args = default_args(shot=1, query_per_class=1, img_size=96, trans_dropout=0.0, device=dev)
+    torch.manual_seed(1)
+    student, teacher = Student(args).to(dev), Teacher(args).to(dev)
+    ep = O.make_episode(902, 5, 1, 1, img=96)
+    labels = ep["target_labels"].long().to(dev)
+
+    def run():
+        student.zero_grad()
+        out = student(ep["support_set"].to(dev), ep["support_labels"].to(dev), ep["target_set"].to(dev))
+        tl = teacher(ep["support_set_feature_teacher"].to(dev), ep["support_labels"].to(dev), ep["target_set_feature_teacher"].to(dev))["logits"]
+        loss = Distiller("fc_2_sup_dist", args.cfg, dev).fc_2_sup_dist(out["logits"], tl, labels)["loss"]
+        loss.backward()
+        return out, loss.item(), {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None}
+    out_x, loss_x, g_x = run()
+    ops.set_conv_compute_dtype("fp32")
+    out_f, loss_f, g_f = run()
+    ops.set_conv_compute_dtype("fp32x3")
+    for k in ("context_features_1", "context_features_2"):
+        a, b = out_x["context_features"][k], out_f["context_features"][k]
+        assert float((a - b).abs().max()) < 1e-4 * float(b.abs().max()), k
+    assert abs(loss_x - loss_f) < 1e-5 * abs(loss_f)
+    num = sum(float((g_x[n] - g_f[n]).double().pow(2).sum()) for n in g_f)
+    den = sum(float(g_f[n].double().pow(2).sum()) for n in g_f)
+    assert math.sqrt(num / den) < 2e-2
