@@ -52,6 +52,11 @@ int lmkd_conv_set_tile(int id); /* tuning: 0 auto, 1 128x128, 2 128x64, 3 64x64,
 /* stat_partial (nullable): [row_tiles][Cout][2] per-tile (sum, sum of squares) for train-mode BatchNorm */
 int lmkd_conv2d_fwd(const float* x, const float* wp_fwd, float* y, float* stat_partial, int N, int H, int W, int Cs, int Cout,
                     int KH, int KW, int stride, int pad, void* stream);
+/* inference (module.eval(), trainwandb.py:366 / test.py): y = relu?(conv(x)*scale[c] + shift[c] (+ res)) in ONE kernel - the eval-mode
+   BatchNorm (bn_stats = the [5][C] table of lmkd_bn_eval_stats), the residual add and the ReLU of torchvision's BasicBlock /
+   Bottleneck run in the convolution's epilogue.  Bit-identical to lmkd_conv2d_fwd followed by lmkd_bn_apply. */
+int lmkd_conv2d_fwd_bn(const float* x, const float* wp_fwd, float* y, const float* bn_stats, const float* res /*nullable*/, int relu,
+                       int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, void* stream);
 /* accumulate != 0: dx += ... (the block's residual-branch gradient is already in dx) */
 int lmkd_conv2d_bwd_data(const float* dy, const float* wp_dgrad, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int accumulate, void* stream);

@@ -27,6 +27,10 @@ struct ConvGemmArgs {
   int Kp, cps, nclass;
   int n_rt, n_ct, xcd_mode;   // row tiles (all classes), column tiles, tile order (XCD-aware 1-D grid, see xcd_decode)
   int accum;   // epilogue: out = acc + out (residual-branch gradient already sits in the output buffer)
+  // STATS == 2 (inference): out = relu?( acc * scale[c] + shift[c] (+ res) ), scale/shift = rows 2/3 of the [5][C] BatchNorm table
+  const float* ep_stats;
+  const float* ep_res;
+  int ep_relu;
   FastDiv div_hw, div_w;
   int ntap[LMKD_MAX_CLASSES];
   Tap taps[LMKD_MAX_CLASSES][LMKD_MAX_TAPS];
@@ -102,13 +106,13 @@ static inline int xcd_grid(int n_rt, int n_ct, int mode) {
   return 8 * cdiv(n_rt, 8) * n_ct;
 }
 
-template <class Cfg, bool SMALLC, bool STATS, bool BF16>
+template <class Cfg, bool SMALLC, int STATS, bool BF16>   // STATS: 0 plain store, 1 + BatchNorm partial sums, 2 BatchNorm-affine (+residual, ReLU) epilogue
 __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a) {
   using LA = LoaderConvGather<Cfg::BM, SMALLC, Cfg::THREADS>;
   using LB = LoaderKMajorDense<Cfg::BN, Cfg::THREADS>;   // packed weights are K-major: Wp[col][k]
   __shared__ __attribute__((aligned(16))) float smem[2 * (LA::LDS_FLOATS + LB::LDS_FLOATS)];
   __shared__ int s_src[Cfg::BM], s_hw[Cfg::BM], s_out[Cfg::BM];
-  __shared__ float s_red[STATS ? Cfg::WM * Cfg::BN * 2 : 1];
+  __shared__ float s_red[STATS == 1 ? Cfg::WM * Cfg::BN * 2 : 1];
 
   const int tid = threadIdx.x;
   int rt, ct;
@@ -197,6 +201,15 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
   float s1[Cfg::TN], s2[Cfg::TN];
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) s1[j] = s2[j] = 0.f;
+  float esc[Cfg::TN], esh[Cfg::TN];
+  if (STATS == 2) {
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = n0 + cl0 + j * 32;
+      esc[j] = col < a.Co ? a.ep_stats[2 * a.Co + col] : 0.f;
+      esh[j] = col < a.Co ? a.ep_stats[3 * a.Co + col] : 0.f;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i) {
 #pragma unroll
@@ -206,17 +219,24 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j) {
         const int col = n0 + cl0 + j * 32;
-        const float v = acc[i][j][e];
+        float v = acc[i][j][e];
         if (ob >= 0 && col < a.Co) {
           float* o = a.out + (long)ob + col;
-          *o = a.accum ? v + *o : v;
+          if (STATS == 2) {   // same operations, in the same order, as bn_apply_kernel: bit-identical to the two-pass form
+            v = fmaf(v, esc[j], esh[j]);
+            if (a.ep_res) v += a.ep_res[(long)ob + col];
+            if (a.ep_relu) v = fmaxf(v, 0.f);
+            *o = v;
+          } else {
+            *o = a.accum ? v + *o : v;
+          }
         }
-        if (STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+        if (STATS == 1) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (STATS) {
+  if (STATS == 1) {
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
       const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
       }
     }
   }
-  if (STATS) {
+  if (STATS == 1) {
     __syncthreads();
     if (tid < Cfg::BN && n0 + tid < a.Co) {
       float s1 = 0.f, s2 = 0.f;
@@ -513,7 +533,7 @@ static int pick_conv_cfg(long rows_per_class, int nclass, int ncols) {
   return best;
 }
 
-template <class Cfg, bool SMALLC, bool STATS, bool BF16 = false>
+template <class Cfg, bool SMALLC, int STATS, bool BF16 = false>
 static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
   a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
   a.n_rt = a.nclass * a.tiles_per_class;
@@ -535,16 +555,18 @@ static void launch_conv_x3(ConvGemmArgs a, int ncols, hipStream_t s) {
   else hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, SMALLC, STATS, 6>), grid, dim3(Cfg::THREADS), 0, s, a);
 }
 
-template <bool SMALLC, bool STATS>
+template <bool SMALLC, int STATS>
 static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
-  if (g_conv_x3) {
-    switch (pick_conv_cfg(a.rows_per_class, a.nclass, ncols)) {
-      case 7: launch_conv_x3<X3Cfg<256, 64, 4, 2>, SMALLC, STATS>(a, ncols, s); break;
-      case 8: launch_conv_x3<X3Cfg<128, 128, 2, 4>, SMALLC, STATS>(a, ncols, s); break;
-      default: launch_conv_x3<X3Cfg<128, 64, 4, 2>, SMALLC, STATS>(a, ncols, s); break;
+  if constexpr (STATS != 2) {
+    if (g_conv_x3) {
+      switch (pick_conv_cfg(a.rows_per_class, a.nclass, ncols)) {
+        case 7: launch_conv_x3<X3Cfg<256, 64, 4, 2>, SMALLC, STATS == 1>(a, ncols, s); break;
+        case 8: launch_conv_x3<X3Cfg<128, 128, 2, 4>, SMALLC, STATS == 1>(a, ncols, s); break;
+        default: launch_conv_x3<X3Cfg<128, 64, 4, 2>, SMALLC, STATS == 1>(a, ncols, s); break;
+      }
+      LMKD_CHECK_LAUNCH("conv_gemm_x3_kernel");
+      return LMKD_OK;
     }
-    LMKD_CHECK_LAUNCH("conv_gemm_x3_kernel");
-    return LMKD_OK;
   }
   if (g_conv_bf16) {   // bf16: load/LDS bound, the big tile reuses operands most; 64-column launches use 64x64
     if (ncols > 64) launch_conv_cfg<TileCfg<128, 128, 2, 4>, SMALLC, STATS, true>(a, ncols, s);
@@ -570,8 +592,9 @@ extern "C" int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, 
   return cdiv(M, cfg_bm(pick_conv_cfg(M, 1, Cout)));
 }
 
-extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float* stat_partial, int N, int H, int W, int Cs,
-                               int Cout, int KH, int KW, int stride, int pad, void* stream) {
+static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* stat_partial, const float* ep_stats,
+                           const float* ep_res, int ep_relu, int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride,
+                           int pad, void* stream) {
   LMKD_REQUIRE(x && wp && y, "lmkd_conv2d_fwd: null pointer");
   LMKD_REQUIRE(aligned16(x) && aligned16(wp), "lmkd_conv2d_fwd: x / packed weights must be 16-byte aligned");
   LMKD_REQUIRE(Cs % 32 == 0 || Cs == 4, "lmkd_conv2d_fwd: channel count %d must be 4 (padded stem) or a multiple of 32", Cs);
@@ -584,6 +607,7 @@ extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float*
   ConvGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.src = x; a.wpk = wp; a.out = y; a.stat_partial = stat_partial;
+  a.ep_stats = ep_stats; a.ep_res = ep_res; a.ep_relu = ep_relu;
   a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cs;
   a.Ho = conv_out(H, KH, stride, pad); a.Wo = conv_out(W, KW, stride, pad); a.Co = Cout;
   LMKD_REQUIRE(a.Ho > 0 && a.Wo > 0, "lmkd_conv2d_fwd: empty output");
@@ -604,8 +628,23 @@ extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float*
       for (int kw = 0; kw < KW; ++kw) a.taps[0][kh * KW + kw] = Tap{kh - pad, kw - pad, (kh * KWp + kw) * Cs};
   }
   hipStream_t s = (hipStream_t)stream;
-  if (smallc) return stat_partial ? launch_conv_gemm<true, true>(a, Cout, s) : launch_conv_gemm<true, false>(a, Cout, s);
-  return stat_partial ? launch_conv_gemm<false, true>(a, Cout, s) : launch_conv_gemm<false, false>(a, Cout, s);
+  if (ep_stats) return smallc ? launch_conv_gemm<true, 2>(a, Cout, s) : launch_conv_gemm<false, 2>(a, Cout, s);
+  if (smallc) return stat_partial ? launch_conv_gemm<true, 1>(a, Cout, s) : launch_conv_gemm<true, 0>(a, Cout, s);
+  return stat_partial ? launch_conv_gemm<false, 1>(a, Cout, s) : launch_conv_gemm<false, 0>(a, Cout, s);
+}
+
+extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float* stat_partial, int N, int H, int W, int Cs,
+                               int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  return conv2d_fwd_impl(x, wp, y, stat_partial, nullptr, nullptr, 0, N, H, W, Cs, Cout, KH, KW, stride, pad, stream);
+}
+
+// Inference form: y = relu?( conv(x) * scale[c] + shift[c] (+ res) ) in the convolution's epilogue (scale/shift = rows 2/3 of
+// the [5][C] table of lmkd_bn_eval_stats); the same operations in the same order as lmkd_conv2d_fwd + lmkd_bn_apply.
+extern "C" int lmkd_conv2d_fwd_bn(const float* x, const float* wp, float* y, const float* bn_stats, const float* res, int relu,
+                                  int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  LMKD_REQUIRE(bn_stats, "lmkd_conv2d_fwd_bn: BatchNorm table missing");
+  LMKD_REQUIRE(!g_conv_x3, "lmkd_conv2d_fwd_bn: not available in the 3xbf16 mode (packed weights have another layout)");
+  return conv2d_fwd_impl(x, wp, y, nullptr, bn_stats, res, relu, N, H, W, Cs, Cout, KH, KW, stride, pad, stream);
 }
 
 // dx[N,H,W,Cin] (+= when accumulate) from dy[N,Ho,Wo,Cout]; wd = weights packed with mode 1
@@ -653,7 +692,7 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
   a.rows_per_class = N * a.Hr * a.Wr;
   a.tiles_per_class = cdiv(a.rows_per_class, 128);
   a.div_hw = make_fastdiv(a.Hr * a.Wr); a.div_w = make_fastdiv(a.Wr);
-  return launch_conv_gemm<false, false>(a, Cin, (hipStream_t)stream);
+  return launch_conv_gemm<false, 0>(a, Cin, (hipStream_t)stream);
 }
 
 // Split-K plan of the weight gradient.  Output tiles are few (Cout x 9*Cin is small) and the reduction is long, so the

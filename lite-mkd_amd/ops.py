@@ -319,6 +319,29 @@ def side_stream(device):
     return _side_streams[key]
 
 
+FUSE_EVAL_BN = True      # eval mode: BatchNorm (+ residual, ReLU) in the convolution epilogue (lmkd_conv2d_fwd_bn)
+
+
+def _eval_fused():
+    return FUSE_EVAL_BN and not torch.is_grad_enabled() and lib().value("lmkd_conv_get_compute_dtype") < 2
+
+
+def conv_bn_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, relu, res=None):
+    """inference: relu?(BN_eval(conv(x)) (+ res)) in one kernel; bit-identical to conv_fwd + bn_stats_eval + bn_apply"""
+    Cout, _, KH, KW = w.shape
+    wp = pack_weights(w, Cs, 0)
+    stats = bn_stats_eval(gamma, beta, rm, rv)
+    _chk(x, wp, res)
+    N, H, W, _ = x.shape
+    Ho, Wo = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
+    y = _empty((N, Ho, Wo, Cout), x)
+    cin = 3 if Cs == 4 else Cs
+    with _timed("conv_gemm_kernel", 2.0 * N * Ho * Wo * Cout * cin * KH * KW, 4 * (x.numel() + y.numel() + wp.numel())):
+        lib().call("lmkd_conv2d_fwd_bn", _p(x), _p(wp), _p(y), _p(stats), _p(res), int(relu), N, H, W, Cs, Cout, KH, KW, stride, pad,
+                   _stream())
+    return y
+
+
 def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training):
     Cout, _, KH, KW = w.shape
     wp = pack_weights(w, Cs, 0)
@@ -402,6 +425,11 @@ class BasicBlockFn(torch.autograd.Function):
     def forward(ctx, x, stride, training, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, wd, gd, bd, rmd, rvd):
         _chk(x, w1, w2, wd)
         Cs = x.shape[-1]
+        if not training and _eval_fused():
+            ctx.training = False
+            a1 = conv_bn_eval(x, w1, Cs, stride, 1, g1, b1, rm1, rv1, True)
+            r = x if wd is None else conv_bn_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, False)
+            return conv_bn_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, True, r)
         c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, stride, 1, g1, b1, rm1, rv1, training)
         a1 = bn_apply(c1, st1, True)
         c2, st2 = _conv_bn_train_or_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training)
@@ -462,6 +490,12 @@ class BottleneckFn(torch.autograd.Function):
         _chk(x, w1, w2, w3, wd)
         Cs = x.shape[-1]
         Cm = w1.shape[0]
+        if not training and _eval_fused():
+            ctx.training = False
+            a1 = conv_bn_eval(x, w1, Cs, 1, 0, g1, b1, rm1, rv1, True)
+            a2 = conv_bn_eval(a1, w2, Cm, stride, 1, g2, b2, rm2, rv2, True)
+            r = x if wd is None else conv_bn_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, False)
+            return conv_bn_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, True, r)
         c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, 1, 0, g1, b1, rm1, rv1, training)
         a1 = bn_apply(c1, st1, True)
         c2, st2 = _conv_bn_train_or_eval(a1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training)

@@ -668,3 +668,33 @@ def test_episode_x3_matches_fp32(dev, x3_convs):
     num = sum(float((g_x[n] - g_f[n]).double().pow(2).sum()) for n in g_f)
     den = sum(float(g_f[n].double().pow(2).sum()) for n in g_f)
     assert math.sqrt(num / den) < 2e-2
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_eval_bn_fused_in_conv_epilogue(dev, arch):
+    """inference path (model.eval(), trainwandb.py:366): BatchNorm + residual + ReLU run in the convolution epilogue
+    (lmkd_conv2d_fwd_bn).  Must be BIT-identical to the two-pass form (conv, then bn_apply) and match the oracle trunk."""
+    from litemkd_amd import ops
+    from litemkd_amd.model.backbone.resnet import ResNet18Trunk, ResNet50Trunk
+    from oracle import ref_cpu as O
+    torch.manual_seed(3)
+    trunk = (ResNet18Trunk() if arch == "resnet18" else ResNet50Trunk()).to(dev)
+    with torch.no_grad():                      # non-trivial running statistics
+        for n, b in trunk.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(torch.randn_like(b) * 0.1)
+            elif n.endswith("running_var"):
+                b.copy_(torch.rand_like(b) + 0.5)
+    trunk.eval()
+    x = torch.rand(6, 3, 64, 64)
+    with torch.no_grad():
+        y_fused = trunk(x.to(dev))
+        ops.FUSE_EVAL_BN = False
+        try:
+            y_two = trunk(x.to(dev))
+        finally:
+            ops.FUSE_EVAL_BN = True
+    assert torch.equal(y_fused, y_two)
+    sd = {k: v.detach().cpu() for k, v in trunk.state_dict().items()}
+    ref = (O.resnet18_trunk if arch == "resnet18" else O.resnet50_trunk)(x, sd, training=False)
+    close(nchw(y_fused), ref, 1e-3, 1e-4 * float(ref.abs().max()), "eval trunk vs oracle")
