@@ -17,7 +17,8 @@ def default_args(**over):
         distill_name="fc_2_sup_dist", model_backbone="resnet18_2fc", model_classifier="TRX_2fcsup",
         model_teacher="test_teacher_TRX_2fcsup_fixed", teacher_checkpoint=None, test_model="student",
         soft_loss_weight=1, hard_loss_weight=1, test=False, cfg=dict(DEFAULT_CFG),
-        checkpoint_dir=None, training_iterations=100010, learning_rate=0.0001, opt="sgd")
+        checkpoint_dir=None, training_iterations=100010, learning_rate=0.0001, opt="sgd",
+        test_iters=[], save_dir="model_save", test_model_path=None)
     for k, v in over.items():
         setattr(a, k, v)
     return a

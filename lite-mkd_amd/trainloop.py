@@ -97,8 +97,23 @@ def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
     return task_loss.detach(), task_accuracy, {"accuracy": task_accuracy}
 
 
+def save_checkpoint(student, iteration, config):
+    """trainwandb.py:171-180: {'iteration', 'model_state_dict'} -> <save_dir>/<yyyymmddHHMM><mode><iteration>.pt (the
+    file load_student / the reference's test.py read).  Rank 0 only: the replicas hold identical weights."""
+    import os
+    import time
+    from .parallel import rank as _rank
+    if _rank() != 0:
+        return None
+    os.makedirs(config.save_dir, exist_ok=True)
+    path = os.path.join(config.save_dir, "%s%s%d.pt" % (time.strftime("%Y%m%d%H%M", time.localtime(time.time())), config.mode, iteration))
+    torch.save({"iteration": iteration, "model_state_dict": {k: v.detach().cpu() for k, v in student.state_dict().items()}}, path)
+    return path
+
+
 def train(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log=None):
-    """trainwandb.py:111-188.  Returns (losses, accuracies) as python floats."""
+    """trainwandb.py:111-188 (optimizer cadence, print, checkpoint every save_freq, test at test_iters).
+    Returns (losses, accuracies) as python floats."""
     losses, accuracies = [], []
     total_iterations = config.training_iterations
     every = max(1, config.tasks_per_batch // world_size())
@@ -118,6 +133,12 @@ def train(student, teacher, video_loader, distiller, optimizer, scheduler, accur
         if log is not None and (iteration + 1) % config.print_freq == 0:
             log(iteration, float(torch.stack(losses[-config.print_freq:]).mean()),
                 float(torch.stack(accuracies[-config.print_freq:]).mean()))
+        if ((iteration + 1) % config.save_freq == 0) and (iteration + 1) != total_iterations:
+            save_checkpoint(student, iteration, config)
+        if ((iteration + 1) in getattr(config, "test_iters", ())) and (iteration + 1) != total_iterations:
+            accuracy_dict = test(student, video_loader, accuracy_fn, config)
+            if log is not None:
+                log(iteration, accuracy_dict, None)
     return [float(x) for x in losses], [float(x) for x in accuracies]
 
 

@@ -109,6 +109,44 @@ def test_train_loop_runs_and_steps(dev):
     assert 0.0 <= acc[cfg.dataset]["accuracy"] <= 100.0
 
 
+def test_train_loop_checkpoint_and_test_iters(dev, tmp_path):
+    """trainwandb.py:171-187: a checkpoint {'iteration','model_state_dict'} every save_freq iterations that load_student
+    (model_select.py:138-153) reads back — also with DataParallel's `module.` prefix on the trunk keys — and the in-training
+    test() call at test_iters; the reloaded student scores the same test episodes identically."""
+    import glob
+    from litemkd_amd import trainloop as TL
+    from litemkd_amd.model.model_select import Student, Teacher, load_student
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd.utils import aggregate_accuracy
+    cfg = default_args(shot=1, query_per_class=1, img_size=64, device=dev, training_iterations=4, tasks_per_batch=2,
+                       learning_rate=1e-2, print_freq=100, save_freq=3, test_iters=[2], num_test_tasks=2, save_dir=str(tmp_path))
+    torch.manual_seed(4)
+    student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
+    opt = TL.FusedOptimizer(student, "sgd", cfg.learning_rate)
+    logged = []
+    src = TL.SyntheticEpisodes(cfg, base_seed=6, device=dev)
+    TL.train(student, teacher, src, Distiller(cfg.distill_name, cfg.cfg, dev), opt, TL.MultiStepLR(opt, cfg.sch),
+             aggregate_accuracy, cfg, log=lambda it, a, b: logged.append((it, a, b)))
+    assert any(isinstance(a, dict) and it == 1 for it, a, _ in logged)          # test() ran at iteration+1 == 2
+    files = glob.glob(str(tmp_path / "*.pt"))
+    assert len(files) == 1 and files[0].endswith("%s2.pt" % cfg.mode)            # (iteration+1) % 3 == 0 -> iteration 2
+    ck = torch.load(files[0], map_location="cpu")
+    assert ck["iteration"] == 2 and set(ck["model_state_dict"]) == set(student.state_dict())
+    # the reference saves DataParallel-wrapped trunks: backbone.resnet.module.N... -> must load too
+    dp = {k.replace("backbone.resnet.", "backbone.resnet.module."): v for k, v in ck["model_state_dict"].items()}
+    torch.save({"iteration": 2, "model_state_dict": dp}, str(tmp_path / "dp.pt"))
+    cfg2 = default_args(**{**vars(cfg), "test_model_path": str(tmp_path / "dp.pt")})
+    restored = load_student(cfg2).to(dev)
+    for k, v in ck["model_state_dict"].items():
+        assert torch.equal(restored.state_dict()[k].cpu(), v), k
+    ev = TL.SyntheticEpisodes(cfg, base_seed=11, device=dev, train=False)
+    student.load_state_dict(ck["model_state_dict"])
+    a1 = TL.test(student, ev, aggregate_accuracy, cfg)
+    a2 = TL.test(restored, ev, aggregate_accuracy, cfg)
+    assert a1 == a2
+
+
 def test_full_size_properties(dev):
     """BASELINE size (5-way 5-shot, 8x224^2): properties that need no oracle —
     BN batch independence of the two trunk calls, permutation equivariance over frames, determinism."""
