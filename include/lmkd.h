@@ -110,6 +110,12 @@ int lmkd_trx_dist_fwd(const float* Qv, const float* proto, float* logits, int Nq
                       void* stream); /* :137-144 */
 int lmkd_trx_dist_bwd(const float* Qv, float* proto_inout, const float* g, float* dQv, int Nq, int way, int T, int D, int nseg,
                       const int* seg_col, void* stream);
+/* TRX_sup (TRX_sup.py:117-172): sim[q][a][b] = cosine similarity of query q's class-a and class-b prototypes; proto is the
+   [nseg][Nq*T][D] prototype buffer of the TRX forward, seg_col[s] (host array) the class of segment s, gram [Nq][nseg][nseg] is kept for backward */
+int lmkd_trx_sup_sim_fwd(const float* proto, const int* seg_col, float* sim, float* gram, int Nq, int way, int nseg, int T, int D,
+                         void* stream);
+int lmkd_trx_sup_sim_bwd(const float* proto, const int* seg_col, const float* gram, const float* dsim, float* dproto, int Nq, int way,
+                         int nseg, int T, int D, void* stream);
 int lmkd_supportdk_fwd(const float* support, float* out, int way, int shot, int seq_len, int D, void* stream);
 int lmkd_supportdk_bwd(const float* support, const float* g, float* dsupport, int way, int shot, int seq_len, int D, void* stream);
 int lmkd_mean_frames(const float* x, float* y, long nv, int L, int D, void* stream);

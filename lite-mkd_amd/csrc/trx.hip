@@ -488,3 +488,119 @@ extern "C" int lmkd_edist_bwd(const float* qm, const float* sm, const int* sup_c
   LMKD_CHECK_LAUNCH("edist_bwd_kernel");
   return LMKD_OK;
 }
+
+
+// ---------------------------------------------------------------------------------
+// TRX_sup (TRX_sup.py:117-172): cosine similarity between the query-specific class prototypes of one query,
+//   sim[q][a][b] = <P_qa, P_qb> / max(|P_qa| |P_qb|, eps),  P_qc = proto[seg(c)][q*T .. q*T+T-1][:]  (T*D values; classes without
+// support keep the reference's all-zero prototype -> similarity 0).  One workgroup per query.
+// ---------------------------------------------------------------------------------
+#define TRXS_MAXW 8
+struct TrxsCols { int c[TRXS_MAXW]; };   // class of each support segment, passed by value (host array at the C ABI)
+__global__ __launch_bounds__(256) void trx_sup_sim_fwd_kernel(const float* __restrict__ proto, TrxsCols seg_col,
+                                                              float* __restrict__ sim, float* __restrict__ gram, int way, int nseg,
+                                                              long Dp, long seg_stride) {
+  const int q = blockIdx.x;
+  float g[TRXS_MAXW * (TRXS_MAXW + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < TRXS_MAXW * (TRXS_MAXW + 1) / 2; ++i) g[i] = 0.f;
+  const float* base = proto + (long)q * Dp;
+  for (long k = threadIdx.x; k < Dp; k += 256) {
+    float v[TRXS_MAXW];
+#pragma unroll
+    for (int a = 0; a < TRXS_MAXW; ++a) v[a] = a < nseg ? base[a * seg_stride + k] : 0.f;
+    int i = 0;
+#pragma unroll
+    for (int a = 0; a < TRXS_MAXW; ++a)
+#pragma unroll
+      for (int b = a; b < TRXS_MAXW; ++b, ++i) g[i] = fmaf(v[a], v[b], g[i]);
+  }
+  __shared__ float G[TRXS_MAXW][TRXS_MAXW];
+  __shared__ float red[4];
+  {
+    int i = 0;
+    for (int a = 0; a < TRXS_MAXW; ++a)
+      for (int b = a; b < TRXS_MAXW; ++b, ++i) {
+        const float t = block_sum_256(g[i], red);
+        if (threadIdx.x == 0) { G[a][b] = t; G[b][a] = t; }
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < way * way; i += 256) sim[(long)q * way * way + i] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nseg * nseg; i += 256) {
+    const int a = i / nseg, b = i - a * nseg;
+    const float den = fmaxf(sqrtf(G[a][a]) * sqrtf(G[b][b]), 1e-8f);
+    sim[((long)q * way + seg_col.c[a]) * way + seg_col.c[b]] = G[a][b] / den;
+    gram[((long)q * nseg + a) * nseg + b] = G[a][b];
+  }
+}
+
+// dP_a = sum_{b != a} (dsim[a][b] + dsim[b][a]) * (P_b / (n_a n_b) - G_ab P_a / (n_a^3 n_b))
+__global__ __launch_bounds__(256) void trx_sup_sim_bwd_kernel(const float* __restrict__ proto, TrxsCols seg_col,
+                                                              const float* __restrict__ gram, const float* __restrict__ dsim,
+                                                              float* __restrict__ dproto, int way, int nseg, long Dp, long seg_stride) {
+  const int q = blockIdx.x;
+  __shared__ float c1[TRXS_MAXW][TRXS_MAXW], c2[TRXS_MAXW];   // dP_a = sum_b c1[a][b] P_b - c2[a] P_a
+  if (threadIdx.x < nseg) {
+    const int a = threadIdx.x;
+    const float* G = gram + (long)q * nseg * nseg;
+    const float na = sqrtf(G[a * nseg + a]);
+    float acc2 = 0.f;
+    for (int b = 0; b < nseg; ++b) {
+      float w = 0.f, cb = 0.f;
+      if (b != a) {
+        const float nb = sqrtf(G[b * nseg + b]);
+        const float den = fmaxf(na * nb, 1e-8f);
+        w = dsim[((long)q * way + seg_col.c[a]) * way + seg_col.c[b]] + dsim[((long)q * way + seg_col.c[b]) * way + seg_col.c[a]];
+        cb = w / den;
+        acc2 += na > 0.f ? w * G[a * nseg + b] / (den * na * na) : 0.f;
+      }
+      c1[a][b] = cb;
+    }
+    c2[a] = acc2;
+  }
+  __syncthreads();
+  const float* base = proto + (long)q * Dp;
+  float* out = dproto + (long)q * Dp;
+  for (long k = threadIdx.x; k < Dp; k += 256) {
+    float v[TRXS_MAXW];
+#pragma unroll
+    for (int a = 0; a < TRXS_MAXW; ++a) v[a] = a < nseg ? base[a * seg_stride + k] : 0.f;
+#pragma unroll
+    for (int a = 0; a < TRXS_MAXW; ++a) {
+      if (a >= nseg) break;
+      float d = -c2[a] * v[a];
+#pragma unroll
+      for (int b = 0; b < TRXS_MAXW; ++b)
+        if (b < nseg) d = fmaf(c1[a][b], v[b], d);
+      out[a * seg_stride + k] = d;
+    }
+  }
+}
+
+extern "C" int lmkd_trx_sup_sim_fwd(const float* proto, const int* seg_col, float* sim, float* gram, int Nq, int way, int nseg, int T,
+                                    int D, void* stream) {
+  LMKD_REQUIRE(proto && seg_col && sim && gram && Nq > 0 && T > 0 && D > 0, "lmkd_trx_sup_sim_fwd: bad arguments");
+  LMKD_REQUIRE(nseg >= 1 && nseg <= way && way <= TRXS_MAXW, "lmkd_trx_sup_sim_fwd: 1 <= classes with support <= way <= %d", TRXS_MAXW);
+  TrxsCols cols;
+  for (int i = 0; i < TRXS_MAXW; ++i) cols.c[i] = i < nseg ? seg_col[i] : 0;
+  for (int i = 0; i < nseg; ++i) LMKD_REQUIRE(seg_col[i] >= 0 && seg_col[i] < way, "lmkd_trx_sup_sim_fwd: class label %d outside [0,%d)", seg_col[i], way);
+  hipLaunchKernelGGL(trx_sup_sim_fwd_kernel, dim3(Nq), dim3(256), 0, (hipStream_t)stream, proto, cols, sim, gram, way, nseg,
+                     (long)T * D, (long)Nq * T * D);
+  LMKD_CHECK_LAUNCH("trx_sup_sim_fwd_kernel");
+  return LMKD_OK;
+}
+
+extern "C" int lmkd_trx_sup_sim_bwd(const float* proto, const int* seg_col, const float* gram, const float* dsim, float* dproto, int Nq,
+                                    int way, int nseg, int T, int D, void* stream) {
+  LMKD_REQUIRE(proto && seg_col && gram && dsim && dproto && Nq > 0 && T > 0 && D > 0, "lmkd_trx_sup_sim_bwd: bad arguments");
+  LMKD_REQUIRE(nseg >= 1 && nseg <= way && way <= TRXS_MAXW, "lmkd_trx_sup_sim_bwd: 1 <= classes with support <= way <= %d", TRXS_MAXW);
+  TrxsCols cols;
+  for (int i = 0; i < TRXS_MAXW; ++i) cols.c[i] = i < nseg ? seg_col[i] : 0;
+  for (int i = 0; i < nseg; ++i) LMKD_REQUIRE(seg_col[i] >= 0 && seg_col[i] < way, "lmkd_trx_sup_sim_bwd: class label %d outside [0,%d)", seg_col[i], way);
+  hipLaunchKernelGGL(trx_sup_sim_bwd_kernel, dim3(Nq), dim3(256), 0, (hipStream_t)stream, proto, cols, gram, dsim, dproto, way, nseg,
+                     (long)T * D, (long)Nq * T * D);
+  LMKD_CHECK_LAUNCH("trx_sup_sim_bwd_kernel");
+  return LMKD_OK;
+}

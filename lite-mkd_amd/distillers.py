@@ -3,8 +3,8 @@ method names; each method is resolved by `getattr(distiller, config.distill_name
 and returns a dict with at least 'loss' (0-dim tensor carrying grad).
 
 All methods built from the three primitives kd_loss / inter_class_relation / cross_entropy run as ONE
-fused HIP launch (values + logits gradients).  All 22 logits-only methods of the reference are provided; `support_sim`
-and `KL_feature` (they need classifier outputs no in-scope plugin produces) raise NotImplementedError."""
+fused HIP launch (values + logits gradients).  All logits-only methods of the reference are provided (23, incl. `support_sim` for the TRX_sup
+classifier); `KL_feature` (needs raw feature tensors no classifier of the reference emits) raises NotImplementedError."""
 import torch
 
 from . import ops
@@ -45,6 +45,18 @@ class Distiller(object):
         w_ce, w_kl = d["hard_loss_weight"] / 16.0, d["soft_loss_weight"]
         loss, kl, _, ce = _terms(s_kl=s, t_kl=t, s_ce=s, labels=test_labels, T=d["temperature"], w_kl=w_kl, w_ce=w_ce)
         return {"hard_loss": w_ce * ce, "soft_loss": w_kl * kl, "loss": loss}
+
+    def support_sim(self, student_logits, teacher_logits, test_labels):
+        """distillers.py:110-124 (classifier TRX_sup): KL on the per-query prototype similarities, reshaped to the reference's
+        hard-coded (20, 25), + KL on the query logits + CE/16."""
+        d = self.distill_dict
+        sim_s = self._to(student_logits["support_set"]).reshape(20, 25)
+        sim_t = self._to(teacher_logits["support_set"]).reshape(20, 25)
+        q_s, q_t = self._to(student_logits["query"]), self._to(teacher_logits["query"])
+        w_sup, w_q, w_ce = d["soft_loss_weight_support"], d["soft_loss_weight_query"], d["hard_loss_weight"] / 16.0
+        l_sup = _terms(s_kl=sim_s, t_kl=sim_t, T=d["temperature"], w_kl=w_sup)[0]
+        l_rest, kl_q, _, ce = _terms(s_kl=q_s, t_kl=q_t, s_ce=q_s, labels=test_labels, T=d["temperature"], w_kl=w_q, w_ce=w_ce)
+        return {"hard_loss": w_ce * ce, "soft_support_loss": l_sup, "soft_query_loss": w_q * kl_q, "loss": l_sup + l_rest}
 
     def ce(self, student_logits, teacher_logits, test_labels):
         """distillers.py:100-108"""
@@ -202,5 +214,5 @@ class Distiller(object):
         raise AttributeError(name)
 
 
-# need per-support-sample similarity logits / raw features that no in-scope classifier produces (distillers.py:110-150)
-_OUT_OF_SCOPE = {"support_sim", "KL_feature"}
+# needs raw feature tensors in the logits dict that no classifier of the reference produces (distillers.py:126-150)
+_OUT_OF_SCOPE = {"KL_feature"}

@@ -55,7 +55,7 @@ class TemporalCrossTransformer(nn.Module):
         seed = (torch.initial_seed() * 1000003 + self._drop_calls) & 0x7FFFFFFFFFFFFFFF
         return ops.dropout_mask((n_rows, 2048), p, seed, device)
 
-    def forward(self, support_set, support_labels, queries):
+    def forward(self, support_set, support_labels, queries, with_sim=False):
         L = self.args.seq_len
         if support_set.shape[1] != L or support_set.shape[2] != 2048:
             raise RuntimeError("TemporalCrossTransformer expects [N,%d,2048] features" % L)
@@ -64,7 +64,11 @@ class TemporalCrossTransformer(nn.Module):
         mask = self._mask((support_set.shape[0] + queries.shape[0]) * L, support_set.device)
         a = (self.k_linear.weight, self.k_linear.bias, self.v_linear.weight, self.v_linear.bias,
              self.norm_k.weight, self.norm_k.bias, pe, mask, plan)
-        if torch.is_grad_enabled() and (support_set.requires_grad or self.k_linear.weight.requires_grad):
+        grad = torch.is_grad_enabled() and (support_set.requires_grad or self.k_linear.weight.requires_grad)
+        if with_sim:      # TRX_sup.py:74-178: + cosine similarity between each query's class prototypes
+            logits, sim = ops.TRXSupFn.apply(support_set, queries, *a) if grad else ops.trx_sup_nograd(support_set, queries, plan, *a[:8])
+            return {"logits": {"support_set": sim, "query": logits}}
+        if grad:
             logits = ops.TRXLogitsFn.apply(support_set, queries, *a)
         else:
             logits = ops.trx_logits_nograd(support_set, queries, plan, *a[:8])
@@ -145,6 +149,34 @@ class TRX_fixed(nn.Module):
             c = context_feature.reshape(-1, L, D)
             t = target_feature.reshape(-1, L, D)
             return {"logits": self.transformers(c, context_labels, t)["logits"]}
+
+
+class TRX_sup(nn.Module):
+    """model/classifiers/TRX_sup.py:194-209 — {'logits': {'support_set': [Nq, way, way] prototype cosine similarities,
+    'query': [Nq, way] TRX logits}} (consumed by Distiller.support_sim)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.train()
+        self.args = args
+        self.transformers = TemporalCrossTransformer(args, 2)
+
+    def forward(self, context_feature, context_labels, target_feature):
+        return self.transformers(context_feature, context_labels, target_feature, with_sim=True)
+
+
+class TRX_sup_fixed(nn.Module):
+    """model/classifiers/TRX_sup.py:212-229 — the same under no_grad (frozen teacher)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.train()
+        self.args = args
+        self.transformers = TemporalCrossTransformer(args, 2)
+
+    def forward(self, context_feature, context_labels, target_feature):
+        with torch.no_grad():
+            return self.transformers(context_feature, context_labels, target_feature, with_sim=True)
 
 
 class TRX_2fc(nn.Module):

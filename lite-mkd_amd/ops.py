@@ -656,7 +656,12 @@ class TRXLogitsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        Xp, Kn, V, Khat, rstd, S, proto, rowmap, wk, wv, gamma, mask = ctx.saved_tensors
+        return _trx_backward(ctx, g)
+
+
+def _trx_backward(ctx, g, gsim=None, gram=None):
+        """backward of TRXLogitsFn (g: d logits) and TRXSupFn (+ gsim: d of the prototype cosine similarities)"""
+        Xp, Kn, V, Khat, rstd, S, proto, rowmap, wk, wv, gamma, mask = ctx.saved_tensors[:12]
         plan, seg_off, seg_cnt = ctx.plan, ctx.seg_off, ctx.seg_cnt
         (Ns, L, Din), (Nq, _, _) = ctx.shapes
         D = wk.shape[0]
@@ -668,8 +673,15 @@ class TRXLogitsFn(torch.autograd.Function):
         dKn = _empty((NV * T, D), Xp)
         dV = _empty((NV * T, D), Xp)
         dSk, dSv, dQk, dQv = dKn[:Rs], dV[:Rs], dKn[Rs:], dV[Rs:]
+        dp_sim = None
+        if gsim is not None:      # needs the prototypes themselves: before they are overwritten below
+            dp_sim = torch.empty_like(proto)
+            lib().call("lmkd_trx_sup_sim_bwd", _p(proto), _ints(plan.classes), _p(gram), _p(gsim.contiguous()), _p(dp_sim), Nq, plan.way,
+                       nseg, T, D, _stream())
         # proto <- dproto ; dQv = -sum_c dproto_c
         lib().call("lmkd_trx_dist_bwd", _p(Qv), _p(proto), _p(g), _p(dQv), Nq, plan.way, T, D, nseg, _ints(plan.classes), _stream())
+        if dp_sim is not None:
+            lib().call("lmkd_axpby", _p(dp_sim), _p(proto), _f32(1.0), _f32(1.0), proto.numel(), _stream())
         dS = _empty((Rq, Rs), Xp)
         if plan.uniform:
             c = seg_cnt[0]
@@ -708,6 +720,42 @@ class TRXLogitsFn(torch.autograd.Function):
         dsup = dX[:Ns * L].reshape(Ns, L, Din)
         dqry = dX[Ns * L:].reshape(Nq, L, Din)
         return dsup, dqry, dwk, dbk, dwv, dbv, dgamma, dbeta, None, None, None
+
+
+def _trx_sup_sim(proto, plan, Nq, T, D):
+    nseg = len(plan.classes)
+    sim = _empty((Nq, plan.way, plan.way), proto)
+    gram = _empty((Nq, nseg, nseg), proto)
+    lib().call("lmkd_trx_sup_sim_fwd", _p(proto), _ints(plan.classes), _p(sim), _p(gram), Nq, plan.way, nseg, T, D, _stream())
+    return sim, gram
+
+
+class TRXSupFn(torch.autograd.Function):
+    """TemporalCrossTransformer.forward of TRX_sup.py:74-178: the TRX logits ('query') plus, per query, the cosine similarity
+    between its class prototypes ('support_set' [Nq, way, way])."""
+
+    @staticmethod
+    def forward(ctx, sup, qry, wk, bk, wv, bv, gamma, beta, pe, mask, plan):
+        _chk(sup, qry, wk, bk, wv, bv, gamma, beta, pe, mask)
+        logits, saved = _trx_forward(sup.contiguous(), qry.contiguous(), plan, wk, bk, wv, bv, gamma, beta, pe, mask, True)
+        Xp, Kn, V, Khat, rstd, S, proto, rowmap, seg_off, seg_cnt = saved
+        L, D = sup.shape[1], wk.shape[0]
+        sim, gram = _trx_sup_sim(proto, plan, qry.shape[0], L * (L - 1) // 2, D)
+        ctx.save_for_backward(Xp, Kn, V, Khat, rstd, S, proto, rowmap, wk, wv, gamma, mask, gram)
+        ctx.plan, ctx.seg_off, ctx.seg_cnt = plan, seg_off, seg_cnt
+        ctx.shapes = (sup.shape, qry.shape)
+        return logits, sim
+
+    @staticmethod
+    def backward(ctx, g, gsim):
+        return _trx_backward(ctx, g, gsim, ctx.saved_tensors[12])
+
+
+def trx_sup_nograd(sup, qry, plan, wk, bk, wv, bv, gamma, beta, pe, mask=None):
+    _chk(sup, qry, wk, bk, wv, bv, gamma, beta, pe, mask)
+    logits, saved = _trx_forward(sup.contiguous(), qry.contiguous(), plan, wk, bk, wv, bv, gamma, beta, pe, mask, False)
+    L, D = sup.shape[1], wk.shape[0]
+    return logits, _trx_sup_sim(saved[6], plan, qry.shape[0], L * (L - 1) // 2, D)[0]
 
 
 def trx_logits_nograd(sup, qry, plan, wk, bk, wv, bv, gamma, beta, pe, mask=None):

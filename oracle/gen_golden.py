@@ -53,6 +53,7 @@ def load_reference():
         sys.modules["torchvision.models"] = tv.models
     torch.Tensor.cuda = lambda self, *a, **k: self
     mods["trx"] = _load("ref_TRX_2fcsup", os.path.join(REF, "model/classifiers/TRX_2fcsup.py"))
+    mods["trx_sup"] = _load("ref_TRX_sup", os.path.join(REF, "model/classifiers/TRX_sup.py"))     # same two shims
     return mods
 
 
@@ -208,6 +209,45 @@ def gen_trx(mods):
     return out
 
 
+def gen_trx_sup(mods):
+    """TRX_sup / TRX_sup_fixed (TRX_sup.py) in eval(), 20 queries (Distiller.support_sim hard-codes reshape(20,25)), and
+    Distiller.support_sim on their outputs."""
+    T = mods["trx_sup"]
+    D = mods["distillers"]
+    out = {}
+    for case, (seed, ns, nq, shuffle) in enumerate([(41, 25, 20, True), (42, 5, 20, True)]):
+        args = Args()
+        args.shot = ns // 5
+        p, sup, qry, sup_t, qry_t, lab = trx_case_inputs(seed, ns, nq, shuffle)
+        clf = T.TRX_sup(args).eval()
+        sd = clf.state_dict()
+        for k, v in p.items():
+            sd["transformers." + k].copy_(v)
+        sup.requires_grad_()
+        qry.requires_grad_()
+        r = clf(sup, lab, qry)["logits"]
+        fx = T.TRX_sup_fixed(args).eval()
+        fsd = fx.state_dict()
+        for k, v in p.items():
+            fsd["transformers." + k].copy_(0.9 * v)           # a different (frozen) teacher
+        rt = fx(sup_t, lab, qry_t)["logits"]
+        labels = torch.arange(nq) % 5
+        res = D.Distiller("support_sim", dict(O.DEFAULT_CFG), torch.device("cpu")).support_sim(r, rt, labels)
+        w = torch.linspace(-1, 1, nq * 25).reshape(nq, 5, 5)
+        (res["loss"] + (r["support_set"] * w).sum() * 1e-2).backward()
+        pre = "c%d_" % case
+        tr = clf.transformers
+        out.update({pre + "seed": seed, pre + "ns": ns, pre + "nq": nq, pre + "shuffle": int(shuffle),
+                    pre + "query": r["query"], pre + "support_set": r["support_set"],
+                    pre + "fixed_query": rt["query"], pre + "fixed_support_set": rt["support_set"],
+                    pre + "loss": res["loss"], pre + "hard_loss": res["hard_loss"], pre + "soft_support_loss": res["soft_support_loss"],
+                    pre + "soft_query_loss": res["soft_query_loss"],
+                    pre + "g_sup": gsum(sup.grad), pre + "g_qry": gsum(qry.grad),
+                    pre + "g_kw_sum": tr.k_linear.weight.grad.sum(dim=1), pre + "g_vw_sum": tr.v_linear.weight.grad.sum(dim=1),
+                    pre + "g_nkw": tr.norm_k.weight.grad})
+    return out
+
+
 def trx_case_inputs(seed, ns, nq, shuffle):
     """Re-creates the exact inputs/weights of gen_trx (used by tests; no reference needed)."""
     g = torch.Generator().manual_seed(1000 + seed)
@@ -228,7 +268,8 @@ def main():
     torch.manual_seed(0)
     mods = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    for name, fn in (("distill", gen_distill), ("distill_methods", gen_distill_methods), ("edist", gen_edist), ("trx", gen_trx)):
+    for name, fn in (("distill", gen_distill), ("distill_methods", gen_distill_methods), ("edist", gen_edist), ("trx", gen_trx),
+                     ("trx_sup", gen_trx_sup)):
         data = t2n(fn(mods))
         path = os.path.join(GOLD, name + ".npz")
         if a.check_only:

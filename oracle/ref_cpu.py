@@ -286,6 +286,38 @@ def trx_logits(support, labels, queries, p, way=5, seq_len=8, out_dim=1152):
     return out
 
 
+def trx_sup_logits(support, labels, queries, p, way=5, seq_len=8, out_dim=1152):
+    """TemporalCrossTransformer.forward of TRX_sup.py:74-178 -> ('query' [Nq,way] logits, 'support_set' [Nq,way,way]):
+    the TRX logits plus the cosine similarity (dim = 28*1152 prototype entries) between each query's class prototypes;
+    classes without support keep a zero prototype."""
+    n_q, n_s = queries.shape[0], support.shape[0]
+    pe = p["pe.pe"][:, :seq_len]
+    support = support + pe
+    queries = queries + pe
+    tuples = frame_tuples(seq_len, 2)
+    s = torch.stack([support[:, t, :].reshape(n_s, -1) for t in tuples], dim=-2)
+    q = torch.stack([queries[:, t, :].reshape(n_q, -1) for t in tuples], dim=-2)
+    T = len(tuples)
+    s_k = F.layer_norm(F.linear(s, p["k_linear.weight"], p["k_linear.bias"]), (out_dim,), p["norm_k.weight"], p["norm_k.bias"], 1e-5)
+    q_k = F.layer_norm(F.linear(q, p["k_linear.weight"], p["k_linear.bias"]), (out_dim,), p["norm_k.weight"], p["norm_k.bias"], 1e-5)
+    s_v = F.linear(s, p["v_linear.weight"], p["v_linear.bias"])
+    q_v = F.linear(q, p["v_linear.weight"], p["v_linear.bias"])
+    protos = [torch.zeros(n_q, T, out_dim) for _ in range(way)]
+    logits = [torch.zeros(n_q) for _ in range(way)]
+    for c in torch.unique(labels):
+        idx = torch.nonzero(labels == c).reshape(-1)
+        ck, cv = s_k[idx], s_v[idx]
+        sc = torch.matmul(q_k.unsqueeze(1), ck.transpose(-2, -1)) / math.sqrt(out_dim)
+        sc = torch.softmax(sc.permute(0, 2, 1, 3).reshape(n_q, T, -1), dim=-1)
+        sc = sc.reshape(n_q, T, -1, T).permute(0, 2, 1, 3)
+        proto = torch.matmul(sc, cv).sum(dim=1)
+        protos[int(c.long())] = proto
+        logits[int(c.long())] = -((q_v - proto).pow(2).sum(dim=(-2, -1))) / T
+    allp = torch.stack(protos, dim=-1).reshape(n_q, -1, way)                       # :171
+    sim = F.cosine_similarity(allp.unsqueeze(2), allp.unsqueeze(3), dim=1)         # :173
+    return torch.stack(logits, dim=1), sim
+
+
 # ----------------------------------------------------------------------------
 # A6  SupportDK.forward (TRX_2fcsup.py:162-189 == e_dist_fc2.py:17-44)
 # ----------------------------------------------------------------------------
@@ -408,6 +440,9 @@ def distill_method(name, s, t, labels, cfg=DEFAULT_CFG):
         return distill_fc_2_sup_dist(s, t, labels, cfg)["loss"]
     if name == "ce":                                                    # :100-108
         return _ce16(s, labels)
+    if name == "support_sim":                                           # :110-124 (20 queries hard-coded)
+        return (cfg["soft_loss_weight_support"] * kd_loss(s["support_set"].reshape(20, 25), t["support_set"].reshape(20, 25), T)
+                + cfg["soft_loss_weight_query"] * kd_loss(s["query"], t["query"], T) + hw * _ce16(s["query"], labels))
     if name == "wsl":                                                   # :76-98
         fw = _focal(F.cross_entropy(s, labels), F.cross_entropy(t, labels))
         return sw * fw * kd_loss(s, t, T) + hw * _ce16(s, labels)

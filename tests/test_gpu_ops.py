@@ -320,6 +320,47 @@ def test_trx_golden(dev, golden_dir, case):
     close(rf["sup"], torch.from_numpy(G[pre + "fixed_sup"]), 1e-4, 2e-2, "fixed sup")
 
 
+@pytest.mark.parametrize("case", [0, 1])
+def test_trx_sup_golden(dev, golden_dir, case):
+    """TRX_sup / TRX_sup_fixed (TRX_sup.py) and Distiller.support_sim vs fixtures produced by the reference's own modules."""
+    import os
+    from litemkd_amd.model import classifiers as C
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import DEFAULT_CFG
+    from oracle.gen_golden import trx_case_inputs
+    G = np.load(os.path.join(golden_dir, "trx_sup.npz"))
+    pre = "c%d_" % case
+    ns, nq = int(G[pre + "ns"]), int(G[pre + "nq"])
+    p, sup, qry, sup_t, qry_t, lab = trx_case_inputs(int(G[pre + "seed"]), ns, nq, bool(G[pre + "shuffle"]))
+    args = _args(dev, shot=ns // 5)
+    clf, fx = C.TRX_sup(args), C.TRX_sup_fixed(args)
+    sd, fsd = clf.state_dict(), fx.state_dict()
+    for k, v in p.items():
+        sd["transformers." + k].copy_(v)
+        fsd["transformers." + k].copy_(0.9 * v)
+    clf, fx = clf.to(dev), fx.to(dev)
+    s, q = sup.to(dev).requires_grad_(), qry.to(dev).requires_grad_()
+    r = clf(s, lab.to(dev), q)["logits"]
+    rt = fx(sup_t.to(dev), lab.to(dev), qry_t.to(dev))["logits"]
+    close(r["query"], torch.from_numpy(G[pre + "query"]), 1e-4, 2e-2, "query logits")
+    close(r["support_set"], torch.from_numpy(G[pre + "support_set"]), 1e-4, 1e-5, "prototype similarities")
+    close(rt["query"], torch.from_numpy(G[pre + "fixed_query"]), 1e-4, 2e-2, "fixed query logits")
+    close(rt["support_set"], torch.from_numpy(G[pre + "fixed_support_set"]), 1e-4, 1e-5, "fixed similarities")
+    labels = (torch.arange(nq) % 5).to(dev)
+    res = Distiller("support_sim", dict(DEFAULT_CFG), dev).support_sim(r, rt, labels)
+    for k in ("loss", "hard_loss", "soft_support_loss", "soft_query_loss"):
+        close(res[k], torch.from_numpy(G[pre + k]), 1e-4, 1e-5, k)
+    w = torch.linspace(-1, 1, nq * 25).reshape(nq, 5, 5).to(dev)
+    (res["loss"] + (r["support_set"] * w).sum() * 1e-2).backward()
+    for name, x in (("g_sup", s), ("g_qry", q)):
+        ref = torch.from_numpy(G[pre + name])
+        close(_gsum(x.grad), ref, 2e-3, 2e-3 * float(ref.abs().max()), name)
+    tr = clf.transformers
+    for name, gt in (("g_nkw", tr.norm_k.weight.grad), ("g_kw_sum", tr.k_linear.weight.grad.sum(1)), ("g_vw_sum", tr.v_linear.weight.grad.sum(1))):
+        ref = torch.from_numpy(G[pre + name])
+        close(gt, ref, 5e-3, 5e-3 * max(float(ref.abs().max()), 1e-4), name)
+
+
 def test_trx_ragged_classes(dev):
     """unequal shots per class + a missing class (column stays 0, like torch.zeros in the reference)"""
     from litemkd_amd import ops

@@ -103,6 +103,37 @@ def test_trx_golden(golden_dir):
         close(rf["sup"], G[pre + "fixed_sup"], rtol=1e-5, atol=1e-3)
 
 
+def test_trx_sup_golden(golden_dir):
+    """TRX_sup / TRX_sup_fixed + Distiller.support_sim (reference modules run here by oracle/gen_golden.py)"""
+    G = np.load(os.path.join(golden_dir, "trx_sup.npz"))
+    for c in range(2):
+        pre = "c%d_" % c
+        ns, nq = int(G[pre + "ns"]), int(G[pre + "nq"])
+        p, sup, qry, sup_t, qry_t, lab = trx_case_inputs(int(G[pre + "seed"]), ns, nq, bool(G[pre + "shuffle"]))
+        for k in ("k_linear.weight", "v_linear.weight", "norm_k.weight"):
+            p[k].requires_grad_()
+        sup.requires_grad_()
+        qry.requires_grad_()
+        q, sim = O.trx_sup_logits(sup, lab, qry, p)
+        close(q, G[pre + "query"], rtol=1e-5, atol=1e-3)
+        close(sim, G[pre + "support_set"], rtol=1e-5, atol=1e-6)
+        pt = {k: (0.9 * v).detach() for k, v in p.items()}
+        qt, simt = O.trx_sup_logits(sup_t, lab, qry_t, pt)
+        close(qt, G[pre + "fixed_query"], rtol=1e-5, atol=1e-3)
+        close(simt, G[pre + "fixed_support_set"], rtol=1e-5, atol=1e-6)
+        labels = torch.arange(nq) % 5
+        loss = O.distill_method("support_sim", {"query": q, "support_set": sim}, {"query": qt, "support_set": simt}, labels)
+        close(loss, G[pre + "loss"], rtol=1e-5, atol=1e-6)
+        w = torch.linspace(-1, 1, nq * 25).reshape(nq, 5, 5)
+        (loss + (sim * w).sum() * 1e-2).backward()
+        close(gsum(sup.grad), G[pre + "g_sup"], rtol=1e-4, atol=1e-5)
+        close(gsum(qry.grad), G[pre + "g_qry"], rtol=1e-4, atol=1e-5)
+        # row sums over 4096 weight-gradient entries of mixed sign: fp32 summation-order noise ~2e-4
+        close(p["k_linear.weight"].grad.sum(1), G[pre + "g_kw_sum"], rtol=1e-3, atol=1e-3)
+        close(p["v_linear.weight"].grad.sum(1), G[pre + "g_vw_sum"], rtol=1e-3, atol=1e-3)
+        close(p["norm_k.weight"].grad, G[pre + "g_nkw"], rtol=1e-4, atol=1e-5)
+
+
 def test_trunk_shapes_and_param_count():
     shp = O.resnet18_trunk_param_shapes()
     n = sum(int(np.prod(s)) for k, s in shp.items() if "running" not in k and "num_batches" not in k)
