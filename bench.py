@@ -40,6 +40,7 @@ def main():
                     "MFMA); bf16: convolution operands rounded to bf16 for the MFMA, fp32 accumulation, everything else fp32 "
                     "(configs[2]); f32x3: fp32 convolutions computed on the bf16 matrix pipe from an exact 3-way bf16 split of "
                     "both operands, 6 products per fp32 product, fp32 accumulation (csrc/conv_x3.h; forward + data gradient)")
+    ap.add_argument("--layer-table", action="store_true", help="print the per-layer-shape conv timing table of the roofline pass to stderr")
     ap.add_argument("--tile", type=int, default=0, help="tuning: force a conv tile configuration (lmkd_conv_set_tile), 0 = auto")
     ap.add_argument("--backbone", default="resnet18_2fc", help="resnet18_2fc (headline) or resnet50_2fc (BASELINE configs[4])")
     ap.add_argument("--live-mfm", action="store_true", help="fuse rgb/depth/flow teacher features with the MFM transformer "
@@ -149,6 +150,17 @@ def main():
         f[1] += e0.elapsed_time(e1) * 1e-3
         f[2] += 1
         f[3] += nbytes
+    if a.layer_table and rank == 0:      # per distinct (kernel family, FLOPs, bytes) launch shape: where the conv time goes
+        shp = {}
+        for name, flops, e0, e1, nbytes in timing:
+            g = shp.setdefault((name, flops, nbytes), [0.0, 0])
+            g[0] += e0.elapsed_time(e1) * 1e-3
+            g[1] += 1
+        tot = sum(g[0] for g in shp.values())
+        print("# kernel family | GFLOP/launch | MB/launch | launches | avg us | TFLOP/s | share of conv time", file=sys.stderr)
+        for (name, flops, nbytes), (t, n) in sorted(shp.items(), key=lambda kv: -kv[1][0]):
+            print("%-18s %7.2f %7.1f %4d %8.1f %6.1f %5.1f%%" % (name, flops / 1e9, nbytes / 1e6, n, t / n * 1e6, flops * n / t / 1e12,
+                                                           100 * t / tot), file=sys.stderr)
     cg = fam.get("conv_gemm_kernel", [0.0, 1.0, 1, 0.0])
     wg = fam.get("conv_wgrad_kernel", [0.0, 1.0, 1, 0.0])
     achieved = cg[0] / cg[1] / 1e12

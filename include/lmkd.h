@@ -68,6 +68,13 @@ int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, floa
 /* crop + horizontal flip + ToTensor of uint8 HWC frames into NHWC4 (video_reader.py:92-112 after Resize); crop/flip per video */
 int lmkd_frames_u8_to_nhwc4(const unsigned char* src, float* dst, const int* crop_y, const int* crop_x, const int* flip, int F, int Hs,
                             int Ws, int H, int W, int frames_per_video, void* stream);
+/* Resize of the frame transform (video_reader.py:96-101 -> videotransforms/functional.py:44-59 = PIL.Image.resize(BILINEAR)):
+   Pillow's 8-bit triangle-filter resampler, bit exact.  lmkd_resize_plan fills the HOST tables of one axis (bounds [out][2],
+   22-bit fixed-point coefficients [out][ksize]) and returns ksize (> 0; call with null tables to size them); the caller
+   uploads them and runs lmkd_resize_pass_u8 over [outer][n_in][inner] uint8 -> [outer][n_out][inner], horizontal axis first. */
+int lmkd_resize_plan(int in_size, int out_size, int* bounds_host, int* coeffs_host);
+int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst, const int* bounds_dev, const int* coeffs_dev, int ksize, long outer,
+                        int n_in, int n_out, long inner, void* stream);
 int lmkd_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int N, int H, int W, void* stream);
 /* stats: [5][C] = mean, invstd, scale, shift, unbiased batch variance.  scratch: >= 65*2*C doubles.
  * running_mean/var may be NULL (update deferred to lmkd_bn_running_update) */

@@ -4,6 +4,8 @@
 // lane along the channel dimension, 256-thread workgroups, grid-stride, deterministic
 // two-level reductions (no float atomics).
 #include "common.h"
+#include <vector>
+#include <cmath>
 
 #define NP_THREADS 256
 static int g_ew_wg_per_cu = 4;
@@ -68,6 +70,77 @@ extern "C" int lmkd_frames_u8_to_nhwc4(const unsigned char* src, float* dst, con
   hipLaunchKernelGGL(frames_u8_to_nhwc4_kernel, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, src, (float4*)dst, crop_y,
                      crop_x, flip, total, Hs, Ws, H, W, frames_per_video);
   LMKD_CHECK_LAUNCH("frames_u8_to_nhwc4_kernel");
+  return LMKD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Resize(256) of the frame transform (video_reader.py:92-112 -> functional.resize_clip, functional.py:44-59, which calls
+// PIL.Image.resize(size, BILINEAR)): Pillow's 8-bit resampler, bit exact.  Triangle filter of support max(scale, 1),
+// coefficients normalised in double and rounded to 22-bit fixed point (host, lmkd_resize_plan), then one pass per axis
+//   out = clip8((2^21 + sum_x pixel[x] * k[x]) >> 22),  horizontal pass first, uint8 in between - exactly Pillow's order.
+// A pass sees the tensor as [outer][n_in][inner] uint8 -> [outer][n_out][inner]  (horizontal: inner = C; vertical: inner = W*C).
+// ---------------------------------------------------------------------------------
+#define LMKD_PIL_PRECISION_BITS 22
+
+extern "C" int lmkd_resize_plan(int in_size, int out_size, int* bounds /*[out][2] or null*/, int* coeffs /*[out][ksize] or null*/) {
+  LMKD_REQUIRE(in_size > 0 && out_size > 0, "lmkd_resize_plan: sizes must be positive");
+  const double scale = (double)in_size / out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;
+  const int ksize = (int)ceil(support) * 2 + 1;
+  if (!bounds || !coeffs) return ksize;
+  const double ss = 1.0 / filterscale;
+  std::vector<double> w(ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < ksize; ++x) w[x] = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+      double a = (x + xmin - center + 0.5) * ss;
+      if (a < 0.0) a = -a;
+      w[x] = a < 1.0 ? 1.0 - a : 0.0;
+      ww += w[x];
+    }
+    for (int x = 0; x < xmax; ++x)
+      if (ww != 0.0) w[x] /= ww;
+    for (int x = 0; x < ksize; ++x)
+      coeffs[xx * ksize + x] = w[x] < 0 ? (int)(-0.5 + w[x] * (1 << LMKD_PIL_PRECISION_BITS)) : (int)(0.5 + w[x] * (1 << LMKD_PIL_PRECISION_BITS));
+    bounds[xx * 2] = xmin;
+    bounds[xx * 2 + 1] = xmax;
+  }
+  return ksize;
+}
+
+__global__ void resize_pass_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, const int* __restrict__ bounds,
+                                      const int* __restrict__ coeffs, int ksize, long total, int n_in, int n_out, long inner) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const long i = p % inner;
+    const long r = p / inner;
+    const int xx = (int)(r % n_out);
+    const long o = r / n_out;
+    const int x0 = bounds[xx * 2], n = bounds[xx * 2 + 1];
+    const unsigned char* s = src + (o * n_in + x0) * inner + i;
+    const int* k = coeffs + (long)xx * ksize;
+    int acc = 1 << (LMKD_PIL_PRECISION_BITS - 1);
+    for (int x = 0; x < n; ++x) acc += (int)s[(long)x * inner] * k[x];
+    acc >>= LMKD_PIL_PRECISION_BITS;
+    dst[p] = (unsigned char)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+  }
+}
+
+extern "C" int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst, const int* bounds_dev, const int* coeffs_dev, int ksize,
+                                   long outer, int n_in, int n_out, long inner, void* stream) {
+  LMKD_REQUIRE(src && dst && bounds_dev && coeffs_dev && ksize > 0 && outer > 0 && n_in > 0 && n_out > 0 && inner > 0,
+               "lmkd_resize_pass_u8: bad arguments");
+  const long total = outer * n_out * inner;
+  hipLaunchKernelGGL(resize_pass_u8_kernel, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, src, dst, bounds_dev, coeffs_dev,
+                     ksize, total, n_in, n_out, inner);
+  LMKD_CHECK_LAUNCH("resize_pass_u8_kernel");
   return LMKD_OK;
 }
 

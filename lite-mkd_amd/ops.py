@@ -416,6 +416,50 @@ def frames_u8_to_nhwc4(frames_u8, crop_y, crop_x, flip, size, frames_per_video=8
     return out
 
 
+_RESIZE_PLANS = {}
+
+
+def _resize_plan(n_in, n_out, device):
+    key = (n_in, n_out, str(device))
+    if key not in _RESIZE_PLANS:
+        ks = lib().value("lmkd_resize_plan", n_in, n_out, None, None)
+        if ks <= 0:
+            raise RuntimeError("lmkd_resize_plan(%d, %d) failed" % (n_in, n_out))
+        b = torch.empty((n_out, 2), dtype=torch.int32)
+        k = torch.empty((n_out, ks), dtype=torch.int32)
+        lib().value("lmkd_resize_plan", n_in, n_out, ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(k.data_ptr()))
+        _RESIZE_PLANS[key] = (b.to(device), k.to(device), ks)
+    return _RESIZE_PLANS[key]
+
+
+def resize_frames_u8(frames_u8, size):
+    """Resize(size) of the reference's frame transform (video_reader.py:96-101; functional.resize_clip -> PIL BILINEAR) on uint8
+    frames [F,H,W,C]: short side -> `size` (int; unchanged if it already matches, functional.py:46-50) or (h, w) tuple.
+    Bit-identical to Pillow (tests/golden/resize.npz)."""
+    _chk(frames_u8)
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
+        raise RuntimeError("resize_frames_u8 expects uint8 [F,H,W,C] frames")
+    F_, H, W, C = frames_u8.shape
+    if isinstance(size, int):
+        if (W <= H and W == size) or (H <= W and H == size):
+            return frames_u8
+        oh, ow = (int(size * H / W), size) if W < H else (size, int(size * W / H))
+    else:
+        oh, ow = size
+    x = frames_u8
+    if ow != W:
+        b, k, ks = _resize_plan(W, ow, x.device)
+        t = torch.empty((F_, H, ow, C), dtype=torch.uint8, device=x.device)
+        lib().call("lmkd_resize_pass_u8", _p(x), _p(t), _p(b), _p(k), ks, F_ * H, W, ow, C, _stream())
+        x = t
+    if oh != H:
+        b, k, ks = _resize_plan(H, oh, x.device)
+        t = torch.empty((F_, oh, ow, C), dtype=torch.uint8, device=x.device)
+        lib().call("lmkd_resize_pass_u8", _p(x), _p(t), _p(b), _p(k), ks, F_, H, oh, ow * C, _stream())
+        x = t
+    return x
+
+
 class BasicBlockFn(torch.autograd.Function):
     """torchvision BasicBlock: conv3x3-BN-ReLU-conv3x3-BN (+1x1/2 conv-BN downsample) + add + ReLU.
     One autograd node per block; backward is hand-scheduled so that the masked gradient buffer

@@ -248,6 +248,25 @@ def gen_trx_sup(mods):
     return out
 
 
+RESIZE_CASES = [(240, 320, 256), (97, 131, 37), (64, 48, 100), (300, 256, 256)]     # (H, W, Resize(size)); last: short side already == size
+
+
+def gen_resize(mods):
+    """the reference's frame Resize (functional.resize_clip -> PIL.Image.resize(BILINEAR)) run with PIL itself"""
+    from PIL import Image
+    fn = _load("ref_functional", os.path.join(REF, "videotransforms/functional.py"))
+    out = {}
+    rng = np.random.default_rng(5)
+    for i, (h, w, size) in enumerate(RESIZE_CASES):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img[: h // 3] = (img[: h // 3] // 32) * 32            # some flat / banded areas next to the noise
+        res = fn.resize_clip([Image.fromarray(img)], size, interpolation="nearest")[0]     # Resize()'s default argument
+        out["c%d_in" % i] = img
+        out["c%d_out" % i] = np.asarray(res)
+        out["c%d_size" % i] = size
+    return out
+
+
 def trx_case_inputs(seed, ns, nq, shuffle):
     """Re-creates the exact inputs/weights of gen_trx (used by tests; no reference needed)."""
     g = torch.Generator().manual_seed(1000 + seed)
@@ -269,8 +288,9 @@ def main():
     mods = load_reference()
     os.makedirs(GOLD, exist_ok=True)
     for name, fn in (("distill", gen_distill), ("distill_methods", gen_distill_methods), ("edist", gen_edist), ("trx", gen_trx),
-                     ("trx_sup", gen_trx_sup)):
-        data = t2n(fn(mods))
+                     ("trx_sup", gen_trx_sup), ("resize", gen_resize)):
+        data = fn(mods)
+        data = t2n(data) if name != "resize" else data
         path = os.path.join(GOLD, name + ".npz")
         if a.check_only:
             old = np.load(path)

@@ -699,3 +699,76 @@ def train_episode(ep, params, teacher_params, way=5, shot=5, cfg=DEFAULT_CFG):
     acc = aggregate_accuracy(out["logits"]["kl"] + out["logits"]["ce"], labels)
     loss["loss"].backward()
     return loss["loss"].detach(), acc, out, t_logits
+
+
+# ----------------------------------------------------------------------------
+# A0 (input side)  Resize(256) of the frame transform: video_reader.py:92-112 -> videotransforms/video_transforms.py:91-110
+# -> functional.resize_clip (functional.py:24-63), which - its `interpolation` test being inverted (:55-58) - calls
+# PIL.Image.resize(size, PIL.Image.BILINEAR) for the default Resize(interpolation='nearest').  The arithmetic is Pillow's
+# (third-party, pinned pillow==9.3.0 in envirment.yml:93; the 8-bit resampler is unchanged through the 12.2.0 installed here):
+# ImagingResample with the triangle filter, support 1.0 * max(scale, 1), coefficients normalised in double and rounded to
+# 22-bit fixed point, a horizontal pass to uint8 and then a vertical pass, each  clip8((2^21 + sum(pixel * k)) >> 22).
+# Restated below in numpy integers and pinned bit-exactly against PIL itself by oracle/gen_golden.py (tests/golden/resize.npz).
+# ----------------------------------------------------------------------------
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_coeffs(in_size, out_size):
+    """-> bounds [out,2] (first input index, count), coefficients [out, ksize] int32, ksize"""
+    import numpy as np
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [0.0] * ksize
+        ww = 0.0
+        for x in range(xmax):
+            a = abs((x + xmin - center + 0.5) * ss)
+            w[x] = 1.0 - a if a < 1.0 else 0.0
+            ww += w[x]
+        for x in range(xmax):
+            if ww != 0.0:
+                w[x] /= ww
+        for x in range(ksize):
+            kk[xx, x] = int(-0.5 + w[x] * (1 << PIL_PRECISION_BITS)) if w[x] < 0 else int(0.5 + w[x] * (1 << PIL_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+def _pil_resample_axis(img, out_size, axis):
+    import numpy as np
+    img = np.moveaxis(img, axis, 0).astype(np.int64)
+    b, kk, _ = pil_bilinear_coeffs(img.shape[0], out_size)
+    out = np.zeros((out_size,) + img.shape[1:], np.int64)
+    for xx in range(out_size):
+        s = np.full(img.shape[1:], 1 << (PIL_PRECISION_BITS - 1), np.int64)
+        for x in range(int(b[xx, 1])):
+            s += img[b[xx, 0] + x] * int(kk[xx, x])
+        out[xx] = np.clip(s >> PIL_PRECISION_BITS, 0, 255)
+    return np.moveaxis(out, 0, axis).astype(np.uint8)
+
+
+def pil_resize_bilinear_u8(img, out_w, out_h):
+    """img uint8 [..., H, W, C] (numpy) -> [..., out_h, out_w, C]: PIL.Image.resize((out_w, out_h), BILINEAR)"""
+    t = img
+    if out_w != img.shape[-2]:
+        t = _pil_resample_axis(t, out_w, t.ndim - 2)          # horizontal pass first
+    if out_h != img.shape[-3]:
+        t = _pil_resample_axis(t, out_h, t.ndim - 3)
+    return t
+
+
+def resize_short_side(im_h, im_w, size):
+    """functional.py:45-52,66-73: output (h, w) of Resize(size) for an int size; unchanged if the short side already matches"""
+    if (im_w <= im_h and im_w == size) or (im_h <= im_w and im_h == size):
+        return im_h, im_w
+    if im_w < im_h:
+        return int(size * im_h / im_w), size
+    return size, int(size * im_w / im_h)

@@ -739,3 +739,69 @@ def test_eval_bn_fused_in_conv_epilogue(dev, arch):
     sd = {k: v.detach().cpu() for k, v in trunk.state_dict().items()}
     ref = (O.resnet18_trunk if arch == "resnet18" else O.resnet50_trunk)(x, sd, training=False)
     close(nchw(y_fused), ref, 1e-3, 1e-4 * float(ref.abs().max()), "eval trunk vs oracle")
+
+
+def test_resize_frames_matches_pillow(dev, golden_dir):
+    """GPU Resize of the frame transform vs fixtures produced by the reference's functional.resize_clip with PIL (bit exact),
+    a batch against the numpy restatement, and the whole transform chain Resize(256) -> crop/flip -> ToTensor into the stem layout."""
+    import os
+    from litemkd_amd import ops
+    from oracle import ref_cpu as O
+    G = np.load(os.path.join(golden_dir, "resize.npz"))
+    for c in range(4):
+        img, ref, size = G["c%d_in" % c], G["c%d_out" % c], int(G["c%d_size" % c])
+        out = ops.resize_frames_u8(torch.from_numpy(img)[None].to(dev), size)
+        assert out.shape[1:] == ref.shape and np.array_equal(out[0].cpu().numpy(), ref), c
+    rng = np.random.default_rng(9)
+    batch = rng.integers(0, 256, (16, 120, 160, 3), dtype=np.uint8)
+    out = ops.resize_frames_u8(torch.from_numpy(batch).to(dev), 128)
+    assert out.shape == (16, 128, 170, 3)
+    assert np.array_equal(out.cpu().numpy(), O.pil_resize_bilinear_u8(batch, 170, 128))
+    # chain: Resize -> per-video crop + flip -> ToTensor (video_reader.py:96-112), 2 videos x 8 frames
+    cy = torch.tensor([3, 10], dtype=torch.int32)
+    cx = torch.tensor([40, 0], dtype=torch.int32)
+    fl = torch.tensor([1, 0], dtype=torch.int32)
+    x = ops.frames_u8_to_nhwc4(out, cy.to(dev), cx.to(dev), fl.to(dev), 112)
+    r = torch.from_numpy(O.pil_resize_bilinear_u8(batch, 170, 128))
+    for f in range(16):
+        v = f // 8
+        ref = r[f, int(cy[v]):int(cy[v]) + 112, int(cx[v]):int(cx[v]) + 112]
+        if int(fl[v]):
+            ref = ref.flip(1)
+        assert torch.equal(x[f, :, :, :3].cpu(), ref.float() / 255.0)
+
+
+def test_gpu_frame_transform_matches_reference_chain(dev):
+    """GpuFrameTransform vs the reference's per-video chain Resize(256) -> RandomHorizontalFlip -> RandomCrop(224) -> ToTensor
+    (video_reader.py:92-112,377-385) restated on the host with the same `random` stream; mixed source resolutions; test mode
+    (CenterCrop) as well.  Bit exact."""
+    import random
+    from litemkd_amd.video_transform import GpuFrameTransform
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(12)
+    vids = [rng.integers(0, 256, (8, h, w, 3), dtype=np.uint8) for (h, w) in [(240, 320), (240, 320), (288, 352), (240, 320), (256, 300)]]
+    tf = GpuFrameTransform(224, dev)
+
+    def host_chain(train):
+        outs = []
+        for v in vids:
+            oh, ow = O.resize_short_side(v.shape[1], v.shape[2], 256)
+            r = O.pil_resize_bilinear_u8(v, ow, oh)
+            if train:
+                flip = random.random() < 0.5
+                x1 = random.randint(0, ow - 224)
+                y1 = random.randint(0, oh - 224)
+            else:
+                flip, x1, y1 = False, int(round((ow - 224) / 2.)), int(round((oh - 224) / 2.))
+            if flip:
+                r = r[:, :, ::-1]
+            c = np.ascontiguousarray(r[:, y1:y1 + 224, x1:x1 + 224])        # the reference flips first, then crops
+            outs.append(torch.from_numpy(c).float() / 255.0)
+        return torch.cat(outs, 0)
+    for train in (True, False):
+        random.seed(77)
+        ref = host_chain(train)
+        random.seed(77)
+        out = tf([torch.from_numpy(v) for v in vids], train=train)
+        assert out.shape == (40, 224, 224, 4)
+        assert torch.equal(out[..., :3].cpu(), ref) and float(out[..., 3].abs().max()) == 0.0

@@ -166,3 +166,20 @@ def test_flat_bucket_allreduce_gloo_world2():
     assert torch.allclose(s0, l0 + l1) and torch.allclose(s1, l0 + l1)
     assert ptrs0[0] == base0                       # .grad tensors are views into the bucket
     assert float(l0.abs().sum()) > 0 and not torch.allclose(l0, l1)
+
+
+def test_resize_plan_tables_match_pillow_restatement():
+    """lmkd_resize_plan (host-side C, no GPU needed): bounds and 22-bit coefficients of Pillow's BILINEAR resampler"""
+    import ctypes
+    import numpy as np
+    import litemkd_amd
+    from oracle import ref_cpu as O
+    L = litemkd_amd.lib()
+    for n_in, n_out in [(320, 341), (240, 256), (1280, 455), (131, 50), (48, 256), (7, 3), (5, 5)]:
+        b_ref, k_ref, ks_ref = O.pil_bilinear_coeffs(n_in, n_out)
+        ks = L.value("lmkd_resize_plan", n_in, n_out, None, None)
+        assert ks == ks_ref
+        b = np.zeros((n_out, 2), np.int32)
+        k = np.zeros((n_out, ks), np.int32)
+        assert L.value("lmkd_resize_plan", n_in, n_out, ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(k.ctypes.data)) == ks
+        assert np.array_equal(b, b_ref) and np.array_equal(k, k_ref)

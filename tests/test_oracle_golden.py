@@ -134,6 +134,18 @@ def test_trx_sup_golden(golden_dir):
         close(p["norm_k.weight"].grad, G[pre + "g_nkw"], rtol=1e-4, atol=1e-5)
 
 
+def test_resize_golden(golden_dir):
+    """frame Resize: the numpy restatement of Pillow's 8-bit BILINEAR resampler vs fixtures made by the reference's
+    functional.resize_clip with PIL itself — bit exact, incl. the 'short side already matches' early return."""
+    G = np.load(os.path.join(golden_dir, "resize.npz"))
+    for c in range(4):
+        img, ref, size = G["c%d_in" % c], G["c%d_out" % c], int(G["c%d_size" % c])
+        oh, ow = O.resize_short_side(img.shape[0], img.shape[1], size)
+        assert (oh, ow) == ref.shape[:2]
+        assert np.array_equal(O.pil_resize_bilinear_u8(img, ow, oh), ref)
+    assert O.resize_short_side(240, 320, 256) == (256, 341) and O.resize_short_side(300, 256, 256) == (300, 256)
+
+
 def test_trunk_shapes_and_param_count():
     shp = O.resnet18_trunk_param_shapes()
     n = sum(int(np.prod(s)) for k, s in shp.items() if "running" not in k and "num_batches" not in k)
