@@ -482,7 +482,8 @@ extern "C" int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, i
   LMKD_REQUIRE((long)ncols * Kp * 6 < 0xffffffe0L, "lmkd_conv2d_split_weights: weights exceed the 4 GiB buffer range");
   int grid = cdiv((long)ncols * Kp, 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(split_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wp, (unsigned short*)wf, ncols, Kp);
+  hipLaunchKernelGGL(split_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wp, (unsigned short*)wf, ncols, Kp,
+                     g_conv_bf16 ? 1 : 3);
   LMKD_CHECK_LAUNCH("split_weights_kernel");
   return LMKD_OK;
 }
@@ -504,13 +505,12 @@ static inline int cfg_wg_per_cu(int id) { return id == 1 ? 2 : (id == 3 ? 4 : 3)
 // Pick the tile that minimises ceil(tiles / 256 CUs) * work per tile: at 64 cycles per fp32 MFMA every configuration is
 // matrix-pipe bound, so what differs is how evenly the launch's tiles divide over the CUs (the tail).
 static int pick_conv_cfg(long rows_per_class, int nclass, int ncols) {
-  if (g_conv_x3) {
+  if (g_conv_x3 || g_conv_bf16) {
     if (g_tile_override >= 7) return (ncols <= 64 && g_tile_override == 8) ? 9 : g_tile_override;
     if (ncols <= 64) return 9;
     // measured (tools/conv_bench_x3.py): 128x128 (one workgroup per CU) wins once the launch has a tile per CU
     return (long)nclass * cdiv(rows_per_class, 128) * cdiv(ncols, 128) >= 256 ? 8 : 9;
   }
-  if (g_conv_bf16) return ncols > 64 ? 5 : 3;
   if (g_tile_override) {
     if (ncols <= 64 && cfg_bn(g_tile_override) == 128) return g_tile_override == 5 ? 6 : (cfg_bm(g_tile_override) == 128 ? 2 : 3);
     return g_tile_override;
@@ -551,14 +551,15 @@ static void launch_conv_x3(ConvGemmArgs a, int ncols, hipStream_t s) {
   a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
   if (g_xcd_mode == 0) a.xcd_mode = 0;
   const dim3 grid(xcd_grid(a.n_rt, a.n_ct, a.xcd_mode));
-  if (g_conv_x3 == 9) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, SMALLC, STATS, 9>), grid, dim3(Cfg::THREADS), 0, s, a);
+  if (g_conv_bf16) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, SMALLC, STATS, 1>), grid, dim3(Cfg::THREADS), 0, s, a);
+  else if (g_conv_x3 == 9) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, SMALLC, STATS, 9>), grid, dim3(Cfg::THREADS), 0, s, a);
   else hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, SMALLC, STATS, 6>), grid, dim3(Cfg::THREADS), 0, s, a);
 }
 
 template <bool SMALLC, int STATS>
 static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
   if constexpr (STATS != 2) {
-    if (g_conv_x3) {
+    if (g_conv_x3 || g_conv_bf16) {      // bf16 planes in LDS, weights in fragment order (conv_x3.h): 1, 6 or 9 products
       switch (pick_conv_cfg(a.rows_per_class, a.nclass, ncols)) {
         case 7: launch_conv_x3<X3Cfg<256, 64, 4, 2>, SMALLC, STATS == 1>(a, ncols, s); break;
         case 8: launch_conv_x3<X3Cfg<128, 128, 2, 4>, SMALLC, STATS == 1>(a, ncols, s); break;
@@ -567,12 +568,6 @@ static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
       LMKD_CHECK_LAUNCH("conv_gemm_x3_kernel");
       return LMKD_OK;
     }
-  }
-  if (g_conv_bf16) {   // bf16: load/LDS bound, the big tile reuses operands most; 64-column launches use 64x64
-    if (ncols > 64) launch_conv_cfg<TileCfg<128, 128, 2, 4>, SMALLC, STATS, true>(a, ncols, s);
-    else launch_conv_cfg<TileCfg<64, 64, 2, 2>, SMALLC, STATS, true>(a, ncols, s);
-    LMKD_CHECK_LAUNCH("conv_gemm_kernel<bf16>");
-    return LMKD_OK;
   }
   switch (pick_conv_cfg(a.rows_per_class, a.nclass, ncols)) {
     case 1: launch_conv_cfg<TileCfg<128, 128, 2, 2>, SMALLC, STATS>(a, ncols, s); break;
@@ -643,7 +638,7 @@ extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float*
 extern "C" int lmkd_conv2d_fwd_bn(const float* x, const float* wp, float* y, const float* bn_stats, const float* res, int relu,
                                   int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, void* stream) {
   LMKD_REQUIRE(bn_stats, "lmkd_conv2d_fwd_bn: BatchNorm table missing");
-  LMKD_REQUIRE(!g_conv_x3, "lmkd_conv2d_fwd_bn: not available in the 3xbf16 mode (packed weights have another layout)");
+  LMKD_REQUIRE(!g_conv_x3 && !g_conv_bf16, "lmkd_conv2d_fwd_bn: fp32 MFMA mode only (the bf16 modes use fragment-order weights)");
   return conv2d_fwd_impl(x, wp, y, nullptr, bn_stats, res, relu, N, H, W, Cs, Cout, KH, KW, stride, pad, stream);
 }
 

@@ -26,7 +26,6 @@ struct X3Cfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
   static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static constexpr int THREADS = 64 * WM * WN;
-  static constexpr int A_BYTES = 3 * BM * X3_LD * 2, B_BYTES = 3 * BN * X3_LD * 2;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
 };
 
@@ -49,6 +48,13 @@ __device__ __forceinline__ void x3_split4(const float4& v, uint2& p0, uint2& p1,
   p2 = make_uint2(x3_hi2(b2[1], b2[0]), x3_hi2(b2[3], b2[2]));
 }
 
+// plain bf16 mode (one plane): round to nearest even, the arithmetic of BASELINE configs[2]
+__device__ __forceinline__ uint2 x3_round4(const float4& v) {
+  union { __bf16 h[4]; uint2 u; } c;
+  c.h[0] = (__bf16)v.x; c.h[1] = (__bf16)v.y; c.h[2] = (__bf16)v.z; c.h[3] = (__bf16)v.w;
+  return c.u;
+}
+
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define X3_OOB 0xfffffff0u   // byte offset past every buffer: the range check of a buffer load returns zeros
 
@@ -63,17 +69,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const void* base, long
 //   Wf[n-tile = col/32][k-group = k/16][plane][lane = col%32 + 32*h][8]  holds plane(W[col][16*kgroup + 8*h + j]), j = 0..7,
 // so the B fragments of one K-step (2 k-groups x 3 planes) of one 32-column tile are 6 KiB contiguous and each lane's 16 bytes
 // are exactly its MFMA operand: a wave loads them straight into registers (L1/L2 resident), no LDS and no barrier involved.
-template <int TN>
+template <int TN, int NPL>
 struct X3FragB {
-  static constexpr int NR = TN * 6;
+  static constexpr int NR = TN * 2 * NPL;
   __amdgpu_buffer_rsrc_t rs;
   unsigned off[TN];     // byte offset of (n-tile, k-group 0, plane 0, this lane)
   __device__ __forceinline__ void init(const void* wf, int ncols, int Kp, int col0 /* of this wave */, int lane) {
-    rs = x3_rsrc(wf, (long)ncols * Kp * 6);
+    rs = x3_rsrc(wf, (long)ncols * Kp * 2 * NPL);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nt = (col0 >> 5) + j;
-      off[j] = (nt * 32 < ncols) ? (unsigned)(((long)nt * (Kp >> 4) * 3 * 64 + lane) * 16) : X3_OOB;
+      off[j] = (nt * 32 < ncols) ? (unsigned)(((long)nt * (Kp >> 4) * NPL * 64 + lane) * 16) : X3_OOB;
     }
   }
   // koff: first k of the K-step (multiple of 32)
@@ -81,8 +87,8 @@ struct X3FragB {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int q = 0; q < 6; ++q)   // q = group * 3 + plane
-        reg[j * 6 + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j] == X3_OOB ? X3_OOB : off[j] + (unsigned)(((koff >> 4) * 3 + q) * 1024), 0, 0);
+      for (int q = 0; q < 2 * NPL; ++q)   // q = group * NPL + plane
+        reg[j * 2 * NPL + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j] == X3_OOB ? X3_OOB : off[j] + (unsigned)(((koff >> 4) * NPL + q) * 1024), 0, 0);
   }
 };
 
@@ -123,27 +129,32 @@ struct X3GatherA {
       reg[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   }
+  template <int NPL>
   __device__ __forceinline__ void store(unsigned char* S, const float4 (&reg)[NI]) const {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      uint2 p0, p1, p2;
-      x3_split4(reg[i], p0, p1, p2);
       unsigned char* d = S + (((tid >> 3) + RPP * i) * X3_LD + kc4) * 2;
-      *reinterpret_cast<uint2*>(d) = p0;
-      *reinterpret_cast<uint2*>(d + ROWS * X3_LD * 2) = p1;
-      *reinterpret_cast<uint2*>(d + 2 * ROWS * X3_LD * 2) = p2;
+      if (NPL == 1) {
+        *reinterpret_cast<uint2*>(d) = x3_round4(reg[i]);
+      } else {
+        uint2 p0, p1, p2;
+        x3_split4(reg[i], p0, p1, p2);
+        *reinterpret_cast<uint2*>(d) = p0;
+        *reinterpret_cast<uint2*>(d + ROWS * X3_LD * 2) = p1;
+        *reinterpret_cast<uint2*>(d + 2 * ROWS * X3_LD * 2) = p2;
+      }
     }
   }
 };
 
 // All MFMAs of one K-step (two groups of 16 k) of a wave's TM x TN tiles: A fragments from the plane tiles in LDS (group 1
 // is read before the MFMAs of group 0 are issued), B fragments from registers.
-template <class Cfg>
-__device__ __forceinline__ void x3_read_group(const unsigned char* __restrict__ ap, int g, bf16x8 (&a)[3][Cfg::TM]) {
+template <class Cfg, int NPL>
+__device__ __forceinline__ void x3_read_group(const unsigned char* __restrict__ ap, int g, bf16x8 (&a)[NPL][Cfg::TM]) {
   constexpr int PA = Cfg::BM * X3_LD * 2;
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < NPL; ++p)
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i) a[p][i] = *reinterpret_cast<const bf16x8*>(ap + p * PA + i * (32 * X3_LD * 2) + g * 32);
 }
@@ -166,19 +177,25 @@ __device__ __forceinline__ bf16x8 x3_as_bf16(const u32x4& v) {
 }
 
 template <class Cfg, int NPROD>
-__device__ __forceinline__ void x3_kstep(const unsigned char* __restrict__ As, int a_row, int h, const u32x4 (&rb)[Cfg::TN * 6],
-                                         f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+__device__ __forceinline__ void x3_kstep(const unsigned char* __restrict__ As, int a_row, int h,
+                                         const u32x4 (&rb)[Cfg::TN * 2 * (NPROD == 1 ? 1 : 3)], f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  constexpr int NPL = NPROD == 1 ? 1 : 3;
   const unsigned char* ap = As + (a_row * X3_LD + 8 * h) * 2;
-  bf16x8 a[2][3][Cfg::TM];
-  x3_read_group<Cfg>(ap, 0, a[0]);
+  bf16x8 a[2][NPL][Cfg::TM];
+  x3_read_group<Cfg, NPL>(ap, 0, a[0]);
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     if (g == 0) {
-      x3_read_group<Cfg>(ap, 1, a[1]);
+      x3_read_group<Cfg, NPL>(ap, 1, a[1]);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
+      if constexpr (NPROD == 1) {
+        const bf16x8 b0 = x3_as_bf16(rb[j * 2 + g]);
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][0][i], b0, acc[i][j], 0, 0, 0);
+      } else {
       const bf16x8 b0 = x3_as_bf16(rb[j * 6 + g * 3 + 0]), b1 = x3_as_bf16(rb[j * 6 + g * 3 + 1]), b2 = x3_as_bf16(rb[j * 6 + g * 3 + 2]);
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i) {
@@ -196,6 +213,7 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* __restrict__ As, i
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][0][i], b0, c, 0, 0, 0);
         acc[i][j] = c;
       }
+      }
     }
   }
 }
@@ -203,8 +221,10 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* __restrict__ As, i
 template <class Cfg, bool SMALLC, bool STATS, int NPROD>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs a) {
   using LA = X3GatherA<Cfg::BM, SMALLC, Cfg::THREADS>;
-  using LB = X3FragB<Cfg::TN>;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Cfg::A_BYTES];
+  constexpr int NPL = NPROD == 1 ? 1 : 3;                 // NPROD == 1: plain bf16 (one RNE-rounded plane, one product)
+  constexpr int A_BYTES = NPL * Cfg::BM * X3_LD * 2;
+  using LB = X3FragB<Cfg::TN, NPL>;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES];
   __shared__ int s_src[Cfg::BM], s_hw[Cfg::BM], s_out[Cfg::BM];
   __shared__ float s_red[STATS ? Cfg::WM * Cfg::BN * 2 : 1];
   const int tid = threadIdx.x;
@@ -275,13 +295,13 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   // is refilled with step t+3.  Waves 4-7 (store first) fetch B(t+1) into `rbn` before their MFMAs; waves 0-3 (MFMAs first)
   // land B(t+1) in `rbn` after theirs and refill `rb` with B(t+2).
   auto step = [&](int t, float4 (&ra)[LA::NI], u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR]) {
-    const unsigned char* cur = smem + (t & 1) * Cfg::A_BYTES;
-    unsigned char* nxt = smem + ((t + 1) & 1) * Cfg::A_BYTES;
+    const unsigned char* cur = smem + (t & 1) * A_BYTES;
+    unsigned char* nxt = smem + ((t + 1) & 1) * A_BYTES;
     if (store_first) {
       x3_landed(ra);
       x3_landed(rb);
       if (t + 1 < nk) {
-        la.store(nxt, ra);
+        la.template store<NPL>(nxt, ra);
         if (t + 3 < nk) issue_a(t + 3, ra);
         issue_b(t + 1, rbn);
       }
@@ -290,7 +310,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
     if (!store_first && t + 1 < nk) {
       x3_landed(ra);
       x3_landed(rbn);
-      la.store(nxt, ra);
+      la.template store<NPL>(nxt, ra);
       if (t + 3 < nk) issue_a(t + 3, ra);
       if (t + 2 < nk) issue_b(t + 2, rb);
     }
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
     issue_b(0, rb0);
     if (nk > 1) issue_a(1, ra1);
     x3_landed(ra0);
-    la.store(smem, ra0);
+    la.template store<NPL>(smem, ra0);
     if (nk > 2) issue_a(2, ra0);
     if (!store_first) {
       x3_landed(rb0);
@@ -362,21 +382,27 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   }
 }
 
-// fp32 K-major packed weights Wp[col][Kp] -> fragment-order bf16 planes (layout: X3FragB)
-__global__ void split_weights_kernel(const float* __restrict__ wp, unsigned short* __restrict__ wf, int ncols, int Kp) {
+// fp32 K-major packed weights Wp[col][Kp] -> fragment-order bf16 planes (layout: X3FragB); npl = 1: one RNE-rounded plane
+__global__ void split_weights_kernel(const float* __restrict__ wp, unsigned short* __restrict__ wf, int ncols, int Kp, int npl) {
   const long total = (long)ncols * Kp;
   const int G = Kp >> 4;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int col = (int)(idx / Kp), k = (int)(idx - (long)col * Kp);
     const float x = wp[idx];
-    const unsigned b0 = __float_as_uint(x);
-    const float r1 = x - __uint_as_float(b0 & 0xffff0000u);
-    const unsigned b1 = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
     const int lane = (col & 31) + 32 * ((k >> 3) & 1);
-    const long o = ((((long)(col >> 5) * G + (k >> 4)) * 3) * 64 + lane) * 8 + (k & 7);
-    wf[o] = (unsigned short)(b0 >> 16);
-    wf[o + 512] = (unsigned short)(b1 >> 16);
-    wf[o + 1024] = (unsigned short)(__float_as_uint(r2) >> 16);
+    const long o = ((((long)(col >> 5) * G + (k >> 4)) * npl) * 64 + lane) * 8 + (k & 7);
+    if (npl == 1) {
+      union { __bf16 h; unsigned short u; } c;
+      c.h = (__bf16)x;
+      wf[o] = c.u;
+    } else {
+      const unsigned b0 = __float_as_uint(x);
+      const float r1 = x - __uint_as_float(b0 & 0xffff0000u);
+      const unsigned b1 = __float_as_uint(r1);
+      const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
+      wf[o] = (unsigned short)(b0 >> 16);
+      wf[o + 512] = (unsigned short)(b1 >> 16);
+      wf[o + 1024] = (unsigned short)(__float_as_uint(r2) >> 16);
+    }
   }
 }

@@ -156,9 +156,10 @@ def _pack_weights(w, Cs, mode):
     wp = _empty((n,), w)
     _chk(w)
     lib().call("lmkd_conv2d_pack_weights", _p(w), _p(wp), Cout, Cin, Cs, KH, KW, mode, _stream())
-    if lib().value("lmkd_conv_get_compute_dtype") >= 2:      # fp32-as-3xbf16: the conv kernels read the three bf16 planes
+    cd = lib().value("lmkd_conv_get_compute_dtype")
+    if cd >= 1:      # bf16 (one RNE plane) / fp32-as-3xbf16 (three planes): weights in MFMA fragment order, fetched into registers
         ncols = Cout if mode == 0 else Cin
-        planes = torch.empty((3 * n,), dtype=torch.int16, device=w.device)
+        planes = torch.empty(((1 if cd == 1 else 3) * n,), dtype=torch.int16, device=w.device)
         lib().call("lmkd_conv2d_split_weights", _p(wp), planes.data_ptr(), ncols, n // ncols, _stream())
         return planes
     return wp
@@ -323,7 +324,7 @@ FUSE_EVAL_BN = True      # eval mode: BatchNorm (+ residual, ReLU) in the convol
 
 
 def _eval_fused():
-    return FUSE_EVAL_BN and not torch.is_grad_enabled() and lib().value("lmkd_conv_get_compute_dtype") < 2
+    return FUSE_EVAL_BN and not torch.is_grad_enabled() and lib().value("lmkd_conv_get_compute_dtype") == 0
 
 
 def conv_bn_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, relu, res=None):
