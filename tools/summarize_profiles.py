@@ -1,7 +1,7 @@
 """Turns the rocprofv3 outputs merged into gpurun_out/ (prof_r1c = --kernel-trace --stats of `bench.py --serial`,
 pmc_fetch / pmc_write = the two PMC passes) into the summaries committed under profiles/."""
 import collections, csv, glob, json, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_v3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_v4"
 def load(d, counter):
     f = sorted(glob.glob('gpurun_out/%s/*/*_counter_collection.csv' % d))[-1]
     agg = collections.defaultdict(lambda: [0.0, 0])
