@@ -183,3 +183,32 @@ def test_resize_plan_tables_match_pillow_restatement():
         k = np.zeros((n_out, ks), np.int32)
         assert L.value("lmkd_resize_plan", n_in, n_out, ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(k.ctypes.data)) == ks
         assert np.array_equal(b, b_ref) and np.array_equal(k, k_ref)
+
+
+def test_cabi_argument_errors_return_codes_not_crashes():
+    """The C ABI never throws and never launches on bad arguments: negative return code + lmkd_last_error() text, and the
+    Python shim turns that into RuntimeError (SURVEY.md 8b 'errors').  No GPU is touched: every check precedes the launch."""
+    import ctypes
+    import pytest
+    import litemkd_amd
+    L = litemkd_amd.lib()
+    cd = L.cdll
+    cd.lmkd_last_error.restype = ctypes.c_char_p
+    null = ctypes.c_void_p(0)
+    # raw C calls
+    assert cd.lmkd_conv2d_fwd(null, null, null, null, 1, 8, 8, 32, 64, 3, 3, 1, 1, null) < 0
+    assert b"null pointer" in cd.lmkd_last_error()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert cd.lmkd_conv2d_fwd(p, p, p, null, 1, 8, 8, 7, 64, 3, 3, 1, 1, null) < 0          # Cs = 7: not 4 or a multiple of 32
+    assert b"channel count 7" in cd.lmkd_last_error()
+    assert cd.lmkd_conv_set_tile(99) < 0 and b"lmkd_conv_set_tile" in cd.lmkd_last_error()
+    assert cd.lmkd_conv_set_compute_dtype(17) < 0
+    assert cd.lmkd_resize_plan(0, 10, null, null) < 0
+    assert cd.lmkd_trx_sup_sim_fwd(p, p, p, p, 4, 9, 3, 28, 1152, null) < 0                  # way > 8
+    assert cd.lmkd_conv2d_split_weights(p, p, 48, 64, null) < 0                              # ncols not a multiple of 32
+    assert cd.lmkd_bn_apply(p, p, null, null, p, 4, 6, 0, 0, null) < 0                       # C % 4 != 0
+    # the shim
+    with pytest.raises(RuntimeError, match="lmkd_conv_set_tile"):
+        L.call("lmkd_conv_set_tile", 99)
+    assert cd.lmkd_conv_set_tile(0) == 0 and cd.lmkd_conv_set_compute_dtype(0) == 0
