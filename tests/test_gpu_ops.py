@@ -660,16 +660,19 @@ def test_conv_x3_mode(dev, cfg, mode):
             ops.set_conv_compute_dtype(m)
             yd, part = ops.conv_fwd(xd, ops._pack_weights(wdv, Cs, 0), Cout, K, K, s, p, True)
             dx = None if Cin == 3 else ops.conv_bwd_data(gyd, ops._pack_weights(wdv, Cin, 1), (N, H, W, Cin), Cout, K, K, s, p)
-            res[m] = (yd, part, dx)
+            res[m] = (yd, part, dx, ops.conv_bwd_weight(xd, gyd, tuple(w.shape), s, p))
     finally:
         ops.set_conv_compute_dtype("fp32")
-    yd, part, dx = res[mode]
+    yd, part, dx, dw = res[mode]
     close(nchw(yd), y.float(), 1e-4, 2e-5 * math.sqrt(Cin * K * K), "x3 conv fwd")
+    close(dw, w.grad.float(), 1e-3, 2e-5 * math.sqrt(N * y.shape[2] * y.shape[3]) * 3, "x3 conv wgrad")
     close(part.double().sum(0).cpu()[:, 0], y.detach().sum((0, 2, 3)), 1e-4, 1e-2, "bn sum")
     close(part.double().sum(0).cpu()[:, 1], (y.detach() ** 2).sum((0, 2, 3)), 1e-4, 1e-2, "bn sum of squares")
     err = lambda a, b: float((a.double().cpu() - b).norm() / b.norm())        # noqa: E731
     e_nat, e_x3 = err(nchw(res["fp32"][0]), y.detach()), err(nchw(yd), y.detach())
     assert e_x3 <= 2.0 * e_nat + 1e-8, (e_x3, e_nat)
+    e_nat, e_x3 = err(res["fp32"][3], w.grad), err(dw, w.grad)
+    assert e_x3 <= 2.0 * e_nat + 1e-8, ("wgrad", e_x3, e_nat)
     if dx is not None:
         close(nchw(dx), x.grad.float(), 1e-4, 2e-5 * math.sqrt(Cout * K * K), "x3 conv dgrad")
         e_nat, e_x3 = err(nchw(res["fp32"][2]), x.grad), err(nchw(dx), x.grad)

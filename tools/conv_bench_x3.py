@@ -22,6 +22,7 @@ for (Cin, H, Cout, K, s, p) in [(64,56,64,3,1,1),(64,56,128,3,2,1),(128,28,128,3
     w = torch.randn(Cout, Cin, K, K, device=dev) * 0.05
     xs = torch.relu(torch.randn(8, H, H, Cin, device=dev)); gys = torch.randn(8, Ho, Ho, Cout, device=dev)
     yref = F.conv2d(xs.permute(0, 3, 1, 2).double(), w.double(), stride=s, padding=p)
+    wref = torch.nn.grad.conv2d_weight(xs.permute(0, 3, 1, 2).double(), tuple(w.shape), gys.permute(0, 3, 1, 2).double(), stride=s, padding=p)
     dref = torch.nn.grad.conv2d_input((8, Cin, H, H), w.double(), gys.permute(0, 3, 1, 2).double(), stride=s, padding=p)
     x = torch.relu(torch.randn(200, H, H, Cin, device=dev)); gy = torch.randn(200, Ho, Ho, Cout, device=dev)
     fl = 2.0 * 200 * Ho * Ho * Cout * Cin * K * K
@@ -38,6 +39,9 @@ for (Cin, H, Cout, K, s, p) in [(64,56,64,3,1,1),(64,56,128,3,2,1),(128,28,128,3
             t1 = tm(lambda: ops.conv_fwd(x, wp, Cout, K, K, s, p, True))
             t2 = tm(lambda: ops.conv_bwd_data(gy, wd, (200, H, H, Cin), Cout, K, K, s, p))
             line += " | t%d fwd %5.1f dgrad %5.1f" % (tile, fl/t1/1e9, fl/t2/1e9)
+        t3 = tm(lambda: ops.conv_bwd_weight(x, gy, tuple(w.shape), s, p))
+        dws = ops.conv_bwd_weight(xs, gys, tuple(w.shape), s, p).double()
+        line += " | wgrad %5.1f err %.2e" % (fl/t3/1e9, ((dws - wref).norm() / wref.norm()).item())
         lib().call("lmkd_conv_set_tile", 0)
         line += "]"
     ops.set_conv_compute_dtype("fp32")
