@@ -170,8 +170,12 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const Tap* taps = a.taps[cls];
+    const int ntap_c = a.ntap[cls];
     auto issue = [&](int t) {
-      const int tp = t / a.cps, cc = t - tp * a.cps;
+      // K order: channel chunk outer, tap inner.  The taps of one 32-channel chunk read the same 128-byte pixel segments (shifted
+      // by a pixel), so the 9x reuse of a 3x3 conv sits in consecutive K-steps and stays in L1/L2; tap-major order re-fetched
+      // the wide rows of layer 4 (2 KB per pixel) once per tap: PMC FETCH_SIZE 790-1080 MB per launch for 50 MB of operands.
+      const int cc = t / ntap_c, tp = t - cc * ntap_c;
       const Tap tap = taps[tp];
       la.load(tap.dh, tap.dw, cc * LMKD_BK);
       lb.load(tap.kofs + cc * LMKD_BK);
@@ -752,9 +756,11 @@ extern "C" int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw
   a.div_hw = make_fastdiv(a.Ho * a.Wo); a.div_w = make_fastdiv(a.Wo);
   hipStream_t s = (hipStream_t)stream;
   a.n_mt = cdiv(Cout, bm); a.n_jt = cdiv(a.Kp, bn); a.splits = splits;
-  // measured: cuts FETCH_SIZE 3-10x on the 160 MB layers but runs 5-20 % slower (84 vs 93 TFLOP/s on layer 1), so it is
-  // off by default; lmkd_conv_set_xcd_mode(2) turns it on for launches with >= 32 splits
-  a.xcd_mode = (g_xcd_mode == 2 && splits >= 32) ? 1 : 0;
+  // all column tiles of one pixel split read the same x / dy rows: with >= 32 splits they are dealt to ONE XCD (ids congruent
+  // mod 8), whose L2 then serves the re-reads.  PMC: FETCH_SIZE 1053 -> 279 MB per launch (algorithmic 160-320 MB); the kernel
+  // alone is a few % slower on layer 1, the two-stream episode is unchanged (20.5 episodes/s), so it is on by default;
+  // lmkd_conv_set_xcd_mode(1) keeps the plain order
+  a.xcd_mode = (g_xcd_mode != 0 && g_xcd_mode != 1 && splits >= 32) ? 1 : 0;
   dim3 grid((a.xcd_mode ? 8 * cdiv(splits, 8) : splits) * a.n_mt * a.n_jt);
 #define LMKD_WGRAD_LAUNCH(CFG, SM, THR)                                                                       \
   do {                                                                                                          \

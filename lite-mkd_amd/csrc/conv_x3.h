@@ -278,7 +278,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   // phase old; loads issued after that point never stand between a value and its use.
   float4 ra0[LA::NI], ra1[LA::NI];
   u32x4 rb0[LB::NR], rb1[LB::NR];
-  auto tap_of = [&](int t, int& tp, int& cc) { tp = t / a.cps; cc = t - tp * a.cps; };
+  const int ntap_c = a.ntap[cls];
+  auto tap_of = [&](int t, int& tp, int& cc) { cc = t / ntap_c; tp = t - cc * ntap_c; };   // chunk outer, tap inner (conv.hip)
   auto issue_a = [&](int t, float4 (&ra)[LA::NI]) {
     int tp, cc;
     tap_of(t, tp, cc);
