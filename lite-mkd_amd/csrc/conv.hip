@@ -122,6 +122,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
   const int tile = rt / a.nclass;
   const int cls = rt - tile * a.nclass;
   const int ph = cls >> 1, pw = cls & 1;
+  if (a.accum && a.ntap[cls] == 0) return;      // out += 0: a parity class no tap reaches (1x1 stride-2 data gradient)
   const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
   for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
     const int m = row0 + r;

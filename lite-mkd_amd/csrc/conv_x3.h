@@ -233,6 +233,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   const int tile = rt / a.nclass;
   const int cls = rt - tile * a.nclass;
   const int ph = cls >> 1, pw = cls & 1;
+  if (a.accum && a.ntap[cls] == 0) return;      // out += 0 (see conv_gemm_kernel)
   const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
   for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
     const int m = row0 + r;

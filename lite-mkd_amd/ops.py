@@ -514,13 +514,14 @@ class BasicBlockFn(torch.autograd.Function):
             dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g)
             dwd = conv_bwd_weight(x, dcd, tuple(wd.shape), stride, 0)
             if need_dx:
-                wdd = pack_weights(wd, Cmid, 1)
-                dx = conv_bwd_data(dcd, wdd, x.shape, Cmid, 1, 1, stride, 0)
+                # the 3x3 gradient writes every input pixel; the 1x1 stride-2 one then accumulates onto the quarter of the
+                # pixels it reaches (parity classes without a tap launch nothing) instead of writing three quarters of zeros
+                dx = conv_bwd_data(dc1, pack_weights(w1, Cmid, 1), x.shape, Cmid, 3, 3, stride, 1)
+                conv_bwd_data(dcd, pack_weights(wd, Cmid, 1), x.shape, Cmid, 1, 1, stride, 0, out=dx, accumulate=True)
         else:
             dx = g                                    # identity branch
-        if need_dx:
-            wd1 = pack_weights(w1, Cmid, 1)
-            conv_bwd_data(dc1, wd1, x.shape, Cmid, 3, 3, stride, 1, out=dx, accumulate=True)   # dx += dgrad(conv1)
+            if need_dx:
+                conv_bwd_data(dc1, pack_weights(w1, Cmid, 1), x.shape, Cmid, 3, 3, stride, 1, out=dx, accumulate=True)   # dx += dgrad(conv1)
         return (dx if need_dx else None, None, None, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None,
                 dwd, dgd, dbd, None, None)
 
@@ -581,12 +582,13 @@ class BottleneckFn(torch.autograd.Function):
         if ctx.has_ds:
             dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g)
             dwd = conv_bwd_weight(x, dcd, tuple(wd.shape), stride, 0)
-            if need_dx:
-                dx = conv_bwd_data(dcd, pack_weights(wd, x.shape[-1], 1), x.shape, Co, 1, 1, stride, 0)
+            if need_dx:      # conv1's gradient first (writes every pixel), the strided downsample one accumulates (BasicBlockFn)
+                dx = conv_bwd_data(dc1, pack_weights(w1, x.shape[-1], 1), x.shape, Cm, 1, 1, 1, 0)
+                conv_bwd_data(dcd, pack_weights(wd, x.shape[-1], 1), x.shape, Co, 1, 1, stride, 0, out=dx, accumulate=True)
         else:
             dx = g
-        if need_dx:
-            conv_bwd_data(dc1, pack_weights(w1, x.shape[-1], 1), x.shape, Cm, 1, 1, 1, 0, out=dx, accumulate=True)
+            if need_dx:
+                conv_bwd_data(dc1, pack_weights(w1, x.shape[-1], 1), x.shape, Cm, 1, 1, 1, 0, out=dx, accumulate=True)
         return (dx if need_dx else None, None, None, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None,
                 dw3, dg3, db3, None, None, dwd, dgd, dbd, None, None)
 
