@@ -41,6 +41,7 @@ def main():
                     "(configs[2]); f32x3: fp32 convolutions computed on the bf16 matrix pipe from an exact 3-way bf16 split of "
                     "both operands, 6 products per fp32 product, fp32 accumulation (csrc/conv_x3.h; forward + data gradient)")
     ap.add_argument("--xcd-mode", type=int, default=-1, help="tuning: lmkd_conv_set_xcd_mode (-1 auto, 0 plain tile orders, 1 auto without XCD-grouped weight-gradient splits)")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the short bf16 / f32x3 side measurements of the default run")
     ap.add_argument("--layer-table", action="store_true", help="print the per-layer-shape conv timing table of the roofline pass to stderr")
     ap.add_argument("--tile", type=int, default=0, help="tuning: force a conv tile configuration (lmkd_conv_set_tile), 0 = auto")
     ap.add_argument("--backbone", default="resnet18_2fc", help="resnet18_2fc (headline) or resnet50_2fc (BASELINE configs[4])")
@@ -201,6 +202,22 @@ def main():
                      "timed_region_conv_tflops_per_gpu": conv_flops_timed / dt / 1e12,
                      "episode_model_tflops": step_tflop * world * a.steps / dt},
     }
+    if world == 1 and a.dtype == "f32" and not a.no_other_modes:
+        # the same job in the two other arithmetic modes of the convolutions, for the record (never part of `value`):
+        # short timed regions right here, same process, same resident episodes
+        other = {}
+        for name, mode in (("bf16", "bf16"), ("f32x3", "fp32x3")):
+            ops.set_conv_compute_dtype(mode)
+            it = run(2, it)
+            fence()
+            t1 = time.perf_counter()
+            it = run(16, it)      # 16 consecutive episodes always contain exactly one optimizer step
+            fence()
+            other[name] = {"value": 16 / (time.perf_counter() - t1), "unit": "episodes/s", "steps": 16}
+        ops.set_conv_compute_dtype("fp32")
+        other["bf16"]["what"] = "conv operands rounded to bf16 (RNE), fp32 accumulate: BASELINE configs[2]"
+        other["f32x3"]["what"] = "fp32 conv operands as an exact 3-way bf16 split, 6 bf16 MFMA products, fp32 accumulate (forward + data gradient)"
+        out["other_modes"] = other
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.shot)
     if rank == 0:
