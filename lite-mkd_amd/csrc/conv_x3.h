@@ -226,6 +226,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   using LB = X3FragB<Cfg::TN, NPL>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES];
   __shared__ int s_src[Cfg::BM], s_hw[Cfg::BM], s_out[Cfg::BM];
+  __shared__ int s_tap_rel[LMKD_MAX_TAPS], s_tap_kofs[LMKD_MAX_TAPS];
   __shared__ float s_red[STATS ? Cfg::WM * Cfg::BN * 2 : 1];
   const int tid = threadIdx.x;
   int rt, ct;
@@ -234,6 +235,13 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   const int cls = rt - tile * a.nclass;
   const int ph = cls >> 1, pw = cls & 1;
   if (a.accum && a.ntap[cls] == 0) return;      // out += 0 (see conv_gemm_kernel)
+  // per-tap byte shift of the A rows and K offset of the weights, read back as LDS broadcasts: a K-step then needs neither a
+  // scalar division nor a kernarg (SMEM) load, whose latency sat in every wave's instruction stream twice per K-step
+  if (tid < a.ntap[cls]) {
+    const Tap tp = a.taps[cls][tid];
+    s_tap_rel[tid] = ((tp.dh * a.Ws + tp.dw) * a.Cs) * 4;
+    s_tap_kofs[tid] = tp.kofs;
+  }
   const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
   for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
     const int m = row0 + r;
@@ -279,18 +287,16 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   // phase old; loads issued after that point never stand between a value and its use.
   float4 ra0[LA::NI], ra1[LA::NI];
   u32x4 rb0[LB::NR], rb1[LB::NR];
+  // K-steps are issued in increasing order (separately for A and B), channel chunk outer, tap inner (conv.hip)
   const int ntap_c = a.ntap[cls];
-  auto tap_of = [&](int t, int& tp, int& cc) { cc = t / ntap_c; tp = t - cc * ntap_c; };   // chunk outer, tap inner (conv.hip)
-  auto issue_a = [&](int t, float4 (&ra)[LA::NI]) {
-    int tp, cc;
-    tap_of(t, tp, cc);
-    const Tap tap = taps[tp];
-    la.load(tp, ((tap.dh * a.Ws + tap.dw) * a.Cs + (SMALLC ? 0 : cc * LMKD_BK)) * 4, ra);
+  int a_tp = 0, a_cc = 0, b_tp = 0, b_cc = 0;
+  auto issue_a = [&](int, float4 (&ra)[LA::NI]) {
+    la.load(a_tp, s_tap_rel[a_tp] + (SMALLC ? 0 : a_cc * (LMKD_BK * 4)), ra);
+    if (++a_tp == ntap_c) { a_tp = 0; ++a_cc; }
   };
-  auto issue_b = [&](int t, u32x4 (&rb)[LB::NR]) {
-    int tp, cc;
-    tap_of(t, tp, cc);
-    lb.load(taps[tp].kofs + cc * LMKD_BK, rb);
+  auto issue_b = [&](int, u32x4 (&rb)[LB::NR]) {
+    lb.load(s_tap_kofs[b_tp] + b_cc * LMKD_BK, rb);
+    if (++b_tp == ntap_c) { b_tp = 0; ++b_cc; }
   };
   const bool store_first = __builtin_amdgcn_readfirstlane(wave) >= Cfg::WM * Cfg::WN / 2;
   // K-step t: MFMAs on LDS buffer t&1 with the B fragments in `rb`; the A set `ra` (step t+1) goes to the other buffer and
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
       }
     }
     __syncthreads();
-    if (tid < Cfg::BN && n0 + tid < a.Co) {
+    if (tid < Cfg::BN && n0 + tid < a.Co && a.stat_partial) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int w = 0; w < Cfg::WM; ++w) {
