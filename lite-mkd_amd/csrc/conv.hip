@@ -203,6 +203,28 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int cl0 = wn * (Cfg::TN * 32) + (lane & 31);
+  if (STATS == 0 && a.accum) {
+    // out += acc: fetch the whole tile's previous values first (independent loads in flight together), then add; the
+    // per-element "load, wait, add, store" form serialised 16 dependent global round trips per wave
+    float prev[Cfg::TM][Cfg::TN][16];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ob = s_out[wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane)];
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+          const int col = n0 + cl0 + j * 32;
+          prev[i][j][e] = (ob >= 0 && col < a.Co) ? a.out[(long)ob + col] : 0.f;
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] + prev[i][j][e];
+  }
   float s1[Cfg::TN], s2[Cfg::TN];
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) s1[j] = s2[j] = 0.f;
@@ -233,7 +255,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
             if (a.ep_relu) v = fmaxf(v, 0.f);
             *o = v;
           } else {
-            *o = a.accum ? v + *o : v;
+            *o = (STATS == 1 && a.accum) ? v + *o : v;      // STATS == 0: the previous values were added above
           }
         }
         if (STATS == 1) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }

@@ -343,6 +343,26 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   }
 
   const int cl0 = wn * (Cfg::TN * 32) + (lane & 31);
+  if (a.accum) {      // out += acc: all previous values first (loads in flight together), then the adds (conv_gemm_kernel)
+    float prev[Cfg::TM][Cfg::TN][16];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ob = s_out[wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane)];
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+          const int col = n0 + cl0 + j * 32;
+          prev[i][j][e] = (ob >= 0 && col < a.Co) ? a.out[(long)ob + col] : 0.f;
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] + prev[i][j][e];
+  }
   float s1[Cfg::TN], s2[Cfg::TN];
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) s1[j] = s2[j] = 0.f;
@@ -356,10 +376,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
       for (int j = 0; j < Cfg::TN; ++j) {
         const int col = n0 + cl0 + j * 32;
         const float v = acc[i][j][e];
-        if (ob >= 0 && col < a.Co) {
-          float* o = a.out + (long)ob + col;
-          *o = a.accum ? v + *o : v;
-        }
+        if (ob >= 0 && col < a.Co) a.out[(long)ob + col] = v;
         if (STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
       }
     }
