@@ -42,6 +42,7 @@ def main():
                     "both operands, 6 products per fp32 product, fp32 accumulation (csrc/conv_x3.h; forward + data gradient)")
     ap.add_argument("--xcd-mode", type=int, default=-1, help="tuning: lmkd_conv_set_xcd_mode (-1 auto, 0 plain tile orders, 1 auto without XCD-grouped weight-gradient splits)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short bf16 / f32x3 side measurements of the default run")
+    ap.add_argument("--ew-wg", type=int, default=0, help="tuning: workgroups per CU of the HBM-bound kernels (lmkd_set_elementwise_wg_per_cu), 0 = default")
     ap.add_argument("--layer-table", action="store_true", help="print the per-layer-shape conv timing table of the roofline pass to stderr")
     ap.add_argument("--tile", type=int, default=0, help="tuning: force a conv tile configuration (lmkd_conv_set_tile), 0 = auto")
     ap.add_argument("--backbone", default="resnet18_2fc", help="resnet18_2fc (headline) or resnet50_2fc (BASELINE configs[4])")
@@ -66,6 +67,8 @@ def main():
     litemkd_amd.lib().call("lmkd_device_check", dev.index)
     litemkd_amd.lib().call("lmkd_conv_set_tile", a.tile)
     litemkd_amd.lib().call("lmkd_conv_set_xcd_mode", a.xcd_mode)
+    if a.ew_wg > 0:
+        litemkd_amd.lib().call("lmkd_set_elementwise_wg_per_cu", a.ew_wg)
     ops.set_conv_compute_dtype({"f32": "fp32", "bf16": "bf16", "f32x3": "fp32x3"}[a.dtype])
     cfg = default_args(shot=a.shot, device=dev, trans_dropout=a.dropout, training_iterations=10 ** 9, print_freq=10 ** 9,
                        model_backbone=a.backbone)

@@ -10,7 +10,7 @@
 #define NP_THREADS 256
 static int g_ew_wg_per_cu = 4;
 extern "C" int lmkd_set_elementwise_wg_per_cu(int n) {
-  if (n < 1 || n > 8) return LMKD_EINVAL;
+  LMKD_REQUIRE(n >= 1 && n <= 8, "lmkd_set_elementwise_wg_per_cu: %d outside 1..8 (the BatchNorm partial buffers hold 2048 rows)", n);
   g_ew_wg_per_cu = n;
   return LMKD_OK;
 }
