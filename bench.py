@@ -60,6 +60,8 @@ def main():
     from litemkd_amd.utils import aggregate_accuracy
     from litemkd_amd.model.backbone import resnet as R
     R.OVERLAP_TRUNK_CALLS = not a.serial
+    ops.SIDE_WGRAD = (not a.serial) and os.environ.get("LMKD_SIDE_WGRAD", "1") != "0"   # weight gradients on a third stream
+    ops.SYNC_WGRAD_AT_BACKWARD_END = os.environ.get("LMKD_SYNC_WG", "0") == "1"           # FusedOptimizer waits for them itself
 
     rank, world, dev = init_distributed()
     assert dev.type == "cuda", "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
@@ -139,6 +141,7 @@ def main():
         timing = timed_events
     else:
         R.OVERLAP_TRUNK_CALLS = False
+        ops.SIDE_WGRAD = False
         ops.CONV_TIMING = []
         # optimizer steps are excluded here on purpose: this pass only prices kernels
         for i in range(a.roofline_episodes):
@@ -147,6 +150,7 @@ def main():
         fence()
         timing, ops.CONV_TIMING = ops.CONV_TIMING, None
         R.OVERLAP_TRUNK_CALLS = True
+        ops.SIDE_WGRAD = os.environ.get("LMKD_SIDE_WGRAD", "1") != "0"
 
     # roofline of the dominant kernel family (implicit-GEMM conv fwd + dgrad, one template): algorithmic FLOPs / HIP-event time
     fam = {}

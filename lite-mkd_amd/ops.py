@@ -245,6 +245,54 @@ def conv_bwd_weight(x, dy, w_shape, stride, pad):
     return dw
 
 
+# The weight gradient of a layer feeds nothing in the backward chain (only the optimizer), so it need not sit on the stream that
+# carries the data-gradient / BatchNorm chain: with SIDE_WGRAD the Functions' backward launches it on ONE extra stream and
+# accumulates it into `weight.grad` there (returning None to autograd, which would otherwise add it on the chain's stream).
+# All weight-gradient accumulations are ordered on that single stream; an end-of-backward engine callback makes the caller's
+# stream wait for it, and the optimizer / all-reduce / zero_grad entry points wait again.  +2.8 % episodes/s (same-box A/B).
+SIDE_WGRAD = True
+# False: no wait at the end of backward(); the caller promises to call wait_weight_grads() before it reads or modifies any
+# weight.grad (trainloop.FusedOptimizer does, so the next episode's forward can overlap the last weight gradients)
+SYNC_WGRAD_AT_BACKWARD_END = True
+_WG_STREAM = {}
+_WG_CB = [False]
+
+
+def wait_weight_grads():
+    """make the current (and the default) stream wait for every weight gradient launched on the side stream"""
+    for dev, sw in _WG_STREAM.items():
+        torch.cuda.current_stream(dev).wait_stream(sw)
+        torch.cuda.default_stream(dev).wait_stream(sw)
+
+
+def _end_of_backward():
+    _WG_CB[0] = False
+    wait_weight_grads()
+
+
+def weight_grad(w, x, dy, stride, pad):
+    """dW of a convolution for autograd — or None after accumulating it into w.grad on the weight-gradient stream."""
+    if not (SIDE_WGRAD and w.is_leaf and w.requires_grad):
+        return conv_bwd_weight(x, dy, tuple(w.shape), stride, pad)
+    dev = x.device.index
+    if dev not in _WG_STREAM:
+        _WG_STREAM[dev] = torch.cuda.Stream(device=x.device)
+    sw = _WG_STREAM[dev]
+    sw.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(sw):
+        dw = conv_bwd_weight(x, dy, tuple(w.shape), stride, pad)
+        if w.grad is None:
+            w.grad = dw
+        else:
+            w.grad.add_(dw)
+    x.record_stream(sw)
+    dy.record_stream(sw)
+    if SYNC_WGRAD_AT_BACKWARD_END and not _WG_CB[0]:
+        _WG_CB[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+    return None
+
+
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -381,8 +429,7 @@ class StemFn(torch.autograd.Function):
         idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
         lib().call("lmkd_bn_relu_maxpool_fwd", _p(c), _p(stats), _p(y), _p(idx), N, Hc, Wc, C, _stream())
         if training:
-            ctx.save_for_backward(x4, c, stats, idx, gamma)
-            ctx.w_shape = tuple(w.shape)
+            ctx.save_for_backward(x4, c, stats, idx, gamma, w)
         ctx.training = training
         return y
 
@@ -390,13 +437,13 @@ class StemFn(torch.autograd.Function):
     def backward(ctx, dy):
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
-        x4, c, stats, idx, gamma = ctx.saved_tensors
+        x4, c, stats, idx, gamma, w = ctx.saved_tensors
         dy = dy.contiguous()
         N, Hc, Wc, C = c.shape
         g = torch.empty_like(c)
         lib().call("lmkd_maxpool_bwd", _p(dy), _p(idx), _p(g), N, Hc, Wc, C, _stream())
         dc, _, dgamma, dbeta = bn_backward(g, c, None, stats, gamma, 2, dx_out=g)
-        dw = conv_bwd_weight(x4, dc, ctx.w_shape, 2, 3)
+        dw = weight_grad(w, x4, dc, 2, 3)
         return None, dw, dgamma, dbeta, None, None, None
 
 
@@ -503,16 +550,16 @@ class BasicBlockFn(torch.autograd.Function):
         dc2, g, dg2, db2 = bn_backward(dy, c2, y, st2, g2, 1, want_g=True)
         wd2 = pack_weights(w2, Cmid, 1)
         da1 = conv_bwd_data(dc2, wd2, a1.shape, Cmid, 3, 3, 1, 1)
-        dw2 = conv_bwd_weight(a1, dc2, tuple(w2.shape), 1, 1)
+        dw2 = weight_grad(w2, a1, dc2, 1, 1)
         del dc2
         dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)    # mask from c1*scale+shift > 0
-        dw1 = conv_bwd_weight(x, dc1, tuple(w1.shape), stride, 1)
+        dw1 = weight_grad(w1, x, dc1, stride, 1)
         dwd = dgd = dbd = None
         need_dx = ctx.needs_input_grad[0]
         dx = None
         if ctx.has_ds:
             dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g)
-            dwd = conv_bwd_weight(x, dcd, tuple(wd.shape), stride, 0)
+            dwd = weight_grad(wd, x, dcd, stride, 0)
             if need_dx:
                 # the 3x3 gradient writes every input pixel; the 1x1 stride-2 one then accumulates onto the quarter of the
                 # pixels it reaches (parity classes without a tap launch nothing) instead of writing three quarters of zeros
@@ -568,20 +615,20 @@ class BottleneckFn(torch.autograd.Function):
         Cm, Co = w1.shape[0], w3.shape[0]
         dc3, g, dg3, db3 = bn_backward(dy, c3, y, st3, g3, 1, want_g=True)
         da2 = conv_bwd_data(dc3, pack_weights(w3, Cm, 1), a2.shape, Co, 1, 1, 1, 0)
-        dw3 = conv_bwd_weight(a2, dc3, tuple(w3.shape), 1, 0)
+        dw3 = weight_grad(w3, a2, dc3, 1, 0)
         del dc3
         dc2, _, dg2, db2 = bn_backward(da2, c2, None, st2, g2, 2, dx_out=da2)
         da1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), a1.shape, Cm, 3, 3, stride, 1)
-        dw2 = conv_bwd_weight(a1, dc2, tuple(w2.shape), stride, 1)
+        dw2 = weight_grad(w2, a1, dc2, stride, 1)
         del dc2, da2
         dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)
-        dw1 = conv_bwd_weight(x, dc1, tuple(w1.shape), 1, 0)
+        dw1 = weight_grad(w1, x, dc1, 1, 0)
         dwd = dgd = dbd = None
         need_dx = ctx.needs_input_grad[0]
         dx = None
         if ctx.has_ds:
             dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g)
-            dwd = conv_bwd_weight(x, dcd, tuple(wd.shape), stride, 0)
+            dwd = weight_grad(wd, x, dcd, stride, 0)
             if need_dx:      # conv1's gradient first (writes every pixel), the strided downsample one accumulates (BasicBlockFn)
                 dx = conv_bwd_data(dc1, pack_weights(w1, x.shape[-1], 1), x.shape, Cm, 1, 1, 1, 0)
                 conv_bwd_data(dcd, pack_weights(wd, x.shape[-1], 1), x.shape, Co, 1, 1, stride, 0, out=dx, accumulate=True)

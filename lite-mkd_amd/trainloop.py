@@ -27,10 +27,12 @@ class FusedOptimizer:
             raise KeyError(opt)
 
     def zero_grad(self):
+        ops.wait_weight_grads()             # weight gradients accumulate on their own stream (ops.SIDE_WGRAD)
         self.bucket.zero_grad()
 
     def step(self):
         b = self.bucket
+        ops.wait_weight_grads()
         b.allreduce_grads()
         self.steps += 1
         ops.WEIGHT_EPOCH[0] += 1            # invalidates the packed-weight cache (raw-pointer update below)
@@ -118,6 +120,20 @@ def train(student, teacher, video_loader, distiller, optimizer, scheduler, accur
     total_iterations = config.training_iterations
     every = max(1, config.tasks_per_batch // world_size())
     iteration = 0
+    # FusedOptimizer waits for the side-stream weight gradients itself (step / zero_grad), so backward() need not: the next
+    # episode's forward then overlaps the tail of the previous episode's weight gradients
+    sync_prev = ops.SYNC_WGRAD_AT_BACKWARD_END
+    ops.SYNC_WGRAD_AT_BACKWARD_END = not isinstance(optimizer, FusedOptimizer)
+    try:
+        return _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log, losses,
+                           accuracies, total_iterations, every, iteration)
+    finally:
+        ops.wait_weight_grads()
+        ops.SYNC_WGRAD_AT_BACKWARD_END = sync_prev
+
+
+def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log, losses, accuracies,
+                total_iterations, every, iteration):
     for task_dict in video_loader:
         if iteration >= total_iterations:
             break

@@ -262,3 +262,44 @@ def test_other_plugin_combinations_run(dev, clf, dist, teacher):
         cp = {k[len("classifier.transformers."):]: v for k, v in sp.items() if k.startswith("classifier.transformers.")}
         ref = O.trx_logits(out["context_features"].detach().cpu(), ep["support_labels"], out["target_features"].detach().cpu(), cp)
         assert torch.allclose(out["logits"].detach().cpu(), ref, rtol=1e-4, atol=2e-2)
+
+
+def test_side_stream_weight_gradients_identical(dev):
+    """ops.SIDE_WGRAD: conv weight gradients launched on their own stream and accumulated into weight.grad there.  After one
+    backward pass they are bit-identical to the autograd path (same kernels, same order); over two passes they agree to fp32
+    rounding (autograd sums the two trunk calls' gradients of a pass in its input buffer before adding them to .grad, the side
+    stream adds them one by one).  Checked with and without the end-of-backward wait (then after wait_weight_grads())."""
+    from litemkd_amd import ops
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from oracle import ref_cpu as O
+    args = default_args(shot=1, query_per_class=1, img_size=64, trans_dropout=0.0, device=dev)
+    torch.manual_seed(5)
+    student, teacher = Student(args).to(dev), Teacher(args).to(dev)
+    ep = O.make_episode(77, 5, 1, 1, img=64)
+    labels = ep["target_labels"].long().to(dev)
+
+    def grads(side, sync_at_end, passes):
+        ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END = side, sync_at_end
+        student.zero_grad(set_to_none=True)
+        for _ in range(passes):
+            out = student(ep["support_set"].to(dev), ep["support_labels"].to(dev), ep["target_set"].to(dev))
+            tl = teacher(ep["support_set_feature_teacher"].to(dev), ep["support_labels"].to(dev), ep["target_set_feature_teacher"].to(dev))["logits"]
+            Distiller("fc_2_sup_dist", args.cfg, dev).fc_2_sup_dist(out["logits"], tl, labels)["loss"].backward()
+        if not sync_at_end:
+            ops.wait_weight_grads()
+        return {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None}
+    try:
+        for passes in (1, 2):
+            ref = grads(False, True, passes)
+            for sync in (True, False):
+                got = grads(True, sync, passes)
+                assert set(got) == set(ref)
+                for n in ref:
+                    if passes == 1:
+                        assert torch.equal(got[n], ref[n]), (n, sync)
+                    else:
+                        assert float((got[n] - ref[n]).abs().max()) <= 2e-6 * float(ref[n].abs().max()) + 1e-12, (n, sync)
+    finally:
+        ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END = True, True
