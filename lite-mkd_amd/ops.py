@@ -549,8 +549,8 @@ class BasicBlockFn(torch.autograd.Function):
         # bn2 (+ReLU mask from y); g = masked dy = gradient of both residual branches
         dc2, g, dg2, db2 = bn_backward(dy, c2, y, st2, g2, 1, want_g=True)
         wd2 = pack_weights(w2, Cmid, 1)
+        dw2 = weight_grad(w2, a1, dc2, 1, 1)      # first: its stream then waits for the BatchNorm backward only, not for the data gradient
         da1 = conv_bwd_data(dc2, wd2, a1.shape, Cmid, 3, 3, 1, 1)
-        dw2 = weight_grad(w2, a1, dc2, 1, 1)
         del dc2
         dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)    # mask from c1*scale+shift > 0
         dw1 = weight_grad(w1, x, dc1, stride, 1)
@@ -614,12 +614,12 @@ class BottleneckFn(torch.autograd.Function):
         stride = ctx.stride
         Cm, Co = w1.shape[0], w3.shape[0]
         dc3, g, dg3, db3 = bn_backward(dy, c3, y, st3, g3, 1, want_g=True)
+        dw3 = weight_grad(w3, a2, dc3, 1, 0)       # weight gradients first (BasicBlockFn)
         da2 = conv_bwd_data(dc3, pack_weights(w3, Cm, 1), a2.shape, Co, 1, 1, 1, 0)
-        dw3 = weight_grad(w3, a2, dc3, 1, 0)
         del dc3
         dc2, _, dg2, db2 = bn_backward(da2, c2, None, st2, g2, 2, dx_out=da2)
-        da1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), a1.shape, Cm, 3, 3, stride, 1)
         dw2 = weight_grad(w2, a1, dc2, stride, 1)
+        da1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), a1.shape, Cm, 3, 3, stride, 1)
         del dc2, da2
         dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)
         dw1 = weight_grad(w1, x, dc1, 1, 0)
