@@ -12,6 +12,10 @@ Reference modules imported (by file path):
       `torchvision.models` stub for a dead import (TRX_2fcsup.py:12) and
       `Tensor.cuda = identity` for the tuple-index tensors (TRX_2fcsup.py:71)
 
+  teacher/code/model.py (MFM fusion)                -- test-only stubs for dead imports: `turtle`, `timm`,
+      `torchvision.models` (matplotlib, einops and the local `transformer` / `utils` modules import as they are);
+      `Tensor.cuda = identity` for extract_feature's `.cuda()` calls (model.py:1649-1651)
+
 usage: python oracle/gen_golden.py [--check-only]
 """
 import argparse
@@ -267,6 +271,72 @@ def gen_resize(mods):
     return out
 
 
+def load_reference_teacher():
+    """teacher/code/model.py as a module.  Its `from utils import ...` / `from transformer import ...` mean the files next
+    to it (teacher/code/utils.py, transformer.py), not the student's utils.py registered by load_reference()."""
+    tdir = os.path.join(REF, "teacher", "code")
+    for name in ("turtle", "timm"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.forward = None
+            sys.modules[name] = m
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tv.models = types.ModuleType("torchvision.models")
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.models"] = tv.models
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    saved = {k: sys.modules.get(k) for k in ("utils", "transformer")}
+    sys.modules["utils"] = _load("utils", os.path.join(tdir, "utils.py"))
+    sys.modules["transformer"] = _load("transformer", os.path.join(tdir, "transformer.py"))
+    import warnings
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mod = _load("ref_teacher_model", os.path.join(tdir, "model.py"))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
+MFM_CASES = [(7001, 2, 1), (7002, 3, 2)]       # (input seed, videos, shirt_num); weights: make_mfm_params(MFM_WEIGHT_SEED)
+MFM_WEIGHT_SEED = 77
+
+
+def gen_mfm(mods):
+    """ThreeTRXShiftLoopTime.extract_feature (teacher/code/model.py:1648-1664) of the reference itself at its fixed width 2048
+    (541 M parameters), eval mode + no_grad as extract_multi_feature.py:113-121 runs it; also the three partial features."""
+    import warnings
+    M = load_reference_teacher()
+    args = argparse.Namespace(seq_len=8, trans_num=2, shirt_num=1, num_gpus=1, temp_set=[2], trans_linear_in_dim=2048,
+                              trans_linear_out_dim=1152, trans_dropout=0.1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = M.ThreeTRXShiftLoopTime(args).eval()
+    p = O.make_mfm_params(MFM_WEIGHT_SEED)
+    sd = model.state_dict()
+    fused = [k for k in sd if k.startswith("fusion.") or k.startswith("three_fusion.")]
+    assert sorted(fused) == sorted(p), "state_dict keys of the reference's fusion modules differ from oracle.mfm_param_shapes()"
+    with torch.no_grad():
+        for k in fused:
+            sd[k].copy_(p[k])
+    out = {"weight_seed": MFM_WEIGHT_SEED}
+    for case, (seed, n, shirt) in enumerate(MFM_CASES):
+        args.shirt_num = shirt
+        rgb, depth, flow = O.make_mfm_inputs(seed, n)
+        with torch.no_grad():
+            y = model.extract_feature({"rgb": rgb, "depth": depth, "flow": flow})
+            f1 = model.three_fusion.extract_feature(rgb, depth, flow)
+            f2 = model.fusion.extract_feature(rgb, torch.roll(depth, -shirt, 1))
+        pre = "c%d_" % case
+        out.update({pre + "seed": seed, pre + "n": n, pre + "shirt": shirt, pre + "out": y, pre + "three": f1, pre + "two_depth": f2})
+    return out
+
+
 def trx_case_inputs(seed, ns, nq, shuffle):
     """Re-creates the exact inputs/weights of gen_trx (used by tests; no reference needed)."""
     g = torch.Generator().manual_seed(1000 + seed)
@@ -288,7 +358,7 @@ def main():
     mods = load_reference()
     os.makedirs(GOLD, exist_ok=True)
     for name, fn in (("distill", gen_distill), ("distill_methods", gen_distill_methods), ("edist", gen_edist), ("trx", gen_trx),
-                     ("trx_sup", gen_trx_sup), ("resize", gen_resize)):
+                     ("trx_sup", gen_trx_sup), ("resize", gen_resize), ("mfm", gen_mfm)):
         data = fn(mods)
         data = t2n(data) if name != "resize" else data
         path = os.path.join(GOLD, name + ".npz")

@@ -17,8 +17,11 @@ Parity pins (see oracle/gen_golden.py, tests/golden/):
     (model/backbone/resnet18_2fc.py:30-33,41-42), the parameter count 11 176 512 and
     the state-dict key names.  The reference holds no tests or golden vectors for it:
     TRUNK PARITY UNPINNED BY THE REFERENCE.
-  * The MFM fusion (teacher/code/model.py) cannot be imported here (needs timm,
-    tkinter, ...): restated from source text, PARITY UNPINNED.
+  * The MFM fusion (teacher/code/model.py:1135-1151,1300-1331,1361-1392,1648-1664) is
+    pinned against the reference's own ThreeTRXShiftLoopTime.extract_feature at its
+    fixed width 2048 (imported in the build container with test-only stubs for the
+    dead imports `turtle`, `timm`, `torchvision.models`; weights from
+    make_mfm_params(seed); outputs in tests/golden/mfm.npz).
 
 All citations are file:line under /root/reference.
 """
@@ -610,6 +613,35 @@ def mfm_param_shapes(d=2048, seq_len=8, num_layers=2, dff=2048):
         pe("fusion.positionEncoding%d" % i)
     enc("fusion", 2 * d)
     return shp
+
+
+def make_mfm_params(seed, d=2048, seq_len=8, num_layers=2, dff=2048):
+    """Seeded weights for the MFM fusion, keyed like the reference's state_dict (`fusion.*`, `three_fusion.*`).
+    Each tensor is drawn from its own generator (seed mixed with a CRC of the key), so the values do not depend on the
+    order in which a module happens to construct its parameters: gen_golden.py loads them into the reference's
+    ThreeTRXShiftLoopTime, the tests into the oracle and into the HIP module.  Scales follow the torch defaults in
+    magnitude (Linear U(+-1/sqrt(fan_in)), in_proj xavier-like) with non-trivial LayerNorm affines and biases."""
+    import zlib
+    out = {}
+    for k, shp in mfm_param_shapes(d, seq_len, num_layers, dff).items():
+        g = torch.Generator().manual_seed((int(seed) * 1000003 + zlib.crc32(k.encode())) & 0x7FFFFFFFFFFFFFFF)
+        if k.endswith("position_embeddings.weight"):
+            t = torch.randn(shp, generator=g)
+        elif "LayerNorm.weight" in k or ".norm1.weight" in k or ".norm2.weight" in k:
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif len(shp) == 1:                       # biases (incl. self_attn.in_proj_bias)
+            t = 0.05 * torch.randn(shp, generator=g)
+        else:                                     # matrices [out, in]
+            bound = 1.0 / math.sqrt(shp[1])
+            t = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        out[k] = t
+    return out
+
+
+def make_mfm_inputs(seed, n, d=2048, seq_len=8):
+    """rgb / depth / flow per-modality features ~ |N(0,1)| (post-ReLU-like)"""
+    g = torch.Generator().manual_seed(seed)
+    return tuple(torch.randn(n, seq_len, d, generator=g).abs() for _ in range(3))
 
 
 # ----------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 All calls go through the C ABI (lite-mkd_amd/_lib.py -> liblmkd_hip.so).  Tolerances are fp32:
 different summation order vs the CPU library, stated per test."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -465,6 +466,33 @@ def test_mfm_fusion(dev, d, N):
     m = m.to(dev)
     out = m.extract_feature({"rgb": rgb.to(dev), "depth": depth.to(dev), "flow": flow.to(dev)})
     close(out, ref, 1e-3, 1e-3, "mfm fused feature")
+
+
+def test_mfm_fusion_full_width_golden(dev, golden_dir):
+    """The HIP MFM fusion at the reference's fixed width 2048 (541 M parameters) against the outputs of the reference's own
+    ThreeTRXShiftLoopTime.extract_feature (teacher/code/model.py:1648-1664; tests/golden/mfm.npz, weights from
+    oracle.make_mfm_params): fused feature, both cases (shirt_num 1 / 2), and the partial encoders."""
+    import argparse
+    from litemkd_amd.teacher import ThreeTRXShiftLoopTime
+    from oracle import ref_cpu as O
+    G = np.load(os.path.join(golden_dir, "mfm.npz"))
+    args = argparse.Namespace(seq_len=8, trans_num=2, shirt_num=1, trans_linear_in_dim=2048)
+    with torch.device(dev):
+        m = ThreeTRXShiftLoopTime(args).eval()
+    p = O.make_mfm_params(int(G["weight_seed"]))
+    m.load_state_dict(p, strict=True)
+    del p
+    for case in (0, 1):
+        pre = "c%d_" % case
+        n, shirt = int(G[pre + "n"]), int(G[pre + "shirt"])
+        rgb, depth, flow = (t.to(dev) for t in O.make_mfm_inputs(int(G[pre + "seed"]), n))
+        args.shirt_num = shirt
+        out = m.extract_feature({"rgb": rgb, "depth": depth, "flow": flow})
+        # fp32 GEMMs with K up to 6144 and a different summation order than the CPU: 2e-4 of the feature scale (~1)
+        close(out, torch.from_numpy(G[pre + "out"]), 2e-4, 2e-4, "mfm fused feature, case %d" % case)
+        close(m.three_fusion.extract_feature(rgb, depth, flow), torch.from_numpy(G[pre + "three"]), 2e-4, 2e-4, "three_fusion")
+        close(m.fusion.extract_feature(rgb, torch.roll(depth, -shirt, 1).contiguous()), torch.from_numpy(G[pre + "two_depth"]),
+              2e-4, 2e-4, "fusion(rgb, depth)")
 
 
 def test_all_distiller_methods_golden(dev, golden_dir):

@@ -163,6 +163,22 @@ def test_mfm_param_count_and_shape():
     assert 5.0e8 < n < 5.8e8                                 # ~541 M
 
 
+def test_mfm_golden(golden_dir):
+    """MFM fusion restatement vs the reference's own ThreeTRXShiftLoopTime.extract_feature at its fixed width 2048
+    (teacher/code/model.py:1648-1664; fixtures by oracle/gen_golden.py: gen_mfm): fused feature and the partial features of
+    the three- and two-modality encoders, two cases (shirt_num 1 and 2)."""
+    G = np.load(os.path.join(golden_dir, "mfm.npz"))
+    p = O.make_mfm_params(int(G["weight_seed"]))
+    for case in (0, 1):
+        pre = "c%d_" % case
+        n, shirt = int(G[pre + "n"]), int(G[pre + "shirt"])
+        rgb, depth, flow = O.make_mfm_inputs(int(G[pre + "seed"]), n)
+        with torch.no_grad():
+            close(O.mfm_three_fusion(rgb, depth, flow, p), G[pre + "three"], 1e-4, 1e-4)
+            close(O.mfm_two_fusion(rgb, torch.roll(depth, -shirt, 1), p), G[pre + "two_depth"], 1e-4, 1e-4)
+            close(O.mfm_extract_feature(rgb, depth, flow, p, shirt, 2), G[pre + "out"], 1e-4, 1e-4)
+
+
 def test_distill_methods_golden(golden_dir):
     """all 22 logits-only Distiller methods of the reference (distillers.py:42-733): value + student-logit gradients"""
     G = np.load(os.path.join(golden_dir, "distill_methods.npz"))
