@@ -5,7 +5,10 @@ student forward over 400 frames (two 200-frame BatchNorm batches), frozen TRX te
 features, D2M loss fc_2_sup_dist, backward; plus the SGD step (and, for N>1, one RCCL all-reduce of the flat
 gradient bucket) every tasks_per_batch/N episodes, as in trainwandb.py:141-143.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+N>1: one rank per GPU over RCCL.  Either the driver launches the ranks (python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...: RANK / WORLD_SIZE are then in the environment), or a plain `python bench.py --gpus N` starts them itself
+as a CHILD `python -m torch.distributed.run` process — before this process has made any GPU call — and exits with its code.
 
 Prints ONE JSON line (rank 0) with `roofline` (conv MFMA kernel, HIP-event timed inside the timed region)
 and `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1 only)."""
@@ -22,6 +25,33 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 FWD_GFLOP_PER_FRAME = 3.627            # SURVEY.md 8d (ResNet-18 trunk, 224x224)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run and return its exit
+    code.  Called before anything in this process touches the GPU (a process that has initialised HIP must never exec)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "2")
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources the .so is built from: ties committed PMC numbers to the kernels they were measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "lite-mkd_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -48,7 +78,10 @@ def main():
     ap.add_argument("--backbone", default="resnet18_2fc", help="resnet18_2fc (headline) or resnet50_2fc (BASELINE configs[4])")
     ap.add_argument("--live-mfm", action="store_true", help="fuse rgb/depth/flow teacher features with the MFM transformer "
                     "inside every episode (BASELINE configs[4]) instead of using precomputed fused features")
+    ap.add_argument("--cpu-episodes", type=int, default=3, help="episodes of the bounded cpu_baseline sample")
     a = ap.parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(a.gpus))
 
     import torch.distributed as dist
     import litemkd_amd  # noqa: F401
@@ -63,9 +96,10 @@ def main():
     ops.SIDE_WGRAD = (not a.serial) and os.environ.get("LMKD_SIDE_WGRAD", "1") != "0"   # weight gradients on a third stream
     ops.SYNC_WGRAD_AT_BACKWARD_END = os.environ.get("LMKD_SYNC_WG", "0") == "1"           # FusedOptimizer waits for them itself
 
+    from litemkd_amd import parallel as PAR
     rank, world, dev = init_distributed()
     assert dev.type == "cuda", "bench.py needs MI355X GPUs (the hot path has no CPU fallback)"
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
+    assert world == a.gpus, "--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus)
     litemkd_amd.lib().call("lmkd_device_check", dev.index)
     litemkd_amd.lib().call("lmkd_conv_set_tile", a.tile)
     litemkd_amd.lib().call("lmkd_conv_set_xcd_mode", a.xcd_mode)
@@ -118,15 +152,34 @@ def main():
     it = run(a.warmup, 0)
     fence()
     ops.CONV_TIMING = []
+    PAR.ALLREDUCE_TIMING = []
+    steps0 = opt.steps
     t0 = time.perf_counter()
     it = run(a.steps, it)
     fence()
     dt = time.perf_counter() - t0
     timed_events, ops.CONV_TIMING = ops.CONV_TIMING, None
+    ar_events, PAR.ALLREDUCE_TIMING = PAR.ALLREDUCE_TIMING, None
+    opt_steps_timed = opt.steps - steps0
+    dist_info = {"backend": None, "world": world, "devices": [torch.cuda.get_device_name(dev)], "allreduce_ms_per_optimizer_step": None,
+                 "optimizer_steps_in_timed_region": opt_steps_timed, "allreduce_bucket_bytes": opt.bucket.numel * 4}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # evidence that the collective ran over `world` ranks on `world` distinct GPUs: backend, every rank's device, and a
+        # checksum all-reduce (sum of rank+1 over the ranks must be world*(world+1)/2)
+        names = [None] * world
+        props = torch.cuda.get_device_properties(dev)
+        dist.all_gather_object(names, "rank %d: cuda:%d %s (%s, pci %s)" % (rank, dev.index, props.name, getattr(props, "gcnArchName", "?"),
+                                                                              getattr(props, "pci_bus_id", "?")))
+        chk = torch.tensor([float(rank + 1)], device=dev)
+        dist.all_reduce(chk)
+        assert int(chk.item()) == world * (world + 1) // 2, "all-reduce checksum: %s" % chk.item()
+        ar = torch.tensor([sum(e0.elapsed_time(e1) for e0, e1 in ar_events) / max(len(ar_events), 1)], device=dev, dtype=torch.float64)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        dist_info.update({"backend": dist.get_backend(), "devices": names, "allreduce_ms_per_optimizer_step": float(ar.item()),
+                          "allreduce_checksum_ok": True})
     conv_flops_timed = sum(r[1] for r in timed_events)
     # the same HIP-event measurement inside the timed region: with two streams a launch's interval also contains the other
     # stream's kernels, so this is a lower bound of the kernel's own rate (reported next to the serialized figure)
@@ -179,10 +232,19 @@ def main():
     # HBM-side traffic of the same kernel family: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950) of `bench.py --serial`,
     # committed under profiles/ — counters cannot be read from inside this process.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("conv_gemm_kernel", {}).get("traffic_bytes_per_launch")
+    # The file records the hash of the kernel sources it was measured on; a number measured on other kernels is not reported.
+    traffic, traffic_note = None, "no PMC file"
+    import glob
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if tfiles:
+        tj = json.load(open(tfiles[-1]))
+        if tj.get("kernel_src_hash") == kernel_source_hash():
+            traffic = tj.get("conv_gemm_kernel", {}).get("traffic_bytes_per_launch")
+            traffic_note = "rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch, %s" % os.path.relpath(tfiles[-1], ROOT)
+        else:
+            traffic_note = "%s was measured on other kernel sources (hash %s, now %s): not reported" % (
+                os.path.relpath(tfiles[-1], ROOT), tj.get("kernel_src_hash"), kernel_source_hash())
+            print("bench.py: " + traffic_note, file=sys.stderr)
     frames = 8 * 5 * (a.shot + cfg.query_per_class)
     step_tflop = 3 * FWD_GFLOP_PER_FRAME * frames / 1e3
     out = {
@@ -200,7 +262,8 @@ def main():
                                % ("v_mfma_f32_32x32x2_f32" if a.dtype == "f32" else "v_mfma_f32_32x32x16_bf16"
                                   + (" x6 per fp32 product; peak = bf16 peak / 6" if a.dtype == "f32x3" else "")),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_hbm_traffic.json)",
+                     "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_note": traffic_note,
+                     "kernel_src_hash": kernel_source_hash(),
                      "algorithmic_bytes_per_launch": cg[3] / max(cg[2], 1),
                      "launches": cg[2], "avg_launch_ms": cg[1] / max(cg[2], 1) * 1e3,
                      "wgrad_kernel_tflops": wg[0] / wg[1] / 1e12, "wgrad_avg_launch_ms": wg[1] / max(wg[2], 1) * 1e3,
@@ -208,6 +271,7 @@ def main():
                      "achieved_in_timed_region": achieved_timed,
                      "timed_region_conv_tflops_per_gpu": conv_flops_timed / dt / 1e12,
                      "episode_model_tflops": step_tflop * world * a.steps / dt},
+        "distributed": dist_info,
     }
     if world == 1 and a.dtype == "f32" and not a.no_other_modes:
         # the same job in the two other arithmetic modes of the convolutions, for the record (never part of `value`):
@@ -226,7 +290,7 @@ def main():
         other["f32x3"]["what"] = "fp32 conv operands as an exact 3-way bf16 split, 6 bf16 MFMA products, fp32 accumulate (forward + data gradient)"
         out["other_modes"] = other
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.shot)
+        out["cpu_baseline"] = cpu_baseline(a.shot, a.cpu_episodes)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

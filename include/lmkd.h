@@ -64,6 +64,10 @@ long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, int Cout, int
 int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, float* workspace, long ws_bytes, int N, int H, int W,
                            int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
 
+/* launch plan (no launch) of lmkd_conv2d_fwd (kind 0) / _bwd_data (1) / _bwd_weight (2) for these shapes in the current mode:
+   info[4] (HOST) = tile id, XCD tile order, parity classes | pixel splits, workgroups.  Test/diagnostic aid. */
+int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, int* info_host);
+
 /* ---- layout / BatchNorm / pooling (torchvision bn1/relu/maxpool/BasicBlock, resnet18_2fc.py:33,41-54) ---- */
 /* crop + horizontal flip + ToTensor of uint8 HWC frames into NHWC4 (video_reader.py:92-112 after Resize); crop/flip per video */
 int lmkd_frames_u8_to_nhwc4(const unsigned char* src, float* dst, const int* crop_y, const int* crop_x, const int* flip, int F, int Hs,

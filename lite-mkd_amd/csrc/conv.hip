@@ -819,3 +819,40 @@ extern "C" int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw
   LMKD_CHECK_LAUNCH("wgrad_reduce_kernel");
   return LMKD_OK;
 }
+
+// Launch plan of a convolution, without launching: which kernel instance and tile order the three entry points above would
+// pick for these shapes in the current arithmetic mode.  info[0] = tile id (lmkd_conv_set_tile numbering; the weight gradient
+// reports 1 = 128x128/8 waves, 2 = 128x64, 3 = 64x64, 4 = 64x128), info[1] = XCD tile order (forward / data gradient: 0 row
+// bands, 1 column slices; weight gradient: 1 = all tiles of a pixel split on one XCD), info[2] = pixel splits (weight gradient)
+// or parity classes (data gradient), info[3] = workgroups launched.  Used by the parity tests to prove that the benchmark's
+// kernel instances are the ones under test.
+extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                int* info) {
+  LMKD_REQUIRE(info && kind >= 0 && kind <= 2, "lmkd_conv2d_plan: kind must be 0 (forward), 1 (data gradient) or 2 (weight gradient)");
+  LMKD_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0, "lmkd_conv2d_plan: bad shape");
+  const int Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
+  if (kind == 2) {
+    const int Kp = KH * kw_padded(Cs, KW) * Cs;
+    int splits, sps, bm, bn;
+    wgrad_plan(N * Ho * Wo, Cout, Kp, &splits, &sps, &bm, &bn);
+    info[0] = (bm == 128 && bn == 128) ? 1 : (bm == 128 ? 2 : (bn == 128 ? 4 : 3));
+    info[1] = (g_xcd_mode != 0 && g_xcd_mode != 1 && splits >= 32) ? 1 : 0;
+    info[2] = splits;
+    info[3] = (info[1] ? 8 * cdiv(splits, 8) : splits) * cdiv(Cout, bm) * cdiv(Kp, bn);
+    return LMKD_OK;
+  }
+  long rows;
+  int nclass = 1, ncols;
+  if (kind == 0) { rows = (long)N * Ho * Wo; ncols = Cout; }
+  else {
+    ncols = Cin;
+    if (stride == 1) rows = (long)N * H * W;
+    else { nclass = 4; rows = (long)N * ((H + 1) / 2) * ((W + 1) / 2); }
+  }
+  const int id = pick_conv_cfg(rows, nclass, ncols);
+  const int n_rt = nclass * cdiv(rows, cfg_bm(id)), n_ct = cdiv(ncols, cfg_bn(id));
+  int xm = (n_ct >= 8 && (n_ct & 7) == 0) ? 1 : 0;
+  if (g_xcd_mode == 0) xm = 0;
+  info[0] = id; info[1] = xm; info[2] = nclass; info[3] = xcd_grid(n_rt, n_ct, xm);
+  return LMKD_OK;
+}

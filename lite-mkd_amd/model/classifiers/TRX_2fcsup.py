@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
+from ...parallel import rank as _rank
 
 
 class PositionalEncoding(nn.Module):
@@ -45,15 +46,22 @@ class TemporalCrossTransformer(nn.Module):
         self.norm_k = nn.LayerNorm(self.args.trans_linear_out_dim)
         self.norm_v = nn.LayerNorm(self.args.trans_linear_out_dim)       # unused by forward (:106), as in the reference
         self.tuples_len = self.args.seq_len * (self.args.seq_len - 1) // 2
-        self._drop_calls = 0
+
+    @staticmethod
+    def draw_dropout_seed():
+        """One 62-bit draw from torch's default (CPU) generator per dropout call, mixed with the distributed rank: every call of
+        every module (student heads, frozen teacher) gets an independent mask, as with the reference's nn.Dropout on the global
+        Philox stream (TRX_2fcsup.py:28,48); ranks that share one torch.manual_seed for equal initial weights still draw
+        different masks for their different episodes; torch.manual_seed / get_rng_state / set_rng_state reproduce and
+        checkpoint the sequence.  No device work, no synchronisation."""
+        s = int(torch.randint(0, 1 << 62, (1,)).item())
+        return (s ^ (_rank() * 0x9E3779B97F4A7C15)) & 0x3FFFFFFFFFFFFFFF
 
     def _mask(self, n_rows, device):
         p = self.pe.p
         if not self.training or p <= 0.0:
             return None
-        self._drop_calls += 1
-        seed = (torch.initial_seed() * 1000003 + self._drop_calls) & 0x7FFFFFFFFFFFFFFF
-        return ops.dropout_mask((n_rows, 2048), p, seed, device)
+        return ops.dropout_mask((n_rows, 2048), p, self.draw_dropout_seed(), device)
 
     def forward(self, support_set, support_labels, queries, with_sim=False):
         L = self.args.seq_len

@@ -250,12 +250,16 @@ def conv_bwd_weight(x, dy, w_shape, stride, pad):
 # accumulates it into `weight.grad` there (returning None to autograd, which would otherwise add it on the chain's stream).
 # All weight-gradient accumulations are ordered on that single stream; an end-of-backward engine callback makes the caller's
 # stream wait for it, and the optimizer / all-reduce / zero_grad entry points wait again.  +2.8 % episodes/s (same-box A/B).
-SIDE_WGRAD = True
+# OFF by default: with it on, torch.autograd.grad() returns None for conv weights and tensor / post-accumulate hooks on them
+# never fire (the gradient does not pass through autograd).  trainloop.train and bench.py, which own the optimizer, switch it
+# on; a weight that carries hooks always takes the autograd path.
+SIDE_WGRAD = False
 # False: no wait at the end of backward(); the caller promises to call wait_weight_grads() before it reads or modifies any
 # weight.grad (trainloop.FusedOptimizer does, so the next episode's forward can overlap the last weight gradients)
 SYNC_WGRAD_AT_BACKWARD_END = True
 _WG_STREAM = {}
-_WG_CB = [False]
+_WG_CB = [None]      # id of the autograd graph task whose end-of-backward callback is queued (a backward that raised leaves a
+                     # stale id behind, which the next backward — a new graph task — does not match)
 
 
 def wait_weight_grads():
@@ -266,13 +270,17 @@ def wait_weight_grads():
 
 
 def _end_of_backward():
-    _WG_CB[0] = False
+    _WG_CB[0] = None
     wait_weight_grads()
+
+
+def _has_hooks(w):
+    return bool(getattr(w, "_backward_hooks", None)) or bool(getattr(w, "_post_accumulate_grad_hooks", None))
 
 
 def weight_grad(w, x, dy, stride, pad):
     """dW of a convolution for autograd — or None after accumulating it into w.grad on the weight-gradient stream."""
-    if not (SIDE_WGRAD and w.is_leaf and w.requires_grad):
+    if not (SIDE_WGRAD and w.is_leaf and w.requires_grad) or _has_hooks(w):
         return conv_bwd_weight(x, dy, tuple(w.shape), stride, pad)
     dev = x.device.index
     if dev not in _WG_STREAM:
@@ -287,9 +295,11 @@ def weight_grad(w, x, dy, stride, pad):
             w.grad.add_(dw)
     x.record_stream(sw)
     dy.record_stream(sw)
-    if SYNC_WGRAD_AT_BACKWARD_END and not _WG_CB[0]:
-        _WG_CB[0] = True
-        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+    if SYNC_WGRAD_AT_BACKWARD_END:
+        task = torch._C._current_graph_task_id()
+        if _WG_CB[0] != task:
+            _WG_CB[0] = task
+            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
     return None
 
 

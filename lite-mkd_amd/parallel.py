@@ -16,14 +16,20 @@ def init_distributed(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
+    backend = backend or os.environ.get("LMKD_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
     if use_cuda:
-        local = local % torch.cuda.device_count()      # rehearsals may run several ranks on one card (gloo only)
+        ndev = torch.cuda.device_count()
+        if local >= ndev:
+            if backend != "gloo":
+                # RCCL needs one device per rank: two ranks of one communicator on the same GPU hang or fail deep inside RCCL
+                raise RuntimeError("LOCAL_RANK %d but only %d visible GPU(s): the %s (RCCL) backend needs one GPU per rank; "
+                                   "several ranks may share a card only with LMKD_DIST_BACKEND=gloo (rehearsals)" % (local, ndev, backend))
+            local = local % ndev                       # gloo rehearsal: several ranks on one card
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or os.environ.get("LMKD_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
@@ -34,6 +40,29 @@ def rank():
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+ALLREDUCE_TIMING = None
+
+
+def averaged_bn_running_stats(module):
+    """{state_dict key: tensor} of every BatchNorm running_mean / running_var of `module`, averaged over the ranks (SURVEY 8e:
+    each rank's BatchNorm sees only its own episodes; the estimates are averaged when a checkpoint is written).  ONE
+    all-reduce of the concatenated buffers; collective: every rank must call it.  The live buffers are not modified."""
+    keys = [k for k in module.state_dict() if k.endswith("running_mean") or k.endswith("running_var")]
+    sd = module.state_dict()
+    if not keys:
+        return {}
+    flat = torch.cat([sd[k].detach().reshape(-1).float() for k in keys])
+    if world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= world_size()
+    out, o = {}, 0
+    for k in keys:
+        n = sd[k].numel()
+        out[k] = flat[o:o + n].reshape(sd[k].shape).clone()
+        o += n
+    return out
 
 
 class FlatParams:
@@ -66,9 +95,17 @@ class FlatParams:
         self.grad.zero_()
 
     def allreduce_grads(self):
-        """One all-reduce(sum) of the whole bucket.  No-op on a single process."""
+        """One all-reduce(sum) of the whole bucket.  No-op on a single process.  With ALLREDUCE_TIMING set to a list, the
+        collective is bracketed by two events on the current stream (bench.py reports the mean)."""
         if world_size() > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+            if ALLREDUCE_TIMING is not None and self.grad.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+                e1.record()
+                ALLREDUCE_TIMING.append((e0, e1))
+            else:
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
 
     def broadcast_params(self, src=0):
         if world_size() > 1:

@@ -46,14 +46,18 @@ class FusedOptimizer:
 
 
 class MultiStepLR:
-    """torch.optim.lr_scheduler.MultiStepLR(milestones, gamma=0.1) on FusedOptimizer.lr."""
+    """torch.optim.lr_scheduler.MultiStepLR(milestones, gamma=0.1) on FusedOptimizer.lr.  The reference calls scheduler.step()
+    once per episode (trainwandb.py:145), so its milestones ([20000, 40000], options.py) count EPISODES.  Under episode
+    parallelism every rank runs the loop over its own episodes; one step() here therefore advances the count by the world size:
+    the milestones stay in global episodes and the learning-rate schedule of an N-GPU run matches the 1-GPU reference run."""
 
-    def __init__(self, optimizer, milestones, gamma=0.1):
+    def __init__(self, optimizer, milestones, gamma=0.1, episodes_per_step=None):
         self.opt, self.milestones, self.gamma, self.n = optimizer, sorted(milestones), gamma, 0
         self.base = optimizer.lr
+        self.inc = world_size() if episodes_per_step is None else episodes_per_step
 
     def step(self):
-        self.n += 1
+        self.n += self.inc
         self.opt.lr = self.base * self.gamma ** sum(1 for m in self.milestones if m <= self.n)
 
 
@@ -101,15 +105,19 @@ def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
 
 def save_checkpoint(student, iteration, config):
     """trainwandb.py:171-180: {'iteration', 'model_state_dict'} -> <save_dir>/<yyyymmddHHMM><mode><iteration>.pt (the
-    file load_student / the reference's test.py read).  Rank 0 only: the replicas hold identical weights."""
+    file load_student / the reference's test.py read).  The replicas hold identical weights; their BatchNorm running
+    statistics (each rank saw its own episodes) are averaged over the ranks into the saved copy (collective: every rank
+    calls this), then rank 0 writes the file."""
     import os
     import time
-    from .parallel import rank as _rank
+    from .parallel import rank as _rank, averaged_bn_running_stats
+    avg = averaged_bn_running_stats(student)
     if _rank() != 0:
         return None
     os.makedirs(config.save_dir, exist_ok=True)
     path = os.path.join(config.save_dir, "%s%s%d.pt" % (time.strftime("%Y%m%d%H%M", time.localtime(time.time())), config.mode, iteration))
-    torch.save({"iteration": iteration, "model_state_dict": {k: v.detach().cpu() for k, v in student.state_dict().items()}}, path)
+    sd = {k: (avg[k] if k in avg else v).detach().cpu() for k, v in student.state_dict().items()}
+    torch.save({"iteration": iteration, "model_state_dict": sd}, path)
     return path
 
 
@@ -122,14 +130,15 @@ def train(student, teacher, video_loader, distiller, optimizer, scheduler, accur
     iteration = 0
     # FusedOptimizer waits for the side-stream weight gradients itself (step / zero_grad), so backward() need not: the next
     # episode's forward then overlaps the tail of the previous episode's weight gradients
-    sync_prev = ops.SYNC_WGRAD_AT_BACKWARD_END
+    sync_prev, side_prev = ops.SYNC_WGRAD_AT_BACKWARD_END, ops.SIDE_WGRAD
     ops.SYNC_WGRAD_AT_BACKWARD_END = not isinstance(optimizer, FusedOptimizer)
+    ops.SIDE_WGRAD = getattr(config, "side_wgrad", True)      # this loop owns the optimizer: weight gradients on their own stream
     try:
         return _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log, losses,
                            accuracies, total_iterations, every, iteration)
     finally:
         ops.wait_weight_grads()
-        ops.SYNC_WGRAD_AT_BACKWARD_END = sync_prev
+        ops.SYNC_WGRAD_AT_BACKWARD_END, ops.SIDE_WGRAD = sync_prev, side_prev
 
 
 def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log, losses, accuracies,

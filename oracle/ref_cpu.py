@@ -733,6 +733,39 @@ def train_episode(ep, params, teacher_params, way=5, shot=5, cfg=DEFAULT_CFG):
     return loss["loss"].detach(), acc, out, t_logits
 
 
+def train_loop(episodes, params, teacher_params, way=5, shot=5, opt="sgd", lr=1e-4, tasks_per_batch=16, milestones=(20000, 40000),
+               total_iterations=None, cfg=DEFAULT_CFG):
+    """A15: make() + train() of the reference (trainwandb.py:101-105 optimizer / MultiStepLR, :111-145 loop) over a list of
+    episodes with torch's own optimizers: torch.optim.SGD(lr) (no momentum) or torch.optim.Adam(lr) on the trainable `params`,
+    MultiStepLR(milestones, gamma=0.1); `iteration` is incremented before use, the step fires when (iteration+1) %
+    tasks_per_batch == 0 or iteration == total_iterations-1, scheduler.step() runs every episode.
+    -> (losses, accuracies); `params` are updated in place."""
+    leaves = [v for k, v in params.items() if v.is_floating_point() and v.requires_grad]
+    if opt == "adam":
+        optimizer = torch.optim.Adam(leaves, lr=lr)
+    elif opt == "sgd":
+        optimizer = torch.optim.SGD(leaves, lr=lr)
+    else:
+        raise KeyError(opt)
+    scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=list(milestones), gamma=0.1)
+    optimizer.zero_grad()
+    total = len(episodes) if total_iterations is None else total_iterations
+    losses, accs = [], []
+    iteration = 0
+    for ep in episodes:
+        if iteration >= total:
+            break
+        iteration += 1
+        loss, acc, _, _ = train_episode(ep, params, teacher_params, way, shot, cfg)
+        losses.append(float(loss))
+        accs.append(float(acc))
+        if ((iteration + 1) % tasks_per_batch == 0) or (iteration == (total - 1)):
+            optimizer.step()
+            optimizer.zero_grad()
+        scheduler.step()
+    return losses, accs
+
+
 # ----------------------------------------------------------------------------
 # A0 (input side)  Resize(256) of the frame transform: video_reader.py:92-112 -> videotransforms/video_transforms.py:91-110
 # -> functional.resize_clip (functional.py:24-63), which - its `interpolation` test being inverted (:55-58) - calls

@@ -6,6 +6,8 @@ import math
 import pytest
 import torch
 
+from _anchor import anchored_dict
+
 pytestmark = pytest.mark.gpu
 
 
@@ -44,13 +46,20 @@ def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb):
     loss = getattr(Distiller(dist, args.cfg, dev), dist)(out["logits"], tl, labels.to(dev))["loss"]
     loss.backward()
     acc, pred = ops.accuracy(out["logits"]["kl"], out["logits"]["ce"], labels.to(dev))
-    for k, v in sp.items():
-        if v.is_floating_point() and "running" not in k and not k.endswith("pe.pe"):
-            v.requires_grad_()
-    o = O.student_forward(ep, sp, 5, shot, classifier=clf, backbone=bb)
-    ot = O.clf_TRX_2fcsup_fixed(ep["support_set_feature_teacher"], ep["support_labels"], ep["target_set_feature_teacher"], tp, 5, shot)
-    ol = O.distill_fc_2_sup_dist(o["logits"], ot, labels)["loss"]
-    ol.backward()
+    def oracle(dt):
+        p = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sp.items()}
+        for k, v in p.items():
+            if v.is_floating_point() and "running" not in k and not k.endswith("pe.pe"):
+                v.requires_grad_()
+        e = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in ep.items()}
+        o = O.student_forward(e, p, 5, shot, classifier=clf, backbone=bb)
+        ot = O.clf_TRX_2fcsup_fixed(e["support_set_feature_teacher"], e["support_labels"], e["target_set_feature_teacher"],
+                                    {k: v.to(dt) for k, v in tp.items()}, 5, shot)
+        ol = O.distill_fc_2_sup_dist(o["logits"], ot, labels)["loss"]
+        ol.backward()
+        return p, o, ot, ol
+    sp32, o, ot, ol = oracle(torch.float32)
+    sp64, _, _, ol64 = oracle(torch.float64)
     # features: rel 2e-3 of max; logits O(1e2..1e3): abs 2e-2 + rel 2e-3; loss rel 1e-3 (fp32, different summation order)
     for k in ("context_features_1", "context_features_2"):
         assert _rel(out["context_features"][k], o["context_features"][k]) < 2e-3, k
@@ -64,23 +73,17 @@ def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb):
     srt = torch.sort(lg, -1).values
     clear = (srt[:, -1] - srt[:, -2]) > 5e-2
     assert torch.equal(pred.cpu()[clear], torch.argmax(lg, -1)[clear])
-    # gradients of every parameter: relative L2 error per tensor < 5e-2.  (Elementwise agreement of a whole-network
-    # gradient is bounded by ReLU-mask flips at pre-activations within fp32 rounding of zero — see
-    # tests/test_gpu_ops.py::test_block_isolated for the tight per-block bounds on identical inputs.)  Tensors whose
-    # gradient is exactly 0 in exact arithmetic (biases that cancel in q - s differences) are compared on an absolute floor.
-    gmax = max(float(v.grad.abs().max()) for v in sp.values() if v.grad is not None)
-    worst = ("", 0.0)
+    # gradients of every parameter, fp64-anchored (tests/_anchor.py): per tensor, the HIP gradient's relative-L2 error against
+    # the oracle run in fp64 is at most 3x the error of the oracle's own fp32 run.  (ReLU-mask flips at pre-activations within
+    # fp32 rounding of zero move BOTH fp32 evaluations by the same order; a bug in the hand-scheduled backward does not.)
+    # Tensors whose exact gradient is 0 (biases that cancel in q - s differences) are judged on an absolute floor.
+    names = [k for k, p in student.named_parameters() if sp64[k].grad is not None]
     for k, p in student.named_parameters():
-        ref = sp[k].grad
-        if ref is None:
+        if sp64[k].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
-            continue
-        d = (p.grad.detach().cpu().double() - ref.double())
-        e = float(d.norm() / (ref.double().norm() + 1e-4 * gmax * math.sqrt(ref.numel())))
-        if e > worst[1]:
-            worst = (k, e)
-    assert worst[1] < 5e-2, worst
-    print("worst grad:", worst, "loss", loss.item(), ol.item())
+    worst = anchored_dict({k: dict(student.named_parameters())[k].grad for k in names}, {k: sp32[k].grad for k in names},
+                          {k: sp64[k].grad for k in names})
+    print("worst HIP/CPU gradient error ratio vs fp64:", worst, "loss", loss.item(), ol.item(), ol64.item())
 
 
 def test_train_loop_runs_and_steps(dev):
@@ -302,4 +305,4 @@ def test_side_stream_weight_gradients_identical(dev):
                     else:
                         assert float((got[n] - ref[n]).abs().max()) <= 2e-6 * float(ref[n].abs().max()) + 1e-12, (n, sync)
     finally:
-        ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END = True, True
+        ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END = False, True

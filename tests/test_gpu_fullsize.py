@@ -1,0 +1,142 @@
+"""GPU: the convolution kernels at the BENCHMARK's shapes (200 frames per trunk call, BASELINE configs[1]) — the kernel
+instances, tile orders and epilogues bench.py times — against fp64 references, with an fp64-anchored criterion
+(tests/_anchor.py): error vs fp64 no worse than 3x the error of torch's own CPU fp32 convolution on the same data.
+
+Forward and data gradient are per-frame independent, so they are checked on a frame subset (first and last frames: first
+and last row tiles of the launch, i.e. both ends of every XCD band); the weight gradient sums over all 200 frames and is
+checked in full.  lmkd_conv2d_plan reports which kernel instance / tile order each launch uses; the test asserts that the
+shapes together exercise every instance the benchmark runs, and forces the remaining tile ids on one shape each."""
+import ctypes
+import zlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _anchor import anchored
+
+pytestmark = pytest.mark.gpu
+
+FRAMES = 200
+# name, H(=W), Cs (NHWC channels), Cin, Cout, K, stride, pad  — every distinct conv of the ResNet-18 trunk at 224x224
+SHAPES = [
+    ("stem7x7", 224, 4, 3, 64, 7, 2, 3),
+    ("layer1.3x3", 56, 64, 64, 64, 3, 1, 1),
+    ("layer2.0.conv1", 56, 64, 64, 128, 3, 2, 1),
+    ("layer2.3x3", 28, 128, 128, 128, 3, 1, 1),
+    ("layer2.ds", 56, 64, 64, 128, 1, 2, 0),
+    ("layer3.0.conv1", 28, 128, 128, 256, 3, 2, 1),
+    ("layer3.3x3", 14, 256, 256, 256, 3, 1, 1),
+    ("layer3.ds", 28, 128, 128, 256, 1, 2, 0),
+    ("layer4.0.conv1", 14, 256, 256, 512, 3, 2, 1),
+    ("layer4.3x3", 7, 512, 512, 512, 3, 1, 1),
+    ("layer4.ds", 14, 256, 256, 512, 1, 2, 0),
+]
+SEEN = {"gemm": set(), "wgrad": set()}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import litemkd_amd
+    litemkd_amd.lib().call("lmkd_device_check", 0)
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    return torch.device("cuda", 0)
+
+
+def plan(kind, N, H, Cs, Cin, Cout, K, s, p):
+    import litemkd_amd
+    info = (ctypes.c_int * 4)()
+    litemkd_amd.lib().call("lmkd_conv2d_plan", kind, N, H, H, Cs, Cin, Cout, K, K, s, p, info)
+    return tuple(info)
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _run_shape(dev, name, H, Cs, Cin, Cout, K, s, p, N=FRAMES, check_wgrad=True):
+    from litemkd_amd import ops
+    g = torch.Generator(device=dev).manual_seed(zlib.crc32(name.encode()) % 10007)
+    x = torch.randn(N, H, H, Cs, device=dev, generator=g)
+    if Cs != Cin:
+        x[..., Cin:] = 0
+    w = torch.randn(Cout, Cin, K, K, device=dev, generator=g) * (2.0 / (Cout * K * K)) ** 0.5
+    Ho = (H + 2 * p - K) // s + 1
+    dy = torch.randn(N, Ho, Ho, Cout, device=dev, generator=g)
+    sub = list(range(4)) + list(range(N - 4, N))                 # first / last row tiles of the launch
+    xs64 = nchw(x[sub][..., :Cin]).cpu().double()
+    w64 = w.cpu().double()
+    res = {}
+    # ---- forward (+ BatchNorm partial sums in the epilogue)
+    y, part = ops.conv_fwd(x, ops.pack_weights(w, Cs, 0), Cout, K, K, s, p, True)
+    ref = F.conv2d(xs64, w64, None, s, p)
+    cpu = F.conv2d(xs64.float(), w64.float(), None, s, p)
+    res["fwd"] = anchored(name + " fwd", nchw(y[sub]), cpu, ref)
+    sums = part.double().sum(0)
+    yd = y.double().reshape(-1, Cout)
+    # per-tile fp32 sums of the fp32 accumulators, combined in fp64: error relative to the sum of magnitudes
+    assert torch.allclose(sums[:, 0], yd.sum(0), rtol=0, atol=2e-6 * float(yd.abs().sum(0).max())), name + " BN sum"
+    assert torch.allclose(sums[:, 1], (yd * yd).sum(0), rtol=1e-5), name + " BN sum of squares"
+    SEEN["gemm"].add(plan(0, N, H, Cs, Cin, Cout, K, s, p)[:2])
+    # ---- data gradient (+ the accumulate epilogue at full size)
+    if Cin != 3:
+        wd = ops.pack_weights(w, Cin, 1)
+        dx = ops.conv_bwd_data(dy, wd, (N, H, H, Cin), Cout, K, K, s, p)
+        dys64 = nchw(dy[sub]).cpu().double()
+        xr = xs64.clone().requires_grad_()
+        F.conv2d(xr, w64, None, s, p).backward(dys64)
+        xr32 = xs64.float().requires_grad_()
+        F.conv2d(xr32, w64.float(), None, s, p).backward(dys64.float())
+        res["dgrad"] = anchored(name + " dgrad", nchw(dx[sub]), xr32.grad, xr.grad)
+        r = torch.randn(N, H, H, Cin, device=dev, generator=g)
+        acc = r.clone()
+        ops.conv_bwd_data(dy, wd, (N, H, H, Cin), Cout, K, K, s, p, out=acc, accumulate=True)
+        # out += dgrad: one fp32 add per element on top of the plain result
+        assert float((acc - (r + dx)).abs().max()) <= 1e-6 * float(dx.abs().max()) + 1e-6 * float(r.abs().max()), name + " dgrad accumulate"
+        SEEN["gemm"].add(plan(1, N, H, Cs, Cin, Cout, K, s, p)[:2])
+    # ---- weight gradient over all frames
+    if check_wgrad:
+        dw = ops.conv_bwd_weight(x, dy, (Cout, Cin, K, K), s, p)
+        x64 = nchw(x[..., :Cin]).cpu().double()
+        dy64 = nchw(dy).cpu().double()
+        wr = w64.clone().requires_grad_()
+        F.conv2d(x64, wr, None, s, p).backward(dy64)
+        wr32 = w64.float().requires_grad_()
+        F.conv2d(x64.float(), wr32, None, s, p).backward(dy64.float())
+        res["wgrad"] = anchored(name + " wgrad", dw, wr32.grad, wr.grad)
+        SEEN["wgrad"].add(plan(2, N, H, Cs, Cin, Cout, K, s, p)[:2])
+    print(name, {k: "hip %.2e cpu %.2e" % v for k, v in res.items()})
+    return res
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[s[0] for s in SHAPES])
+def test_conv_benchmark_shapes_vs_fp64(dev, shape):
+    _run_shape(dev, *shape)
+
+
+def test_benchmark_instances_were_exercised(dev):
+    """the shapes above must have run both conv_gemm tiles the benchmark selects (64x64/4 waves = 3, 128x128/8 waves = 5) in
+    both XCD tile orders, and the weight-gradient tiles 128x128, 128x64, 64x64 with and without XCD-grouped splits"""
+    if len(SEEN["gemm"]) == 0:
+        pytest.skip("run together with test_conv_benchmark_shapes_vs_fp64")
+    assert {(3, 0), (3, 1), (5, 0)} <= SEEN["gemm"], SEEN
+    assert {t for t, _ in SEEN["wgrad"]} >= {1, 2, 3} and {x for _, x in SEEN["wgrad"]} == {0, 1}, SEEN
+
+
+@pytest.mark.parametrize("tile", [1, 2, 4, 6])
+def test_other_tile_instances_at_full_size(dev, tile):
+    """the conv_gemm instances the automatic choice does not pick at the benchmark shapes, forced on a 200-frame layer-2 conv"""
+    import litemkd_amd
+    L = litemkd_amd.lib()
+    L.call("lmkd_conv_set_tile", tile)
+    try:
+        assert plan(0, FRAMES, 28, 128, 128, 128, 3, 1, 1)[0] == tile
+        _run_shape(dev, "layer2.3x3.tile%d" % tile, 28, 128, 128, 128, 3, 1, 1, check_wgrad=False)
+    finally:
+        L.call("lmkd_conv_set_tile", 0)

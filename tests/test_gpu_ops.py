@@ -172,21 +172,29 @@ def _trunk_params(seed):
 
 
 def test_trunk_forward_backward(dev):
-    """whole ResNet-18 trunk (stem + 8 BasicBlocks + pooled head) fwd + bwd vs the oracle, 6 frames 64x64"""
+    """whole ResNet-18 trunk (stem + 8 BasicBlocks + pooled head) fwd + bwd vs the oracle, 6 frames 64x64.  Gradients are
+    judged against an fp64 run of the oracle: per tensor, the HIP error may be at most 3x the error of the oracle's own fp32
+    run (tests/_anchor.py) — ReLU-mask flips at pre-activations within rounding of zero show on both fp32 sides."""
     from litemkd_amd import ops
     from litemkd_amd.model.backbone.resnet import ResNet18Trunk
     from oracle import ref_cpu as O
+    from _anchor import anchored_dict
     sd = _trunk_params(5)
     trunk = ResNet18Trunk()
     trunk.load_state_dict(sd)
     trunk = trunk.to(dev).train()
     x = torch.rand(6, 3, 64, 64, generator=torch.Generator().manual_seed(6))
-    osd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
-    taps = {}
-    fm = O.resnet18_trunk(x, osd, True, True, taps)
-    feat = O.pooled_frame_features(fm)
-    gfeat = rnd(*feat.shape, seed=7)
-    feat.backward(gfeat)
+    gfeat = rnd(6, 512, seed=7)
+
+    def oracle(dt):
+        osd = {k: (v.clone().to(dt).requires_grad_() if v.is_floating_point() and "running" not in k else
+                   (v.clone().to(dt) if v.is_floating_point() else v.clone())) for k, v in sd.items()}
+        fm = O.resnet18_trunk(x.to(dt), osd, True, True, {})
+        feat = O.pooled_frame_features(fm)
+        feat.backward(gfeat.to(dt))
+        return osd, fm, feat
+    osd, fm, feat = oracle(torch.float32)
+    osd64, fm64, feat64 = oracle(torch.float64)
     y = trunk(x.to(dev))
     close(nchw(y), fm, 2e-3, 2e-3, "trunk feature map")
     f = ops.PoolHeadFn.apply(y)
@@ -194,45 +202,54 @@ def test_trunk_forward_backward(dev):
     f.backward(gfeat.to(dev))
     close(trunk.state_dict()["1.running_var"], osd["1.running_var"], 1e-3, 1e-4, "stem running_var")
     close(trunk.state_dict()["7.1.bn2.running_mean"], osd["7.1.bn2.running_mean"], 1e-3, 1e-4, "last running_mean")
-    # A whole-trunk gradient is only as reproducible as its ReLU masks: a pre-activation within fp32 rounding of 0
-    # flips (y = 0 on one side, 5e-6 on the other) and with few samples per channel one flip moves that channel's
-    # gradient by percents.  So: relative L2 per tensor here, tight elementwise bounds in test_block_isolated below.
-    worst = 0.0
-    for k, p in trunk.named_parameters():
-        ref = osd[k].grad.double()
-        err = float((p.grad.cpu().double() - ref).norm() / (ref.norm() + 1e-30))
-        worst = max(worst, err)
-        assert err < 5e-2, "grad %s: rel-L2 err %.3e" % (k, err)
-    print("trunk worst grad rel-L2 err:", worst)
+    names = [k for k, _ in trunk.named_parameters()]
+    worst = anchored_dict({k: p.grad for k, p in trunk.named_parameters()}, {k: osd[k].grad for k in names},
+                          {k: osd64[k].grad for k in names})
+    print("trunk gradients, worst HIP/CPU error ratio vs fp64:", worst)
 
 
-@pytest.mark.parametrize("N,cin,cout,H,stride", [(6, 256, 512, 6, 2), (6, 512, 512, 3, 1), (6, 64, 128, 24, 2), (6, 64, 64, 24, 1)])
+@pytest.mark.parametrize("N,cin,cout,H,stride", [(6, 256, 512, 6, 2), (6, 512, 512, 3, 1), (6, 64, 128, 24, 2), (6, 64, 64, 24, 1),
+                                                 (40, 64, 128, 56, 2), (40, 128, 128, 28, 1)])
 def test_block_isolated(dev, N, cin, cout, H, stride):
-    """one BasicBlock (with / without downsample) fwd + bwd on identical inputs: elementwise fp32 agreement"""
+    """one BasicBlock (with / without downsample) fwd + bwd on identical inputs.  The hand-scheduled backward (accumulate
+    epilogue, bn1 mask recompute, strided 1x1 gradient accumulated onto the pixels it reaches) is judged per tensor against an
+    fp64 evaluation: error at most 3x torch-CPU-fp32's own error vs fp64 (tests/_anchor.py).  The 40-frame cases are large
+    enough for the 128x128 tile, the 4-class stride-2 data gradient with many tiles per class and XCD-banded tile orders."""
     from litemkd_amd.model.backbone import resnet as R
+    from _anchor import anchored, anchored_dict
     torch.manual_seed(0)
     blk = R._Block(cin, cout, stride)
-    x = torch.relu(torch.randn(N, cin, H, H)).requires_grad_()
-    ref = {k: v.detach().clone().requires_grad_() for k, v in blk.named_parameters()}
+    x0 = torch.relu(torch.randn(N, cin, H, H))
+    gy = torch.randn(N, cout, H // stride, H // stride)
 
-    def bn(t, pre):
-        return F.batch_norm(t, torch.zeros(cout), torch.ones(cout), ref[pre + ".weight"], ref[pre + ".bias"], True, 0.1, 1e-5)
-    out = F.relu(bn(F.conv2d(x, ref["conv1.weight"], None, stride, 1), "bn1"))
-    out = bn(F.conv2d(out, ref["conv2.weight"], None, 1, 1), "bn2")
-    idn = x
-    if blk.downsample is not None:
-        idn = bn(F.conv2d(x, ref["downsample.0.weight"], None, stride, 0), "downsample.1")
-    y = F.relu(out + idn)
-    gy = torch.randn(y.shape)
-    y.backward(gy)
+    def ref_run(dt):
+        x = x0.detach().clone().to(dt).requires_grad_()
+        ref = {k: v.detach().clone().to(dt).requires_grad_() for k, v in blk.named_parameters()}
+
+        def bn(t, pre):
+            return F.batch_norm(t, torch.zeros(cout, dtype=dt), torch.ones(cout, dtype=dt), ref[pre + ".weight"], ref[pre + ".bias"],
+                                True, 0.1, 1e-5)
+        out = F.relu(bn(F.conv2d(x, ref["conv1.weight"], None, stride, 1), "bn1"))
+        out = bn(F.conv2d(out, ref["conv2.weight"], None, 1, 1), "bn2")
+        idn = x
+        if blk.downsample is not None:
+            idn = bn(F.conv2d(x, ref["downsample.0.weight"], None, stride, 0), "downsample.1")
+        y = F.relu(out + idn)
+        y.backward(gy.to(dt))
+        g = {k: v.grad for k, v in ref.items()}
+        g["x"] = x.grad
+        return y.detach(), g
+    y32, g32 = ref_run(torch.float32)
+    y64, g64 = ref_run(torch.float64)
     blk = blk.to(dev).train()
-    xd = nhwc(x.detach()).to(dev).requires_grad_()
+    xd = nhwc(x0).to(dev).requires_grad_()
     yd = blk(xd)
     yd.backward(nhwc(gy).to(dev))
-    close(nchw(yd), y, 1e-4, 1e-4, "block y")
-    close(nchw(xd.grad), x.grad, 1e-3, 1e-4 * float(x.grad.abs().max()), "block dx", flip_frac=0.1)
-    for k, v in blk.named_parameters():
-        close(v.grad, ref[k].grad, 1e-3, 1e-4 * float(ref[k].grad.abs().max()), "block " + k, flip_frac=0.1)
+    anchored("block y", nchw(yd), y32, y64)
+    hip = {k: v.grad for k, v in blk.named_parameters()}
+    hip["x"] = nchw(xd.grad)
+    worst = anchored_dict(hip, g32, g64)
+    print("block gradients, worst HIP/CPU error ratio vs fp64:", worst)
 
 
 def test_pool_head(dev):

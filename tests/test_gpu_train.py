@@ -1,0 +1,229 @@
+"""GPU: optimizer kernels against torch.optim, the episode loop against the oracle loop (A15, trainwandb.py:101-105,111-145),
+and the TRX dropout path (A4, TRX_2fcsup.py:28,44-48)."""
+import math
+
+import pytest
+import torch
+
+from _anchor import anchored_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import litemkd_amd
+    litemkd_amd.lib().call("lmkd_device_check", 0)
+    return torch.device("cuda", 0)
+
+
+class _Toy(torch.nn.Module):
+    """parameter sizes that are not multiples of 4: FlatParams pads every parameter to a 16-byte boundary"""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.a = torch.nn.Parameter(torch.randn(7, 5, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(13, generator=g))
+        self.c = torch.nn.Parameter(torch.randn(64, 3, 3, 3, generator=g))
+        self.d = torch.nn.Parameter(torch.randn(1, generator=g))
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_fused_optimizer_matches_torch_optim(dev, opt):
+    """lmkd_sgd_step / lmkd_adam_step on the flat buffers vs torch.optim.SGD / torch.optim.Adam (the optimizers the reference
+    builds, trainwandb.py:101-104) on identical gradients, 7 steps with MultiStepLR milestones in between; the padding
+    elements of the flat buffers stay zero."""
+    from litemkd_amd import trainloop as TL
+    lr = 0.05 if opt == "sgd" else 0.01
+    m = _Toy().to(dev)
+    ref = _Toy()
+    fo = TL.FusedOptimizer(m, opt, lr)
+    sch = TL.MultiStepLR(fo, [2, 5])
+    to = (torch.optim.SGD if opt == "sgd" else torch.optim.Adam)(ref.parameters(), lr=lr)
+    tsch = torch.optim.lr_scheduler.MultiStepLR(to, milestones=[2, 5], gamma=0.1)
+    g = torch.Generator().manual_seed(9)
+    pad_mask = torch.ones(fo.bucket.numel, dtype=torch.bool, device=dev)
+    for p, o in zip(fo.bucket.params, fo.bucket.offsets):
+        pad_mask[o:o + p.numel()] = False
+    assert int(pad_mask.sum()) > 0
+    for step in range(7):
+        for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            gr = torch.randn(q.shape, generator=g) * (10.0 ** (step % 3 - 1))
+            q.grad = gr.clone()
+            p.grad.copy_(gr)
+        fo.step()
+        fo.zero_grad()
+        to.step()
+        to.zero_grad()
+        sch.step()
+        tsch.step()
+        assert abs(fo.lr - to.param_groups[0]["lr"]) < 1e-12 * max(1.0, lr), (step, fo.lr, to.param_groups[0]["lr"])
+        for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            err = float((p.detach().cpu() - q.detach()).abs().max())
+            assert err <= 1e-6 * float(q.abs().max()) + 2e-6 * lr, (opt, step, n, err)
+        assert float(fo.bucket.flat[pad_mask].abs().max()) == 0.0 and float(fo.bucket.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("opt,lr", [("sgd", 1e-2), ("adam", 1e-4)])
+def test_episode_loop_matches_oracle_loop(dev, opt, lr):
+    """trainloop.train on the real modules vs the oracle loop with torch.optim (trainwandb.py:101-105,111-145): 4 episodes,
+    tasks_per_batch 3 -> optimizer steps after episodes 2 (two accumulated episodes) and 3 (iteration == total-1).  Losses of
+    all episodes (the last two see updated weights), and the weight UPDATE of every tensor, fp64-anchored: error vs the oracle
+    loop run in fp64 at most 3x the error of the oracle loop run in fp32."""
+    from litemkd_amd import trainloop as TL
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd.utils import aggregate_accuracy
+    from oracle import ref_cpu as O
+    cfg = default_args(shot=1, query_per_class=1, img_size=64, trans_dropout=0.0, device=dev, training_iterations=4, tasks_per_batch=3,
+                       learning_rate=lr, opt=opt, print_freq=100, save_freq=10 ** 9, sch=[2, 40000])
+    torch.manual_seed(21)
+    student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
+    sp0 = {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
+    tp = {k[len("classifier.transformers."):]: v.detach().cpu().clone() for k, v in teacher.state_dict().items()
+          if k.startswith("classifier.transformers.")}
+    eps = [O.make_episode(3100 + i, 5, 1, 1, img=64) for i in range(4)]
+    fo = TL.FusedOptimizer(student, opt, lr)
+    losses, accs = TL.train(student, teacher, [{k: v.unsqueeze(0) for k, v in e.items()} for e in eps],
+                            Distiller(cfg.distill_name, cfg.cfg, dev), fo, TL.MultiStepLR(fo, cfg.sch), aggregate_accuracy, cfg)
+    assert fo.steps == 2
+
+    def oracle(dt):
+        p = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sp0.items()}
+        for k, v in p.items():
+            if v.is_floating_point() and "running" not in k and not k.endswith("pe.pe"):
+                v.requires_grad_()
+        e = [{k: (v.to(dt) if v.is_floating_point() else v) for k, v in ep.items()} for ep in eps]
+        lo, ac = O.train_loop(e, p, {k: v.to(dt) for k, v in tp.items()}, 5, 1, opt, lr, 3, (2, 40000), 4)
+        return p, lo, ac
+    p32, lo32, ac32 = oracle(torch.float32)
+    p64, lo64, _ = oracle(torch.float64)
+    for i in range(4):
+        assert abs(losses[i] - lo32[i]) < 1e-3 * max(1.0, abs(lo32[i])), (i, losses, lo32, lo64)
+    names = [k for k, v in p64.items() if v.is_floating_point() and v.requires_grad]
+    d64 = {k: (p64[k].detach() - sp0[k].double()) for k in names}
+    # Adam turns an exactly-zero gradient (biases that cancel in q - s differences: fp32 rounding noise vs eps = 1e-8) into an
+    # update of rounding-noise sign: those tensors are compared through their gradient-free invariants only
+    dmax = max(float(v.abs().max()) for v in d64.values())
+    names = [k for k in names if float(d64[k].abs().max()) > 1e-4 * dmax]
+    assert len(names) > 55
+    sd = student.state_dict()
+    hip = {k: sd[k].detach().cpu().double() - sp0[k].double() for k in names}
+    c32 = {k: p32[k].detach().double() - sp0[k].double() for k in names}
+    worst = anchored_dict(hip, c32, {k: d64[k] for k in names}, floor=5e-6)
+    # BatchNorm running statistics after 8 trunk calls (support, query per episode): order and momentum as the reference
+    for k in ("backbone.resnet.1.running_mean", "backbone.resnet.7.1.bn2.running_var", "backbone.resnet.5.0.downsample.1.running_var"):
+        a, b = sd[k].cpu(), p32[k]
+        assert float((a - b).abs().max()) < 1e-3 * float(b.abs().max()) + 1e-6, k
+    assert int(sd["backbone.resnet.1.num_batches_tracked"]) == 8
+    print(opt, "losses", losses, lo32, "worst update error ratio", worst)
+
+
+def test_dropout_mask_properties(dev):
+    """hash-RNG dropout mask (lmkd_dropout_mask): values in {0, 1/(1-p)}, keep rate within 3 sigma of 1-p, deterministic per
+    seed, independent across seeds"""
+    from litemkd_amd import ops
+    n, p = 400 * 2048, 0.1
+    m1 = ops.dropout_mask((400, 2048), p, 12345, dev)
+    m2 = ops.dropout_mask((400, 2048), p, 12345, dev)
+    m3 = ops.dropout_mask((400, 2048), p, 12346, dev)
+    assert torch.equal(m1, m2)
+    vals = torch.unique(m1).cpu()
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1.0 / 0.9) < 1e-6, vals
+    sigma = math.sqrt(p * (1 - p) / n)
+    for m in (m1, m3):
+        keep = float((m > 0).double().mean())
+        assert abs(keep - (1 - p)) < 3 * sigma, keep
+        rows = (m > 0).double().mean(1)            # no structure along rows / columns
+        cols = (m > 0).double().mean(0)
+        assert float((rows - 0.9).abs().max()) < 6 * math.sqrt(0.09 / 2048) and float((cols - 0.9).abs().max()) < 6 * math.sqrt(0.09 / 400)
+    both = float(((m1 > 0) & (m3 > 0)).double().mean())                 # independent masks: P(both kept) = 0.81
+    assert abs(both - 0.81) < 4 * math.sqrt(0.81 * 0.19 / n), both
+
+
+def test_trx_dropout_forward_and_backward_use_the_same_mask(dev):
+    """TemporalCrossTransformer in train mode, trans_dropout 0.1 (the benchmark's and the reference's setting).  With the mask
+    m the module drew (reproduced from the torch RNG state), dropout(x + pe) = (x + pe) * m, so the train-mode logits on x must
+    equal the eval-mode logits on x' = (x + pe) * m - pe, and d loss / d x = m * d loss / d x' (kept values scaled by 1/0.9,
+    dropped positions get exactly zero gradient): forward and backward apply the identical mask."""
+    from litemkd_amd import ops
+    from litemkd_amd.model.classifiers.TRX_2fcsup import TemporalCrossTransformer
+    from litemkd_amd.options import default_args
+    args = default_args(shot=2, query_per_class=1, trans_dropout=0.1, device=dev)
+    torch.manual_seed(5)
+    t = TemporalCrossTransformer(args).to(dev).train()
+    g = torch.Generator().manual_seed(6)
+    sup = (torch.randn(10, 8, 2048, generator=g) * 0.5).to(dev)
+    qry = (torch.randn(5, 8, 2048, generator=g) * 0.5).to(dev)
+    lab = torch.arange(5).repeat_interleave(2)[torch.randperm(10, generator=g)].float().to(dev)
+    w = torch.linspace(-1, 1, 25, device=dev).reshape(5, 5)
+    state = torch.get_rng_state()
+    s1, q1 = sup.clone().requires_grad_(), qry.clone().requires_grad_()
+    l1 = t(s1, lab, q1)["logits"]
+    (l1 * w).sum().backward()
+    gk = t.k_linear.weight.grad.clone()
+    t.zero_grad()
+    torch.set_rng_state(state)
+    m = ops.dropout_mask((15 * 8, 2048), 0.1, TemporalCrossTransformer.draw_dropout_seed(), dev)
+    keep = float((m > 0).double().mean())
+    assert abs(keep - 0.9) < 3 * math.sqrt(0.09 / m.numel())
+    ms, mq = m[:80].reshape(10, 8, 2048), m[80:].reshape(5, 8, 2048)
+    pe = t.pe.pe[0, :8]
+    t.eval()
+    s2 = ((sup + pe) * ms - pe).requires_grad_()
+    q2 = ((qry + pe) * mq - pe).requires_grad_()
+    l2 = t(s2, lab, q2)["logits"]
+    (l2 * w).sum().backward()
+    assert float((l1 - l2).abs().max()) <= 2e-5 * float(l2.abs().max()), float((l1 - l2).abs().max())
+    for a, b, mm in ((s1.grad, s2.grad, ms), (q1.grad, q2.grad, mq)):
+        assert float(a[mm == 0].abs().max()) == 0.0                       # dropped positions: exactly zero gradient
+        assert float((a - b * mm).abs().max()) <= 2e-5 * float(b.abs().max())
+    assert float((gk - t.k_linear.weight.grad).abs().max()) <= 2e-5 * float(gk.abs().max())
+    # a second train-mode call draws a new mask
+    t.train()
+    l3 = t(sup, lab, qry)["logits"]
+    assert float((l3 - l1).abs().max()) > 0
+
+
+def test_data_parallel_world2_equals_world1(dev, tmp_path):
+    """Episode parallelism (parallel.py): 16 global episodes dealt to 2 ranks (two processes on this one GPU, gloo
+    — the bucket / all-reduce / optimizer code is the one RCCL runs), one all-reduce of the flat gradient bucket, one SGD
+    step: the updated weights equal the 1-process run over the same 16 episodes to fp32 rounding (different summation
+    order of the 16 episode gradients only).  The checkpoint holds the rank-averaged BatchNorm running statistics."""
+    import glob
+    import os
+    import socket
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_worker.py")
+
+    def launch(world):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       LMKD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+            procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path), "16"], env=env))
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+    launch(1)
+    launch(2)
+    a, b = torch.load(str(tmp_path / "flat_w1.pt")), torch.load(str(tmp_path / "flat_w2.pt"))
+    assert torch.equal(a["w0"], b["w0"])
+    d1, d2 = (a["w1"] - a["w0"]).double(), (b["w1"] - b["w0"]).double()
+    assert float(d1.norm()) > 0
+    assert float((d1 - d2).norm() / d1.norm()) < 1e-5, float((d1 - d2).norm() / d1.norm())
+    assert float((d1 - d2).abs().max()) <= 1e-5 * float(d1.abs().max())
+    # checkpoint of the 2-rank run: running statistics = mean over the ranks' own estimates
+    r0, r1 = torch.load(str(tmp_path / "bn_w2_r0.pt")), torch.load(str(tmp_path / "bn_w2_r1.pt"))
+    ck = torch.load(glob.glob(str(tmp_path / "*w2_1.pt"))[0])["model_state_dict"]
+    for k in r0:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert torch.allclose(ck[k], (r0[k] + r1[k]) / 2, rtol=1e-6, atol=1e-7), k
+    assert not torch.equal(r0["backbone.resnet.1.running_mean"], r1["backbone.resnet.1.running_mean"])

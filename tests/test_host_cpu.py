@@ -146,7 +146,23 @@ def _gloo_worker(rank, world, port, q):
     m(x).sum().backward()                         # accumulation into the flat views
     local = fp.grad.clone()
     fp.allreduce_grads()
-    q.put((rank, local, fp.grad.clone(), [p.grad.data_ptr() for p in m.parameters()], fp.grad.data_ptr()))
+    # checkpoint-time BatchNorm averaging (one collective) and the scheduler's global-episode count
+    from litemkd_amd.parallel import averaged_bn_running_stats
+    from litemkd_amd.trainloop import MultiStepLR
+    bn = torch.nn.Sequential(torch.nn.BatchNorm1d(3), torch.nn.BatchNorm1d(2))
+    with torch.no_grad():
+        bn[0].running_mean.fill_(float(rank + 1))
+        bn[1].running_var.fill_(10.0 * (rank + 1))
+    avg = averaged_bn_running_stats(bn)
+
+    class _O:
+        lr = 1.0
+    sch = MultiStepLR(_O(), [4])
+    sch.step()
+    lr1 = sch.opt.lr
+    sch.step()
+    q.put((rank, local, fp.grad.clone(), [p.grad.data_ptr() for p in m.parameters()], fp.grad.data_ptr(),
+           {k: v.clone() for k, v in avg.items()}, bn[0].running_mean.clone(), (lr1, sch.opt.lr)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -162,10 +178,16 @@ def test_flat_bucket_allreduce_gloo_world2():
     res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
     for p in ps:
         p.join(60)
-    (r0, l0, s0, ptrs0, base0), (r1, l1, s1, _, _) = res
+    (r0, l0, s0, ptrs0, base0, avg0, live0, lrs0), (r1, l1, s1, _, _, avg1, live1, _) = res
     assert torch.allclose(s0, l0 + l1) and torch.allclose(s1, l0 + l1)
     assert ptrs0[0] == base0                       # .grad tensors are views into the bucket
     assert float(l0.abs().sum()) > 0 and not torch.allclose(l0, l1)
+    # BatchNorm running statistics averaged over the ranks for the checkpoint; the live buffers stay per-rank
+    assert set(avg0) == {"0.running_mean", "0.running_var", "1.running_mean", "1.running_var"}
+    assert torch.allclose(avg0["0.running_mean"], torch.full((3,), 1.5)) and torch.allclose(avg1["1.running_var"], torch.full((2,), 15.0))
+    assert float(live0[0]) == 1.0 and float(live1[0]) == 2.0
+    # MultiStepLR counts GLOBAL episodes: at world 2 the milestone 4 is reached after 2 local episodes
+    assert lrs0 == (1.0, 0.1) or abs(lrs0[1] - 0.1) < 1e-12 and lrs0[0] == 1.0
 
 
 def test_resize_plan_tables_match_pillow_restatement():
@@ -212,3 +234,25 @@ def test_cabi_argument_errors_return_codes_not_crashes():
     with pytest.raises(RuntimeError, match="lmkd_conv_set_tile"):
         L.call("lmkd_conv_set_tile", 99)
     assert cd.lmkd_conv_set_tile(0) == 0 and cd.lmkd_conv_set_compute_dtype(0) == 0
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+    child process (never an exec of a process that touched the GPU) and returns its exit code"""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "8", "--warmup", "2"])
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "8", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert len(bench.kernel_source_hash()) == 16
