@@ -518,6 +518,12 @@ def resize_frames_u8(frames_u8, size):
     return x
 
 
+# Test aid: with BLOCK_TAPS set to a list, every BasicBlockFn / StemFn training forward appends its BatchNorm inputs and
+# statistics, so a test can reproduce the exact ReLU masks the HIP backward uses (mask flips at pre-activations within fp32
+# rounding of zero are the one legitimate source of percent-level gradient differences between two fp32 implementations).
+BLOCK_TAPS = None
+
+
 class BasicBlockFn(torch.autograd.Function):
     """torchvision BasicBlock: conv3x3-BN-ReLU-conv3x3-BN (+1x1/2 conv-BN downsample) + add + ReLU.
     One autograd node per block; backward is hand-scheduled so that the masked gradient buffer
@@ -544,6 +550,8 @@ class BasicBlockFn(torch.autograd.Function):
         ctx.training = training
         ctx.stride = stride
         ctx.has_ds = wd is not None
+        if BLOCK_TAPS is not None:
+            BLOCK_TAPS.append({"c1": c1, "st1": st1, "y": y})
         if training:
             ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, y, wd, gd, cd, std)
         return y

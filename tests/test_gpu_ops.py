@@ -208,48 +208,90 @@ def test_trunk_forward_backward(dev):
     print("trunk gradients, worst HIP/CPU error ratio vs fp64:", worst)
 
 
+class _MaskedReLU(torch.autograd.Function):
+    """ReLU with an imposed 0/1 mask (forward t * mask, backward g * mask)"""
+
+    @staticmethod
+    def forward(ctx, t, mask):
+        ctx.save_for_backward(mask)
+        return t * mask
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask, None
+
+
 @pytest.mark.parametrize("N,cin,cout,H,stride", [(6, 256, 512, 6, 2), (6, 512, 512, 3, 1), (6, 64, 128, 24, 2), (6, 64, 64, 24, 1),
-                                                 (40, 64, 128, 56, 2), (40, 128, 128, 28, 1)])
+                                                 (40, 64, 128, 56, 2), (40, 128, 128, 28, 1), (40, 256, 512, 14, 2)])
 def test_block_isolated(dev, N, cin, cout, H, stride):
     """one BasicBlock (with / without downsample) fwd + bwd on identical inputs.  The hand-scheduled backward (accumulate
     epilogue, bn1 mask recompute, strided 1x1 gradient accumulated onto the pixels it reaches) is judged per tensor against an
-    fp64 evaluation: error at most 3x torch-CPU-fp32's own error vs fp64 (tests/_anchor.py).  The 40-frame cases are large
-    enough for the 128x128 tile, the 4-class stride-2 data gradient with many tiles per class and XCD-banded tile orders."""
+    fp64 evaluation: error at most 3x torch-CPU-fp32's own error vs fp64 (tests/_anchor.py).
+
+    Two fp32 evaluations of a ReLU network legitimately differ where a pre-activation lies within rounding of zero: ONE flipped
+    mask among 4 M elements moves a channel's gradient sum by ~1e-3 of the tensor norm (measured: the 40-frame cases flip 1-2
+    elements on the HIP side, none on the CPU side).  So the references run with the HIP path's OWN masks imposed (both ReLUs),
+    after checking that those masks differ from the fp64 masks only where the fp64 pre-activation is within 1e-5 of zero: what
+    remains is a linear map of the upstream gradient, where any indexing / scheduling / accumulation bug shows at full size.
+    The 40-frame cases are large enough for the 128x128 tile, the 4-class stride-2 data gradient with many tiles per class,
+    XCD-banded tile orders and multi-round weight-gradient splits."""
+    from litemkd_amd import ops
     from litemkd_amd.model.backbone import resnet as R
     from _anchor import anchored, anchored_dict
     torch.manual_seed(0)
     blk = R._Block(cin, cout, stride)
     x0 = torch.relu(torch.randn(N, cin, H, H))
     gy = torch.randn(N, cout, H // stride, H // stride)
+    params = {k: v.detach().clone() for k, v in blk.named_parameters()}
+    blk = blk.to(dev).train()
+    xd = nhwc(x0).to(dev).requires_grad_()
+    ops.BLOCK_TAPS = []
+    try:
+        yd = blk(xd)
+        tap = ops.BLOCK_TAPS[0]
+    finally:
+        ops.BLOCK_TAPS = None
+    yd.backward(nhwc(gy).to(dev))
+    m1 = nchw(ops.bn_apply(tap["c1"], tap["st1"], True) > 0).cpu()          # fmaf(c1, scale, shift) > 0: what the backward recomputes
+    my = nchw(yd.detach() > 0).cpu()
 
-    def ref_run(dt):
+    def ref_run(dt, masks):
         x = x0.detach().clone().to(dt).requires_grad_()
-        ref = {k: v.detach().clone().to(dt).requires_grad_() for k, v in blk.named_parameters()}
+        ref = {k: v.detach().clone().to(dt).requires_grad_() for k, v in params.items()}
 
         def bn(t, pre):
             return F.batch_norm(t, torch.zeros(cout, dtype=dt), torch.ones(cout, dtype=dt), ref[pre + ".weight"], ref[pre + ".bias"],
                                 True, 0.1, 1e-5)
-        out = F.relu(bn(F.conv2d(x, ref["conv1.weight"], None, stride, 1), "bn1"))
-        out = bn(F.conv2d(out, ref["conv2.weight"], None, 1, 1), "bn2")
+
+        def relu(t, i):
+            return F.relu(t) if masks is None else _MaskedReLU.apply(t, masks[i].to(dt))
+        pre1 = bn(F.conv2d(x, ref["conv1.weight"], None, stride, 1), "bn1")
+        out = bn(F.conv2d(relu(pre1, 0), ref["conv2.weight"], None, 1, 1), "bn2")
         idn = x
-        if blk.downsample is not None:
+        if "downsample.0.weight" in ref:
             idn = bn(F.conv2d(x, ref["downsample.0.weight"], None, stride, 0), "downsample.1")
-        y = F.relu(out + idn)
+        pre2 = out + idn
+        y = relu(pre2, 1)
         y.backward(gy.to(dt))
         g = {k: v.grad for k, v in ref.items()}
         g["x"] = x.grad
-        return y.detach(), g
-    y32, g32 = ref_run(torch.float32)
-    y64, g64 = ref_run(torch.float64)
-    blk = blk.to(dev).train()
-    xd = nhwc(x0).to(dev).requires_grad_()
-    yd = blk(xd)
-    yd.backward(nhwc(gy).to(dev))
+        return y.detach(), g, (pre1.detach(), pre2.detach())
+    y64n, _, (p1, p2) = ref_run(torch.float64, None)
+    flips = 0
+    for m, pre in ((m1, p1), (my, p2)):
+        diff = m != (pre > 0)
+        flips += int(diff.sum())
+        # a flipped mask is legitimate only at a pre-activation within fp32 rounding of zero
+        assert int(diff.sum()) <= max(4, m.numel() // 200000) and (not bool(diff.any()) or float(pre[diff].abs().max()) < 1e-5 * float(pre.abs().max())), \
+            "ReLU masks of the HIP path differ from fp64 at %d elements (|pre| up to %.2e)" % (int(diff.sum()), float(pre[diff].abs().max()))
+    y32, g32, _ = ref_run(torch.float32, (m1, my))
+    y64, g64, _ = ref_run(torch.float64, (m1, my))
     anchored("block y", nchw(yd), y32, y64)
     hip = {k: v.grad for k, v in blk.named_parameters()}
     hip["x"] = nchw(xd.grad)
     worst = anchored_dict(hip, g32, g64)
-    print("block gradients, worst HIP/CPU error ratio vs fp64:", worst)
+    print("block gradients (HIP masks imposed, %d flips vs fp64), worst HIP/CPU error ratio vs fp64:" % flips, worst)
 
 
 def test_pool_head(dev):
