@@ -52,6 +52,11 @@ int lmkd_conv_set_tile(int id); /* tuning: 0 auto, 1 128x128, 2 128x64, 3 64x64,
 /* stat_partial (nullable): [row_tiles][Cout][2] per-tile (sum, sum of squares) for train-mode BatchNorm */
 int lmkd_conv2d_fwd(const float* x, const float* wp_fwd, float* y, float* stat_partial, int N, int H, int W, int Cs, int Cout,
                     int KH, int KW, int stride, int pad, void* stream);
+/* training forward of a convolution fed by relu(BatchNorm(x_raw)) (torchvision BasicBlock / Bottleneck inner convs,
+   resnet18_2fc.py:41-42): x_raw = raw output of the previous convolution, pre_stats = its [5][Cs] table from lmkd_bn_finalize;
+   the loader normalises + rectifies while filling LDS (bit-identical to lmkd_bn_apply first), fp32 mode, Cs % 32 == 0 */
+int lmkd_conv2d_fwd_pre(const float* x_raw, const float* pre_stats, const float* wp_fwd, float* y, float* stat_partial, int N, int H,
+                        int W, int Cs, int Cout, int KH, int KW, int stride, int pad, void* stream);
 /* inference (module.eval(), trainwandb.py:366 / test.py): y = relu?(conv(x)*scale[c] + shift[c] (+ res)) in ONE kernel - the eval-mode
    BatchNorm (bn_stats = the [5][C] table of lmkd_bn_eval_stats), the residual add and the ReLU of torchvision's BasicBlock /
    Bottleneck run in the convolution's epilogue.  Bit-identical to lmkd_conv2d_fwd followed by lmkd_bn_apply. */
@@ -63,6 +68,10 @@ int lmkd_conv2d_bwd_data(const float* dy, const float* wp_dgrad, float* dx, int 
 long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad);
 int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, float* workspace, long ws_bytes, int N, int H, int W,
                            int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+/* the same for a convolution run with lmkd_conv2d_fwd_pre: relu(BatchNorm(x_raw)) is recomputed in the loader */
+int lmkd_conv2d_bwd_weight_pre(const float* x_raw, const float* pre_stats, const float* dy, float* dw_oihw, float* workspace,
+                               long ws_bytes, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                               void* stream);
 
 /* launch plan (no launch) of lmkd_conv2d_fwd (kind 0) / _bwd_data (1) / _bwd_weight (2) for these shapes in the current mode:
    info[4] (HOST) = tile id, XCD tile order, parity classes | pixel splits, workgroups.  Test/diagnostic aid. */
@@ -87,11 +96,13 @@ int lmkd_bn_finalize(const float* partial, int T, int C, long count, const float
 int lmkd_bn_running_update(float* running_mean, float* running_var, const float* stats, int C, float momentum, void* stream);
 int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                        float* stats, void* stream);
-/* y = act(x*scale+shift [+res | +res*rscale+rshift]); res_mode 0 none, 1 plain, 2 affine */
+/* y = act(x*scale+shift [+res | +res*rscale+rshift]); res_mode 0 none, 1 plain, 2 affine.  mask_bits (nullable; needs
+   C % 32 == 0): rows*C/32 words, bit e = (y[e] > 0) - the ReLU mask for lmkd_bn_backward(mask_mode 3) at 1/32 of y's bytes */
 int lmkd_bn_apply(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows, int C, int relu,
-                  int res_mode, void* stream);
+                  int res_mode, unsigned* mask_bits, void* stream);
 long lmkd_bn_bwd_workspace(int C);
-/* mask_mode 0 none, 1 (yact>0), 2 (x*scale+shift>0); coef: [3][C] scratch; g_out (nullable) = masked dy */
+/* mask_mode 0 none, 1 (yact>0), 2 (x*scale+shift>0), 3 (yact = the bit mask of lmkd_bn_apply); coef: [3][C] scratch;
+   g_out (nullable) = masked dy */
 int lmkd_bn_backward(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dx,
                      float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, long rows, int C, int mask_mode,
                      void* stream);

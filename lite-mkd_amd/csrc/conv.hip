@@ -31,13 +31,17 @@ struct ConvGemmArgs {
   const float* ep_stats;
   const float* ep_res;
   int ep_relu;
+  // PRE (training): src holds the RAW output of the previous convolution; the loader applies that layer's train-mode BatchNorm
+  // and ReLU, relu(fmaf(v, scale[c], shift[c])) with scale/shift = rows 2/3 of its [5][C] table, while it fills LDS - the
+  // normalised activation never exists in HBM.  Zero padding stays zero (it pads the activation, not the raw tensor).
+  const float* pre_stats;
   FastDiv div_hw, div_w;
   int ntap[LMKD_MAX_CLASSES];
   Tap taps[LMKD_MAX_CLASSES][LMKD_MAX_TAPS];
 };
 
 // K-major implicit-im2col loader (rows = output pixels of this tile).
-template <int ROWS, bool SMALLC, int THREADS = LMKD_THREADS>
+template <int ROWS, bool SMALLC, int THREADS = LMKD_THREADS, bool PRE = false>
 struct LoaderConvGather {
   static constexpr bool ROWK = true;
   static constexpr int RPP = THREADS / 8;
@@ -48,10 +52,19 @@ struct LoaderConvGather {
   float4 reg[NI];
   const float* src;
   int Hs, Ws, Cs, kc4;
+  float4 psc, psh;      // PRE: BatchNorm scale / shift of this lane's 4 channels of the current 32-channel chunk
+  unsigned inb;         // PRE: which of the NI prefetched rows are real pixels (zero padding must stay zero)
+  // the chunk's table entries: fetched once per chunk (the K loop runs the taps of one chunk back to back).  Like the tile
+  // loads they are only CONSUMED in store(), after the MFMAs of the current K-step: nothing waits for memory in between.
+  __device__ __forceinline__ void load_pre(const float* __restrict__ stats, int coff) {
+    psc = *reinterpret_cast<const float4*>(stats + 2 * Cs + coff + kc4);
+    psh = *reinterpret_cast<const float4*>(stats + 3 * Cs + coff + kc4);
+  }
   __device__ __forceinline__ void init(const float* src_, int Hs_, int Ws_, int Cs_, const int* s_src, const int* s_hw) {
     const int tid = threadIdx.x;
     src = src_; Hs = Hs_; Ws = Ws_; Cs = Cs_;
     kc4 = (tid & 7) * 4;
+    inb = 0u;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       base[i] = s_src[(tid >> 3) + RPP * i];
@@ -65,16 +78,26 @@ struct LoaderConvGather {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int h = (hw[i] >> 16) + dh, w = (hw[i] & 0xffff) + dwe;
-      if (hw[i] >= 0 && (unsigned)h < (unsigned)Hs && (unsigned)w < (unsigned)Ws)
+      if (hw[i] >= 0 && (unsigned)h < (unsigned)Hs && (unsigned)w < (unsigned)Ws) {
         reg[i] = *reinterpret_cast<const float4*>(src + (long)(base[i] + rel));
-      else
+        if (PRE) inb |= 1u << i;
+      } else {
         reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PRE) inb &= ~(1u << i);
+      }
     }
   }
   __device__ __forceinline__ void store(float* S) const {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(S + ((tid >> 3) + RPP * i) * LMKD_LDK + kc4) = reg[i];
+    for (int i = 0; i < NI; ++i) {
+      float4 v = reg[i];
+      if (PRE && ((inb >> i) & 1u)) {      // the same operations as bn_apply_kernel: bit-identical to the materialised activation
+        v.x = fmaxf(fmaf(v.x, psc.x, psh.x), 0.f); v.y = fmaxf(fmaf(v.y, psc.y, psh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, psc.z, psh.z), 0.f); v.w = fmaxf(fmaf(v.w, psc.w, psh.w), 0.f);
+      }
+      *reinterpret_cast<float4*>(S + ((tid >> 3) + RPP * i) * LMKD_LDK + kc4) = v;
+    }
   }
 };
 
@@ -106,9 +129,9 @@ static inline int xcd_grid(int n_rt, int n_ct, int mode) {
   return 8 * cdiv(n_rt, 8) * n_ct;
 }
 
-template <class Cfg, bool SMALLC, int STATS, bool BF16>   // STATS: 0 plain store, 1 + BatchNorm partial sums, 2 BatchNorm-affine (+residual, ReLU) epilogue
+template <class Cfg, bool SMALLC, int STATS, bool BF16, bool PRE = false>   // STATS: 0 plain store, 1 + BatchNorm partial sums, 2 BatchNorm-affine (+residual, ReLU) epilogue
 __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a) {
-  using LA = LoaderConvGather<Cfg::BM, SMALLC, Cfg::THREADS>;
+  using LA = LoaderConvGather<Cfg::BM, SMALLC, Cfg::THREADS, PRE>;
   using LB = LoaderKMajorDense<Cfg::BN, Cfg::THREADS>;   // packed weights are K-major: Wp[col][k]
   __shared__ __attribute__((aligned(16))) float smem[2 * (LA::LDS_FLOATS + LB::LDS_FLOATS)];
   __shared__ int s_src[Cfg::BM], s_hw[Cfg::BM], s_out[Cfg::BM];
@@ -178,6 +201,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
       // the wide rows of layer 4 (2 KB per pixel) once per tap: PMC FETCH_SIZE 790-1080 MB per launch for 50 MB of operands.
       const int cc = t / ntap_c, tp = t - cc * ntap_c;
       const Tap tap = taps[tp];
+      if (PRE && tp == 0) la.load_pre(a.pre_stats, cc * LMKD_BK);
       la.load(tap.dh, tap.dw, cc * LMKD_BK);
       lb.load(tap.kofs + cc * LMKD_BK);
     };
@@ -186,17 +210,23 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
       la.store(As0);
       lb.store(Bs0);
       __syncthreads();
-      for (int t = 0; t < nk; ++t) {
+      // last K-step peeled: no condition sits between a tile's prefetch and its LDS store inside the loop (with one, hipcc
+      // copies the prefetched registers in front of the MFMAs - and waits for the loads there - in the PRE instances)
+      for (int t = 0; t + 1 < nk; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nk) issue(t + 1);
+        issue(t + 1);
         if (BF16) mfma_kstep_bf16<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
         else mfma_kstep<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
-        if (t + 1 < nk) {
-          la.store(As0 + (cur ^ 1) * SA);
-          lb.store(Bs0 + (cur ^ 1) * SB);
-        }
+        // keep the store side (incl. the PRE loader's BatchNorm+ReLU arithmetic) BEHIND the MFMAs: hoisted above them it drags the
+        // s_waitcnt vmcnt(0) of the prefetched tile in front of the matrix work and the prefetch hides nothing
+        __builtin_amdgcn_sched_barrier(0);
+        la.store(As0 + (cur ^ 1) * SA);
+        lb.store(Bs0 + (cur ^ 1) * SB);
         __syncthreads();
       }
+      const int last = (nk - 1) & 1;
+      if (BF16) mfma_kstep_bf16<Cfg, LA, LB>(As0 + last * SA, Bs0 + last * SB, a_row, b_row, h, acc);
+      else mfma_kstep<Cfg, LA, LB>(As0 + last * SA, Bs0 + last * SB, a_row, b_row, h, acc);
     }
   }
 
@@ -303,10 +333,11 @@ struct WgradArgs {
   int stride, pad, KH, KW, KWp;
   int Kp, Mpix, steps_total, steps_per_split;
   int n_mt, n_jt, splits, xcd_mode;   // 1-D grid decode (xcd_mode 1: all tiles of pixel split z run on XCD z % 8)
+  const float* pre_stats;             // PRE: x is a raw conv output; the loader applies relu(BatchNorm(x)) (see ConvGemmArgs)
   FastDiv div_hw, div_w;
 };
 
-template <int ROWS, bool SMALLC, int THREADS = LMKD_THREADS>
+template <int ROWS, bool SMALLC, int THREADS = LMKD_THREADS, bool PRE = false>
 struct LoaderWgradGather {
   static constexpr bool ROWK = false;
   static constexpr int LD = ROWS;
@@ -320,7 +351,10 @@ struct LoaderWgradGather {
   float4 reg[NI];
   int dh, dw, coff, r4;
   bool tap_ok;
+  float4 psc, psh;
+  unsigned inb;      // PRE: rows of the prefetched slab that are real pixels; the transform runs in store(), behind the MFMAs
   __device__ __forceinline__ void init(const WgradArgs& a, int j0) {
+    inb = 0u;
     x = a.x; div_hw = a.div_hw; div_w = a.div_w;
     Mpix = a.Mpix; HoWo = a.Ho * a.Wo; Wo = a.Wo; Hs = a.Hs; Ws = a.Ws; Cs = a.Cs; stride = a.stride;
     const int tid = threadIdx.x;
@@ -337,6 +371,10 @@ struct LoaderWgradGather {
       dh = kh - a.pad; dw = kw - a.pad;
       tap_ok = col < a.Kp && kw < a.KW;
     }
+    if (PRE && tap_ok) {      // this thread's 4 channels never change over the pixel loop
+      psc = *reinterpret_cast<const float4*>(a.pre_stats + 2 * a.Cs + coff);
+      psh = *reinterpret_cast<const float4*>(a.pre_stats + 3 * a.Cs + coff);
+    }
   }
   __device__ __forceinline__ void load(int koff) {
     const int tid = threadIdx.x;
@@ -350,9 +388,11 @@ struct LoaderWgradGather {
         const int oh = fdiv(rem, div_w);
         const int ow = rem - oh * Wo;
         const int h = oh * stride + dh, w = ow * stride + dw;
-        if ((unsigned)h < (unsigned)Hs && (unsigned)w < (unsigned)Ws)
+        if ((unsigned)h < (unsigned)Hs && (unsigned)w < (unsigned)Ws) {
           v = *reinterpret_cast<const float4*>(x + ((long)(n * Hs + h) * Ws + w) * Cs + coff);
-      }
+          if (PRE) inb |= 1u << i;
+        } else if (PRE) inb &= ~(1u << i);
+      } else if (PRE) inb &= ~(1u << i);
       reg[i] = v;
     }
   }
@@ -361,15 +401,20 @@ struct LoaderWgradGather {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       int k = tid / CPR + KPP * i;
-      *reinterpret_cast<float4*>(S + k * LD + r4) = reg[i];
+      float4 v = reg[i];
+      if (PRE && ((inb >> i) & 1u)) {
+        v.x = fmaxf(fmaf(v.x, psc.x, psh.x), 0.f); v.y = fmaxf(fmaf(v.y, psc.y, psh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, psc.z, psh.z), 0.f); v.w = fmaxf(fmaf(v.w, psc.w, psh.w), 0.f);
+      }
+      *reinterpret_cast<float4*>(S + k * LD + r4) = v;
     }
   }
 };
 
-template <class Cfg, bool SMALLC, bool BF16>
+template <class Cfg, bool SMALLC, bool BF16, bool PRE = false>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgradArgs a) {
   using LA = LoaderMMajorDense<Cfg::BM, Cfg::THREADS>;
-  using LB = LoaderWgradGather<Cfg::BN, SMALLC, Cfg::THREADS>;
+  using LB = LoaderWgradGather<Cfg::BN, SMALLC, Cfg::THREADS, PRE>;
   __shared__ __attribute__((aligned(16))) float smem[2 * (LA::LDS_FLOATS + LB::LDS_FLOATS)];
   // Tile order.  The 9 column tiles (taps) of one pixel split read the same x rows and the same dy rows; in plain order
   // they land on different XCDs and every XCD fetches those rows again (PMC: 2.6-3.1 GB per launch on the 160 MB layers).
@@ -395,7 +440,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgradArgs a) {
   if (nk > a.steps_per_split) nk = a.steps_per_split;
   f32x16 acc[Cfg::TM][Cfg::TN];
   auto koff = [s0](int t) { return (s0 + t) * LMKD_BK; };
-  gemm_mainloop<Cfg, LA, LB, decltype(koff), decltype(koff), BF16>(la, lb, nk, koff, koff, smem, acc);
+  gemm_mainloop<Cfg, LA, LB, decltype(koff), decltype(koff), BF16, PRE>(la, lb, nk, koff, koff, smem, acc);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -567,7 +612,14 @@ static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
   a.n_ct = cdiv(ncols, Cfg::BN);
   a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
   if (g_xcd_mode == 0) a.xcd_mode = 0;
-  hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS, BF16>), dim3(xcd_grid(a.n_rt, a.n_ct, a.xcd_mode)), dim3(Cfg::THREADS), 0, s, a);
+  const dim3 grid(xcd_grid(a.n_rt, a.n_ct, a.xcd_mode));
+  if constexpr (STATS == 1 && !SMALLC && !BF16) {      // the training forward of a conv that follows a BatchNorm + ReLU
+    if (a.pre_stats) {
+      hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS, BF16, true>), grid, dim3(Cfg::THREADS), 0, s, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS, BF16>), grid, dim3(Cfg::THREADS), 0, s, a);
 }
 
 template <class Cfg, bool SMALLC, bool STATS>
@@ -620,7 +672,7 @@ extern "C" int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, 
 
 static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* stat_partial, const float* ep_stats,
                            const float* ep_res, int ep_relu, int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride,
-                           int pad, void* stream) {
+                           int pad, void* stream, const float* pre_stats = nullptr) {
   LMKD_REQUIRE(x && wp && y, "lmkd_conv2d_fwd: null pointer");
   LMKD_REQUIRE(aligned16(x) && aligned16(wp), "lmkd_conv2d_fwd: x / packed weights must be 16-byte aligned");
   LMKD_REQUIRE(Cs % 32 == 0 || Cs == 4, "lmkd_conv2d_fwd: channel count %d must be 4 (padded stem) or a multiple of 32", Cs);
@@ -634,6 +686,9 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
   memset(&a, 0, sizeof(a));
   a.src = x; a.wpk = wp; a.out = y; a.stat_partial = stat_partial;
   a.ep_stats = ep_stats; a.ep_res = ep_res; a.ep_relu = ep_relu;
+  a.pre_stats = pre_stats;
+  LMKD_REQUIRE(!pre_stats || (stat_partial && !smallc && !g_conv_x3 && !g_conv_bf16),
+               "lmkd_conv2d_fwd_pre: the fused BatchNorm+ReLU loader exists for the fp32 training forward (stat_partial given, Cs %% 32 == 0)");
   a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cs;
   a.Ho = conv_out(H, KH, stride, pad); a.Wo = conv_out(W, KW, stride, pad); a.Co = Cout;
   LMKD_REQUIRE(a.Ho > 0 && a.Wo > 0, "lmkd_conv2d_fwd: empty output");
@@ -662,6 +717,15 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
 extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float* stat_partial, int N, int H, int W, int Cs,
                                int Cout, int KH, int KW, int stride, int pad, void* stream) {
   return conv2d_fwd_impl(x, wp, y, stat_partial, nullptr, nullptr, 0, N, H, W, Cs, Cout, KH, KW, stride, pad, stream);
+}
+
+// Training form for a convolution that consumes relu(BatchNorm(x_raw)): x_raw is the previous convolution's raw output and
+// pre_stats its [5][Cs] BatchNorm table (lmkd_bn_finalize); normalise + ReLU happen in the loader, bit-identical to running
+// lmkd_bn_apply first (torchvision BasicBlock: conv2(relu(bn1(conv1(x)))), resnet18_2fc.py:41-42).
+extern "C" int lmkd_conv2d_fwd_pre(const float* x_raw, const float* pre_stats, const float* wp, float* y, float* stat_partial, int N,
+                                   int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  LMKD_REQUIRE(pre_stats, "lmkd_conv2d_fwd_pre: BatchNorm table of the input missing");
+  return conv2d_fwd_impl(x_raw, wp, y, stat_partial, nullptr, nullptr, 0, N, H, W, Cs, Cout, KH, KW, stride, pad, stream, pre_stats);
 }
 
 // Inference form: y = relu?( conv(x) * scale[c] + shift[c] (+ res) ) in the convolution's epilogue (scale/shift = rows 2/3 of
@@ -759,17 +823,18 @@ extern "C" long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, in
 }
 
 // dw_oihw[Cout,Cin,KH,KW] from x[N,H,W,Cs] (Cs >= Cin channel-padded) and dy[N,Ho,Wo,Cout]
-extern "C" int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, float* workspace, long ws_bytes,
-                                      int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                      void* stream) {
+static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const float* dy, float* dw_oihw, float* workspace,
+                                  long ws_bytes, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                  void* stream) {
   LMKD_REQUIRE(x && dy && dw_oihw && workspace, "lmkd_conv2d_bwd_weight: null pointer");
   LMKD_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(workspace), "lmkd_conv2d_bwd_weight: operands must be 16-byte aligned");
   LMKD_REQUIRE(Cs % 32 == 0 || Cs == 4, "lmkd_conv2d_bwd_weight: channel count %d must be 4 or a multiple of 32", Cs);
   LMKD_REQUIRE(Cout % 4 == 0, "lmkd_conv2d_bwd_weight: Cout %% 4 != 0");
   const bool smallc = Cs == 4;
+  LMKD_REQUIRE(!pre_stats || (!smallc && !g_conv_bf16), "lmkd_conv2d_bwd_weight_pre: fp32 mode, Cs %% 32 == 0 only");
   WgradArgs a;
   memset(&a, 0, sizeof(a));
-  a.dy = dy; a.x = x; a.slab = workspace;
+  a.dy = dy; a.x = x; a.slab = workspace; a.pre_stats = pre_stats;
   a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cs;
   a.Ho = conv_out(H, KH, stride, pad); a.Wo = conv_out(W, KW, stride, pad); a.Co = Cout;
   a.stride = stride; a.pad = pad; a.KH = KH; a.KW = KW; a.KWp = kw_padded(Cs, KW);
@@ -792,6 +857,7 @@ extern "C" int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw
 #define LMKD_WGRAD_LAUNCH(CFG, SM, THR)                                                                       \
   do {                                                                                                          \
     if (g_conv_bf16) hipLaunchKernelGGL((conv_wgrad_kernel<CFG, SM, true>), grid, dim3(THR), 0, s, a);          \
+    else if (!SM && pre_stats) hipLaunchKernelGGL((conv_wgrad_kernel<CFG, false, false, true>), grid, dim3(THR), 0, s, a); \
     else hipLaunchKernelGGL((conv_wgrad_kernel<CFG, SM, false>), grid, dim3(THR), 0, s, a);                     \
   } while (0)
   using C64 = TileCfg<64, 64, 2, 2>;
@@ -818,6 +884,21 @@ extern "C" int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw
                      KH, KW, a.KWp, a.Kp);
   LMKD_CHECK_LAUNCH("wgrad_reduce_kernel");
   return LMKD_OK;
+}
+
+extern "C" int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, float* workspace, long ws_bytes,
+                                      int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                      void* stream) {
+  return conv2d_bwd_weight_impl(x, nullptr, dy, dw_oihw, workspace, ws_bytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, stream);
+}
+
+// weight gradient of a convolution whose input was relu(BatchNorm(x_raw)) computed in the forward loader (lmkd_conv2d_fwd_pre):
+// the same transform is applied to x_raw here, so the normalised activation is never stored
+extern "C" int lmkd_conv2d_bwd_weight_pre(const float* x_raw, const float* pre_stats, const float* dy, float* dw_oihw,
+                                          float* workspace, long ws_bytes, int N, int H, int W, int Cs, int Cin, int Cout, int KH,
+                                          int KW, int stride, int pad, void* stream) {
+  LMKD_REQUIRE(pre_stats, "lmkd_conv2d_bwd_weight_pre: BatchNorm table of the input missing");
+  return conv2d_bwd_weight_impl(x_raw, pre_stats, dy, dw_oihw, workspace, ws_bytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, stream);
 }
 
 // Launch plan of a convolution, without launching: which kernel instance and tile order the three entry points above would

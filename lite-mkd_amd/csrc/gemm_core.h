@@ -220,7 +220,7 @@ __device__ __forceinline__ void mfma_kstep_bf16(const float* __restrict__ As, co
 }
 
 // Runs nk K-steps.  koffA(t)/koffB(t) give each loader its K offset for step t.
-template <class Cfg, class LA, class LB, class FA, class FB, bool BF16 = false>
+template <class Cfg, class LA, class LB, class FA, class FB, bool BF16 = false, bool FENCE_STORE = false>
 __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nk, FA koffA, FB koffB, float* smem,
                                               f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
   constexpr int SA = LA::LDS_FLOATS, SB = LB::LDS_FLOATS;
@@ -243,20 +243,22 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nk, FA koffA, 
   la.store(As0);
   lb.store(Bs0);
   __syncthreads();
-  for (int t = 0; t < nk; ++t) {
+  // last K-step peeled (see conv_gemm_kernel): no condition between a tile's prefetch and its LDS store inside the loop
+  for (int t = 0; t + 1 < nk; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nk) {
-      la.load(koffA(t + 1));
-      lb.load(koffB(t + 1));
-    }
+    la.load(koffA(t + 1));
+    lb.load(koffB(t + 1));
     if (BF16) mfma_kstep_bf16<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
     else mfma_kstep<Cfg, LA, LB>(As0 + cur * SA, Bs0 + cur * SB, a_row, b_row, h, acc);
-    if (t + 1 < nk) {
-      la.store(As0 + (cur ^ 1) * SA);
-      lb.store(Bs0 + (cur ^ 1) * SB);
-    }
+    __builtin_amdgcn_sched_barrier(0);      // the LDS stores (and store-side loader arithmetic) stay behind the MFMAs
+    (void)FENCE_STORE;
+    la.store(As0 + (cur ^ 1) * SA);
+    lb.store(Bs0 + (cur ^ 1) * SB);
     __syncthreads();
   }
+  const int last = (nk - 1) & 1;
+  if (BF16) mfma_kstep_bf16<Cfg, LA, LB>(As0 + last * SA, Bs0 + last * SB, a_row, b_row, h, acc);
+  else mfma_kstep<Cfg, LA, LB>(As0 + last * SA, Bs0 + last * SB, a_row, b_row, h, acc);
 }
 
 // Accumulator element e of lane -> (row, col) inside a 32x32 MFMA tile (C/D map, guide §3).

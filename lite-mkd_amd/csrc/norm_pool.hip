@@ -297,8 +297,12 @@ extern "C" int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, 
 // BN apply:  y = act( x*scale + shift  [+ r]  [+ r*rscale + rshift] )
 // res_mode: 0 none, 1 plain residual, 2 residual with its own BN affine (downsample branch)
 // ---------------------------------------------------------------------------------
+// mask_bits (nullable, training): bit e of the array = (y[e] > 0) for flat element e, i.e. the ReLU mask the BatchNorm backward
+// needs, at 1/32 of the bytes of y.  Lane i owns elements 4i..4i+3 = one nibble; 8 lanes assemble a word with three shuffles
+// (n4 % 8 == 0 because C % 32 == 0, so a group of 8 lanes is active or inactive as a whole).
 __global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __restrict__ stats, const float4* __restrict__ res,
-                                const float* __restrict__ rstats, float4* __restrict__ y, long n4, int C, int relu, int res_mode) {
+                                const float* __restrict__ rstats, float4* __restrict__ y, long n4, int C, int relu, int res_mode,
+                                unsigned* __restrict__ mask_bits) {
   const int C4 = C >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
@@ -317,30 +321,43 @@ __global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __res
     }
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     y[i] = v;
+    if (mask_bits) {
+      unsigned nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+      unsigned wbits = nib << (4 * (threadIdx.x & 7));
+      wbits |= __shfl_xor(wbits, 1, 64);
+      wbits |= __shfl_xor(wbits, 2, 64);
+      wbits |= __shfl_xor(wbits, 4, 64);
+      if ((threadIdx.x & 7) == 0) mask_bits[i >> 3] = wbits;
+    }
   }
 }
 
 extern "C" int lmkd_bn_apply(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows,
-                             int C, int relu, int res_mode, void* stream) {
+                             int C, int relu, int res_mode, unsigned* mask_bits, void* stream) {
   LMKD_REQUIRE(x && stats && y && rows > 0 && C > 0 && C % 4 == 0, "lmkd_bn_apply: bad arguments (C=%d)", C);
   LMKD_REQUIRE(res_mode == 0 || res, "lmkd_bn_apply: residual pointer missing");
   LMKD_REQUIRE(res_mode != 2 || rstats, "lmkd_bn_apply: residual stats missing");
+  LMKD_REQUIRE(!mask_bits || C % 32 == 0, "lmkd_bn_apply: the ReLU bit mask needs C %% 32 == 0 (C=%d)", C);
   const long n4 = rows * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const float4*)x, stats,
-                     (const float4*)res, rstats, (float4*)y, n4, C, relu, res_mode);
+                     (const float4*)res, rstats, (float4*)y, n4, C, relu, res_mode, mask_bits);
   LMKD_CHECK_LAUNCH("bn_apply_kernel");
   return LMKD_OK;
 }
 
 // ---------------------------------------------------------------------------------
-// BN backward.  g = dy * mask, mask_mode: 0 none, 1 (yact > 0), 2 (x*scale+shift > 0)
+// BN backward.  g = dy * mask, mask_mode: 0 none, 1 (yact > 0), 2 (x*scale+shift > 0), 3 (bit mask written by bn_apply:
+//   `yact` then points at the packed words)
 //   reduce: partial[b][C][2] = (sum g, sum g*xhat)     xhat = (x-mean)*invstd
 //   apply : dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M);  optional g_out = g
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float4 bn_masked_grad(const float4 dy, const float4 xv, const float4* yact, long i, const float* stats,
                                                  int C, int c, int mask_mode) {
   float4 g = dy;
-  if (mask_mode == 1) {
+  if (mask_mode == 3) {
+    const unsigned nib = (reinterpret_cast<const unsigned*>(yact)[i >> 3] >> (4 * (int)(i & 7))) & 15u;
+    g.x = (nib & 1u) ? g.x : 0.f; g.y = (nib & 2u) ? g.y : 0.f; g.z = (nib & 4u) ? g.z : 0.f; g.w = (nib & 8u) ? g.w : 0.f;
+  } else if (mask_mode == 1) {
     const float4 yv = yact[i];
     g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
   } else if (mask_mode == 2) {
@@ -434,7 +451,8 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
   LMKD_REQUIRE(dy && x && stats && dx && coef && workspace, "lmkd_bn_backward: null pointer");
   const int CC = C > 1024 ? 1024 : C;   // channel chunk handled by one workgroup column
   LMKD_REQUIRE(C % 4 == 0 && C % CC == 0 && 256 % (CC / 4) == 0, "lmkd_bn_backward: unsupported channel count %d", C);
-  LMKD_REQUIRE(mask_mode != 1 || yact, "lmkd_bn_backward: mask_mode 1 needs the activation output");
+  LMKD_REQUIRE((mask_mode != 1 && mask_mode != 3) || yact, "lmkd_bn_backward: mask_mode 1 / 3 needs the activation output / its bit mask");
+  LMKD_REQUIRE(mask_mode != 3 || C % 32 == 0, "lmkd_bn_backward: bit masks need C %% 32 == 0");
   hipStream_t s = (hipStream_t)stream;
   const int RL = NP_THREADS / (CC / 4);
   int nb = cdiv(rows, (long)RL * 8);

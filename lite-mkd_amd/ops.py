@@ -204,9 +204,10 @@ class _timed:
             CONV_TIMING.append(self.rec)
 
 
-def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats):
-    """x NHWC [N,H,W,Cs] -> (y [N,Ho,Wo,Cout], stat partial [T,Cout,2] | None)"""
-    _chk(x, wp)
+def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None):
+    """x NHWC [N,H,W,Cs] -> (y [N,Ho,Wo,Cout], stat partial [T,Cout,2] | None).  pre_stats: x is the RAW output of the previous
+    convolution and the loader applies relu(BatchNorm(x)) with that layer's [5][Cs] table (lmkd_conv2d_fwd_pre)."""
+    _chk(x, wp, pre_stats)
     N, H, W, Cs = x.shape
     Ho, Wo = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
     y = _empty((N, Ho, Wo, Cout), x)
@@ -216,7 +217,10 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats):
         part = _empty((T, Cout, 2), x)
     cin = 3 if Cs == 4 else Cs
     with _timed("conv_gemm_kernel", 2.0 * N * Ho * Wo * Cout * cin * KH * KW, 4 * (x.numel() + y.numel() + wp.numel())):
-        lib().call("lmkd_conv2d_fwd", _p(x), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, _stream())
+        if pre_stats is not None:
+            lib().call("lmkd_conv2d_fwd_pre", _p(x), _p(pre_stats), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, _stream())
+        else:
+            lib().call("lmkd_conv2d_fwd", _p(x), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, _stream())
     return y, part
 
 
@@ -232,16 +236,21 @@ def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumula
     return dx
 
 
-def conv_bwd_weight(x, dy, w_shape, stride, pad):
+def conv_bwd_weight(x, dy, w_shape, stride, pad, pre_stats=None):
+    """pre_stats: x is a raw conv output, relu(BatchNorm(x)) is recomputed in the loader (lmkd_conv2d_bwd_weight_pre)"""
     Cout, Cin, KH, KW = w_shape
     N, H, W, Cs = x.shape
-    _chk(x, dy)
+    _chk(x, dy, pre_stats)
     nbytes = lib().value("lmkd_conv2d_bwd_weight_workspace", N, H, W, Cs, Cout, KH, KW, stride, pad)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     dw = _empty(w_shape, x)
     with _timed("conv_wgrad_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
                 4 * (x.numel() + dy.numel() + dw.numel())):
-        lib().call("lmkd_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, _stream())
+        if pre_stats is not None:
+            lib().call("lmkd_conv2d_bwd_weight_pre", _p(x), _p(pre_stats), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW,
+                       stride, pad, _stream())
+        else:
+            lib().call("lmkd_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, _stream())
     return dw
 
 
@@ -278,17 +287,17 @@ def _has_hooks(w):
     return bool(getattr(w, "_backward_hooks", None)) or bool(getattr(w, "_post_accumulate_grad_hooks", None))
 
 
-def weight_grad(w, x, dy, stride, pad):
+def weight_grad(w, x, dy, stride, pad, pre_stats=None):
     """dW of a convolution for autograd — or None after accumulating it into w.grad on the weight-gradient stream."""
     if not (SIDE_WGRAD and w.is_leaf and w.requires_grad) or _has_hooks(w):
-        return conv_bwd_weight(x, dy, tuple(w.shape), stride, pad)
+        return conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats)
     dev = x.device.index
     if dev not in _WG_STREAM:
         _WG_STREAM[dev] = torch.cuda.Stream(device=x.device)
     sw = _WG_STREAM[dev]
     sw.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(sw):
-        dw = conv_bwd_weight(x, dy, tuple(w.shape), stride, pad)
+        dw = conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats)
         if w.grad is None:
             w.grad = dw
         else:
@@ -323,18 +332,20 @@ def bn_stats_eval(gamma, beta, running_mean, running_var):
     return stats
 
 
-def bn_apply(x, stats, relu, res=None, rstats=None):
+def bn_apply(x, stats, relu, res=None, rstats=None, want_bits=False):
+    """-> y, or (y, bits) with want_bits: the packed ReLU mask (y > 0), one bit per element, for bn_backward(mask_mode 3)"""
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty_like(x)
     mode = 0 if res is None else (2 if rstats is not None else 1)
     _chk(x, stats, res, rstats)
-    lib().call("lmkd_bn_apply", _p(x), _p(stats), _p(res), _p(rstats), _p(y), rows, C, int(relu), mode, _stream())
-    return y
+    bits = torch.empty(x.numel() // 32, dtype=torch.int32, device=x.device) if want_bits else None
+    lib().call("lmkd_bn_apply", _p(x), _p(stats), _p(res), _p(rstats), _p(y), rows, C, int(relu), mode, _p(bits), _stream())
+    return (y, bits) if want_bits else y
 
 
 def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None):
-    """-> dx, g (masked dy) | None, dgamma, dbeta"""
+    """-> dx, g (masked dy) | None, dgamma, dbeta.  mask_mode 1: yact = the activation output; 3: yact = its packed bit mask"""
     C = x.shape[-1]
     rows = x.numel() // C
     _chk(dy, x, yact, stats, gamma)
@@ -401,10 +412,20 @@ def conv_bn_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, relu, res=None):
     return y
 
 
-def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training):
+# Training: the BatchNorm + ReLU between two convolutions of a block runs in the CONSUMER's loader (forward conv and weight
+# gradient), so the normalised activation is never written to HBM; the block output is written once, together with its ReLU
+# mask as bits for the backward.  fp32 MFMA mode only (the bf16-plane kernels have their own loader).
+FUSE_TRAIN_BN = True
+
+
+def _train_fused():
+    return FUSE_TRAIN_BN and lib().value("lmkd_conv_get_compute_dtype") == 0
+
+
+def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training, pre_stats=None):
     Cout, _, KH, KW = w.shape
     wp = pack_weights(w, Cs, 0)
-    y, part = conv_fwd(x, wp, Cout, KH, KW, stride, pad, training)
+    y, part = conv_fwd(x, wp, Cout, KH, KW, stride, pad, training, pre_stats)
     if training:
         if _DEFER is not None:
             stats = bn_stats_train(part, y.numel() // Cout, gamma, beta, None, None)
@@ -538,22 +559,33 @@ class BasicBlockFn(torch.autograd.Function):
             a1 = conv_bn_eval(x, w1, Cs, stride, 1, g1, b1, rm1, rv1, True)
             r = x if wd is None else conv_bn_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, False)
             return conv_bn_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, True, r)
+        fused = training and _train_fused()
         c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, stride, 1, g1, b1, rm1, rv1, training)
-        a1 = bn_apply(c1, st1, True)
-        c2, st2 = _conv_bn_train_or_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training)
+        if fused:       # conv2 normalises + rectifies c1 in its loader: a1 = relu(bn1(c1)) is never stored
+            a1 = None
+            c2, st2 = _conv_bn_train_or_eval(c1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training, pre_stats=st1)
+        else:
+            a1 = bn_apply(c1, st1, True)
+            c2, st2 = _conv_bn_train_or_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training)
         if wd is not None:
             cd, std = _conv_bn_train_or_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, training)
-            y = bn_apply(c2, st2, True, cd, std)
+            res, rst = cd, std
         else:
             cd = std = None
-            y = bn_apply(c2, st2, True, x)
+            res, rst = x, None
+        if fused:
+            y, ybits = bn_apply(c2, st2, True, res, rst, want_bits=True)
+        else:
+            y, ybits = bn_apply(c2, st2, True, res, rst), None
         ctx.training = training
         ctx.stride = stride
         ctx.has_ds = wd is not None
+        ctx.fused = fused
         if BLOCK_TAPS is not None:
             BLOCK_TAPS.append({"c1": c1, "st1": st1, "y": y})
         if training:
-            ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, y, wd, gd, cd, std)
+            # fused: the backward needs neither a1 (recomputed from c1 in the weight-gradient loader) nor y (its mask travels as bits)
+            ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, ybits if fused else y, wd, gd, cd, std)
         return y
 
     @staticmethod
@@ -564,11 +596,12 @@ class BasicBlockFn(torch.autograd.Function):
         dy = dy.contiguous()
         stride = ctx.stride
         Cmid = w1.shape[0]
-        # bn2 (+ReLU mask from y); g = masked dy = gradient of both residual branches
-        dc2, g, dg2, db2 = bn_backward(dy, c2, y, st2, g2, 1, want_g=True)
+        # bn2 (+ReLU mask from y, or from its bits); g = masked dy = gradient of both residual branches
+        dc2, g, dg2, db2 = bn_backward(dy, c2, y, st2, g2, 3 if ctx.fused else 1, want_g=True)
         wd2 = pack_weights(w2, Cmid, 1)
-        dw2 = weight_grad(w2, a1, dc2, 1, 1)      # first: its stream then waits for the BatchNorm backward only, not for the data gradient
-        da1 = conv_bwd_data(dc2, wd2, a1.shape, Cmid, 3, 3, 1, 1)
+        # first: its stream then waits for the BatchNorm backward only, not for the data gradient
+        dw2 = weight_grad(w2, c1, dc2, 1, 1, st1) if ctx.fused else weight_grad(w2, a1, dc2, 1, 1)
+        da1 = conv_bwd_data(dc2, wd2, c1.shape, Cmid, 3, 3, 1, 1)
         del dc2
         dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)    # mask from c1*scale+shift > 0
         dw1 = weight_grad(w1, x, dc1, stride, 1)
@@ -607,20 +640,30 @@ class BottleneckFn(torch.autograd.Function):
             a2 = conv_bn_eval(a1, w2, Cm, stride, 1, g2, b2, rm2, rv2, True)
             r = x if wd is None else conv_bn_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, False)
             return conv_bn_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, True, r)
+        fused = training and _train_fused()
         c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, 1, 0, g1, b1, rm1, rv1, training)
-        a1 = bn_apply(c1, st1, True)
-        c2, st2 = _conv_bn_train_or_eval(a1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training)
-        a2 = bn_apply(c2, st2, True)
-        c3, st3 = _conv_bn_train_or_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, training)
+        if fused:       # conv2 / conv3 normalise + rectify their raw inputs in the loader (BasicBlockFn)
+            a1 = a2 = None
+            c2, st2 = _conv_bn_train_or_eval(c1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training, pre_stats=st1)
+            c3, st3 = _conv_bn_train_or_eval(c2, w3, Cm, 1, 0, g3, b3, rm3, rv3, training, pre_stats=st2)
+        else:
+            a1 = bn_apply(c1, st1, True)
+            c2, st2 = _conv_bn_train_or_eval(a1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training)
+            a2 = bn_apply(c2, st2, True)
+            c3, st3 = _conv_bn_train_or_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, training)
         if wd is not None:
             cd, std = _conv_bn_train_or_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, training)
-            y = bn_apply(c3, st3, True, cd, std)
+            res, rst = cd, std
         else:
             cd = std = None
-            y = bn_apply(c3, st3, True, x)
-        ctx.training, ctx.stride, ctx.has_ds = training, stride, wd is not None
+            res, rst = x, None
+        if fused:
+            y, ybits = bn_apply(c3, st3, True, res, rst, want_bits=True)
+        else:
+            y, ybits = bn_apply(c3, st3, True, res, rst), None
+        ctx.training, ctx.stride, ctx.has_ds, ctx.fused = training, stride, wd is not None, fused
         if training:
-            ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, a2, w3, g3, c3, st3, y, wd, gd, cd, std)
+            ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, a2, w3, g3, c3, st3, ybits if fused else y, wd, gd, cd, std)
         return y
 
     @staticmethod
@@ -630,14 +673,15 @@ class BottleneckFn(torch.autograd.Function):
         x, w1, g1, c1, st1, a1, w2, g2, c2, st2, a2, w3, g3, c3, st3, y, wd, gd, cd, std = ctx.saved_tensors
         dy = dy.contiguous()
         stride = ctx.stride
+        fused = ctx.fused
         Cm, Co = w1.shape[0], w3.shape[0]
-        dc3, g, dg3, db3 = bn_backward(dy, c3, y, st3, g3, 1, want_g=True)
-        dw3 = weight_grad(w3, a2, dc3, 1, 0)       # weight gradients first (BasicBlockFn)
-        da2 = conv_bwd_data(dc3, pack_weights(w3, Cm, 1), a2.shape, Co, 1, 1, 1, 0)
+        dc3, g, dg3, db3 = bn_backward(dy, c3, y, st3, g3, 3 if fused else 1, want_g=True)
+        dw3 = weight_grad(w3, c2, dc3, 1, 0, st2) if fused else weight_grad(w3, a2, dc3, 1, 0)       # weight gradients first (BasicBlockFn)
+        da2 = conv_bwd_data(dc3, pack_weights(w3, Cm, 1), c2.shape, Co, 1, 1, 1, 0)
         del dc3
         dc2, _, dg2, db2 = bn_backward(da2, c2, None, st2, g2, 2, dx_out=da2)
-        dw2 = weight_grad(w2, a1, dc2, stride, 1)
-        da1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), a1.shape, Cm, 3, 3, stride, 1)
+        dw2 = weight_grad(w2, c1, dc2, stride, 1, st1) if fused else weight_grad(w2, a1, dc2, stride, 1)
+        da1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), c1.shape, Cm, 3, 3, stride, 1)
         del dc2, da2
         dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)
         dw1 = weight_grad(w1, x, dc1, 1, 0)

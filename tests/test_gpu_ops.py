@@ -158,6 +158,87 @@ def test_bn_train_apply_backward(dev):
     close(db, beta.grad, 1e-3, 1e-3, "dbeta")
 
 
+@pytest.mark.parametrize("cfg", [(5, 64, 14, 14, 64, 3, 1, 1), (3, 128, 9, 11, 128, 3, 2, 1), (4, 256, 7, 7, 64, 1, 1, 0), (40, 128, 28, 28, 128, 3, 1, 1)])
+def test_conv_fused_bn_relu_loader_bit_identical(dev, cfg):
+    """training-mode fusion (lmkd_conv2d_fwd_pre / lmkd_conv2d_bwd_weight_pre): the convolution reads the RAW previous conv
+    output and applies relu(BatchNorm(.)) in its loader; results (output, BatchNorm partial sums, weight gradient) must be
+    BIT-identical to materialising the activation with lmkd_bn_apply first — zero padding included (it pads the activation)."""
+    from litemkd_amd import ops
+    N, C, H, W, Cout, K, s, p = cfg
+    c1 = (rnd(N, H, W, C, seed=40) * 1.5 + 0.2).to(dev)
+    gamma, beta = (1 + 0.2 * rnd(C, seed=41)).to(dev), (0.3 * rnd(C, seed=42)).to(dev)
+    flat = c1.reshape(-1, C)
+    part = torch.stack([flat.sum(0, keepdim=True), (flat ** 2).sum(0, keepdim=True)], -1).contiguous()
+    st = ops.bn_stats_train(part, flat.shape[0], gamma, beta, None, None)
+    w = (rnd(Cout, C, K, K, seed=43) * math.sqrt(2.0 / (Cout * K * K))).to(dev)
+    wp = ops.pack_weights(w, C, 0)
+    a1 = ops.bn_apply(c1, st, True)
+    y0, p0 = ops.conv_fwd(a1, wp, Cout, K, K, s, p, True)
+    y1, p1 = ops.conv_fwd(c1, wp, Cout, K, K, s, p, True, pre_stats=st)
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    dy = rnd(*y0.shape, seed=44).to(dev)
+    dw0 = ops.conv_bwd_weight(a1, dy, (Cout, C, K, K), s, p)
+    dw1 = ops.conv_bwd_weight(c1, dy, (Cout, C, K, K), s, p, pre_stats=st)
+    assert torch.equal(dw0, dw1)
+    assert float((a1 == 0).float().mean()) > 0.2          # the ReLU did clip: the test would not see a missing max otherwise
+
+
+def test_bn_apply_relu_bit_mask(dev):
+    """lmkd_bn_apply's packed ReLU mask (bit e = y[e] > 0) and lmkd_bn_backward(mask_mode 3) reading it: bit-identical to the
+    backward that reads y itself (mask_mode 1)"""
+    from litemkd_amd import ops
+    N, C, H, W = 6, 128, 9, 7
+    x = (rnd(N, H, W, C, seed=50) * 2).to(dev)
+    res = rnd(N, H, W, C, seed=51).to(dev)
+    gamma, beta = (1 + 0.1 * rnd(C, seed=52)).to(dev), (0.1 * rnd(C, seed=53)).to(dev)
+    flat = x.reshape(-1, C)
+    part = torch.stack([flat.sum(0, keepdim=True), (flat ** 2).sum(0, keepdim=True)], -1).contiguous()
+    st = ops.bn_stats_train(part, flat.shape[0], gamma, beta, None, None)
+    y, bits = ops.bn_apply(x, st, True, res, want_bits=True)
+    assert torch.equal(y, ops.bn_apply(x, st, True, res))
+    un = ((bits.reshape(-1, 1) >> torch.arange(32, device=dev, dtype=torch.int32)) & 1).reshape(-1).bool()
+    assert torch.equal(un, (y > 0).reshape(-1))
+    dy = rnd(N, H, W, C, seed=54).to(dev)
+    r1 = ops.bn_backward(dy, x, y, st, gamma, 1, want_g=True)
+    r3 = ops.bn_backward(dy, x, bits, st, gamma, 3, want_g=True)
+    for a, b in zip(r1, r3):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kind,cin,cout,stride", [("basic", 64, 128, 2), ("basic", 64, 64, 1), ("bottleneck", 256, 128, 2), ("bottleneck", 512, 128, 1)])
+def test_block_fused_training_path_bit_identical(dev, kind, cin, cout, stride):
+    """BasicBlock / Bottleneck with the BatchNorm+ReLU of the inner activations fused into the consumers' loaders and the
+    output mask as bits (ops.FUSE_TRAIN_BN) vs the materialising path: outputs, input gradient and every parameter gradient
+    bit-identical (same arithmetic, fewer passes over HBM)"""
+    from litemkd_amd import ops
+    from litemkd_amd.model.backbone import resnet as R
+    torch.manual_seed(3)
+    blk = (R._Block(cin, cout, stride) if kind == "basic" else R._Bottleneck(cin, cout, stride)).to(dev).train()
+    with torch.no_grad():
+        for n_, p_ in blk.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    x = torch.relu(torch.randn(6, 12, 12, cin, device=dev))
+    gy = None
+    outs = []
+    for fuse in (False, True):
+        ops.FUSE_TRAIN_BN = fuse
+        try:
+            blk.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_()
+            y = blk(xi)
+            if gy is None:
+                gy = torch.randn_like(y)
+            y.backward(gy)
+            outs.append((y.detach().clone(), xi.grad.clone(), {k: v.grad.clone() for k, v in blk.named_parameters()}))
+        finally:
+            ops.FUSE_TRAIN_BN = True
+    (y0, dx0, g0), (y1, dx1, g1) = outs
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+
+
 def _trunk_params(seed):
     from oracle import ref_cpu as O
     g = torch.Generator().manual_seed(seed)

@@ -229,7 +229,7 @@ def test_cabi_argument_errors_return_codes_not_crashes():
     assert cd.lmkd_resize_plan(0, 10, null, null) < 0
     assert cd.lmkd_trx_sup_sim_fwd(p, p, p, p, 4, 9, 3, 28, 1152, null) < 0                  # way > 8
     assert cd.lmkd_conv2d_split_weights(p, p, 48, 64, null) < 0                              # ncols not a multiple of 32
-    assert cd.lmkd_bn_apply(p, p, null, null, p, 4, 6, 0, 0, null) < 0                       # C % 4 != 0
+    assert cd.lmkd_bn_apply(p, p, null, null, p, 4, 6, 0, 0, null, null) < 0                       # C % 4 != 0
     # the shim
     with pytest.raises(RuntimeError, match="lmkd_conv_set_tile"):
         L.call("lmkd_conv_set_tile", 99)
