@@ -157,6 +157,10 @@ int lmkd_mha_small(const float* qkv, float* out, int B, int L, int D, int H, voi
 int lmkd_d2m_loss(const float* s_kl, const float* t_kl, const float* s_ce, const long long* labels, const float* s_sup,
                   const float* t_sup, int Rq, int C, int Rs, int Cs, float T, float w_kl, float w_sup, float w_ce, float* out4,
                   float* g_kl, float* g_ce, float* g_sup, void* stream);
+/* F.mse_loss(student_feature, teacher_feature) of Distiller.KL_feature (distillers.py:126-150, fed by trainwandb.py:209-226):
+   out1[0] = mean((s-t)^2), grad (nullable) = 2 (s-t) / n; workspace: lmkd_mse_loss_workspace() bytes */
+long lmkd_mse_loss_workspace(void);
+int lmkd_mse_loss(const float* s, const float* t, long n, float* out1, float* grad, void* workspace, void* stream);
 int lmkd_accuracy(const float* l1, const float* l2, const long long* labels, long long* pred, float* acc, int R, int C, void* stream);
 int lmkd_sgd_step(float* param, float* grad, float lr, long n, int zero_grad, void* stream);
 int lmkd_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,

@@ -600,6 +600,9 @@ static int pick_conv_cfg(long rows_per_class, int nclass, int ncols) {
     // tiles (2 waves per SIMD) 92-103.
     double cost = (double)cdiv(tiles, 256) * cfg_bm(id) * cfg_bn(id);
     cost *= (id == 5 ? 0.92 : (id == 3 ? 1.00 : 1.07));
+    // stride-2 data gradient: a parity class runs only 1-4 of the 9 taps, i.e. 4-64 K-steps per tile; the big tiles' longer
+    // prologue / epilogue then dominates (measured, 200 frames: layer3.0.conv1 dgrad 79 TFLOP/s with 64x64 vs 59 with 128x128)
+    if (nclass == 4 && id != 3) cost *= 1.5;
     if (cost < best_cost) { best_cost = cost; best = id; }
   }
   return best;

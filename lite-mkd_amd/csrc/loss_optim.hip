@@ -160,6 +160,49 @@ extern "C" int lmkd_accuracy(const float* l1, const float* l2, const long long* 
 }
 
 // ---------------------------------------------------------------------------------
+// F.mse_loss(student_feature, teacher_feature) of Distiller.KL_feature (distillers.py:138): mean squared difference and its
+// gradient 2 (s - t) / n wrt the student, one pass; deterministic two-level reduction (per-workgroup partials, then one workgroup)
+// ---------------------------------------------------------------------------------
+__global__ void mse_partial_kernel(const float4* __restrict__ s, const float4* __restrict__ t, float4* __restrict__ grad, long n4,
+                                   float gscale, double* __restrict__ partial) {
+  __shared__ double red[LO_THREADS / 64];
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 a = s[i], b = t[i];
+    const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    acc += (double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z + (double)d.w * d.w;
+    if (grad) grad[i] = make_float4(gscale * d.x, gscale * d.y, gscale * d.z, gscale * d.w);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+    for (int w = 0; w < LO_THREADS / 64; ++w) v += red[w];
+    partial[blockIdx.x] = v;
+  }
+}
+__global__ void mse_finish_kernel(const double* __restrict__ partial, int nb, double inv_n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double v = 0.0;
+    for (int b = 0; b < nb; ++b) v += partial[b];
+    out[0] = (float)(v * inv_n);
+  }
+}
+extern "C" long lmkd_mse_loss_workspace(void) { return 1024 * (long)sizeof(double); }
+extern "C" int lmkd_mse_loss(const float* s, const float* t, long n, float* out1, float* grad, void* workspace, void* stream) {
+  LMKD_REQUIRE(s && t && out1 && workspace && n > 0 && n % 4 == 0 && aligned16(s) && aligned16(t) && (!grad || aligned16(grad)),
+               "lmkd_mse_loss: n %% 4 == 0 and 16-byte aligned buffers required");
+  long gsz = (n / 4 + LO_THREADS - 1) / LO_THREADS;
+  if (gsz > 1024) gsz = 1024;
+  hipLaunchKernelGGL(mse_partial_kernel, dim3((unsigned)gsz), dim3(LO_THREADS), 0, (hipStream_t)stream, (const float4*)s, (const float4*)t,
+                     (float4*)grad, n / 4, 2.f / (float)n, (double*)workspace);
+  hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, (int)gsz, 1.0 / (double)n, out1);
+  LMKD_CHECK_LAUNCH("mse_loss kernels");
+  return LMKD_OK;
+}
+
+// ---------------------------------------------------------------------------------
 // optimizers over the flat parameter / gradient buffers
 // ---------------------------------------------------------------------------------
 __global__ void sgd_kernel(float4* __restrict__ p, const float4* __restrict__ g, float lr, long n4, int zero_grad, float4* gz) {

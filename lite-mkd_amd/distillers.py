@@ -4,7 +4,7 @@ and returns a dict with at least 'loss' (0-dim tensor carrying grad).
 
 All methods built from the three primitives kd_loss / inter_class_relation / cross_entropy run as ONE
 fused HIP launch (values + logits gradients).  All logits-only methods of the reference are provided (23, incl. `support_sim` for the TRX_sup
-classifier); `KL_feature` (needs raw feature tensors no classifier of the reference emits) raises NotImplementedError."""
+classifier), and `KL_feature` (logits + the raw [N,8,2048] features that train_task packs into the dicts, trainwandb.py:209-226)."""
 import torch
 
 from . import ops
@@ -57,6 +57,15 @@ class Distiller(object):
         l_sup = _terms(s_kl=sim_s, t_kl=sim_t, T=d["temperature"], w_kl=w_sup)[0]
         l_rest, kl_q, _, ce = _terms(s_kl=q_s, t_kl=q_t, s_ce=q_s, labels=test_labels, T=d["temperature"], w_kl=w_q, w_ce=w_ce)
         return {"hard_loss": w_ce * ce, "soft_support_loss": l_sup, "soft_query_loss": w_q * kl_q, "loss": l_sup + l_rest}
+
+    def KL_feature(self, student_logits, teacher_logits, test_labels):
+        """distillers.py:126-150: CE/16 + KL on the logits + MSE between the student's and the teacher's features"""
+        d = self.distill_dict
+        s, t = self._to(student_logits["logits"]), self._to(teacher_logits["logits"])
+        w_ce, w_kl, w_f = d["hard_loss_weight"] / 16.0, d["soft_loss_weight"], d["feature_loss_weight"]
+        loss, kl, _, ce = _terms(s_kl=s, t_kl=t, s_ce=s, labels=test_labels, T=d["temperature"], w_kl=w_kl, w_ce=w_ce)
+        feat = w_f * ops.MSELossFn.apply(student_logits["feature"], teacher_logits["feature"])
+        return {"hard_loss": w_ce * ce, "soft_loss": w_kl * kl, "feature_loss": feat, "loss": loss + feat}
 
     def ce(self, student_logits, teacher_logits, test_labels):
         """distillers.py:100-108"""
@@ -214,5 +223,4 @@ class Distiller(object):
         raise AttributeError(name)
 
 
-# needs raw feature tensors in the logits dict that no classifier of the reference produces (distillers.py:126-150)
-_OUT_OF_SCOPE = {"KL_feature"}
+_OUT_OF_SCOPE = set()

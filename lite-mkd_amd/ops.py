@@ -304,6 +304,8 @@ def weight_grad(w, x, dy, stride, pad, pre_stats=None):
             w.grad.add_(dw)
     x.record_stream(sw)
     dy.record_stream(sw)
+    if pre_stats is not None:      # read by the side-stream kernel too: its block must not be recycled under it
+        pre_stats.record_stream(sw)
     if SYNC_WGRAD_AT_BACKWARD_END:
         task = torch._C._current_graph_task_id()
         if _WG_CB[0] != task:
@@ -1019,6 +1021,27 @@ class D2MLossFn(torch.autograd.Function):
         def sc(t):
             return None if t is None else t * s
         return sc(g_kl), None, sc(g_ce), None, sc(g_sup), None, None, None, None, None
+
+
+class MSELossFn(torch.autograd.Function):
+    """F.mse_loss(student, teacher) (mean reduction; distillers.py:138): value + student gradient in one pass."""
+
+    @staticmethod
+    def forward(ctx, s, t):
+        s, t = s.contiguous(), t.contiguous()
+        _chk(s, t)
+        if s.shape != t.shape:
+            raise RuntimeError("The size of tensor a %s must match the size of tensor b %s" % (tuple(s.shape), tuple(t.shape)))
+        out = _empty((1,), s)
+        g = torch.empty_like(s)
+        ws = torch.empty(lib().value("lmkd_mse_loss_workspace"), dtype=torch.uint8, device=s.device)
+        lib().call("lmkd_mse_loss", _p(s), _p(t), s.numel(), _p(out), _p(g), _p(ws), _stream())
+        ctx.g = g
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        return ctx.g * gout, None
 
 
 def accuracy(l1, l2, labels):

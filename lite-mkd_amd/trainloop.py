@@ -91,8 +91,15 @@ def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
     teacher_model_dict = teacher(context_teacher_feature, context_labels, target_teacher_feature)
     target_logits = model_dict["logits"]
     teacher_logits = teacher_model_dict["logits"]
+    if config.distill_name == "KL_feature":         # trainwandb.py:209-226: the features travel inside the logits dicts
+        target_logits = {"logits": target_logits,
+                         "feature": torch.cat([model_dict["context_features"], model_dict["target_features"]], 0)}
+        teacher_logits = {"logits": teacher_logits,
+                          "feature": torch.cat([context_teacher_feature, target_teacher_feature], 0)}
     loss = getattr(distiller, config.distill_name)(target_logits, teacher_logits, target_labels)
     task_loss = loss["loss"]
+    if config.distill_name == "KL_feature":         # :243-244
+        target_logits = target_logits["logits"]
     if isinstance(target_logits, dict) and "kl" in target_logits and "ce" in target_logits:
         task_accuracy, _ = ops.accuracy(target_logits["kl"], target_logits["ce"], target_labels)     # :247-257,278
     elif isinstance(target_logits, dict):

@@ -136,6 +136,30 @@ def gen_distill_methods(mods):
     return out
 
 
+def kl_feature_inputs(seed, nq=25, nv=50):
+    g = torch.Generator().manual_seed(seed)
+    s = {"logits": torch.randn(nq, 5, generator=g) * 30 - 300, "feature": torch.randn(nv, 8, 2048, generator=g)}
+    t = {"logits": torch.randn(nq, 5, generator=g) * 30 - 300, "feature": torch.randn(nv, 8, 2048, generator=g) * 0.8 + 0.1}
+    return s, t, torch.randint(0, 5, (nq,), generator=g)
+
+
+def gen_kl_feature(mods):
+    """Distiller.KL_feature (distillers.py:126-150) on the dicts train_task builds (trainwandb.py:209-226)"""
+    D = mods["distillers"]
+    out = {}
+    for case, (seed, nq, nv) in enumerate([(61, 25, 50), (62, 5, 10)]):
+        s, t, labels = kl_feature_inputs(seed, nq, nv)
+        s["logits"].requires_grad_()
+        s["feature"].requires_grad_()
+        r = D.Distiller("KL_feature", dict(O.DEFAULT_CFG), torch.device("cpu")).KL_feature(s, t, labels)
+        r["loss"].backward()
+        pre = "c%d_" % case
+        out.update({pre + "seed": seed, pre + "nq": nq, pre + "nv": nv, pre + "loss": r["loss"], pre + "hard": r["hard_loss"],
+                    pre + "soft": r["soft_loss"], pre + "feature_loss": r["feature_loss"], pre + "g_logits": s["logits"].grad,
+                    pre + "g_feature": gsum(s["feature"].grad), pre + "g_feature_row0": s["feature"].grad[0, :, :128].clone()})
+    return out
+
+
 def feature_case(seed, ns=25, nq=25, scale=1.0, shuffle=True):
     g = torch.Generator().manual_seed(seed)
     sup = torch.randn(ns, 8, 2048, generator=g) * scale
@@ -358,7 +382,7 @@ def main():
     mods = load_reference()
     os.makedirs(GOLD, exist_ok=True)
     for name, fn in (("distill", gen_distill), ("distill_methods", gen_distill_methods), ("edist", gen_edist), ("trx", gen_trx),
-                     ("trx_sup", gen_trx_sup), ("resize", gen_resize), ("mfm", gen_mfm)):
+                     ("trx_sup", gen_trx_sup), ("resize", gen_resize), ("mfm", gen_mfm), ("kl_feature", gen_kl_feature)):
         data = fn(mods)
         data = t2n(data) if name != "resize" else data
         path = os.path.join(GOLD, name + ".npz")

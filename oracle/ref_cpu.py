@@ -519,6 +519,14 @@ def distill_inputs(name, seed, nq=25):
     return s, t, labels
 
 
+def distill_KL_feature(student, teacher, labels, cfg=DEFAULT_CFG):
+    """Distiller.KL_feature (distillers.py:126-150): CE/16 + T^2 KL + MSE(student feature, teacher feature)"""
+    ce = cfg["hard_loss_weight"] * F.cross_entropy(student["logits"], labels) / 16
+    kl = cfg["soft_loss_weight"] * kd_loss(student["logits"], teacher["logits"], cfg["temperature"])
+    feat = cfg["feature_loss_weight"] * F.mse_loss(student["feature"], teacher["feature"])
+    return {"hard_loss": ce, "soft_loss": kl, "feature_loss": feat, "loss": ce + kl + feat}
+
+
 # A14 ------------------------------------------------------------------------
 def aggregate_accuracy(logits, labels):
     """utils.py:116-121."""
@@ -715,6 +723,8 @@ def student_forward(ep, params, way=5, shot=5, classifier="TRX_2fcsup", backbone
         logits = clf_e_dist_fc2_sup(ctx, ep["support_labels"], tgt, way, shot)
     elif classifier == "e_dist_1fc_sup":
         logits = clf_e_dist_1fc_sup(ctx, ep["support_labels"], tgt, way, shot)
+    elif classifier == "TRX":                      # model/classifiers/TRX.py:167-183: one head, bare [Nq, way] logits
+        logits = trx_logits(ctx, ep["support_labels"], tgt, cp)
     else:
         raise KeyError(classifier)
     return {"logits": logits, "context_features": ctx, "target_features": tgt}

@@ -150,6 +150,52 @@ def test_train_loop_checkpoint_and_test_iters(dev, tmp_path):
     assert a1 == a2
 
 
+def test_kl_feature_episode_and_evaluator(dev, tmp_path):
+    """(1) the KL_feature training branch (trainwandb.py:209-226,243-244): single-head student (resnet18_student + TRX), the
+    features packed into the logits dicts, loss = CE/16 + KL + MSE vs the oracle on the same episode;  (2) the stand-alone
+    evaluator (test.py:65-299 + select_test): a saved student checkpoint scores the same test episodes as trainloop.test, and a
+    teacher checkpoint in the MFM key layout loads through load_teacher."""
+    from litemkd_amd import trainloop as TL
+    from litemkd_amd.evaluate import Evaluator
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd.utils import aggregate_accuracy
+    from oracle import ref_cpu as O
+    cfg = default_args(shot=1, query_per_class=1, img_size=64, trans_dropout=0.0, device=dev, model_backbone="resnet18_student",
+                       model_classifier="TRX", model_teacher="train_teacher", distill_name="KL_feature", save_dir=str(tmp_path),
+                       num_test_tasks=3)
+    torch.manual_seed(8)
+    student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
+    ep = O.make_episode(515, 5, 1, 1, img=64)
+    loss, acc, _ = TL.train_task({k: v.unsqueeze(0) for k, v in ep.items()}, student, teacher, Distiller("KL_feature", cfg.cfg, dev),
+                                 aggregate_accuracy, cfg)
+    sp = {k: v.detach().cpu() for k, v in student.state_dict().items()}
+    tp = {k[len("classifier.transformers."):]: v.detach().cpu() for k, v in teacher.state_dict().items()}
+    o = O.student_forward(ep, sp, 5, 1, classifier="TRX", backbone="resnet18_student", update_running=False)
+    t_log = O.trx_logits(ep["support_set_feature_teacher"], ep["support_labels"], ep["target_set_feature_teacher"], tp)
+    ref = O.distill_KL_feature({"logits": o["logits"], "feature": torch.cat([o["context_features"], o["target_features"]], 0)},
+                               {"logits": t_log, "feature": torch.cat([ep["support_set_feature_teacher"], ep["target_set_feature_teacher"]], 0)},
+                               ep["target_labels"].long())["loss"]
+    assert abs(float(loss) - float(ref)) < 1e-3 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+    assert torch.isfinite(loss) and sum(1 for p in student.parameters() if p.grad is not None) > 60
+    # evaluator on a student checkpoint
+    path = TL.save_checkpoint(student, 7, cfg)
+    ecfg = default_args(**{**vars(cfg), "test_model": "student", "test_model_path": path})
+    lines = []
+    res = Evaluator(ecfg, log=lines.append).test()
+    ref_acc = TL.test(student, TL.SyntheticEpisodes(cfg, base_seed=777, device=dev, train=False), aggregate_accuracy, cfg)
+    assert res == ref_acc and len(lines) == 4 and 0.0 <= res[cfg.dataset]["accuracy"] <= 100.0
+    # evaluator on a teacher: MFM checkpoint layout `bracnch.transformers.0.*` (model_select.py:105-117)
+    tsd = {"bracnch.transformers.0." + k[len("classifier.transformers."):]: v.detach().cpu() for k, v in teacher.state_dict().items()}
+    torch.save({"iteration": 1, "model_state_dict": tsd}, str(tmp_path / "teacher.pt"))
+    tcfg = default_args(**{**vars(cfg), "test_model": "teacher", "teacher_checkpoint": str(tmp_path / "teacher.pt")})
+    ev = Evaluator(tcfg, log=lambda s: None)
+    for k, v in teacher.classifier.transformers.state_dict().items():
+        assert torch.equal(ev.model.transformers.state_dict()[k].cpu(), v.cpu()), k
+    assert 0.0 <= ev.test()[cfg.dataset]["accuracy"] <= 100.0
+
+
 def test_full_size_properties(dev):
     """BASELINE size (5-way 5-shot, 8x224^2): properties that need no oracle —
     BN batch independence of the two trunk calls, permutation equivariance over frames, determinism."""

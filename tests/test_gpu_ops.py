@@ -635,6 +635,29 @@ def test_mfm_fusion_full_width_golden(dev, golden_dir):
               2e-4, 2e-4, "fusion(rgb, depth)")
 
 
+def test_kl_feature_golden(dev, golden_dir):
+    """Distiller.KL_feature (lmkd_d2m_loss + lmkd_mse_loss) vs the reference's own method: loss terms, logits gradient and the
+    feature gradient 2 w (s - t) / n"""
+    from litemkd_amd.distillers import Distiller
+    from oracle import ref_cpu as O
+    from oracle.gen_golden import kl_feature_inputs, gsum
+    G = np.load(os.path.join(golden_dir, "kl_feature.npz"))
+    for case in (0, 1):
+        pre = "c%d_" % case
+        s, t, labels = kl_feature_inputs(int(G[pre + "seed"]), int(G[pre + "nq"]), int(G[pre + "nv"]))
+        s = {k: v.to(dev).requires_grad_() for k, v in s.items()}
+        t = {k: v.to(dev) for k, v in t.items()}
+        r = Distiller("KL_feature", dict(O.DEFAULT_CFG), dev).KL_feature(s, t, labels.to(dev))
+        r["loss"].backward()
+        close(r["loss"], torch.from_numpy(G[pre + "loss"]), 1e-5, 1e-5, "KL_feature loss")
+        close(r["feature_loss"], torch.from_numpy(G[pre + "feature_loss"]), 1e-5, 1e-6, "feature loss")
+        close(r["hard_loss"], torch.from_numpy(G[pre + "hard"]), 1e-5, 1e-6, "hard loss")
+        close(r["soft_loss"], torch.from_numpy(G[pre + "soft"]), 1e-5, 1e-5, "soft loss")
+        close(s["logits"].grad, torch.from_numpy(G[pre + "g_logits"]), 1e-4, 1e-7, "logits grad")
+        close(gsum(s["feature"].grad.cpu()), torch.from_numpy(G[pre + "g_feature"]), 1e-4, 1e-8, "feature grad (chunk sums)")
+        close(s["feature"].grad[0, :, :128], torch.from_numpy(G[pre + "g_feature_row0"]), 1e-5, 1e-10, "feature grad row 0")
+
+
 def test_all_distiller_methods_golden(dev, golden_dir):
     """every logits-only Distiller method against the fixtures produced by the reference's distillers.py"""
     import os

@@ -67,7 +67,7 @@ def test_fused_optimizer_matches_torch_optim(dev, opt):
         assert float(fo.bucket.flat[pad_mask].abs().max()) == 0.0 and float(fo.bucket.grad.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("opt,lr", [("sgd", 1e-2), ("adam", 1e-4)])
+@pytest.mark.parametrize("opt,lr", [("sgd", 2e-3), ("adam", 1e-4)])
 def test_episode_loop_matches_oracle_loop(dev, opt, lr):
     """trainloop.train on the real modules vs the oracle loop with torch.optim (trainwandb.py:101-105,111-145): 4 episodes,
     tasks_per_batch 3 -> optimizer steps after episodes 2 (two accumulated episodes) and 3 (iteration == total-1).  Losses of
@@ -102,8 +102,13 @@ def test_episode_loop_matches_oracle_loop(dev, opt, lr):
         return p, lo, ac
     p32, lo32, ac32 = oracle(torch.float32)
     p64, lo64, _ = oracle(torch.float64)
+    # losses: the first two episodes see the initial weights (fp32 tolerance); the last two see weights after one / two optimizer
+    # steps, where a loss is as sensitive to gradient rounding as the step is large: fp64-anchored like the weights
     for i in range(4):
-        assert abs(losses[i] - lo32[i]) < 1e-3 * max(1.0, abs(lo32[i])), (i, losses, lo32, lo64)
+        e_hip, e_cpu = abs(losses[i] - lo64[i]), abs(lo32[i] - lo64[i])
+        assert e_hip <= 3 * e_cpu + 1e-4 * abs(lo64[i]), (i, losses, lo32, lo64)
+        if i < 2:
+            assert abs(losses[i] - lo32[i]) < 1e-4 * max(1.0, abs(lo32[i])), (i, losses, lo32)
     names = [k for k, v in p64.items() if v.is_floating_point() and v.requires_grad]
     d64 = {k: (p64[k].detach() - sp0[k].double()) for k in names}
     # Adam turns an exactly-zero gradient (biases that cancel in q - s differences: fp32 rounding noise vs eps = 1e-8) into an
@@ -114,11 +119,24 @@ def test_episode_loop_matches_oracle_loop(dev, opt, lr):
     sd = student.state_dict()
     hip = {k: sd[k].detach().cpu().double() - sp0[k].double() for k in names}
     c32 = {k: p32[k].detach().double() - sp0[k].double() for k in names}
-    worst = anchored_dict(hip, c32, {k: d64[k] for k in names}, floor=5e-6)
+    if opt == "sgd":
+        worst = anchored_dict(hip, c32, {k: d64[k] for k in names}, floor=5e-6)
+    else:
+        # Adam's first update is lr * g / (|g| + eps) ~ lr * sign(g): an element whose gradient is rounding noise around zero moves
+        # by +-lr in every fp32 evaluation (one such element in a 64-element tensor is a 25 % relative-L2 "error" against fp64).
+        # So per tensor: the FRACTION of elements whose update is off by more than 0.2 lr, again anchored on the CPU fp32 run.
+        # (The kernel itself is compared exactly with torch.optim.Adam on identical gradients above.)
+        worst = (0.0, "")
+        for k in names:
+            bad_hip = float(((hip[k] - d64[k]).abs() > 0.2 * lr).double().mean())
+            bad_cpu = float(((c32[k] - d64[k]).abs() > 0.2 * lr).double().mean())
+            assert bad_hip <= 3 * bad_cpu + 0.05, (k, bad_hip, bad_cpu)
+            worst = max(worst, (bad_hip, k))
     # BatchNorm running statistics after 8 trunk calls (support, query per episode): order and momentum as the reference
     for k in ("backbone.resnet.1.running_mean", "backbone.resnet.7.1.bn2.running_var", "backbone.resnet.5.0.downsample.1.running_var"):
-        a, b = sd[k].cpu(), p32[k]
-        assert float((a - b).abs().max()) < 1e-3 * float(b.abs().max()) + 1e-6, k
+        a, b, r = sd[k].cpu().double(), p32[k].double(), p64[k]
+        e_hip, e_cpu = float((a - r).abs().max()), float((b - r).abs().max())
+        assert e_hip <= 3 * e_cpu + 1e-4 * float(r.abs().max()), (k, e_hip, e_cpu)
     assert int(sd["backbone.resnet.1.num_batches_tracked"]) == 8
     print(opt, "losses", losses, lo32, "worst update error ratio", worst)
 

@@ -70,8 +70,7 @@ def test_registry_and_state_dict_keys():
     from litemkd_amd.distillers import Distiller
     d = Distiller("fc_2_sup_dist", a.cfg, "cpu")
     assert callable(getattr(d, "fc_2_sup_dist")) and callable(getattr(d, "KD"))
-    with pytest.raises(NotImplementedError):
-        d.KL_feature(None, None, None)
+    assert callable(getattr(d, "KL_feature"))        # every method of the reference's Distiller exists
     with pytest.raises(AttributeError):
         d.not_a_method
 

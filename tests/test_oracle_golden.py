@@ -179,6 +179,23 @@ def test_mfm_golden(golden_dir):
             close(O.mfm_extract_feature(rgb, depth, flow, p, shirt, 2), G[pre + "out"], 1e-4, 1e-4)
 
 
+def test_kl_feature_golden(golden_dir):
+    """Distiller.KL_feature (distillers.py:126-150) restatement vs the reference's own method"""
+    from oracle.gen_golden import kl_feature_inputs
+    G = np.load(os.path.join(golden_dir, "kl_feature.npz"))
+    for case in (0, 1):
+        pre = "c%d_" % case
+        s, t, labels = kl_feature_inputs(int(G[pre + "seed"]), int(G[pre + "nq"]), int(G[pre + "nv"]))
+        s["logits"].requires_grad_()
+        s["feature"].requires_grad_()
+        r = O.distill_KL_feature(s, t, labels)
+        r["loss"].backward()
+        close(r["loss"], G[pre + "loss"], 1e-5, 1e-5)
+        close(r["feature_loss"], G[pre + "feature_loss"], 1e-5, 1e-6)
+        close(s["logits"].grad, G[pre + "g_logits"], 1e-4, 1e-7)
+        close(gsum(s["feature"].grad), G[pre + "g_feature"], 1e-4, 1e-8)
+
+
 def test_distill_methods_golden(golden_dir):
     """all 22 logits-only Distiller methods of the reference (distillers.py:42-733): value + student-logit gradients"""
     G = np.load(os.path.join(golden_dir, "distill_methods.npz"))
