@@ -77,6 +77,11 @@ int lmkd_conv2d_bwd_weight_pre(const float* x_raw, const float* pre_stats, const
    info[4] (HOST) = tile id, XCD tile order, parity classes | pixel splits, workgroups.  Test/diagnostic aid. */
 int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, int* info_host);
 
+/* dw_oihw += weight gradient (dw_oihw = the parameter's .grad; accumulation over trunk calls / episodes, trainwandb.py:141-143);
+   pre_stats nullable (as lmkd_conv2d_bwd_weight_pre) */
+int lmkd_conv2d_bwd_weight_acc(const float* x, const float* pre_stats, const float* dy, float* dw_oihw, float* workspace, long ws_bytes,
+                               int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+
 /* ---- layout / BatchNorm / pooling (torchvision bn1/relu/maxpool/BasicBlock, resnet18_2fc.py:33,41-54) ---- */
 /* crop + horizontal flip + ToTensor of uint8 HWC frames into NHWC4 (video_reader.py:92-112 after Resize); crop/flip per video */
 int lmkd_frames_u8_to_nhwc4(const unsigned char* src, float* dst, const int* crop_y, const int* crop_x, const int* flip, int F, int Hs,
@@ -138,7 +143,8 @@ int lmkd_trx_sup_sim_fwd(const float* proto, const int* seg_col, float* sim, flo
                          void* stream);
 int lmkd_trx_sup_sim_bwd(const float* proto, const int* seg_col, const float* gram, const float* dsim, float* dproto, int Nq, int way,
                          int nseg, int T, int D, void* stream);
-int lmkd_supportdk_fwd(const float* support, float* out, int way, int shot, int seq_len, int D, void* stream);
+long lmkd_supportdk_workspace(int way);
+int lmkd_supportdk_fwd(const float* support, float* out, int way, int shot, int seq_len, int D, void* workspace, void* stream);
 int lmkd_supportdk_bwd(const float* support, const float* g, float* dsupport, int way, int shot, int seq_len, int D, void* stream);
 int lmkd_mean_frames(const float* x, float* y, long nv, int L, int D, void* stream);
 int lmkd_mean_frames_bwd(const float* dy, float* dx, long nv, int L, int D, void* stream);

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgradArgs a) {
 // dW (OIHW) = sum over split slabs of slab[z][co][(kh*KWp+kw)*Cs + ci]  (coalesced slab reads, 8 loads in flight per
 // thread; the scattered 4-byte OIHW writes are ~11 M floats per trunk call in total)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Co, int Cin,
-                                    int Cs, int KH, int KW, int KWp, int Kp) {
+                                    int Cs, int KH, int KW, int KWp, int Kp, int accumulate) {
   const long total = (long)Co * KH * KW * Cin;
   const long zs = (long)Co * Kp;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -480,7 +480,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
       s0 += a0; s1 += a1; s2 += a2; s3 += a3; s0 += a4; s1 += a5; s2 += a6; s3 += a7;
     }
     for (; z < splits; ++z) s0 += p[z * zs];
-    dw[(((long)co * Cin + ci) * KH + kh) * KW + kw] = (s0 + s1) + (s2 + s3);
+    float* o = dw + (((long)co * Cin + ci) * KH + kh) * KW + kw;
+    const float v = (s0 + s1) + (s2 + s3);
+    *o = accumulate ? *o + v : v;      // accumulate: dw is weight.grad itself (gradient accumulation over trunk calls / episodes)
   }
 }
 
@@ -828,7 +830,7 @@ extern "C" long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, in
 // dw_oihw[Cout,Cin,KH,KW] from x[N,H,W,Cs] (Cs >= Cin channel-padded) and dy[N,Ho,Wo,Cout]
 static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const float* dy, float* dw_oihw, float* workspace,
                                   long ws_bytes, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                  void* stream) {
+                                  void* stream, int accumulate = 0) {
   LMKD_REQUIRE(x && dy && dw_oihw && workspace, "lmkd_conv2d_bwd_weight: null pointer");
   LMKD_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(workspace), "lmkd_conv2d_bwd_weight: operands must be 16-byte aligned");
   LMKD_REQUIRE(Cs % 32 == 0 || Cs == 4, "lmkd_conv2d_bwd_weight: channel count %d must be 4 or a multiple of 32", Cs);
@@ -884,7 +886,7 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   int rg = cdiv(total, 256);
   if (rg > 4096) rg = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, s, (const float*)workspace, dw_oihw, splits, Cout, Cin, Cs,
-                     KH, KW, a.KWp, a.Kp);
+                     KH, KW, a.KWp, a.Kp, accumulate);
   LMKD_CHECK_LAUNCH("wgrad_reduce_kernel");
   return LMKD_OK;
 }
@@ -902,6 +904,14 @@ extern "C" int lmkd_conv2d_bwd_weight_pre(const float* x_raw, const float* pre_s
                                           int KW, int stride, int pad, void* stream) {
   LMKD_REQUIRE(pre_stats, "lmkd_conv2d_bwd_weight_pre: BatchNorm table of the input missing");
   return conv2d_bwd_weight_impl(x_raw, pre_stats, dy, dw_oihw, workspace, ws_bytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, stream);
+}
+
+// dw_oihw += weight gradient (dw_oihw is the parameter's .grad: gradient accumulation over the two trunk calls of an episode and
+// over the episodes between two optimizer steps, trainwandb.py:141-143, without a separate add pass); pre_stats nullable
+extern "C" int lmkd_conv2d_bwd_weight_acc(const float* x, const float* pre_stats, const float* dy, float* dw_oihw, float* workspace,
+                                          long ws_bytes, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride,
+                                          int pad, void* stream) {
+  return conv2d_bwd_weight_impl(x, pre_stats, dy, dw_oihw, workspace, ws_bytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, stream, 1);
 }
 
 // Launch plan of a convolution, without launching: which kernel instance and tile order the three entry points above would

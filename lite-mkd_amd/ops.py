@@ -236,17 +236,21 @@ def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumula
     return dx
 
 
-def conv_bwd_weight(x, dy, w_shape, stride, pad, pre_stats=None):
-    """pre_stats: x is a raw conv output, relu(BatchNorm(x)) is recomputed in the loader (lmkd_conv2d_bwd_weight_pre)"""
+def conv_bwd_weight(x, dy, w_shape, stride, pad, pre_stats=None, acc_into=None):
+    """pre_stats: x is a raw conv output, relu(BatchNorm(x)) is recomputed in the loader (lmkd_conv2d_bwd_weight_pre).
+    acc_into: a contiguous OIHW tensor (the weight's .grad) that receives `+= dW` in the slab-reduce kernel itself."""
     Cout, Cin, KH, KW = w_shape
     N, H, W, Cs = x.shape
-    _chk(x, dy, pre_stats)
+    _chk(x, dy, pre_stats, acc_into)
     nbytes = lib().value("lmkd_conv2d_bwd_weight_workspace", N, H, W, Cs, Cout, KH, KW, stride, pad)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    dw = _empty(w_shape, x)
+    dw = acc_into if acc_into is not None else _empty(w_shape, x)
     with _timed("conv_wgrad_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
                 4 * (x.numel() + dy.numel() + dw.numel())):
-        if pre_stats is not None:
+        if acc_into is not None:
+            lib().call("lmkd_conv2d_bwd_weight_acc", _p(x), _p(pre_stats), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW,
+                       stride, pad, _stream())
+        elif pre_stats is not None:
             lib().call("lmkd_conv2d_bwd_weight_pre", _p(x), _p(pre_stats), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW,
                        stride, pad, _stream())
         else:
@@ -297,11 +301,14 @@ def weight_grad(w, x, dy, stride, pad, pre_stats=None):
     sw = _WG_STREAM[dev]
     sw.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(sw):
-        dw = conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats)
-        if w.grad is None:
-            w.grad = dw
+        if w.grad is not None and w.grad.is_contiguous() and w.grad.dtype == torch.float32:
+            conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats, acc_into=w.grad)      # += in the slab reduce
         else:
-            w.grad.add_(dw)
+            dw = conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats)
+            if w.grad is None:
+                w.grad = dw
+            else:
+                w.grad.add_(dw)
     x.record_stream(sw)
     dy.record_stream(sw)
     if pre_stats is not None:      # read by the side-stream kernel too: its block must not be recycled under it
@@ -754,6 +761,14 @@ class ClassPlan:
         self.rowmap = torch.tensor(pos, dtype=torch.int32, device=dev)
         self.cls = torch.tensor(vals, dtype=torch.int32, device=dev)
         self.uniform = len(set(self.counts)) == 1
+        self._full = {}
+
+    def full_rowmap(self, nv):
+        """support rows class-sorted, query rows in place: [Ns + Nq] int32 (cached per query count: the student heads and the
+        teacher head of an episode share it)"""
+        if nv not in self._full:
+            self._full[nv] = torch.cat([self.rowmap, torch.arange(self.ns, nv, dtype=torch.int32, device=self.rowmap.device)])
+        return self._full[nv]
 
 
 def _trx_forward(sup, qry, plan, wk, bk, wv, bv, gamma, beta, pe, mask, want_grad):
@@ -771,7 +786,7 @@ def _trx_forward(sup, qry, plan, wk, bk, wv, bv, gamma, beta, pe, mask, want_gra
     P = _empty((NV * L, 4 * D), X)
     gemm("K", "K", NV * L, D, Din, Xp, Din, wk, 2 * Din, P, 4 * D, batch=2, sB=Din, sC=D)
     gemm("K", "K", NV * L, D, Din, Xp, Din, wv, 2 * Din, P, 4 * D, batch=2, sB=Din, sC=D, C_off=2 * D)
-    rowmap = torch.cat([plan.rowmap, torch.arange(Ns, NV, dtype=torch.int32, device=X.device)])
+    rowmap = plan.full_rowmap(NV)
     Kn = _empty((NV * T, D), X)
     V = _empty((NV * T, D), X)
     Khat = _empty((NV * T, D), X) if want_grad else None
@@ -938,7 +953,8 @@ class SupportDKFn(torch.autograd.Function):
         if Ns != way * shot:
             raise RuntimeError("shape '[%d, %d, %d, %d]' is invalid for input of size %d" % (way, shot, L, D, sup.numel()))
         out = _empty((way, way - 1), sup)
-        lib().call("lmkd_supportdk_fwd", _p(sup), _p(out), way, shot, L, D, _stream())
+        ws = torch.empty(lib().value("lmkd_supportdk_workspace", way), dtype=torch.uint8, device=sup.device)
+        lib().call("lmkd_supportdk_fwd", _p(sup), _p(out), way, shot, L, D, _p(ws), _stream())
         ctx.save_for_backward(sup)
         ctx.ws = (way, shot)
         return out
