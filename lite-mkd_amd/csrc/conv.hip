@@ -486,6 +486,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
+#include "wgrad_x3.h"
+
 // K-major packed weights (the GEMM's B operand: one row of K per output column):
 // mode 0 (forward): Wp[co][(kh*KWp+kw)*Cs + ci] = W[co][ci][kh][kw]   (zero for padded kw / ci)
 // mode 1 (dgrad)  : Wd[ci][(kh*KW+kw)*Co + co] = W[co][ci][kh][kw]
@@ -793,14 +795,26 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
 // Split-K plan of the weight gradient.  Output tiles are few (Cout x 9*Cin is small) and the reduction is long, so the
 // pixel range is split over gridDim.z.  The split count is chosen so that the launch is (just under) a whole number of
 // rounds of resident workgroups: an arbitrary count leaves a 1.5-round launch that runs as long as a 2-round one.
-static void wgrad_plan(int Mpix, int Cout, int Kp, int* splits, int* steps_per_split, int* bm, int* bn) {
+static int g_wgrad_planes = 1;   // bf16 / 3xbf16 modes: weight gradient on the bf16-plane kernel (wgrad_x3.h); 0 = fp32-tile kernel
+extern "C" int lmkd_conv_set_wgrad_planes(int on) { g_wgrad_planes = on ? 1 : 0; return LMKD_OK; }
+static inline bool wgrad_uses_planes(int Cs) { return (g_conv_x3 || g_conv_bf16) && g_wgrad_planes && Cs != 4; }
+
+static void wgrad_plan(int Mpix, int Cout, int Kp, int* splits, int* steps_per_split, int* bm, int* bn, bool planes = false) {
   // both operands are K-outer here (b32 fragment reads): the 128-wide tiles (1 read per MFMA) beat 64x64 (2 per MFMA):
   // measured 91.6 vs 74.8 TFLOP/s over the trunk's weight gradients
   *bm = Cout <= 64 ? 64 : 128;
   *bn = (Kp % 128 == 0 && Kp >= 1024) ? 128 : 64;
+  int per_cu = (*bm == 128 && *bn == 128) ? 2 : ((*bm == 64 && *bn == 64) ? 4 : 3);
+  if (planes) {      // wgrad_x3.h: 4-wave workgroups, LDS = planes x 32 k rows x (2 bytes per column + 64) per operand
+    if (*bm == 64 && *bn == 128) *bn = 64;
+    const int npl = g_conv_bf16 ? 1 : 3;
+    const long lds = 1L * npl * LMKD_BK * ((*bm * 2 + 64) + (*bn * 2 + 64));      // single LDS buffer
+    per_cu = (int)(160 * 1024 / lds);
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+  }
   const int tiles = cdiv(Cout, *bm) * cdiv(Kp, *bn);
   const int steps = cdiv(Mpix, LMKD_BK);
-  const int per_cu = (*bm == 128 && *bn == 128) ? 2 : ((*bm == 64 && *bn == 64) ? 4 : 3);
   const int slots = 256 * per_cu;
   int best_sp = 1;
   double best_cost = 1e30;
@@ -823,7 +837,7 @@ extern "C" long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, in
   const int Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
   const int Kp = KH * kw_padded(Cs, KW) * Cs;
   int splits, sps, bm, bn;
-  wgrad_plan(N * Ho * Wo, Cout, Kp, &splits, &sps, &bm, &bn);
+  wgrad_plan(N * Ho * Wo, Cout, Kp, &splits, &sps, &bm, &bn, wgrad_uses_planes(Cs));
   return (long)splits * Cout * Kp * sizeof(float);
 }
 
@@ -836,7 +850,7 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   LMKD_REQUIRE(Cs % 32 == 0 || Cs == 4, "lmkd_conv2d_bwd_weight: channel count %d must be 4 or a multiple of 32", Cs);
   LMKD_REQUIRE(Cout % 4 == 0, "lmkd_conv2d_bwd_weight: Cout %% 4 != 0");
   const bool smallc = Cs == 4;
-  LMKD_REQUIRE(!pre_stats || (!smallc && !g_conv_bf16), "lmkd_conv2d_bwd_weight_pre: fp32 mode, Cs %% 32 == 0 only");
+  LMKD_REQUIRE(!pre_stats || (!smallc && (!g_conv_bf16 || g_wgrad_planes)), "lmkd_conv2d_bwd_weight_pre: Cs %% 32 == 0 only");
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.x = x; a.slab = workspace; a.pre_stats = pre_stats;
@@ -847,7 +861,8 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   a.Mpix = N * a.Ho * a.Wo;
   LMKD_REQUIRE((long)N * H * W * Cs < 2147483647L && (long)a.Mpix * Cout < 2147483647L, "lmkd_conv2d_bwd_weight: tensor too large");
   int splits, bm, bn;
-  wgrad_plan(a.Mpix, Cout, a.Kp, &splits, &a.steps_per_split, &bm, &bn);
+  const bool planes = wgrad_uses_planes(Cs);
+  wgrad_plan(a.Mpix, Cout, a.Kp, &splits, &a.steps_per_split, &bm, &bn, planes);
   a.steps_total = cdiv(a.Mpix, LMKD_BK);
   LMKD_REQUIRE(ws_bytes >= (long)splits * Cout * a.Kp * (long)sizeof(float), "lmkd_conv2d_bwd_weight: workspace too small");
   a.div_hw = make_fastdiv(a.Ho * a.Wo); a.div_w = make_fastdiv(a.Wo);
@@ -865,6 +880,29 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
     else if (!SM && pre_stats) hipLaunchKernelGGL((conv_wgrad_kernel<CFG, false, false, true>), grid, dim3(THR), 0, s, a); \
     else hipLaunchKernelGGL((conv_wgrad_kernel<CFG, SM, false>), grid, dim3(THR), 0, s, a);                     \
   } while (0)
+  if (planes) {
+#define LMKD_WGX3(CFG)                                                                                                   \
+  do {                                                                                                                   \
+    if (g_conv_bf16) {                                                                                                   \
+      if (pre_stats) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, true, 1, true>), grid, dim3(256), 0, s, a);          \
+      else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, true, 1, false>), grid, dim3(256), 0, s, a);                   \
+    } else if (g_conv_x3 == 9) {                                                                                         \
+      if (pre_stats) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 9, true>), grid, dim3(256), 0, s, a);         \
+      else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 9, false>), grid, dim3(256), 0, s, a);                  \
+    } else {                                                                                                             \
+      if (pre_stats) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 6, true>), grid, dim3(256), 0, s, a);         \
+      else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 6, false>), grid, dim3(256), 0, s, a);                  \
+    }                                                                                                                    \
+  } while (0)
+    using W128 = WgCfg<128, 128, 2, 2>;
+    using W128x64 = WgCfg<128, 64, 2, 2>;
+    using W64 = WgCfg<64, 64, 2, 2>;
+    if (bm == 128 && bn == 128) LMKD_WGX3(W128);
+    else if (bm == 128) LMKD_WGX3(W128x64);
+    else LMKD_WGX3(W64);
+#undef LMKD_WGX3
+    LMKD_CHECK_LAUNCH("conv_wgrad_x3_kernel");
+  } else {
   using C64 = TileCfg<64, 64, 2, 2>;
   using C128x64 = TileCfg<128, 64, 2, 2>;
   using C64x128 = TileCfg<64, 128, 2, 2>;
@@ -882,6 +920,7 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
     LMKD_WGRAD_LAUNCH(C128, false, 512);
   }
   LMKD_CHECK_LAUNCH("conv_wgrad_kernel");
+  }
   const long total = (long)Cout * KH * KW * Cin;
   int rg = cdiv(total, 256);
   if (rg > 4096) rg = 4096;
@@ -928,7 +967,7 @@ extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, 
   if (kind == 2) {
     const int Kp = KH * kw_padded(Cs, KW) * Cs;
     int splits, sps, bm, bn;
-    wgrad_plan(N * Ho * Wo, Cout, Kp, &splits, &sps, &bm, &bn);
+    wgrad_plan(N * Ho * Wo, Cout, Kp, &splits, &sps, &bm, &bn, wgrad_uses_planes(Cs));
     info[0] = (bm == 128 && bn == 128) ? 1 : (bm == 128 ? 2 : (bn == 128 ? 4 : 3));
     info[1] = (g_xcd_mode != 0 && g_xcd_mode != 1 && splits >= 32) ? 1 : 0;
     info[2] = splits;

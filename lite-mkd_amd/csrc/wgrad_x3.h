@@ -1,0 +1,202 @@
+// Weight gradient of a convolution on the bf16 matrix pipe: plain bf16 (one RNE plane, BASELINE configs[2]) or fp32 as an
+// exact 3-way bf16 split with 6 (or 9) products per fp32 product (conv_x3.h).
+//
+//   dW[co][(tap, ci)] = sum_pix dy[pix][co] * x[pix shifted by tap][ci]
+//
+// Both GEMM operands are K-OUTER in memory (K = pixels: dy[pix][Cout], x[pix][Cin]), while an MFMA 32x32x16 lane wants 8
+// consecutive k of ONE row / column.  The fp32 kernel (conv_wgrad_kernel) reads such fragments element by element
+// (ds_read_b32); a register transpose costs more VALU than the bf16 MFMAs take.  gfx950's ds_read_b64_tr_b16 does the
+// transpose inside the LDS read: the operand tiles are stored as they arrive, as bf16 planes  img[plane][k][col]
+// (ds_write_b64 of 4 channels of one pixel), and a 16-lane group reads a 4 (k) x 16 (col) block column-major, i.e. every lane
+// receives 4 consecutive k of its own column.  Row stride = cols * 2 + 64 bytes: an odd multiple of 64 B, so the four k rows of
+// a block fall on four different quarters of the 64 banks (conflict free for the 2 x 4-row blocks of a 32-lane half).
+//
+// The operands are converted when a tile is stored to LDS (after the MFMAs of the current K-step, like every loader here):
+// one v_cvt_pk per pair (bf16) or the exact three-way split (x3); the optional BatchNorm+ReLU of the x operand
+// (lmkd_conv2d_bwd_weight_pre) runs at the same place.  One 256-thread workgroup, wave tiles of up to 64x64 (TM = TN = 2:
+// one tr read per MFMA and product plane), double-buffered LDS, one barrier per K-step of 32 pixels, split-K slabs and the
+// slab reduction of conv_wgrad_kernel.
+#pragma once
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct WgCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static constexpr int THREADS = 64 * WM * WN;
+  static_assert(TM >= 1 && TN >= 1 && WM * WN == 4, "4 waves");
+};
+
+template <int COLS>
+struct TrImg {
+  static constexpr int LDB = COLS * 2 + 64;            // bytes per k row
+  static constexpr int PLANE = LMKD_BK * LDB;          // bytes per plane
+  static_assert((LDB / 64) % 2 == 1, "row stride must be an odd multiple of 64 bytes");
+};
+
+// 8 consecutive k (k0 + 8h .. +7, h = lane >> 5) of column col0 + (lane & 31) of a K-outer image: two transposed reads
+template <int LDB>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* __restrict__ img, int lane_off) {
+  const unsigned char* a = img + lane_off;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a + 4 * LDB));
+  union { s16x4_t s[2]; bf16x8 b; } u;
+  u.s[0] = lo; u.s[1] = hi;
+  return u.b;
+}
+// byte offset of this lane's block row inside an image (before adding k-group and tile offsets):
+// lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of the group's 16 columns
+__device__ __forceinline__ int tr_lane_off(int ldb, int lane) {
+  const int idx = lane & 15;
+  return (8 * (lane >> 5) + (idx >> 2)) * ldb + (16 * ((lane >> 4) & 1) + 4 * (idx & 3)) * 2;
+}
+
+// store one float4 (4 consecutive columns of k row `k`) as NPL bf16 planes
+template <int NPL, int LDB, int PLANE>
+__device__ __forceinline__ void tr_store4(unsigned char* __restrict__ img, int k, int col, const float4& v) {
+  unsigned char* d = img + k * LDB + col * 2;
+  if (NPL == 1) {
+    *reinterpret_cast<uint2*>(d) = x3_round4(v);
+  } else {
+    uint2 p0, p1, p2;
+    x3_split4(v, p0, p1, p2);
+    *reinterpret_cast<uint2*>(d) = p0;
+    *reinterpret_cast<uint2*>(d + PLANE) = p1;
+    *reinterpret_cast<uint2*>(d + 2 * PLANE) = p2;
+  }
+}
+
+template <class Cfg, bool BF16ONLY, int NPROD, bool PRE>
+__global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a) {
+  constexpr int NPL = NPROD == 1 ? 1 : 3;
+  using LA = LoaderMMajorDense<Cfg::BM, Cfg::THREADS>;
+  using LB = LoaderWgradGather<Cfg::BN, false, Cfg::THREADS, PRE>;
+  using IA = TrImg<Cfg::BM>;
+  using IB = TrImg<Cfg::BN>;
+  constexpr int A_BYTES = NPL * IA::PLANE, B_BYTES = NPL * IB::PLANE;
+  // ONE LDS buffer and two barriers per K-step: at 3 planes a double-buffered 128x128 tile (120 KB) leaves one workgroup (one
+  // wave per SIMD) per CU, and nothing then runs beside the conversion / split VALU work of a wave; with a single buffer two
+  // workgroups share the CU and one's MFMAs overlap the other's loads, conversion and LDS stores (the next tile is still
+  // prefetched into registers while the current one is multiplied)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
+  (void)BF16ONLY;
+  int z, tz;
+  const int tiles_per_z = a.n_mt * a.n_jt;
+  if (a.xcd_mode) {
+    const int xj = blockIdx.x >> 3;
+    z = (blockIdx.x & 7) + 8 * (xj / tiles_per_z);
+    if (z >= a.splits) return;
+    tz = xj - (xj / tiles_per_z) * tiles_per_z;
+  } else {
+    z = blockIdx.x / tiles_per_z;
+    tz = blockIdx.x - z * tiles_per_z;
+  }
+  const int m0 = (tz % a.n_mt) * Cfg::BM, j0 = (tz / a.n_mt) * Cfg::BN;
+  LA la;
+  LB lb;
+  la.init(a.dy, a.Co, m0, a.Co, a.Mpix);
+  lb.init(a, j0);
+  const int s0 = z * a.steps_per_split;
+  int nk = a.steps_total - s0;
+  if (nk > a.steps_per_split) nk = a.steps_per_split;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int offA = tr_lane_off(IA::LDB, lane) + wm * (Cfg::TM * 32) * 2;
+  const int offB = tr_lane_off(IB::LDB, lane) + wn * (Cfg::TN * 32) * 2;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto store_tiles = [&](unsigned char* sa, unsigned char* sb) {
+#pragma unroll
+    for (int i = 0; i < LA::NI; ++i) tr_store4<NPL, IA::LDB, IA::PLANE>(sa, tid / LA::CPR + LA::KPP * i, la.r4, la.reg[i]);
+#pragma unroll
+    for (int i = 0; i < LB::NI; ++i) {
+      float4 v = lb.reg[i];
+      if (PRE && ((lb.inb >> i) & 1u)) {
+        v.x = fmaxf(fmaf(v.x, lb.psc.x, lb.psh.x), 0.f); v.y = fmaxf(fmaf(v.y, lb.psc.y, lb.psh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, lb.psc.z, lb.psh.z), 0.f); v.w = fmaxf(fmaf(v.w, lb.psc.w, lb.psh.w), 0.f);
+      }
+      tr_store4<NPL, IB::LDB, IB::PLANE>(sb, tid / LB::CPR + LB::KPP * i, lb.r4, v);
+    }
+  };
+  auto kstep = [&](const unsigned char* sa, const unsigned char* sb) {
+    bf16x8 fa[2][NPL][Cfg::TM], fb[2][NPL][Cfg::TN];
+    auto read_group = [&](int g, bf16x8 (&xa)[NPL][Cfg::TM], bf16x8 (&xb)[NPL][Cfg::TN]) {
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i) xa[p][i] = tr_frag<IA::LDB>(sa, offA + p * IA::PLANE + g * 16 * IA::LDB + i * 64);
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) xb[p][j] = tr_frag<IB::LDB>(sb, offB + p * IB::PLANE + g * 16 * IB::LDB + j * 64);
+      }
+    };
+    read_group(0, fa[0], fb[0]);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      if (g == 0) {
+        read_group(1, fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+          f32x16 c = acc[i][j];
+          if constexpr (NPROD == 1) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0][i], fb[g][0][j], c, 0, 0, 0);
+          } else {
+            if (NPROD == 9) {
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][2][i], fb[g][2][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][1][i], fb[g][2][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][2][i], fb[g][1][j], c, 0, 0, 0);
+            }
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][1][i], fb[g][1][j], c, 0, 0, 0);     // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0][i], fb[g][2][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][2][i], fb[g][0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0][i], fb[g][1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][1][i], fb[g][0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0][i], fb[g][0][j], c, 0, 0, 0);
+          }
+          acc[i][j] = c;
+        }
+    }
+  };
+
+  if (nk > 0) {
+    unsigned char* A0 = smem;
+    unsigned char* B0 = smem + A_BYTES;
+    la.load((s0 + 0) * LMKD_BK);
+    lb.load((s0 + 0) * LMKD_BK);
+    for (int t = 0; t < nk; ++t) {
+      store_tiles(A0, B0);                    // waits for the prefetched registers of step t
+      __syncthreads();
+      if (t + 1 < nk) {
+        la.load((s0 + t + 1) * LMKD_BK);
+        lb.load((s0 + t + 1) * LMKD_BK);
+      }
+      kstep(A0, B0);
+      __syncthreads();                        // every wave has read the tile before it is overwritten
+    }
+  }
+
+  float* C = a.slab + (long)z * a.Co * a.Kp;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = j0 + wn * (Cfg::TN * 32) + j * 32 + (lane & 31);
+    if (col >= a.Kp) continue;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane);
+        if (row < a.Co) C[(long)row * a.Kp + col] = acc[i][j][e];
+      }
+  }
+}

@@ -23,10 +23,22 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-@pytest.mark.parametrize("shot,query,img,clf,dist,bb", [(1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc"),
-                                                        (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc"),
-                                                        (1, 1, 64, "TRX_2fcsup", "fc_2_sup_dist", "resnet50_2fc")])
-def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb):
+@pytest.mark.parametrize("shot,query,img,clf,dist,bb,mode", [(1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32"),
+                                                             (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc", "fp32"),
+                                                             (1, 1, 64, "TRX_2fcsup", "fc_2_sup_dist", "resnet50_2fc", "fp32"),
+                                                             (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3"),
+                                                             (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3")])
+def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode):
+    """mode fp32x3: the convolutions (forward, data and weight gradient) in the 3xbf16 arithmetic, under the same fp32 criteria"""
+    from litemkd_amd import ops
+    ops.set_conv_compute_dtype(mode)
+    try:
+        _episode_matches_oracle(dev, shot, query, img, clf, dist, bb)
+    finally:
+        ops.set_conv_compute_dtype("fp32")
+
+
+def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb):
     from litemkd_amd.model.model_select import Student, Teacher
     from litemkd_amd.distillers import Distiller
     from litemkd_amd.options import default_args

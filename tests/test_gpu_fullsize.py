@@ -120,6 +120,19 @@ def test_conv_benchmark_shapes_vs_fp64(dev, shape):
     _run_shape(dev, *shape)
 
 
+@pytest.mark.parametrize("shape", SHAPES, ids=[s[0] for s in SHAPES])
+def test_conv_benchmark_shapes_x3_mode_vs_fp64(dev, shape):
+    """the same launches in the fp32-as-3xbf16 arithmetic (conv_x3.h forward / data gradient, wgrad_x3.h weight gradient: exact
+    3-way bf16 split of both operands, 6 bf16 MFMA products per fp32 product, fp32 accumulation) under the SAME fp64-anchored
+    criterion as the native fp32 MFMA kernels: fp32-class error, not reduced precision"""
+    from litemkd_amd import ops
+    ops.set_conv_compute_dtype("fp32x3")
+    try:
+        _run_shape(dev, *shape)
+    finally:
+        ops.set_conv_compute_dtype("fp32")
+
+
 def test_benchmark_instances_were_exercised(dev):
     """the shapes above must have run both conv_gemm tiles the benchmark selects (64x64/4 waves = 3, 128x128/8 waves = 5) in
     both XCD tile orders, and the weight-gradient tiles 128x128, 128x64, 64x64 with and without XCD-grouped splits"""
