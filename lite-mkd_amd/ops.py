@@ -468,6 +468,8 @@ class StemFn(torch.autograd.Function):
         y = _empty((N, Ho, Wo, C), x)
         idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
         lib().call("lmkd_bn_relu_maxpool_fwd", _p(c), _p(stats), _p(y), _p(idx), N, Hc, Wc, C, _stream())
+        if BLOCK_TAPS is not None:
+            BLOCK_TAPS.append({"stem_c": c, "stem_st": stats})
         if training:
             ctx.save_for_backward(x4, c, stats, idx, gamma, w)
         ctx.training = training
