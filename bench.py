@@ -66,10 +66,12 @@ def main():
     ap.add_argument("--serial", action="store_true", help="queue the two trunk calls on ONE stream (no kernel overlap); use this "
                     "mode under rocprofv3 so per-kernel durations are not inflated by concurrent kernels")
     ap.add_argument("--roofline-episodes", type=int, default=2)
-    ap.add_argument("--dtype", choices=["f32", "bf16", "f32x3"], default="f32", help="f32 (headline, BASELINE configs[1]: fp32 "
-                    "MFMA); bf16: convolution operands rounded to bf16 for the MFMA, fp32 accumulation, everything else fp32 "
-                    "(configs[2]); f32x3: fp32 convolutions computed on the bf16 matrix pipe from an exact 3-way bf16 split of "
-                    "both operands, 6 products per fp32 product, fp32 accumulation (csrc/conv_x3.h; forward + data gradient)")
+    ap.add_argument("--dtype", choices=["f32", "f32native", "bf16", "f32x3"], default="f32", help="f32 (headline, BASELINE "
+                    "configs[1]): fp32 tensors, fp32 accumulation, the convolution products on the bf16 matrix pipe from an EXACT "
+                    "3-way bf16 split of both operands, 6 products per fp32 product (csrc/conv_x3.h, wgrad_x3.h; error vs fp64 of "
+                    "the class of the native fp32 MFMA: tests/test_gpu_fullsize.py); f32x3: alias of f32; f32native: the same "
+                    "job on v_mfma_f32_32x32x2_f32 (round 1's headline arithmetic, reported under other_modes by default); "
+                    "bf16 (configs[2]): convolution operands rounded to bf16, fp32 accumulation, everything else fp32")
     ap.add_argument("--xcd-mode", type=int, default=-1, help="tuning: lmkd_conv_set_xcd_mode (-1 auto, 0 plain tile orders, 1 auto without XCD-grouped weight-gradient splits)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short bf16 / f32x3 side measurements of the default run")
     ap.add_argument("--ew-wg", type=int, default=0, help="tuning: workgroups per CU of the HBM-bound kernels (lmkd_set_elementwise_wg_per_cu), 0 = default")
@@ -105,7 +107,10 @@ def main():
     litemkd_amd.lib().call("lmkd_conv_set_xcd_mode", a.xcd_mode)
     if a.ew_wg > 0:
         litemkd_amd.lib().call("lmkd_set_elementwise_wg_per_cu", a.ew_wg)
-    ops.set_conv_compute_dtype({"f32": "fp32", "bf16": "bf16", "f32x3": "fp32x3"}[a.dtype])
+    if a.dtype == "f32x3":
+        a.dtype = "f32"
+    MODE = {"f32": "fp32x3", "f32native": "fp32", "bf16": "bf16"}
+    ops.set_conv_compute_dtype(MODE[a.dtype])
     cfg = default_args(shot=a.shot, device=dev, trans_dropout=a.dropout, training_iterations=10 ** 9, print_freq=10 ** 9,
                        model_backbone=a.backbone)
     torch.manual_seed(1234)                                  # identical initial weights on every rank
@@ -190,9 +195,8 @@ def main():
     # launch's HIP-event duration includes time shared with the other stream's kernels.  The kernel-quality number is
     # therefore taken from `--roofline-episodes` extra episodes with the overlap switched off (same kernels, same shapes,
     # same process, right after the timed region); with --serial the timed region itself is used.
-    if a.serial:
-        timing = timed_events
-    else:
+    def roofline_pass():
+        """`--roofline-episodes` extra episodes with the stream overlap switched off -> per-launch HIP-event records"""
         R.OVERLAP_TRUNK_CALLS = False
         ops.SIDE_WGRAD = False
         ops.CONV_TIMING = []
@@ -201,18 +205,25 @@ def main():
             TL.train_task(pool[i % len(pool)], student, teacher, distiller, aggregate_accuracy, cfg)
         opt.zero_grad()
         fence()
-        timing, ops.CONV_TIMING = ops.CONV_TIMING, None
+        rec, ops.CONV_TIMING = ops.CONV_TIMING, None
         R.OVERLAP_TRUNK_CALLS = True
         ops.SIDE_WGRAD = os.environ.get("LMKD_SIDE_WGRAD", "1") != "0"
+        return rec
+
+    def families(rec):
+        fam = {}
+        for name, flops, e0, e1, nbytes in rec:
+            f = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
+            f[0] += flops
+            f[1] += e0.elapsed_time(e1) * 1e-3
+            f[2] += 1
+            f[3] += nbytes
+        return fam
+
+    timing = timed_events if a.serial else roofline_pass()
 
     # roofline of the dominant kernel family (implicit-GEMM conv fwd + dgrad, one template): algorithmic FLOPs / HIP-event time
-    fam = {}
-    for name, flops, e0, e1, nbytes in timing:
-        f = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
-        f[0] += flops
-        f[1] += e0.elapsed_time(e1) * 1e-3
-        f[2] += 1
-        f[3] += nbytes
+    fam = families(timing)
     if a.layer_table and rank == 0:      # per distinct (kernel family, FLOPs, bytes) launch shape: where the conv time goes
         shp = {}
         for name, flops, e0, e1, nbytes in timing:
@@ -227,8 +238,13 @@ def main():
     cg = fam.get("conv_gemm_kernel", [0.0, 1.0, 1, 0.0])
     wg = fam.get("conv_wgrad_kernel", [0.0, 1.0, 1, 0.0])
     achieved = cg[0] / cg[1] / 1e12
-    # dense MFMA peaks (MI355X_MICROARCH.md); f32x3 issues 6 bf16 MFMA flops per algorithmic fp32 flop
-    peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": 2500.0, "f32x3": 2500.0 / 6}[a.dtype]
+    # dense MFMA peaks (MI355X_MICROARCH.md); the 3xbf16 arithmetic issues 6 bf16 MFMA flops per algorithmic fp32 flop
+    PEAK = {"f32": 2500.0 / 6, "f32native": PEAK_FP32_MFMA_TFLOPS, "bf16": 2500.0}
+    KERNEL = {"f32": "conv_gemm_x3_kernel (implicit-GEMM conv fwd + dgrad): v_mfma_f32_32x32x16_bf16 x6 per fp32 product, exact 3-way bf16 "
+                     "operand split, fp32 accumulate; peak = dense bf16 MFMA peak / 6",
+              "f32native": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad, v_mfma_f32_32x32x2_f32)",
+              "bf16": "conv_gemm_x3_kernel, one bf16 plane (implicit-GEMM conv fwd + dgrad, v_mfma_f32_32x32x16_bf16)"}
+    peak = PEAK[a.dtype]
     # HBM-side traffic of the same kernel family: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950) of `bench.py --serial`,
     # committed under profiles/ — counters cannot be read from inside this process.
@@ -253,14 +269,17 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "HMDB-shape 5-way %d-shot %s + TRX_2fcsup + D2M fc_2_sup_dist training episode%s, %s"
                                % (a.shot, a.backbone, " + live MFM fusion" if a.live_mfm else "",
-                                  {"f32": "fp32", "bf16": "bf16 conv operands / fp32 accumulate",
-                                   "f32x3": "fp32 conv operands as 3 bf16 planes, 6 bf16 MFMA products, fp32 accumulate"}[a.dtype]),
+                                  {"f32": "fp32", "f32native": "fp32", "bf16": "bf16 conv operands / fp32 accumulate"}[a.dtype]),
+                   "conv_arithmetic": {"f32": "fp32 tensors and accumulation; products on the bf16 matrix pipe from an exact 3-way bf16 "
+                                              "split of both operands, 6 of 9 cross products (stem weight gradient on the fp32 MFMA); "
+                                              "error vs fp64 within 3x of torch-CPU fp32 per layer and per parameter gradient "
+                                              "(tests/test_gpu_fullsize.py, test_gpu_episode.py)",
+                                       "f32native": "v_mfma_f32_32x32x2_f32 (exact fp32 products)",
+                                       "bf16": "conv operands rounded to bf16 (RNE), fp32 accumulation; activations / BatchNorm / loss fp32"}[a.dtype],
                    "frames_per_episode": frames, "img": 224, "tasks_per_batch": cfg.tasks_per_batch, "optimizer": cfg.opt,
                    "episodes_per_optimizer_step_per_rank": every, "parallelism": "episode-parallel dp%d" % world,
                    "trans_dropout": a.dropout, "trunk_calls_overlapped_on_two_streams": not a.serial},
-        "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad, %s)"
-                               % ("v_mfma_f32_32x32x2_f32" if a.dtype == "f32" else "v_mfma_f32_32x32x16_bf16"
-                                  + (" x6 per fp32 product; peak = bf16 peak / 6" if a.dtype == "f32x3" else "")),
+        "roofline": {"bound": "mfma", "kernel": KERNEL[a.dtype],
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_note": traffic_note,
                      "kernel_src_hash": kernel_source_hash(),
@@ -275,19 +294,32 @@ def main():
     }
     if world == 1 and a.dtype == "f32" and not a.no_other_modes:
         # the same job in the two other arithmetic modes of the convolutions, for the record (never part of `value`):
-        # short timed regions right here, same process, same resident episodes
+        # short timed regions right here, same process, same resident episodes, each with its own per-kernel roofline pass
         other = {}
-        for name, mode in (("bf16", "bf16"), ("f32x3", "fp32x3")):
-            ops.set_conv_compute_dtype(mode)
+        ALG_BYTES_PER_EPISODE = 3 * 25.8e6 * frames      # 25.8 MB of fp32 activation traffic per frame forward, x3 for a step
+        for name in ("f32native", "bf16"):
+            ops.set_conv_compute_dtype(MODE[name])
             it = run(2, it)
             fence()
             t1 = time.perf_counter()
             it = run(16, it)      # 16 consecutive episodes always contain exactly one optimizer step
             fence()
-            other[name] = {"value": 16 / (time.perf_counter() - t1), "unit": "episodes/s", "steps": 16}
-        ops.set_conv_compute_dtype("fp32")
-        other["bf16"]["what"] = "conv operands rounded to bf16 (RNE), fp32 accumulate: BASELINE configs[2]"
-        other["f32x3"]["what"] = "fp32 conv operands as an exact 3-way bf16 split, 6 bf16 MFMA products, fp32 accumulate (forward + data gradient)"
+            v = 16 / (time.perf_counter() - t1)
+            f2 = families(roofline_pass())
+            g2, w2 = f2.get("conv_gemm_kernel", [0.0, 1.0, 1, 0.0]), f2.get("conv_wgrad_kernel", [0.0, 1.0, 1, 0.0])
+            ach = g2[0] / g2[1] / 1e12
+            other[name] = {"value": v, "unit": "episodes/s", "steps": 16,
+                           "roofline": {"bound": "mfma", "kernel": KERNEL[name], "achieved": ach, "peak": PEAK[name], "unit": "TFLOP/s",
+                                        "frac": ach / PEAK[name], "avg_launch_ms": g2[1] / max(g2[2], 1) * 1e3,
+                                        "wgrad_kernel_tflops": w2[0] / w2[1] / 1e12}}
+        ops.set_conv_compute_dtype(MODE["f32"])
+        other["f32native"]["what"] = "round 1's headline arithmetic: every convolution on the fp32 MFMA (157.3 TFLOP/s peak)"
+        other["bf16"]["what"] = "BASELINE configs[2]: conv operands rounded to bf16 (RNE), fp32 accumulate; activations in HBM still fp32"
+        # configs[2] sits at the ridge of the bf16 roofline: report the HBM side as well, on algorithmic bytes
+        gbs = ALG_BYTES_PER_EPISODE * other["bf16"]["value"] / 1e9
+        other["bf16"]["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                                         "algorithmic_bytes_per_episode": ALG_BYTES_PER_EPISODE,
+                                         "note": "fp32 activations: 3 x 25.8 MB per frame (SURVEY 8d); whole-job average, not one kernel"}
         out["other_modes"] = other
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.shot, a.cpu_episodes)
