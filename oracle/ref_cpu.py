@@ -107,13 +107,48 @@ def _relu(t):
     return F.relu(t) if RELU_HOOK is None else RELU_HOOK(t)
 
 
+# BASELINE configs[2] ("bf16, MFMA conv path"): the reference runs its convolutions under autocast; the build's bf16 mode rounds
+# the operands of EVERY convolution GEMM to bf16 (round to nearest even) and accumulates in fp32 - forward: conv(r(x), r(w));
+# data gradient: from r(dy) and r(w); weight gradient: from r(x) and r(dy) - while activations, BatchNorm and the loss stay
+# fp32.  CONV_BF16 = True makes the trunks below compute exactly that arithmetic on the CPU (in the dtype of the inputs: run it
+# in fp64 for an accumulation-exact reference of the bf16 mode).
+CONV_BF16 = False
+
+
+def _r16(t):
+    return t.detach().to(torch.bfloat16).to(t.dtype)
+
+
+class _ConvBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        ctx.save_for_backward(x, w)
+        ctx.sp = (stride, pad)
+        return F.conv2d(_r16(x), _r16(w), None, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.sp
+        dyr = _r16(dy)
+        dx = torch.nn.grad.conv2d_input(x.shape, _r16(w), dyr, stride=stride, padding=pad) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv2d_weight(_r16(x), w.shape, dyr, stride=stride, padding=pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+def _conv(x, w, stride=1, pad=0):
+    if CONV_BF16:
+        return _ConvBF16.apply(x, w, stride, pad)
+    return F.conv2d(x, w, None, stride, pad)
+
+
 def resnet18_trunk(x, sd, training=True, update_running=True, taps=None):
     """[F,3,H,W] -> [F,512,H/32,W/32].  BN in train mode uses the batch statistics of
     THIS call (reference: Student.__init__ calls self.train(), model_select.py:21)."""
     def tap(name, t):
         if taps is not None:
             taps[name] = t
-    x = F.conv2d(x, sd["0.weight"], None, 2, 3)
+    x = _conv(x, sd["0.weight"], 2, 3)
     tap("conv1", x)
     x = _relu(_bn(x, sd, "1", training, update_running))
     x = F.max_pool2d(x, 3, 2, 1)
@@ -123,12 +158,12 @@ def resnet18_trunk(x, sd, training=True, update_running=True, taps=None):
             p = "%d.%d" % (idx, b)
             s = stride if b == 0 else 1
             idn = x
-            out = F.conv2d(x, sd[p + ".conv1.weight"], None, s, 1)
+            out = _conv(x, sd[p + ".conv1.weight"], s, 1)
             out = _relu(_bn(out, sd, p + ".bn1", training, update_running))
-            out = F.conv2d(out, sd[p + ".conv2.weight"], None, 1, 1)
+            out = _conv(out, sd[p + ".conv2.weight"], 1, 1)
             out = _bn(out, sd, p + ".bn2", training, update_running)
             if (p + ".downsample.0.weight") in sd:
-                idn = F.conv2d(x, sd[p + ".downsample.0.weight"], None, s, 0)
+                idn = _conv(x, sd[p + ".downsample.0.weight"], s, 0)
                 idn = _bn(idn, sd, p + ".downsample.1", training, update_running)
             x = _relu(out + idn)
             tap(p, x)

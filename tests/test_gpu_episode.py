@@ -27,13 +27,17 @@ def _rel(a, b):
                                                              (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc", "fp32"),
                                                              (1, 1, 64, "TRX_2fcsup", "fc_2_sup_dist", "resnet50_2fc", "fp32"),
                                                              (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3"),
-                                                             (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3")])
+                                                             (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3"),
+                                                             (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "bf16")])
 def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode):
-    """mode fp32x3: the convolutions (forward, data and weight gradient) in the 3xbf16 arithmetic, under the same fp32 criteria"""
+    """mode fp32x3: the convolutions (forward, data and weight gradient) in the 3xbf16 arithmetic, under the same fp32 criteria.
+    mode bf16 (BASELINE configs[2]): against the ORACLE RUN ON BF16-ROUNDED CONVOLUTION OPERANDS (oracle.CONV_BF16: forward
+    conv(r(x), r(w)), data gradient from r(dy), r(w), weight gradient from r(x), r(dy), fp32 everywhere else) - the same
+    arithmetic on the CPU, not the GPU's own fp32 run."""
     from litemkd_amd import ops
     ops.set_conv_compute_dtype(mode)
     try:
-        _episode_matches_oracle(dev, shot, query, img, clf, dist, bb)
+        _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode == "bf16")
     finally:
         ops.set_conv_compute_dtype("fp32")
 
@@ -64,7 +68,7 @@ def _hip_relu_masks(taps):
     return masks
 
 
-def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb):
+def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
     from litemkd_amd.model.model_select import Student, Teacher
     from litemkd_amd.distillers import Distiller
     from litemkd_amd.options import default_args
@@ -111,13 +115,18 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb):
                 diff = m != (t.detach() > 0)
                 flips[0] += int(diff.sum())
                 flips[1] += m.numel()
-                assert not bool(diff.any()) or float(t.detach()[diff].abs().max()) < 1e-5 * float(t.detach().abs().max()), site[0]
+                # bf16 mode: an activation within fp32 rounding of a bf16 rounding boundary rounds the other way in the other
+                # implementation (1 bf16 ulp = 0.4 %), so downstream pre-activations agree to ~1e-4, not 1e-6
+                lim = (1e-2 if bf16 else 1e-5) * float(t.detach().abs().max())
+                assert not bool(diff.any()) or float(t.detach()[diff].abs().max()) < lim, site[0]
             return _MaskedReLU.apply(t, m.to(dt))
         O.RELU_HOOK = hook if imposed else None
+        O.CONV_BF16 = bf16
         try:
             o = O.student_forward(e, p, 5, shot, classifier=clf, backbone=bb)
         finally:
             O.RELU_HOOK = None
+            O.CONV_BF16 = False
         ot = O.clf_TRX_2fcsup_fixed(e["support_set_feature_teacher"], e["support_labels"], e["target_set_feature_teacher"],
                                     {k: v.to(dt) for k, v in tp.items()}, 5, shot)
         ol = O.distill_fc_2_sup_dist(o["logits"], ot, labels)["loss"]
@@ -126,19 +135,31 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb):
     _, o, ot, ol = oracle(torch.float32, False)                  # forward values, logits, loss: the plain oracle
     sp32, _, _, _ = oracle(torch.float32, impose)               # gradients: both precisions with the HIP masks imposed
     sp64, _, _, ol64 = oracle(torch.float64, impose)
-    assert flips[0] <= max(8, flips[1] // 100000), flips
-    # features: rel 2e-3 of max; logits O(1e2..1e3): abs 2e-2 + rel 2e-3; loss rel 1e-3 (fp32, different summation order)
-    for k in ("context_features_1", "context_features_2"):
-        assert _rel(out["context_features"][k], o["context_features"][k]) < 2e-3, k
-    for k in ("kl", "ce", "sup"):
-        a, b = out["logits"][k].detach().cpu(), o["logits"][k].detach()
-        assert torch.allclose(a, b, rtol=2e-3, atol=2e-2), (k, float((a - b).abs().max()))
-        assert torch.allclose(tl[k].cpu(), ot[k], rtol=1e-4, atol=2e-2) if k != "ce" else True
-    assert abs(loss.item() - ol.item()) < 1e-3 * max(1.0, abs(ol.item()))
+    assert flips[0] <= max(8, flips[1] // (2000 if bf16 else 100000)), flips
+    if bf16:
+        # bf16 convolution operands: two fp32 implementations of this arithmetic agree only to ~1e-4 RMS (an activation within
+        # fp32 rounding of a bf16 rounding boundary rounds the other way: 1 bf16 ulp = 0.4 % of that element), so the forward is
+        # ANCHORED like the gradients: error against the oracle in fp64 (exact accumulation of the same bf16-rounded products) at
+        # most 3x the error of the oracle's own fp32 run
+        _, o64, ot64, ol64u = oracle(torch.float64, False)
+        for k in ("context_features_1", "context_features_2"):
+            anchored(k, out["context_features"][k], o["context_features"][k], o64["context_features"][k], 3.0, 1e-5)
+        for k in ("kl", "ce", "sup"):
+            anchored("logits " + k, out["logits"][k], o["logits"][k], o64["logits"][k], 3.0, 1e-5)
+        assert abs(loss.item() - ol64u.item()) <= 3 * abs(ol.item() - ol64u.item()) + 1e-3 * abs(ol64u.item()), (loss.item(), ol.item(), ol64u.item())
+    else:
+        # features: rel 2e-3 of max; logits O(1e2..1e3): abs 2e-2 + rel 2e-3; loss rel 1e-3 (fp32, different summation order)
+        for k in ("context_features_1", "context_features_2"):
+            assert _rel(out["context_features"][k], o["context_features"][k]) < 2e-3, k
+        for k in ("kl", "ce", "sup"):
+            a, b = out["logits"][k].detach().cpu(), o["logits"][k].detach()
+            assert torch.allclose(a, b, rtol=2e-3, atol=2e-2), (k, float((a - b).abs().max()))
+            assert torch.allclose(tl[k].cpu(), ot[k], rtol=1e-4, atol=2e-2) if k != "ce" else True
+        assert abs(loss.item() - ol.item()) < 1e-3 * max(1.0, abs(ol.item()))
     # argmax bit-exact wherever the oracle's top-2 margin exceeds the logit tolerance
     lg = o["logits"]["kl"].detach() + o["logits"]["ce"].detach()
     srt = torch.sort(lg, -1).values
-    clear = (srt[:, -1] - srt[:, -2]) > 5e-2
+    clear = (srt[:, -1] - srt[:, -2]) > (1.0 if bf16 else 5e-2)
     assert torch.equal(pred.cpu()[clear], torch.argmax(lg, -1)[clear])
     # gradients of every parameter, fp64-anchored (tests/_anchor.py): per tensor, the HIP gradient's relative-L2 error against
     # the oracle run in fp64 is at most 3x the error of the oracle's own fp32 run.  For the BasicBlock trunks both oracle runs use
