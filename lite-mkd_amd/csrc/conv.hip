@@ -797,7 +797,7 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
 // rounds of resident workgroups: an arbitrary count leaves a 1.5-round launch that runs as long as a 2-round one.
 static int g_wgrad_planes = 1;   // bf16 / 3xbf16 modes: weight gradient on the bf16-plane kernel (wgrad_x3.h); 0 = fp32-tile kernel
 extern "C" int lmkd_conv_set_wgrad_planes(int on) { g_wgrad_planes = on ? 1 : 0; return LMKD_OK; }
-static inline bool wgrad_uses_planes(int Cs) { return (g_conv_x3 || g_conv_bf16) && g_wgrad_planes && Cs != 4; }
+static inline bool wgrad_uses_planes(int Cs) { (void)Cs; return (g_conv_x3 || g_conv_bf16) && g_wgrad_planes; }
 
 static void wgrad_plan(int Mpix, int Cout, int Kp, int* splits, int* steps_per_split, int* bm, int* bn, bool planes = false) {
   // both operands are K-outer here (b32 fragment reads): the 128-wide tiles (1 read per MFMA) beat 64x64 (2 per MFMA):
@@ -883,9 +883,13 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   if (planes) {
 #define LMKD_WGX3(CFG)                                                                                                   \
   do {                                                                                                                   \
-    if (g_conv_bf16) {                                                                                                   \
-      if (pre_stats) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, true, 1, true>), grid, dim3(256), 0, s, a);          \
-      else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, true, 1, false>), grid, dim3(256), 0, s, a);                   \
+    if (smallc) {                                                                                                        \
+      if (g_conv_bf16) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, true, 1, false>), grid, dim3(256), 0, s, a);       \
+      else if (g_conv_x3 == 9) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, true, 9, false>), grid, dim3(256), 0, s, a); \
+      else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, true, 6, false>), grid, dim3(256), 0, s, a);                    \
+    } else if (g_conv_bf16) {                                                                                            \
+      if (pre_stats) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 1, true>), grid, dim3(256), 0, s, a);         \
+      else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 1, false>), grid, dim3(256), 0, s, a);                  \
     } else if (g_conv_x3 == 9) {                                                                                         \
       if (pre_stats) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 9, true>), grid, dim3(256), 0, s, a);         \
       else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 9, false>), grid, dim3(256), 0, s, a);                  \
@@ -897,6 +901,7 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
     using W128 = WgCfg<128, 128, 2, 2>;
     using W128x64 = WgCfg<128, 64, 2, 2>;
     using W64 = WgCfg<64, 64, 2, 2>;
+    LMKD_REQUIRE(!smallc || (bm == 64 && bn == 64), "lmkd_conv2d_bwd_weight: padded-stem path expects Cout <= 64");
     if (bm == 128 && bn == 128) LMKD_WGX3(W128);
     else if (bm == 128) LMKD_WGX3(W128x64);
     else LMKD_WGX3(W64);
