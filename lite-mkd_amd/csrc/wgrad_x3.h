@@ -168,17 +168,6 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
     }
   };
 
-  // Blocked summation for the 64x64 configuration (Cout <= 64: the stem and layer 1, whose reductions run over 0.6 - 2.5 M
-  // pixels): every FLUSH K-steps the MFMA accumulators are added into a second set of fp32 sums and cleared, so a rounding
-  // error is relative to a 16-step partial sum instead of the whole slab's running sum (measured against fp64 on the 200-frame
-  // stem: relative L2 error 8.3e-6 -> as the fp32 MFMA kernel).  One accumulator tile = 16 extra registers.
-  constexpr bool BLOCKED = Cfg::TM * Cfg::TN == 1;
-  constexpr int FLUSH = 16;
-  f32x16 tot[BLOCKED ? 1 : 0 + 1];
-  if (BLOCKED) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) tot[0][e] = 0.f;
-  }
   if (nk > 0) {
     unsigned char* A0 = smem;
     unsigned char* B0 = smem + A_BYTES;
@@ -192,16 +181,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
         lb.load((s0 + t + 1) * LMKD_BK);
       }
       kstep(A0, B0);
-      if (BLOCKED && (t % FLUSH) == FLUSH - 1) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { tot[0][e] += acc[0][0][e]; acc[0][0][e] = 0.f; }
-      }
       __syncthreads();                        // every wave has read the tile before it is overwritten
     }
-  }
-  if (BLOCKED) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[0][0][e] += tot[0][e];
   }
 
   float* C = a.slab + (long)z * a.Co * a.Kp;
