@@ -254,9 +254,11 @@ def main():
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
     if tfiles:
         tj = json.load(open(tfiles[-1]))
-        if tj.get("kernel_src_hash") == kernel_source_hash():
-            traffic = tj.get("conv_gemm_kernel", {}).get("traffic_bytes_per_launch")
-            traffic_note = "rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch, %s" % os.path.relpath(tfiles[-1], ROOT)
+        if a.dtype != "f32":
+            traffic_note = "%s holds the PMC passes of the headline arithmetic only" % os.path.relpath(tfiles[-1], ROOT)
+        elif tj.get("kernel_src_hash") == kernel_source_hash():
+            traffic = tj.get("conv_gemm_x3_kernel", {}).get("traffic_bytes_per_launch")
+            traffic_note = "rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch of conv_gemm_x3_kernel, %s" % os.path.relpath(tfiles[-1], ROOT)
         else:
             traffic_note = "%s was measured on other kernel sources (hash %s, now %s): not reported" % (
                 os.path.relpath(tfiles[-1], ROOT), tj.get("kernel_src_hash"), kernel_source_hash())
