@@ -641,6 +641,14 @@ static void launch_conv_x3(ConvGemmArgs a, int ncols, hipStream_t s) {
   // main loop of the instance without the statistics epilogue worse (register copies in front of the MFMAs: 105 vs 148 TFLOP/s
   // on the same layer), so that instance is not built
   (void)STATS;
+  if constexpr (!SMALLC) {
+    if (a.pre_stats) {      // training forward fed by relu(BatchNorm(raw)): normalise + rectify when the tile is stored to LDS
+      if (g_conv_bf16) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, false, true, 1, true>), grid, dim3(Cfg::THREADS), 0, s, a);
+      else if (g_conv_x3 == 9) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, false, true, 9, true>), grid, dim3(Cfg::THREADS), 0, s, a);
+      else hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, false, true, 6, true>), grid, dim3(Cfg::THREADS), 0, s, a);
+      return;
+    }
+  }
   if (g_conv_bf16) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, SMALLC, true, 1>), grid, dim3(Cfg::THREADS), 0, s, a);
   else if (g_conv_x3 == 9) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, SMALLC, true, 9>), grid, dim3(Cfg::THREADS), 0, s, a);
   else hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, SMALLC, true, 6>), grid, dim3(Cfg::THREADS), 0, s, a);
@@ -694,8 +702,8 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
   a.src = x; a.wpk = wp; a.out = y; a.stat_partial = stat_partial;
   a.ep_stats = ep_stats; a.ep_res = ep_res; a.ep_relu = ep_relu;
   a.pre_stats = pre_stats;
-  LMKD_REQUIRE(!pre_stats || (stat_partial && !smallc && !g_conv_x3 && !g_conv_bf16),
-               "lmkd_conv2d_fwd_pre: the fused BatchNorm+ReLU loader exists for the fp32 training forward (stat_partial given, Cs %% 32 == 0)");
+  LMKD_REQUIRE(!pre_stats || (stat_partial && !smallc),
+               "lmkd_conv2d_fwd_pre: the fused BatchNorm+ReLU loader exists for the training forward (stat_partial given, Cs %% 32 == 0)");
   a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cs;
   a.Ho = conv_out(H, KH, stride, pad); a.Wo = conv_out(W, KW, stride, pad); a.Co = Cout;
   LMKD_REQUIRE(a.Ho > 0 && a.Wo > 0, "lmkd_conv2d_fwd: empty output");

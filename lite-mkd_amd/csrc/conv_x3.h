@@ -129,17 +129,25 @@ struct X3GatherA {
       reg[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   }
-  template <int NPL>
-  __device__ __forceinline__ void store(unsigned char* S, const float4 (&reg)[NI]) const {
+  // PRE (training forward of a convolution fed by relu(BatchNorm(raw))): the tile in `reg` holds RAW values of tap `tp`; rows
+  // whose tap falls on a real pixel are normalised + rectified here, at store time (bit-identical to bn_apply_kernel); the
+  // zero padding stays zero
+  template <int NPL, bool PRE = false>
+  __device__ __forceinline__ void store(unsigned char* S, const float4 (&reg)[NI], int tp = 0, float4 psc = float4(), float4 psh = float4()) const {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       unsigned char* d = S + (((tid >> 3) + RPP * i) * X3_LD + kc4) * 2;
+      float4 v = reg[i];
+      if (PRE && ((mask[i] >> tp) & 1u)) {
+        v.x = fmaxf(fmaf(v.x, psc.x, psh.x), 0.f); v.y = fmaxf(fmaf(v.y, psc.y, psh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, psc.z, psh.z), 0.f); v.w = fmaxf(fmaf(v.w, psc.w, psh.w), 0.f);
+      }
       if (NPL == 1) {
-        *reinterpret_cast<uint2*>(d) = x3_round4(reg[i]);
+        *reinterpret_cast<uint2*>(d) = x3_round4(v);
       } else {
         uint2 p0, p1, p2;
-        x3_split4(reg[i], p0, p1, p2);
+        x3_split4(v, p0, p1, p2);
         *reinterpret_cast<uint2*>(d) = p0;
         *reinterpret_cast<uint2*>(d + ROWS * X3_LD * 2) = p1;
         *reinterpret_cast<uint2*>(d + 2 * ROWS * X3_LD * 2) = p2;
@@ -218,7 +226,7 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* __restrict__ As, i
   }
 }
 
-template <class Cfg, bool SMALLC, bool STATS, int NPROD>
+template <class Cfg, bool SMALLC, bool STATS, int NPROD, bool PRE = false>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs a) {
   using LA = X3GatherA<Cfg::BM, SMALLC, Cfg::THREADS>;
   constexpr int NPL = NPROD == 1 ? 1 : 3;                 // NPROD == 1: plain bf16 (one RNE-rounded plane, one product)
@@ -298,6 +306,32 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
     lb.load(s_tap_kofs[b_tp] + b_cc * LMKD_BK, rb);
     if (++b_tp == ntap_c) { b_tp = 0; ++b_cc; }
   };
+  // PRE: (tap, chunk) of the NEXT tile to be stored, and the BatchNorm scale / shift of this lane's 4 channels for the current
+  // chunk and the one after it (fetched a whole chunk = ntap K-steps ahead of their first use)
+  int s_tp = 0, s_cc = 0;
+  float4 psc_cur = float4(), psh_cur = float4(), psc_nxt = float4(), psh_nxt = float4();
+  auto pre_fetch = [&](int cc, float4& sc, float4& sh) {
+    const int c = (cc < a.cps ? cc : a.cps - 1) * LMKD_BK + la.kc4;
+    sc = *reinterpret_cast<const float4*>(a.pre_stats + 2 * a.Cs + c);
+    sh = *reinterpret_cast<const float4*>(a.pre_stats + 3 * a.Cs + c);
+  };
+  if (PRE) {
+    pre_fetch(0, psc_cur, psh_cur);
+    pre_fetch(1, psc_nxt, psh_nxt);
+  }
+  auto store_a = [&](unsigned char* dst, float4 (&ra)[LA::NI]) {
+    if constexpr (PRE) {
+      la.template store<NPL, true>(dst, ra, s_tp, psc_cur, psh_cur);
+      if (++s_tp == ntap_c) {
+        s_tp = 0;
+        ++s_cc;
+        psc_cur = psc_nxt; psh_cur = psh_nxt;
+        pre_fetch(s_cc + 1, psc_nxt, psh_nxt);
+      }
+    } else {
+      la.template store<NPL>(dst, ra);
+    }
+  };
   const bool store_first = __builtin_amdgcn_readfirstlane(wave) >= Cfg::WM * Cfg::WN / 2;
   // K-step t: MFMAs on LDS buffer t&1 with the B fragments in `rb`; the A set `ra` (step t+1) goes to the other buffer and
   // is refilled with step t+3.  Waves 4-7 (store first) fetch B(t+1) into `rbn` before their MFMAs; waves 0-3 (MFMAs first)
@@ -309,7 +343,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
       x3_landed(ra);
       x3_landed(rb);
       if (t + 1 < nk) {
-        la.template store<NPL>(nxt, ra);
+        store_a(nxt, ra);
         if (t + 3 < nk) issue_a(t + 3, ra);
         issue_b(t + 1, rbn);
       }
@@ -318,7 +352,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
     if (!store_first && t + 1 < nk) {
       x3_landed(ra);
       x3_landed(rbn);
-      la.template store<NPL>(nxt, ra);
+      store_a(nxt, ra);
       if (t + 3 < nk) issue_a(t + 3, ra);
       if (t + 2 < nk) issue_b(t + 2, rb);
     }
@@ -329,7 +363,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
     issue_b(0, rb0);
     if (nk > 1) issue_a(1, ra1);
     x3_landed(ra0);
-    la.template store<NPL>(smem, ra0);
+    store_a(smem, ra0);
     if (nk > 2) issue_a(2, ra0);
     if (!store_first) {
       x3_landed(rb0);

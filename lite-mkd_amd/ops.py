@@ -423,12 +423,22 @@ def conv_bn_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, relu, res=None):
 
 # Training: the BatchNorm + ReLU between two convolutions of a block runs in the CONSUMER's loader (forward conv and weight
 # gradient), so the normalised activation is never written to HBM; the block output is written once, together with its ReLU
-# mask as bits for the backward.  fp32 MFMA mode only (the bf16-plane kernels have their own loader).
+# mask as bits for the backward.  The loaders exist in all arithmetic modes (conv_gemm_kernel / conv_gemm_x3_kernel, conv_wgrad_kernel /
+# conv_wgrad_x3_kernel, bit-identical to the materialising path in each); the POLICY uses them in the native fp32 mode only: measured
+# at 200 frames, the bf16-plane forward pays 14-112 us (3xbf16) / 32-81 us (bf16) for the store-side arithmetic and the weight
+# gradient up to 30 us, against 12-56 us for the bn_apply launch they save (tools/pre_bench.py).  FUSE_PRE_ALL_MODES forces them on.
 FUSE_TRAIN_BN = True
+FUSE_PRE_ALL_MODES = False
 
 
 def _train_fused():
-    return FUSE_TRAIN_BN and lib().value("lmkd_conv_get_compute_dtype") == 0
+    """block-output ReLU mask as bits (every mode)"""
+    return FUSE_TRAIN_BN
+
+
+def _train_pre():
+    """inner BatchNorm + ReLU in the consumers' loaders"""
+    return FUSE_TRAIN_BN and (FUSE_PRE_ALL_MODES or lib().value("lmkd_conv_get_compute_dtype") == 0)
 
 
 def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training, pre_stats=None):
@@ -571,8 +581,9 @@ class BasicBlockFn(torch.autograd.Function):
             r = x if wd is None else conv_bn_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, False)
             return conv_bn_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, True, r)
         fused = training and _train_fused()
+        pre = training and _train_pre()
         c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, stride, 1, g1, b1, rm1, rv1, training)
-        if fused:       # conv2 normalises + rectifies c1 in its loader: a1 = relu(bn1(c1)) is never stored
+        if pre:         # conv2 normalises + rectifies c1 in its loader: a1 = relu(bn1(c1)) is never stored
             a1 = None
             c2, st2 = _conv_bn_train_or_eval(c1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training, pre_stats=st1)
         else:
@@ -611,7 +622,7 @@ class BasicBlockFn(torch.autograd.Function):
         dc2, g, dg2, db2 = bn_backward(dy, c2, y, st2, g2, 3 if ctx.fused else 1, want_g=True)
         wd2 = pack_weights(w2, Cmid, 1)
         # first: its stream then waits for the BatchNorm backward only, not for the data gradient
-        dw2 = weight_grad(w2, c1, dc2, 1, 1, st1) if ctx.fused else weight_grad(w2, a1, dc2, 1, 1)
+        dw2 = weight_grad(w2, c1, dc2, 1, 1, st1) if a1 is None else weight_grad(w2, a1, dc2, 1, 1)
         da1 = conv_bwd_data(dc2, wd2, c1.shape, Cmid, 3, 3, 1, 1)
         del dc2
         dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)    # mask from c1*scale+shift > 0
@@ -652,8 +663,9 @@ class BottleneckFn(torch.autograd.Function):
             r = x if wd is None else conv_bn_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, False)
             return conv_bn_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, True, r)
         fused = training and _train_fused()
+        pre = training and _train_pre()
         c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, 1, 0, g1, b1, rm1, rv1, training)
-        if fused:       # conv2 / conv3 normalise + rectify their raw inputs in the loader (BasicBlockFn)
+        if pre:         # conv2 / conv3 normalise + rectify their raw inputs in the loader (BasicBlockFn)
             a1 = a2 = None
             c2, st2 = _conv_bn_train_or_eval(c1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training, pre_stats=st1)
             c3, st3 = _conv_bn_train_or_eval(c2, w3, Cm, 1, 0, g3, b3, rm3, rv3, training, pre_stats=st2)
@@ -687,11 +699,11 @@ class BottleneckFn(torch.autograd.Function):
         fused = ctx.fused
         Cm, Co = w1.shape[0], w3.shape[0]
         dc3, g, dg3, db3 = bn_backward(dy, c3, y, st3, g3, 3 if fused else 1, want_g=True)
-        dw3 = weight_grad(w3, c2, dc3, 1, 0, st2) if fused else weight_grad(w3, a2, dc3, 1, 0)       # weight gradients first (BasicBlockFn)
+        dw3 = weight_grad(w3, c2, dc3, 1, 0, st2) if a2 is None else weight_grad(w3, a2, dc3, 1, 0)       # weight gradients first (BasicBlockFn)
         da2 = conv_bwd_data(dc3, pack_weights(w3, Cm, 1), c2.shape, Co, 1, 1, 1, 0)
         del dc3
         dc2, _, dg2, db2 = bn_backward(da2, c2, None, st2, g2, 2, dx_out=da2)
-        dw2 = weight_grad(w2, c1, dc2, stride, 1, st1) if fused else weight_grad(w2, a1, dc2, stride, 1)
+        dw2 = weight_grad(w2, c1, dc2, stride, 1, st1) if a1 is None else weight_grad(w2, a1, dc2, stride, 1)
         da1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), c1.shape, Cm, 3, 3, stride, 1)
         del dc2, da2
         dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)

@@ -158,8 +158,9 @@ def test_bn_train_apply_backward(dev):
     close(db, beta.grad, 1e-3, 1e-3, "dbeta")
 
 
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3", "bf16"])
 @pytest.mark.parametrize("cfg", [(5, 64, 14, 14, 64, 3, 1, 1), (3, 128, 9, 11, 128, 3, 2, 1), (4, 256, 7, 7, 64, 1, 1, 0), (40, 128, 28, 28, 128, 3, 1, 1)])
-def test_conv_fused_bn_relu_loader_bit_identical(dev, cfg):
+def test_conv_fused_bn_relu_loader_bit_identical(dev, cfg, mode):
     """training-mode fusion (lmkd_conv2d_fwd_pre / lmkd_conv2d_bwd_weight_pre): the convolution reads the RAW previous conv
     output and applies relu(BatchNorm(.)) in its loader; results (output, BatchNorm partial sums, weight gradient) must be
     BIT-identical to materialising the activation with lmkd_bn_apply first — zero padding included (it pads the activation)."""
@@ -171,15 +172,19 @@ def test_conv_fused_bn_relu_loader_bit_identical(dev, cfg):
     part = torch.stack([flat.sum(0, keepdim=True), (flat ** 2).sum(0, keepdim=True)], -1).contiguous()
     st = ops.bn_stats_train(part, flat.shape[0], gamma, beta, None, None)
     w = (rnd(Cout, C, K, K, seed=43) * math.sqrt(2.0 / (Cout * K * K))).to(dev)
-    wp = ops.pack_weights(w, C, 0)
-    a1 = ops.bn_apply(c1, st, True)
-    y0, p0 = ops.conv_fwd(a1, wp, Cout, K, K, s, p, True)
-    y1, p1 = ops.conv_fwd(c1, wp, Cout, K, K, s, p, True, pre_stats=st)
-    assert torch.equal(y0, y1) and torch.equal(p0, p1)
-    dy = rnd(*y0.shape, seed=44).to(dev)
-    dw0 = ops.conv_bwd_weight(a1, dy, (Cout, C, K, K), s, p)
-    dw1 = ops.conv_bwd_weight(c1, dy, (Cout, C, K, K), s, p, pre_stats=st)
-    assert torch.equal(dw0, dw1)
+    ops.set_conv_compute_dtype(mode)
+    try:
+        wp = ops.pack_weights(w, C, 0)
+        a1 = ops.bn_apply(c1, st, True)
+        y0, p0 = ops.conv_fwd(a1, wp, Cout, K, K, s, p, True)
+        y1, p1 = ops.conv_fwd(c1, wp, Cout, K, K, s, p, True, pre_stats=st)
+        assert torch.equal(y0, y1) and torch.equal(p0, p1)
+        dy = rnd(*y0.shape, seed=44).to(dev)
+        dw0 = ops.conv_bwd_weight(a1, dy, (Cout, C, K, K), s, p)
+        dw1 = ops.conv_bwd_weight(c1, dy, (Cout, C, K, K), s, p, pre_stats=st)
+        assert torch.equal(dw0, dw1)
+    finally:
+        ops.set_conv_compute_dtype("fp32")
     assert float((a1 == 0).float().mean()) > 0.2          # the ReLU did clip: the test would not see a missing max otherwise
 
 
@@ -205,8 +210,9 @@ def test_bn_apply_relu_bit_mask(dev):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3", "bf16"])
 @pytest.mark.parametrize("kind,cin,cout,stride", [("basic", 64, 128, 2), ("basic", 64, 64, 1), ("bottleneck", 256, 128, 2), ("bottleneck", 512, 128, 1)])
-def test_block_fused_training_path_bit_identical(dev, kind, cin, cout, stride):
+def test_block_fused_training_path_bit_identical(dev, kind, cin, cout, stride, mode):
     """BasicBlock / Bottleneck with the BatchNorm+ReLU of the inner activations fused into the consumers' loaders and the
     output mask as bits (ops.FUSE_TRAIN_BN) vs the materialising path: outputs, input gradient and every parameter gradient
     bit-identical (same arithmetic, fewer passes over HBM)"""
@@ -221,6 +227,8 @@ def test_block_fused_training_path_bit_identical(dev, kind, cin, cout, stride):
     x = torch.relu(torch.randn(6, 12, 12, cin, device=dev))
     gy = None
     outs = []
+    ops.set_conv_compute_dtype(mode)
+    ops.FUSE_PRE_ALL_MODES = True          # the loaders of the bf16-plane kernels too (policy: native fp32 only, ops._train_pre)
     for fuse in (False, True):
         ops.FUSE_TRAIN_BN = fuse
         try:
@@ -233,6 +241,9 @@ def test_block_fused_training_path_bit_identical(dev, kind, cin, cout, stride):
             outs.append((y.detach().clone(), xi.grad.clone(), {k: v.grad.clone() for k, v in blk.named_parameters()}))
         finally:
             ops.FUSE_TRAIN_BN = True
+            if fuse:
+                ops.set_conv_compute_dtype("fp32")
+                ops.FUSE_PRE_ALL_MODES = False
     (y0, dx0, g0), (y1, dx1, g1) = outs
     assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
     for k in g0:

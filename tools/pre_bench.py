@@ -13,6 +13,9 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+import sys
+MODE = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+ops.set_conv_compute_dtype(MODE)
 for name, H, C, Cout in [("layer1", 56, 64, 64), ("layer2", 28, 128, 128), ("layer3", 14, 256, 256), ("layer4", 7, 512, 512)]:
     N = 200
     c1 = torch.randn(N, H, H, C, device=dev)
