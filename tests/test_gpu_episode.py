@@ -299,6 +299,45 @@ def test_kl_feature_episode_and_evaluator(dev, tmp_path):
     assert 0.0 <= ev.test()[cfg.dataset]["accuracy"] <= 100.0
 
 
+def test_live_mfm_episode_resnet50(dev):
+    """BASELINE configs[4] shape in the loop: ResNet-50 student (resnet50_2fc) + the MFM fusion computing the teacher features of
+    the episode LIVE from rgb / depth / flow per-modality features (ThreeTRXShiftLoopTime.extract_feature at its full width 2048,
+    teacher/code/model.py:1648-1664), frozen TRX_2fcsup_fixed teacher on them, fc_2_sup_dist, backward.  The fused features equal
+    the oracle's MFM on the same weights and the teacher logits the oracle's TRX on them; the student side is finite and complete."""
+    import argparse
+    from litemkd_amd import trainloop as TL
+    from litemkd_amd.teacher import ThreeTRXShiftLoopTime
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd.utils import aggregate_accuracy
+    from oracle import ref_cpu as O
+    cfg = default_args(shot=1, query_per_class=1, img_size=64, trans_dropout=0.0, device=dev, model_backbone="resnet50_2fc")
+    torch.manual_seed(13)
+    student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
+    with torch.device(dev):
+        mfm = ThreeTRXShiftLoopTime(argparse.Namespace(seq_len=8, trans_num=2, shirt_num=1)).eval()
+    p = O.make_mfm_params(5)
+    mfm.load_state_dict(p, strict=True)
+    rgb, depth, flow = O.make_mfm_inputs(6, 10)
+    fused = mfm.extract_feature({"rgb": rgb.to(dev), "depth": depth.to(dev), "flow": flow.to(dev)})
+    with torch.no_grad():
+        ref = O.mfm_extract_feature(rgb, depth, flow, p, 1, 2)
+    assert float((fused.cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max()) + 2e-4
+    ep = O.make_episode(321, 5, 1, 1, img=64)
+    ep = dict(ep, support_set_feature_teacher=fused[:5].cpu(), target_set_feature_teacher=fused[5:].cpu())
+    loss, acc, _ = TL.train_task({k: v.unsqueeze(0) for k, v in ep.items()}, student, teacher, Distiller("fc_2_sup_dist", cfg.cfg, dev),
+                                 aggregate_accuracy, cfg)
+    assert torch.isfinite(loss) and 0.0 <= float(acc) <= 1.0
+    tp = {k[len("classifier.transformers."):]: v.detach().cpu() for k, v in teacher.state_dict().items() if k.startswith("classifier.transformers.")}
+    tl = teacher(fused[:5], ep["support_labels"].to(dev), fused[5:])["logits"]
+    ot = O.clf_TRX_2fcsup_fixed(ref[:5], ep["support_labels"], ref[5:], tp, 5, 1)
+    for k in ("kl", "sup"):
+        assert torch.allclose(tl[k].cpu(), ot[k], rtol=2e-3, atol=5e-2), (k, float((tl[k].cpu() - ot[k]).abs().max()))
+    g = [q.grad for q in student.parameters() if q.grad is not None]
+    assert len(g) > 150 and all(torch.isfinite(x).all() for x in g)
+
+
 def test_full_size_properties(dev):
     """BASELINE size (5-way 5-shot, 8x224^2): properties that need no oracle —
     BN batch independence of the two trunk calls, permutation equivariance over frames, determinism."""

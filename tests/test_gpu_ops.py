@@ -315,7 +315,8 @@ class _MaskedReLU(torch.autograd.Function):
 
 
 @pytest.mark.parametrize("N,cin,cout,H,stride", [(6, 256, 512, 6, 2), (6, 512, 512, 3, 1), (6, 64, 128, 24, 2), (6, 64, 64, 24, 1),
-                                                 (40, 64, 128, 56, 2), (40, 128, 128, 28, 1), (40, 256, 512, 14, 2)])
+                                                 (40, 64, 128, 56, 2), (40, 128, 128, 28, 1), (40, 256, 512, 14, 2),
+                                                 (200, 128, 256, 28, 2), (200, 256, 256, 14, 1)])
 def test_block_isolated(dev, N, cin, cout, H, stride):
     """one BasicBlock (with / without downsample) fwd + bwd on identical inputs.  The hand-scheduled backward (accumulate
     epilogue, bn1 mask recompute, strided 1x1 gradient accumulated onto the pixels it reaches) is judged per tensor against an
@@ -327,7 +328,9 @@ def test_block_isolated(dev, N, cin, cout, H, stride):
     after checking that those masks differ from the fp64 masks only where the fp64 pre-activation is within 1e-5 of zero: what
     remains is a linear map of the upstream gradient, where any indexing / scheduling / accumulation bug shows at full size.
     The 40-frame cases are large enough for the 128x128 tile, the 4-class stride-2 data gradient with many tiles per class,
-    XCD-banded tile orders and multi-round weight-gradient splits."""
+    XCD-banded tile orders and multi-round weight-gradient splits; the 200-frame cases ARE two of the benchmark's blocks (layer 3,
+    with and without downsample): full-size backward with the accumulate epilogue, the strided 1x1 gradient accumulating onto
+    the pixels it reaches and the fused BatchNorm loaders, all inside one hand-scheduled backward."""
     from litemkd_amd import ops
     from litemkd_amd.model.backbone import resnet as R
     from _anchor import anchored, anchored_dict
