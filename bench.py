@@ -66,12 +66,14 @@ def main():
     ap.add_argument("--serial", action="store_true", help="queue the two trunk calls on ONE stream (no kernel overlap); use this "
                     "mode under rocprofv3 so per-kernel durations are not inflated by concurrent kernels")
     ap.add_argument("--roofline-episodes", type=int, default=2)
-    ap.add_argument("--dtype", choices=["f32", "f32native", "bf16", "f32x3"], default="f32", help="f32 (headline, BASELINE "
+    ap.add_argument("--dtype", choices=["f32", "f32native", "bf16", "bf16conv", "f32x3"], default="f32", help="f32 (headline, BASELINE "
                     "configs[1]): fp32 tensors, fp32 accumulation, the convolution products on the bf16 matrix pipe from an EXACT "
                     "3-way bf16 split of both operands, 6 products per fp32 product (csrc/conv_x3.h, wgrad_x3.h; error vs fp64 of "
                     "the class of the native fp32 MFMA: tests/test_gpu_fullsize.py); f32x3: alias of f32; f32native: the same "
                     "job on v_mfma_f32_32x32x2_f32 (round 1's headline arithmetic, reported under other_modes by default); "
-                    "bf16 (configs[2]): convolution operands rounded to bf16, fp32 accumulation, everything else fp32")
+                    "bf16 (configs[2]): bf16 tensors in HBM for every activation / activation gradient of the trunk, bf16 MFMA with "
+                    "fp32 accumulation, fp32 statistics, weights and heads; bf16conv: round 1's variant (fp32 tensors, only the "
+                    "convolution operands rounded)")
     ap.add_argument("--xcd-mode", type=int, default=-1, help="tuning: lmkd_conv_set_xcd_mode (-1 auto, 0 plain tile orders, 1 auto without XCD-grouped weight-gradient splits)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short bf16 / f32x3 side measurements of the default run")
     ap.add_argument("--ew-wg", type=int, default=0, help="tuning: workgroups per CU of the HBM-bound kernels (lmkd_set_elementwise_wg_per_cu), 0 = default")
@@ -109,8 +111,12 @@ def main():
         litemkd_amd.lib().call("lmkd_set_elementwise_wg_per_cu", a.ew_wg)
     if a.dtype == "f32x3":
         a.dtype = "f32"
-    MODE = {"f32": "fp32x3", "f32native": "fp32", "bf16": "bf16"}
-    ops.set_conv_compute_dtype(MODE[a.dtype])
+    MODE = {"f32": "fp32x3", "f32native": "fp32", "bf16": "bf16", "bf16conv": "bf16"}
+
+    def set_mode(name):
+        ops.set_conv_compute_dtype(MODE[name])
+        ops.set_activation_dtype("bf16" if name == "bf16" else "fp32")
+    set_mode(a.dtype)
     cfg = default_args(shot=a.shot, device=dev, trans_dropout=a.dropout, training_iterations=10 ** 9, print_freq=10 ** 9,
                        model_backbone=a.backbone)
     torch.manual_seed(1234)                                  # identical initial weights on every rank
@@ -239,11 +245,12 @@ def main():
     wg = fam.get("conv_wgrad_kernel", [0.0, 1.0, 1, 0.0])
     achieved = cg[0] / cg[1] / 1e12
     # dense MFMA peaks (MI355X_MICROARCH.md); the 3xbf16 arithmetic issues 6 bf16 MFMA flops per algorithmic fp32 flop
-    PEAK = {"f32": 2500.0 / 6, "f32native": PEAK_FP32_MFMA_TFLOPS, "bf16": 2500.0}
+    PEAK = {"f32": 2500.0 / 6, "f32native": PEAK_FP32_MFMA_TFLOPS, "bf16": 2500.0, "bf16conv": 2500.0}
     KERNEL = {"f32": "conv_gemm_x3_kernel (implicit-GEMM conv fwd + dgrad): v_mfma_f32_32x32x16_bf16 x6 per fp32 product, exact 3-way bf16 "
                      "operand split, fp32 accumulate; peak = dense bf16 MFMA peak / 6",
               "f32native": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad, v_mfma_f32_32x32x2_f32)",
-              "bf16": "conv_gemm_x3_kernel, one bf16 plane (implicit-GEMM conv fwd + dgrad, v_mfma_f32_32x32x16_bf16)"}
+              "bf16": "conv_gemm_x3_kernel, one bf16 plane, bf16 tensors (implicit-GEMM conv fwd + dgrad, v_mfma_f32_32x32x16_bf16)",
+              "bf16conv": "conv_gemm_x3_kernel, one bf16 plane, fp32 tensors"}
     peak = PEAK[a.dtype]
     # HBM-side traffic of the same kernel family: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950) of `bench.py --serial`,
@@ -271,13 +278,15 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "HMDB-shape 5-way %d-shot %s + TRX_2fcsup + D2M fc_2_sup_dist training episode%s, %s"
                                % (a.shot, a.backbone, " + live MFM fusion" if a.live_mfm else "",
-                                  {"f32": "fp32", "f32native": "fp32", "bf16": "bf16 conv operands / fp32 accumulate"}[a.dtype]),
+                                  {"f32": "fp32", "f32native": "fp32", "bf16": "bf16 tensors / fp32 accumulate", "bf16conv": "bf16 conv operands / fp32 tensors"}[a.dtype]),
                    "conv_arithmetic": {"f32": "fp32 tensors and accumulation; products on the bf16 matrix pipe from an exact 3-way bf16 "
                                               "split of both operands, 6 of 9 cross products (stem weight gradient on the fp32 MFMA); "
                                               "error vs fp64 within 3x of torch-CPU fp32 per layer and per parameter gradient "
                                               "(tests/test_gpu_fullsize.py, test_gpu_episode.py)",
                                        "f32native": "v_mfma_f32_32x32x2_f32 (exact fp32 products)",
-                                       "bf16": "conv operands rounded to bf16 (RNE), fp32 accumulation; activations / BatchNorm / loss fp32"}[a.dtype],
+                                       "bf16": "trunk activations and their gradients stored as bf16 in HBM, bf16 MFMA, fp32 accumulation; BatchNorm "
+                                               "statistics, weights, weight gradients, heads and loss fp32",
+                                       "bf16conv": "conv operands rounded to bf16 (RNE), fp32 accumulation; activations / BatchNorm / loss fp32"}[a.dtype],
                    "frames_per_episode": frames, "img": 224, "tasks_per_batch": cfg.tasks_per_batch, "optimizer": cfg.opt,
                    "episodes_per_optimizer_step_per_rank": every, "parallelism": "episode-parallel dp%d" % world,
                    "trans_dropout": a.dropout, "trunk_calls_overlapped_on_two_streams": not a.serial},
@@ -298,9 +307,9 @@ def main():
         # the same job in the two other arithmetic modes of the convolutions, for the record (never part of `value`):
         # short timed regions right here, same process, same resident episodes, each with its own per-kernel roofline pass
         other = {}
-        ALG_BYTES_PER_EPISODE = 3 * 25.8e6 * frames      # 25.8 MB of fp32 activation traffic per frame forward, x3 for a step
+        ALG_BYTES_PER_EPISODE = 3 * 12.9e6 * frames      # 12.9 MB of bf16 activation traffic per frame forward, x3 for a step
         for name in ("f32native", "bf16"):
-            ops.set_conv_compute_dtype(MODE[name])
+            set_mode(name)
             it = run(2, it)
             fence()
             t1 = time.perf_counter()
@@ -314,14 +323,14 @@ def main():
                            "roofline": {"bound": "mfma", "kernel": KERNEL[name], "achieved": ach, "peak": PEAK[name], "unit": "TFLOP/s",
                                         "frac": ach / PEAK[name], "avg_launch_ms": g2[1] / max(g2[2], 1) * 1e3,
                                         "wgrad_kernel_tflops": w2[0] / w2[1] / 1e12}}
-        ops.set_conv_compute_dtype(MODE["f32"])
+        set_mode("f32")
         other["f32native"]["what"] = "round 1's headline arithmetic: every convolution on the fp32 MFMA (157.3 TFLOP/s peak)"
-        other["bf16"]["what"] = "BASELINE configs[2]: conv operands rounded to bf16 (RNE), fp32 accumulate; activations in HBM still fp32"
+        other["bf16"]["what"] = "BASELINE configs[2]: bf16 tensors in HBM (activations and their gradients), bf16 MFMA, fp32 accumulate / statistics / weights"
         # configs[2] sits at the ridge of the bf16 roofline: report the HBM side as well, on algorithmic bytes
         gbs = ALG_BYTES_PER_EPISODE * other["bf16"]["value"] / 1e9
         other["bf16"]["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                                          "algorithmic_bytes_per_episode": ALG_BYTES_PER_EPISODE,
-                                         "note": "fp32 activations: 3 x 25.8 MB per frame (SURVEY 8d); whole-job average, not one kernel"}
+                                         "note": "bf16 activations: 3 x 12.9 MB per frame (SURVEY 8d); whole-job average, not one kernel"}
         out["other_modes"] = other
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.shot, a.cpu_episodes)

@@ -22,6 +22,12 @@ extern "C" {
 int lmkd_abi_version(void);
 const char* lmkd_last_error(void);
 int lmkd_device_check(int device); /* 0 iff `device` is gfx950 */
+/* storage type of the trunk's activation and activation-gradient tensors in HBM: 0 = fp32 (default), 1 = bf16 (BASELINE configs[2]:
+   the reference trains under autocast, trainwandb.py:20,126).  In mode 1 the activation pointers (`float*` below) of the
+   convolution, BatchNorm and pooling entry points address bf16 tensors; statistics, weights, weight gradients, workspaces and
+   everything after the pooled head stay fp32.  Needs lmkd_conv_set_compute_dtype(1). */
+int lmkd_set_activation_dtype(int mode);
+int lmkd_get_activation_dtype(void);
 
 /* ---- generic fp32 MFMA GEMM: C = alpha*op(A)*op(B) + beta*C + bias[col] (+relu), strided batched.
  * layA 'K': A[m*lda+k], 'M': A[k*lda+m];  layB 'K': B[n*ldb+k], 'N': B[k*ldb+n].

@@ -29,3 +29,12 @@ extern "C" int lmkd_device_check(int device) {
   }
   return LMKD_OK;
 }
+
+// storage type of the trunk's activation / activation-gradient tensors in HBM: 0 = fp32 (default), 1 = bf16 (common.h)
+int g_lmkd_act_bf16 = 0;
+extern "C" int lmkd_set_activation_dtype(int mode) {
+  LMKD_REQUIRE(mode == 0 || mode == 1, "lmkd_set_activation_dtype: 0 = fp32, 1 = bf16");
+  g_lmkd_act_bf16 = mode;
+  return LMKD_OK;
+}
+extern "C" int lmkd_get_activation_dtype(void) { return g_lmkd_act_bf16; }

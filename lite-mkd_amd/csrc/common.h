@@ -85,3 +85,48 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
   __syncthreads();
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
+
+// ---- activation storage type -------------------------------------------------------------------------------------------
+// BASELINE configs[2] stores every activation and activation-gradient tensor of the trunk in HBM as bf16 (the reference runs
+// under autocast, trainwandb.py:20,126); statistics, accumulators and everything after the pooled head stay fp32.  The
+// process-wide switch lmkd_set_activation_dtype selects which instance of the HBM-bound kernels and of the convolution loaders /
+// epilogues the entry points launch; in that mode the `float*` activation arguments of the C ABI address bf16 tensors.
+extern int g_lmkd_act_bf16;
+typedef unsigned short lmkd_bf16_t;      // raw bf16 bits
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float v) {      // round to nearest even (v_cvt_pk_bf16_f32)
+  union { __bf16 h; unsigned short u; } c;
+  c.h = (__bf16)v;
+  return c.u;
+}
+__device__ __forceinline__ float round_bf16(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+// 4 consecutive elements starting at element index 4*i4
+template <typename T> __device__ __forceinline__ float4 ld4(const T* __restrict__ p, long i4);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* __restrict__ p, long i4) { return reinterpret_cast<const float4*>(p)[i4]; }
+template <> __device__ __forceinline__ float4 ld4<lmkd_bf16_t>(const lmkd_bf16_t* __restrict__ p, long i4) {
+  const uint2 u = reinterpret_cast<const uint2*>(p)[i4];
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4(T* __restrict__ p, long i4, const float4& v);
+template <> __device__ __forceinline__ void st4<float>(float* __restrict__ p, long i4, const float4& v) { reinterpret_cast<float4*>(p)[i4] = v; }
+template <> __device__ __forceinline__ void st4<lmkd_bf16_t>(lmkd_bf16_t* __restrict__ p, long i4, const float4& v) {
+  uint2 u;
+  u.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+  u.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+  reinterpret_cast<uint2*>(p)[i4] = u;
+}
+template <typename T> __device__ __forceinline__ float ld1(const T* __restrict__ p, long i);
+template <> __device__ __forceinline__ float ld1<float>(const float* __restrict__ p, long i) { return p[i]; }
+template <> __device__ __forceinline__ float ld1<lmkd_bf16_t>(const lmkd_bf16_t* __restrict__ p, long i) { return bf16_to_f32(p[i]); }
+template <typename T> __device__ __forceinline__ void st1(T* __restrict__ p, long i, float v);
+template <> __device__ __forceinline__ void st1<float>(float* __restrict__ p, long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st1<lmkd_bf16_t>(lmkd_bf16_t* __restrict__ p, long i, float v) { p[i] = f32_to_bf16(v); }
+
+// launch the fp32 or the bf16-activation instance of a kernel template `K<T>` (first template argument = storage type)
+#define LMKD_ACT_DISPATCH(K, grid, block, shmem, stream, ...)                                                     \
+  do {                                                                                                             \
+    if (g_lmkd_act_bf16) hipLaunchKernelGGL((K<lmkd_bf16_t>), grid, block, shmem, stream, __VA_ARGS__);            \
+    else hipLaunchKernelGGL((K<float>), grid, block, shmem, stream, __VA_ARGS__);                                  \
+  } while (0)

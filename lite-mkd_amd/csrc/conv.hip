@@ -641,6 +641,11 @@ static void launch_conv_x3(ConvGemmArgs a, int ncols, hipStream_t s) {
   // main loop of the instance without the statistics epilogue worse (register copies in front of the MFMAs: 105 vs 148 TFLOP/s
   // on the same layer), so that instance is not built
   (void)STATS;
+  if (g_lmkd_act_bf16) {      // bf16 tensors in HBM (one-plane mode): the loader copies, the epilogue rounds; the stem input stays fp32
+    if constexpr (SMALLC) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, true, true, 1, false, 2>), grid, dim3(Cfg::THREADS), 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, false, true, 1, false, 3>), grid, dim3(Cfg::THREADS), 0, s, a);
+    return;
+  }
   if constexpr (!SMALLC) {
     if (a.pre_stats) {      // training forward fed by relu(BatchNorm(raw)): normalise + rectify when the tile is stored to LDS
       if (g_conv_bf16) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, false, true, 1, true>), grid, dim3(Cfg::THREADS), 0, s, a);
@@ -702,8 +707,9 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
   a.src = x; a.wpk = wp; a.out = y; a.stat_partial = stat_partial;
   a.ep_stats = ep_stats; a.ep_res = ep_res; a.ep_relu = ep_relu;
   a.pre_stats = pre_stats;
-  LMKD_REQUIRE(!pre_stats || (stat_partial && !smallc),
-               "lmkd_conv2d_fwd_pre: the fused BatchNorm+ReLU loader exists for the training forward (stat_partial given, Cs %% 32 == 0)");
+  LMKD_REQUIRE(!pre_stats || (stat_partial && !smallc && !g_lmkd_act_bf16),
+               "lmkd_conv2d_fwd_pre: the fused BatchNorm+ReLU loader exists for the training forward with fp32 activations (stat_partial given, Cs %% 32 == 0)");
+  LMKD_REQUIRE(!g_lmkd_act_bf16 || (g_conv_bf16 && !ep_stats), "bf16 activations need lmkd_conv_set_compute_dtype(1) (training / plain forward)");
   a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cs;
   a.Ho = conv_out(H, KH, stride, pad); a.Wo = conv_out(W, KW, stride, pad); a.Co = Cout;
   LMKD_REQUIRE(a.Ho > 0 && a.Wo > 0, "lmkd_conv2d_fwd: empty output");
@@ -760,6 +766,7 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
   LMKD_REQUIRE(Cout % 32 == 0, "lmkd_conv2d_bwd_data: Cout=%d must be a multiple of 32", Cout);
   LMKD_REQUIRE(stride == 1 || stride == 2, "lmkd_conv2d_bwd_data: stride %d unsupported", stride);
   LMKD_REQUIRE(KH * KW <= LMKD_MAX_TAPS, "lmkd_conv2d_bwd_data: kernel too large");
+  LMKD_REQUIRE(!g_lmkd_act_bf16 || g_conv_bf16, "bf16 activations need lmkd_conv_set_compute_dtype(1)");
   const int Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
   LMKD_REQUIRE((long)N * H * W * Cin < 2147483647L && (long)N * Ho * Wo * Cout < 2147483647L,
                "lmkd_conv2d_bwd_data: tensor exceeds 2^31 elements");
@@ -863,7 +870,8 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   LMKD_REQUIRE(Cs % 32 == 0 || Cs == 4, "lmkd_conv2d_bwd_weight: channel count %d must be 4 or a multiple of 32", Cs);
   LMKD_REQUIRE(Cout % 4 == 0, "lmkd_conv2d_bwd_weight: Cout %% 4 != 0");
   const bool smallc = Cs == 4;
-  LMKD_REQUIRE(!pre_stats || (!smallc && (!g_conv_bf16 || g_wgrad_planes)), "lmkd_conv2d_bwd_weight_pre: Cs %% 32 == 0 only");
+  LMKD_REQUIRE(!pre_stats || (!smallc && (!g_conv_bf16 || g_wgrad_planes) && !g_lmkd_act_bf16), "lmkd_conv2d_bwd_weight_pre: Cs %% 32 == 0, fp32 activations only");
+  LMKD_REQUIRE(!g_lmkd_act_bf16 || (g_conv_bf16 && g_wgrad_planes), "bf16 activations need lmkd_conv_set_compute_dtype(1) and the plane weight-gradient kernel");
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.x = x; a.slab = workspace; a.pre_stats = pre_stats;
@@ -896,7 +904,10 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   if (planes) {
 #define LMKD_WGX3(CFG)                                                                                                   \
   do {                                                                                                                   \
-    if (smallc) {                                                                                                        \
+    if (g_lmkd_act_bf16) {                                                                                               \
+      if (smallc) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, true, 1, false, true>), grid, dim3(256), 0, s, a);      \
+      else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 1, false, true>), grid, dim3(256), 0, s, a);            \
+    } else if (smallc) {                                                                                                 \
       if (g_conv_bf16) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, true, 1, false>), grid, dim3(256), 0, s, a);       \
       else if (g_conv_x3 == 9) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, true, 9, false>), grid, dim3(256), 0, s, a); \
       else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, true, 6, false>), grid, dim3(256), 0, s, a);                    \

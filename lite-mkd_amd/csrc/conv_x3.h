@@ -96,6 +96,8 @@ struct X3FragB {
 // K-step's loads are  offset = valid ? base + tap shift : out of range  (no branches, no 64-bit address arithmetic)
 template <int ROWS, bool SMALLC, int THREADS>
 struct X3GatherA {
+  typedef float4 Reg;
+  static constexpr int ESZ = 4;          // bytes per element of the gathered tensor
   static constexpr int RPP = THREADS / 8;
   static constexpr int NI = ROWS / RPP;
   static_assert(ROWS % RPP == 0, "tile rows vs threads");
@@ -153,6 +155,52 @@ struct X3GatherA {
         *reinterpret_cast<uint2*>(d + 2 * ROWS * X3_LD * 2) = p2;
       }
     }
+  }
+};
+
+// The same gather for a tensor stored as bf16 (lmkd_set_activation_dtype(1), one-plane mode only): a row's 32 k of a K-step are
+// 64 bytes = 4 lanes x 16 B (8 channels each), and what is loaded IS the LDS plane - no conversion, one ds_write_b128 per row.
+template <int ROWS, int THREADS>
+struct X3GatherA16 {
+  typedef u32x4 Reg;
+  static constexpr int ESZ = 2;
+  static constexpr int RPP = THREADS / 4;
+  static constexpr int NI = ROWS / RPP;
+  static_assert(ROWS % RPP == 0 && NI >= 1, "tile rows vs threads");
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned base[NI], mask[NI];
+  int kc4;      // first channel of this lane's 8 inside the 32-channel chunk (name kept for the shared kernel body)
+  __device__ __forceinline__ void init(const float* src, long elems, int Hs, int Ws, const int* s_src, const int* s_hw,
+                                       const Tap* taps, int ntap) {
+    rs = x3_rsrc(src, elems * 2);
+    const int tid = threadIdx.x;
+    kc4 = (tid & 3) * 8;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = (tid >> 2) + RPP * i;
+      const int hw = s_hw[row];
+      base[i] = (unsigned)(s_src[row] + kc4) * 2u;
+      unsigned m = 0;
+      for (int tp = 0; tp < ntap; ++tp) {
+        const int h = (hw >> 16) + taps[tp].dh, w = (hw & 0xffff) + taps[tp].dw;
+        if (hw >= 0 && (unsigned)h < (unsigned)Hs && (unsigned)w < (unsigned)Ws) m |= 1u << tp;
+      }
+      mask[i] = m;
+    }
+  }
+  __device__ __forceinline__ void load(int tp, int rel, Reg (&reg)[NI]) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const unsigned o = ((mask[i] >> tp) & 1u) ? base[i] + (unsigned)rel : X3_OOB;
+      reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+    }
+  }
+  template <int NPL, bool PRE = false>
+  __device__ __forceinline__ void store(unsigned char* S, const Reg (&reg)[NI], int = 0, float4 = float4(), float4 = float4()) const {
+    static_assert(NPL == 1 && !PRE, "bf16 activations: one plane, no store-side arithmetic");
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(S + (((tid >> 2) + RPP * i) * X3_LD + kc4) * 2) = reg[i];
   }
 };
 
@@ -226,9 +274,12 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* __restrict__ As, i
   }
 }
 
-template <class Cfg, bool SMALLC, bool STATS, int NPROD, bool PRE = false>
+// IO: bit 0 = the gathered tensor is stored as bf16, bit 1 = the output tensor is stored as bf16 (lmkd_set_activation_dtype(1))
+template <class Cfg, bool SMALLC, bool STATS, int NPROD, bool PRE = false, int IO = 0>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs a) {
-  using LA = X3GatherA<Cfg::BM, SMALLC, Cfg::THREADS>;
+  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+  static_assert(!(IN16 && SMALLC) && (IO == 0 || NPROD == 1), "bf16 activations: one-plane mode; the stem input stays fp32");
+  using LA = typename std::conditional<IN16, X3GatherA16<Cfg::BM, Cfg::THREADS>, X3GatherA<Cfg::BM, SMALLC, Cfg::THREADS>>::type;
   constexpr int NPL = NPROD == 1 ? 1 : 3;                 // NPROD == 1: plain bf16 (one RNE-rounded plane, one product)
   constexpr int A_BYTES = NPL * Cfg::BM * X3_LD * 2;
   using LB = X3FragB<Cfg::TN, NPL>;
@@ -247,7 +298,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   // scalar division nor a kernarg (SMEM) load, whose latency sat in every wave's instruction stream twice per K-step
   if (tid < a.ntap[cls]) {
     const Tap tp = a.taps[cls][tid];
-    s_tap_rel[tid] = ((tp.dh * a.Ws + tp.dw) * a.Cs) * 4;
+    s_tap_rel[tid] = ((tp.dh * a.Ws + tp.dw) * a.Cs) * LA::ESZ;
     s_tap_kofs[tid] = tp.kofs;
   }
   const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
@@ -293,13 +344,13 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   // for loads issued a moment ago.  So every set is "landed" (x3_landed: an empty asm that consumes and redefines the
   // registers) at ONE point per K-step, right before the split/store, when every outstanding load is at least one MFMA
   // phase old; loads issued after that point never stand between a value and its use.
-  float4 ra0[LA::NI], ra1[LA::NI];
+  typename LA::Reg ra0[LA::NI], ra1[LA::NI];
   u32x4 rb0[LB::NR], rb1[LB::NR];
   // K-steps are issued in increasing order (separately for A and B), channel chunk outer, tap inner (conv.hip)
   const int ntap_c = a.ntap[cls];
   int a_tp = 0, a_cc = 0, b_tp = 0, b_cc = 0;
-  auto issue_a = [&](int, float4 (&ra)[LA::NI]) {
-    la.load(a_tp, s_tap_rel[a_tp] + (SMALLC ? 0 : a_cc * (LMKD_BK * 4)), ra);
+  auto issue_a = [&](int, typename LA::Reg (&ra)[LA::NI]) {
+    la.load(a_tp, s_tap_rel[a_tp] + (SMALLC ? 0 : a_cc * (LMKD_BK * LA::ESZ)), ra);
     if (++a_tp == ntap_c) { a_tp = 0; ++a_cc; }
   };
   auto issue_b = [&](int, u32x4 (&rb)[LB::NR]) {
@@ -319,7 +370,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
     pre_fetch(0, psc_cur, psh_cur);
     pre_fetch(1, psc_nxt, psh_nxt);
   }
-  auto store_a = [&](unsigned char* dst, float4 (&ra)[LA::NI]) {
+  auto store_a = [&](unsigned char* dst, typename LA::Reg (&ra)[LA::NI]) {
     if constexpr (PRE) {
       la.template store<NPL, true>(dst, ra, s_tp, psc_cur, psh_cur);
       if (++s_tp == ntap_c) {
@@ -336,7 +387,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   // K-step t: MFMAs on LDS buffer t&1 with the B fragments in `rb`; the A set `ra` (step t+1) goes to the other buffer and
   // is refilled with step t+3.  Waves 4-7 (store first) fetch B(t+1) into `rbn` before their MFMAs; waves 0-3 (MFMAs first)
   // land B(t+1) in `rbn` after theirs and refill `rb` with B(t+2).
-  auto step = [&](int t, float4 (&ra)[LA::NI], u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR]) {
+  auto step = [&](int t, typename LA::Reg (&ra)[LA::NI], u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR]) {
     const unsigned char* cur = smem + (t & 1) * A_BYTES;
     unsigned char* nxt = smem + ((t + 1) & 1) * A_BYTES;
     if (store_first) {
@@ -377,6 +428,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   }
 
   const int cl0 = wn * (Cfg::TN * 32) + (lane & 31);
+  lmkd_bf16_t* out16 = reinterpret_cast<lmkd_bf16_t*>(a.out);
   if (a.accum) {      // out += acc: all previous values first (loads in flight together), then the adds (conv_gemm_kernel)
     float prev[Cfg::TM][Cfg::TN][16];
 #pragma unroll
@@ -387,7 +439,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) {
           const int col = n0 + cl0 + j * 32;
-          prev[i][j][e] = (ob >= 0 && col < a.Co) ? a.out[(long)ob + col] : 0.f;
+          prev[i][j][e] = (ob >= 0 && col < a.Co) ? (OUT16 ? bf16_to_f32(out16[(long)ob + col]) : a.out[(long)ob + col]) : 0.f;
         }
       }
 #pragma unroll
@@ -409,8 +461,14 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j) {
         const int col = n0 + cl0 + j * 32;
-        const float v = acc[i][j][e];
-        if (ob >= 0 && col < a.Co) a.out[(long)ob + col] = v;
+        float v = acc[i][j][e];
+        if (OUT16) {      // the tensor in HBM is bf16: the BatchNorm statistics are those of the stored (rounded) values
+          const lmkd_bf16_t b = f32_to_bf16(v);
+          if (ob >= 0 && col < a.Co) out16[(long)ob + col] = b;
+          v = bf16_to_f32(b);
+        } else if (ob >= 0 && col < a.Co) {
+          a.out[(long)ob + col] = v;
+        }
         if (STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
       }
     }

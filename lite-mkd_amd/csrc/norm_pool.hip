@@ -300,27 +300,28 @@ extern "C" int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, 
 // mask_bits (nullable, training): bit e of the array = (y[e] > 0) for flat element e, i.e. the ReLU mask the BatchNorm backward
 // needs, at 1/32 of the bytes of y.  Lane i owns elements 4i..4i+3 = one nibble; 8 lanes assemble a word with three shuffles
 // (n4 % 8 == 0 because C % 32 == 0, so a group of 8 lanes is active or inactive as a whole).
-__global__ void bn_apply_kernel(const float4* __restrict__ x, const float* __restrict__ stats, const float4* __restrict__ res,
-                                const float* __restrict__ rstats, float4* __restrict__ y, long n4, int C, int relu, int res_mode,
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const T* __restrict__ res,
+                                const float* __restrict__ rstats, T* __restrict__ y, long n4, int C, int relu, int res_mode,
                                 unsigned* __restrict__ mask_bits) {
   const int C4 = C >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
     const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + c);
     const float4 sh = *reinterpret_cast<const float4*>(stats + 3 * C + c);
-    float4 v = x[i];
+    float4 v = ld4<T>(x, i);
     v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
     if (res_mode == 1) {
-      const float4 r = res[i];
+      const float4 r = ld4<T>(res, i);
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     } else if (res_mode == 2) {
-      const float4 r = res[i];
+      const float4 r = ld4<T>(res, i);
       const float4 rs = *reinterpret_cast<const float4*>(rstats + 2 * C + c);
       const float4 rh = *reinterpret_cast<const float4*>(rstats + 3 * C + c);
       v.x += fmaf(r.x, rs.x, rh.x); v.y += fmaf(r.y, rs.y, rh.y); v.z += fmaf(r.z, rs.z, rh.z); v.w += fmaf(r.w, rs.w, rh.w);
     }
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    y[i] = v;
+    st4<T>(y, i, v);      // bf16 storage: a positive value never rounds to zero, so the mask below equals (stored y > 0)
     if (mask_bits) {
       unsigned nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
       unsigned wbits = nib << (4 * (threadIdx.x & 7));
@@ -339,8 +340,12 @@ extern "C" int lmkd_bn_apply(const float* x, const float* stats, const float* re
   LMKD_REQUIRE(res_mode != 2 || rstats, "lmkd_bn_apply: residual stats missing");
   LMKD_REQUIRE(!mask_bits || C % 32 == 0, "lmkd_bn_apply: the ReLU bit mask needs C %% 32 == 0 (C=%d)", C);
   const long n4 = rows * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const float4*)x, stats,
-                     (const float4*)res, rstats, (float4*)y, n4, C, relu, res_mode, mask_bits);
+  if (g_lmkd_act_bf16)
+    hipLaunchKernelGGL(bn_apply_kernel<lmkd_bf16_t>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)x, stats,
+                       (const lmkd_bf16_t*)res, rstats, (lmkd_bf16_t*)y, n4, C, relu, res_mode, mask_bits);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, stats, res, rstats, y, n4, C,
+                       relu, res_mode, mask_bits);
   LMKD_CHECK_LAUNCH("bn_apply_kernel");
   return LMKD_OK;
 }
@@ -351,14 +356,15 @@ extern "C" int lmkd_bn_apply(const float* x, const float* stats, const float* re
 //   reduce: partial[b][C][2] = (sum g, sum g*xhat)     xhat = (x-mean)*invstd
 //   apply : dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M);  optional g_out = g
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ float4 bn_masked_grad(const float4 dy, const float4 xv, const float4* yact, long i, const float* stats,
+template <typename T>
+__device__ __forceinline__ float4 bn_masked_grad(const float4 dy, const float4 xv, const T* yact, long i, const float* stats,
                                                  int C, int c, int mask_mode) {
   float4 g = dy;
   if (mask_mode == 3) {
     const unsigned nib = (reinterpret_cast<const unsigned*>(yact)[i >> 3] >> (4 * (int)(i & 7))) & 15u;
     g.x = (nib & 1u) ? g.x : 0.f; g.y = (nib & 2u) ? g.y : 0.f; g.z = (nib & 4u) ? g.z : 0.f; g.w = (nib & 8u) ? g.w : 0.f;
   } else if (mask_mode == 1) {
-    const float4 yv = yact[i];
+    const float4 yv = ld4<T>(yact, i);
     g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
   } else if (mask_mode == 2) {
     const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + c);
@@ -370,7 +376,8 @@ __device__ __forceinline__ float4 bn_masked_grad(const float4 dy, const float4 x
 }
 
 // block: 256 threads = RL row lanes x CC4 channel-quads of one channel chunk (chunk = min(C, 1024) channels, blockIdx.y)
-__global__ void bn_bwd_reduce_kernel(const float4* __restrict__ dy, const float4* __restrict__ x, const float4* __restrict__ yact,
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
                                      const float* __restrict__ stats, float* __restrict__ partial, long rows, int C, int CC,
                                      int mask_mode) {
   extern __shared__ float sm[];  // [RL][CC][2]
@@ -385,8 +392,8 @@ __global__ void bn_bwd_reduce_kernel(const float4* __restrict__ dy, const float4
     const float4 istd = *reinterpret_cast<const float4*>(stats + C + c);
     for (long r = (long)blockIdx.x * RL + rl; r < rows; r += (long)gridDim.x * RL) {
       const long i = r * C4 + (c >> 2);
-      const float4 xv = x[i];
-      const float4 g = bn_masked_grad(dy[i], xv, yact, i, stats, C, c, mask_mode);
+      const float4 xv = ld4<T>(x, i);
+      const float4 g = bn_masked_grad<T>(ld4<T>(dy, i), xv, yact, i, stats, C, c, mask_mode);
       s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
       s2.x = fmaf(g.x, (xv.x - mean.x) * istd.x, s2.x); s2.y = fmaf(g.y, (xv.y - mean.y) * istd.y, s2.y);
       s2.z = fmaf(g.z, (xv.z - mean.z) * istd.z, s2.z); s2.w = fmaf(g.w, (xv.w - mean.w) * istd.w, s2.w);
@@ -418,14 +425,15 @@ __global__ void bn_bwd_coef_kernel(const float* __restrict__ pf, const double* _
   if (dbeta) dbeta[c] = (float)sg;
 }
 
-__global__ void bn_bwd_apply_kernel(const float4* __restrict__ dy, const float4* __restrict__ x, const float4* __restrict__ yact,
-                                    const float* __restrict__ stats, const float* __restrict__ coef, float4* __restrict__ dx,
-                                    float4* __restrict__ g_out, long n4, int C, int mask_mode) {
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
+                                    const float* __restrict__ stats, const float* __restrict__ coef, T* __restrict__ dx,
+                                    T* __restrict__ g_out, long n4, int C, int mask_mode) {
   const int C4 = C >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
-    const float4 xv = x[i];
-    const float4 g = bn_masked_grad(dy[i], xv, yact, i, stats, C, c, mask_mode);
+    const float4 xv = ld4<T>(x, i);
+    const float4 g = bn_masked_grad<T>(ld4<T>(dy, i), xv, yact, i, stats, C, c, mask_mode);
     const float4 mean = *reinterpret_cast<const float4*>(stats + c);
     const float4 istd = *reinterpret_cast<const float4*>(stats + C + c);
     const float4 A = *reinterpret_cast<const float4*>(coef + c);
@@ -436,8 +444,8 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ dy, const float4*
     o.y = A.y * (g.y - mg.y - (xv.y - mean.y) * istd.y * mgx.y);
     o.z = A.z * (g.z - mg.z - (xv.z - mean.z) * istd.z * mgx.z);
     o.w = A.w * (g.w - mg.w - (xv.w - mean.w) * istd.w * mgx.w);
-    dx[i] = o;
-    if (g_out) g_out[i] = g;
+    st4<T>(dx, i, o);
+    if (g_out) st4<T>(g_out, i, g);
   }
 }
 
@@ -460,8 +468,12 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
   if (nb < 1) nb = 1;
   float* partial = (float*)workspace;
   double* dscr = (double*)((char*)workspace + (((long)2048 * 2 * C * sizeof(float) + 63) / 64) * 64);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, C / CC), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s,
-                     (const float4*)dy, (const float4*)x, (const float4*)yact, stats, partial, rows, C, CC, mask_mode);
+  if (g_lmkd_act_bf16)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<lmkd_bf16_t>, dim3(nb, C / CC), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s,
+                       (const lmkd_bf16_t*)dy, (const lmkd_bf16_t*)x, (const lmkd_bf16_t*)yact, stats, partial, rows, C, CC, mask_mode);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb, C / CC), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s, dy, x, yact,
+                       stats, partial, rows, C, CC, mask_mode);
   LMKD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
   const float* pf = partial;
   const double* pd = nullptr;
@@ -474,23 +486,31 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, pf, pd, T, C, (double)rows, gamma, stats, coef, dgamma,
                      dbeta);
   const long n4 = rows * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, (const float4*)dy, (const float4*)x,
-                     (const float4*)yact, stats, (const float*)coef, (float4*)dx, (float4*)g_out, n4, C, mask_mode);
+  if (g_lmkd_act_bf16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<lmkd_bf16_t>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, (const lmkd_bf16_t*)dy, (const lmkd_bf16_t*)x,
+                       (const lmkd_bf16_t*)yact, stats, (const float*)coef, (lmkd_bf16_t*)dx, (lmkd_bf16_t*)g_out, n4, C, mask_mode);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, dy, x, yact, stats, (const float*)coef, dx, g_out,
+                       n4, C, mask_mode);
   LMKD_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return LMKD_OK;
 }
 
 // plain ReLU backward (eval-mode / no-BN paths): g = dy * (y > 0)
-__global__ void relu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ y, float4* __restrict__ g, long n4) {
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ g, long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const float4 d = dy[i], v = y[i];
-    g[i] = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
+    const float4 d = ld4<T>(dy, i), v = ld4<T>(y, i);
+    st4<T>(g, i, make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f));
   }
 }
 extern "C" int lmkd_relu_backward(const float* dy, const float* y, float* g, long n, void* stream) {
   LMKD_REQUIRE(dy && y && g && n > 0 && n % 4 == 0, "lmkd_relu_backward: bad arguments");
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n / 4)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const float4*)dy,
-                     (const float4*)y, (float4*)g, n / 4);
+  if (g_lmkd_act_bf16)
+    hipLaunchKernelGGL(relu_bwd_kernel<lmkd_bf16_t>, dim3(ew_grid(n / 4)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)dy,
+                       (const lmkd_bf16_t*)y, (lmkd_bf16_t*)g, n / 4);
+  else
+    hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(NP_THREADS), 0, (hipStream_t)stream, dy, y, g, n / 4);
   LMKD_CHECK_LAUNCH("relu_bwd_kernel");
   return LMKD_OK;
 }
@@ -498,7 +518,8 @@ extern "C" int lmkd_relu_backward(const float* dy, const float* y, float* g, lon
 // ---------------------------------------------------------------------------------
 // stem: y = maxpool3x3/s2/p1( relu( x*scale + shift ) ), argmax (0..8, first max in scan order)
 // ---------------------------------------------------------------------------------
-__global__ void bn_relu_maxpool_kernel(const float4* __restrict__ x, const float* __restrict__ stats, float4* __restrict__ y,
+template <typename T>
+__global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ stats, T* __restrict__ y,
                                        uchar4* __restrict__ idx, int N, int H, int W, int C, int OH, int OW) {
   const int C4 = C >> 2;
   const long total = (long)N * OH * OW * C4;
@@ -520,7 +541,7 @@ __global__ void bn_relu_maxpool_kernel(const float4* __restrict__ x, const float
       for (int kw = 0; kw < 3; ++kw) {
         const int w = ow * 2 - 1 + kw;
         if ((unsigned)w >= (unsigned)W) continue;
-        float4 v = x[((long)(n * H + h) * W + w) * C4 + cq];
+        float4 v = ld4<T>(x, ((long)(n * H + h) * W + w) * C4 + cq);
         v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
         v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
         const unsigned char t = (unsigned char)(kh * 3 + kw);
@@ -530,7 +551,7 @@ __global__ void bn_relu_maxpool_kernel(const float4* __restrict__ x, const float
         if (v.w > m.w || am.w == 255) { m.w = v.w; am.w = t; }
       }
     }
-    y[i] = m;
+    st4<T>(y, i, m);
     idx[i] = am;
   }
 }
@@ -540,14 +561,19 @@ extern "C" int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, floa
   LMKD_REQUIRE(x && stats && y && idx && C % 4 == 0, "lmkd_bn_relu_maxpool_fwd: bad arguments");
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long total = (long)N * OH * OW * C / 4;
-  hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const float4*)x, stats,
-                     (float4*)y, (uchar4*)idx, N, H, W, C, OH, OW);
+  if (g_lmkd_act_bf16)
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<lmkd_bf16_t>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)x,
+                       stats, (lmkd_bf16_t*)y, (uchar4*)idx, N, H, W, C, OH, OW);
+  else
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, stats, y, (uchar4*)idx,
+                       N, H, W, C, OH, OW);
   LMKD_CHECK_LAUNCH("bn_relu_maxpool_kernel");
   return LMKD_OK;
 }
 
 // gather form of the maxpool backward: g[n,h,w,c] = sum over the (<=4) windows covering (h,w) whose argmax is (h,w)
-__global__ void maxpool_bwd_kernel(const float4* __restrict__ dy, const uchar4* __restrict__ idx, float4* __restrict__ g, int N, int H,
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uchar4* __restrict__ idx, T* __restrict__ g, int N, int H,
                                    int W, int C, int OH, int OW) {
   const int C4 = C >> 2;
   const long total = (long)N * H * W * C4;
@@ -570,14 +596,14 @@ __global__ void maxpool_bwd_kernel(const float4* __restrict__ dy, const uchar4* 
         const unsigned char t = (unsigned char)(kh * 3 + kw);
         const long o = ((long)(n * OH + oh) * OW + ow) * C4 + cq;
         const uchar4 am = idx[o];
-        const float4 d = dy[o];
+        const float4 d = ld4<T>(dy, o);
         if (am.x == t) acc.x += d.x;
         if (am.y == t) acc.y += d.y;
         if (am.z == t) acc.z += d.z;
         if (am.w == t) acc.w += d.w;
       }
     }
-    g[i] = acc;
+    st4<T>(g, i, acc);
   }
 }
 
@@ -585,8 +611,12 @@ extern "C" int lmkd_maxpool_bwd(const float* dy, const unsigned char* idx, float
   LMKD_REQUIRE(dy && idx && g && C % 4 == 0, "lmkd_maxpool_bwd: bad arguments");
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long total = (long)N * H * W * C / 4;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const float4*)dy,
-                     (const uchar4*)idx, (float4*)g, N, H, W, C, OH, OW);
+  if (g_lmkd_act_bf16)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<lmkd_bf16_t>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)dy,
+                       (const uchar4*)idx, (lmkd_bf16_t*)g, N, H, W, C, OH, OW);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, dy, (const uchar4*)idx, g, N, H,
+                       W, C, OH, OW);
   LMKD_CHECK_LAUNCH("maxpool_bwd_kernel");
   return LMKD_OK;
 }
@@ -595,12 +625,13 @@ extern "C" int lmkd_maxpool_bwd(const float* dy, const unsigned char* idx, float
 // head: AdaptiveMaxPool2d((4,4)) + mean over the 16 patches.  x [F,H,W,C] -> y [F,C]
 // window i of an axis of length L: [floor(i*L/4), ceil((i+1)*L/4))
 // ---------------------------------------------------------------------------------
-__global__ void adaptive_maxpool_mean_kernel(const float* __restrict__ x, float* __restrict__ y, int F, int H, int W, int C) {
+template <typename T>      // x: activation storage type; y (pooled frame features) fp32
+__global__ void adaptive_maxpool_mean_kernel(const T* __restrict__ x, float* __restrict__ y, int F, int H, int W, int C) {
   const long total = (long)F * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const int f = (int)(i / C);
-    const float* b = x + (long)f * H * W * C + c;
+    const T* b = x + (long)f * H * W * C + c;
     float s = 0.f;
     for (int ph = 0; ph < 4; ++ph) {
       const int h0 = (ph * H) / 4, h1 = ((ph + 1) * H + 3) / 4;
@@ -608,7 +639,7 @@ __global__ void adaptive_maxpool_mean_kernel(const float* __restrict__ x, float*
         const int w0 = (pw * W) / 4, w1 = ((pw + 1) * W + 3) / 4;
         float m = -INFINITY;
         for (int h = h0; h < h1; ++h)
-          for (int w = w0; w < w1; ++w) m = fmaxf(m, b[(long)(h * W + w) * C]);
+          for (int w = w0; w < w1; ++w) m = fmaxf(m, ld1<T>(b, (long)(h * W + w) * C));
         s += m;
       }
     }
@@ -617,14 +648,15 @@ __global__ void adaptive_maxpool_mean_kernel(const float* __restrict__ x, float*
 }
 
 // dx[f,h,w,c] = sum over windows whose (first) argmax is (h,w) of dy[f,c]/16.  H*W <= 64.
-__global__ void adaptive_maxpool_mean_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+template <typename T>      // x, dx: activation storage type; dy fp32
+__global__ void adaptive_maxpool_mean_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dy, T* __restrict__ dx,
                                                  int F, int H, int W, int C) {
   const long total = (long)F * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const int f = (int)(i / C);
-    const float* b = x + (long)f * H * W * C + c;
-    float* d = dx + (long)f * H * W * C + c;
+    const T* b = x + (long)f * H * W * C + c;
+    T* d = dx + (long)f * H * W * C + c;
     const float gv = dy[i] * (1.f / 16.f);
     unsigned long long cnt_lo = 0, cnt_hi = 0, cnt_4 = 0;   // 3 bit planes: a position is the argmax of at most 4 windows
     for (int ph = 0; ph < 4; ++ph) {
@@ -635,7 +667,7 @@ __global__ void adaptive_maxpool_mean_bwd_kernel(const float* __restrict__ x, co
         int am = h0 * W + w0;
         for (int h = h0; h < h1; ++h)
           for (int w = w0; w < w1; ++w) {
-            const float v = b[(long)(h * W + w) * C];
+            const float v = ld1<T>(b, (long)(h * W + w) * C);
             if (v > m) { m = v; am = h * W + w; }
           }
         // ripple-add 1 into the per-position counter held as bit planes
@@ -649,21 +681,30 @@ __global__ void adaptive_maxpool_mean_bwd_kernel(const float* __restrict__ x, co
     }
     for (int p = 0; p < H * W; ++p) {
       const int k = (int)((cnt_lo >> p) & 1ull) + 2 * (int)((cnt_hi >> p) & 1ull) + 4 * (int)((cnt_4 >> p) & 1ull);
-      d[(long)p * C] = gv * (float)k;
+      st1<T>(d, (long)p * C, gv * (float)k);
     }
   }
 }
 
 extern "C" int lmkd_adaptive_maxpool_mean_fwd(const float* x, float* y, int F, int H, int W, int C, void* stream) {
   LMKD_REQUIRE(x && y && F > 0 && H >= 1 && W >= 1 && C > 0, "lmkd_adaptive_maxpool_mean_fwd: bad arguments");
-  hipLaunchKernelGGL(adaptive_maxpool_mean_kernel, dim3(ew_grid((long)F * C)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, y, F, H, W, C);
+  if (g_lmkd_act_bf16)
+    hipLaunchKernelGGL(adaptive_maxpool_mean_kernel<lmkd_bf16_t>, dim3(ew_grid((long)F * C)), dim3(NP_THREADS), 0, (hipStream_t)stream,
+                       (const lmkd_bf16_t*)x, y, F, H, W, C);
+  else
+    hipLaunchKernelGGL(adaptive_maxpool_mean_kernel<float>, dim3(ew_grid((long)F * C)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, y, F, H, W, C);
   LMKD_CHECK_LAUNCH("adaptive_maxpool_mean_kernel");
   return LMKD_OK;
 }
 extern "C" int lmkd_adaptive_maxpool_mean_bwd(const float* x, const float* dy, float* dx, int F, int H, int W, int C, void* stream) {
   LMKD_REQUIRE(x && dy && dx && F > 0 && H * W <= 64, "lmkd_adaptive_maxpool_mean_bwd: bad arguments (H*W must be <= 64)");
   LMKD_REQUIRE(H >= 2 && W >= 2 && H <= 8 && W <= 8, "lmkd_adaptive_maxpool_mean_bwd: H, W must be in [2,8] (at most 2 overlapping windows per axis)");
-  hipLaunchKernelGGL(adaptive_maxpool_mean_bwd_kernel, dim3(ew_grid((long)F * C)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, dy, dx, F, H, W, C);
+  if (g_lmkd_act_bf16)
+    hipLaunchKernelGGL(adaptive_maxpool_mean_bwd_kernel<lmkd_bf16_t>, dim3(ew_grid((long)F * C)), dim3(NP_THREADS), 0, (hipStream_t)stream,
+                       (const lmkd_bf16_t*)x, dy, (lmkd_bf16_t*)dx, F, H, W, C);
+  else
+    hipLaunchKernelGGL(adaptive_maxpool_mean_bwd_kernel<float>, dim3(ew_grid((long)F * C)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, dy, dx, F,
+                       H, W, C);
   LMKD_CHECK_LAUNCH("adaptive_maxpool_mean_bwd_kernel");
   return LMKD_OK;
 }

@@ -67,11 +67,85 @@ __device__ __forceinline__ void tr_store4(unsigned char* __restrict__ img, int k
   }
 }
 
-template <class Cfg, bool SMALLC, int NPROD, bool PRE>      // SMALLC: the channel-padded (NHWC4) stem input, columns = (kh, kw, 4 channels)
+__device__ __forceinline__ void tr_store8(unsigned char* __restrict__ img, int ldb, int k, int col, const u32x4& v) {
+  *reinterpret_cast<u32x4*>(img + k * ldb + col * 2) = v;      // 8 bf16 columns of k row `k`, already in plane format
+}
+
+// Operands stored as bf16 in HBM (lmkd_set_activation_dtype(1)): what is loaded IS the LDS plane (8 columns = 16 B per lane).
+template <int ROWS, int THREADS>
+struct LoaderMMajorDense16 {      // elem(k, row) = base[k*ld + row]
+  static constexpr int CPR = ROWS / 8, KPP = THREADS / CPR, NI = LMKD_BK / KPP;
+  static_assert(THREADS % CPR == 0 && LMKD_BK % KPP == 0 && NI >= 1, "tile rows vs threads");
+  const lmkd_bf16_t* base;
+  long ld;
+  u32x4 reg[NI];
+  int K, r4;
+  bool rin;
+  __device__ __forceinline__ void init(const float* base_, long ld_, int row0, int nrows, int K_) {
+    r4 = (threadIdx.x % CPR) * 8;
+    rin = (row0 + r4) < nrows;
+    base = reinterpret_cast<const lmkd_bf16_t*>(base_) + row0 + r4;
+    ld = ld_; K = K_;
+  }
+  __device__ __forceinline__ void load(int koff) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = koff + threadIdx.x / CPR + KPP * i;
+      reg[i] = (rin && k < K) ? *reinterpret_cast<const u32x4*>(base + (long)k * ld) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+};
+template <int ROWS, int THREADS>
+struct LoaderWgradGather16 {      // implicit im2col of a bf16 NHWC tensor, K-outer (Cs % 32 == 0: a lane's 8 columns lie in one tap)
+  static constexpr int CPR = ROWS / 8, KPP = THREADS / CPR, NI = LMKD_BK / KPP;
+  const lmkd_bf16_t* x;
+  FastDiv div_hw, div_w;
+  int Mpix, HoWo, Wo, Hs, Ws, Cs, stride;
+  u32x4 reg[NI];
+  int dh, dw, coff, r4;
+  bool tap_ok;
+  unsigned inb;             // members the kernel body shares with the fp32 loader
+  float4 psc, psh;
+  __device__ __forceinline__ void init(const WgradArgs& a, int j0) {
+    x = reinterpret_cast<const lmkd_bf16_t*>(a.x); div_hw = a.div_hw; div_w = a.div_w;
+    Mpix = a.Mpix; HoWo = a.Ho * a.Wo; Wo = a.Wo; Hs = a.Hs; Ws = a.Ws; Cs = a.Cs; stride = a.stride;
+    inb = 0u;
+    r4 = (threadIdx.x % CPR) * 8;
+    const int col = j0 + r4;
+    const int tap = col / a.Cs;
+    coff = col - tap * a.Cs;
+    const int kh = tap / a.KWp, kw = tap - kh * a.KWp;
+    dh = kh - a.pad; dw = kw - a.pad;
+    tap_ok = col < a.Kp && kw < a.KW;
+  }
+  __device__ __forceinline__ void load(int koff) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = koff + threadIdx.x / CPR + KPP * i;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (tap_ok && p < Mpix) {
+        const int n = fdiv(p, div_hw);
+        const int rem = p - n * HoWo;
+        const int oh = fdiv(rem, div_w);
+        const int ow = rem - oh * Wo;
+        const int h = oh * stride + dh, w = ow * stride + dw;
+        if ((unsigned)h < (unsigned)Hs && (unsigned)w < (unsigned)Ws)
+          v = *reinterpret_cast<const u32x4*>(x + ((long)(n * Hs + h) * Ws + w) * Cs + coff);
+      }
+      reg[i] = v;
+    }
+  }
+};
+
+// SMALLC: the channel-padded (NHWC4) stem input, columns = (kh, kw, 4 channels).  ACT16: dy (and, except for the fp32 stem input,
+// x) are bf16 tensors in HBM (one-plane mode only).
+template <class Cfg, bool SMALLC, int NPROD, bool PRE, bool ACT16 = false>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a) {
   constexpr int NPL = NPROD == 1 ? 1 : 3;
-  using LA = LoaderMMajorDense<Cfg::BM, Cfg::THREADS>;
-  using LB = LoaderWgradGather<Cfg::BN, SMALLC, Cfg::THREADS, PRE>;
+  static_assert(!ACT16 || (NPROD == 1 && !PRE), "bf16 activations: one plane, no store-side arithmetic");
+  constexpr bool B16 = ACT16 && !SMALLC;
+  using LA = typename std::conditional<ACT16, LoaderMMajorDense16<Cfg::BM, Cfg::THREADS>, LoaderMMajorDense<Cfg::BM, Cfg::THREADS>>::type;
+  using LB = typename std::conditional<B16, LoaderWgradGather16<Cfg::BN, Cfg::THREADS>, LoaderWgradGather<Cfg::BN, SMALLC, Cfg::THREADS, PRE>>::type;
   using IA = TrImg<Cfg::BM>;
   using IB = TrImg<Cfg::BN>;
   constexpr int A_BYTES = NPL * IA::PLANE, B_BYTES = NPL * IB::PLANE;
@@ -114,7 +188,14 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
 
   auto store_tiles = [&](unsigned char* sa, unsigned char* sb) {
 #pragma unroll
-    for (int i = 0; i < LA::NI; ++i) tr_store4<NPL, IA::LDB, IA::PLANE>(sa, tid / LA::CPR + LA::KPP * i, la.r4, la.reg[i]);
+    for (int i = 0; i < LA::NI; ++i) {
+      if constexpr (ACT16) tr_store8(sa, IA::LDB, tid / LA::CPR + LA::KPP * i, la.r4, la.reg[i]);
+      else tr_store4<NPL, IA::LDB, IA::PLANE>(sa, tid / LA::CPR + LA::KPP * i, la.r4, la.reg[i]);
+    }
+    if constexpr (B16) {
+#pragma unroll
+      for (int i = 0; i < LB::NI; ++i) tr_store8(sb, IB::LDB, tid / LB::CPR + LB::KPP * i, lb.r4, lb.reg[i]);
+    } else {
 #pragma unroll
     for (int i = 0; i < LB::NI; ++i) {
       float4 v = lb.reg[i];
@@ -123,6 +204,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
         v.z = fmaxf(fmaf(v.z, lb.psc.z, lb.psh.z), 0.f); v.w = fmaxf(fmaf(v.w, lb.psc.w, lb.psh.w), 0.f);
       }
       tr_store4<NPL, IB::LDB, IB::PLANE>(sb, tid / LB::CPR + LB::KPP * i, lb.r4, v);
+    }
     }
   };
   auto kstep = [&](const unsigned char* sa, const unsigned char* sb) {

@@ -30,7 +30,7 @@ def _chk(*tensors):
             continue
         if not t.is_cuda:
             raise RuntimeError("lite-mkd_amd ops need CUDA(HIP) tensors; got a %s tensor — the HIP hot path has no CPU fallback" % t.device)
-        if t.dtype not in (torch.float32, torch.int64, torch.int32, torch.uint8, torch.int16):
+        if t.dtype not in (torch.float32, torch.int64, torch.int32, torch.uint8, torch.int16, torch.bfloat16):
             raise RuntimeError("unsupported dtype %s" % t.dtype)
         if not t.is_contiguous():
             raise RuntimeError("non-contiguous tensor passed to a HIP op")
@@ -46,6 +46,29 @@ def _f32(x):
 
 def _empty(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# Storage type of the trunk's activation / activation-gradient tensors in HBM (lmkd_set_activation_dtype): fp32, or bf16 for
+# BASELINE configs[2] (the reference trains under autocast).  Statistics, weights, weight gradients and everything after the pooled
+# head stay fp32.
+_ACT_DTYPE = [torch.float32]
+
+
+def set_activation_dtype(name):
+    """'fp32' | 'bf16' (needs set_conv_compute_dtype('bf16'))"""
+    modes = {"fp32": (0, torch.float32), "bf16": (1, torch.bfloat16)}
+    if name not in modes:
+        raise ValueError(name)
+    lib().call("lmkd_set_activation_dtype", modes[name][0])
+    _ACT_DTYPE[0] = modes[name][1]
+
+
+def get_activation_dtype():
+    return "bf16" if _ACT_DTYPE[0] is torch.bfloat16 else "fp32"
+
+
+def _empty_act(shape, like):
+    return torch.empty(shape, dtype=_ACT_DTYPE[0], device=like.device)
 
 
 # ------------------------------------------------------------------------------------------
@@ -173,6 +196,8 @@ def set_conv_compute_dtype(dtype):
         raise ValueError(dtype)
     WEIGHT_EPOCH[0] += 1                                     # packed-weight caches hold the other mode's layout
     lib().call("lmkd_conv_set_compute_dtype", modes[dtype])
+    if dtype != "bf16" and _ACT_DTYPE[0] is not torch.float32:
+        set_activation_dtype("fp32")                         # bf16 tensors exist in the one-plane mode only
 
 
 def get_conv_compute_dtype():
@@ -210,7 +235,7 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None):
     _chk(x, wp, pre_stats)
     N, H, W, Cs = x.shape
     Ho, Wo = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
-    y = _empty((N, Ho, Wo, Cout), x)
+    y = _empty_act((N, Ho, Wo, Cout), x)
     part = None
     if want_stats:
         T = lib().value("lmkd_conv2d_fwd_row_tiles", N, H, W, Cout, KH, KW, stride, pad)
@@ -229,7 +254,7 @@ def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumula
     _chk(dy, wd, out)
     if accumulate and out is None:
         raise ValueError("accumulate needs an output buffer")
-    dx = out if out is not None else _empty((N, H, W, Cin), dy)
+    dx = out if out is not None else _empty_act((N, H, W, Cin), dy)
     with _timed("conv_gemm_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
                 4 * (dy.numel() + dx.numel() * (2 if accumulate else 1) + wd.numel())):
         lib().call("lmkd_conv2d_bwd_data", _p(dy), _p(wd), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, int(accumulate), _stream())
@@ -475,7 +500,7 @@ class StemFn(torch.autograd.Function):
         c, stats = _conv_bn_train_or_eval(x4, w, 4, 2, 3, gamma, beta, rm, rv, training)
         N, Hc, Wc, C = c.shape
         Ho, Wo = conv_out_size(Hc, 3, 2, 1), conv_out_size(Wc, 3, 2, 1)
-        y = _empty((N, Ho, Wo, C), x)
+        y = _empty_act((N, Ho, Wo, C), x)
         idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
         lib().call("lmkd_bn_relu_maxpool_fwd", _p(c), _p(stats), _p(y), _p(idx), N, Hc, Wc, C, _stream())
         if BLOCK_TAPS is not None:

@@ -142,30 +142,52 @@ def _conv(x, w, stride=1, pad=0):
     return F.conv2d(x, w, None, stride, pad)
 
 
+# configs[2] with bf16 TENSORS in HBM (lmkd_set_activation_dtype(1); the reference's autocast keeps its activations in reduced
+# precision too): every activation the trunk stores - convolution outputs, BatchNorm+ReLU outputs, block outputs, the pooled stem
+# output - and the gradient that flows back through the same place is rounded to bf16 (RNE); BatchNorm statistics are those of the
+# stored (rounded) convolution output; arithmetic between two stored tensors is fp32.  ACT_BF16 = True inserts exactly these
+# rounding points (forward and backward) into the trunk below; use together with CONV_BF16.
+ACT_BF16 = False
+
+
+class _RoundSTE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return _r16(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r16(g)
+
+
+def _act(t):
+    return _RoundSTE.apply(t) if ACT_BF16 else t
+
+
 def resnet18_trunk(x, sd, training=True, update_running=True, taps=None):
     """[F,3,H,W] -> [F,512,H/32,W/32].  BN in train mode uses the batch statistics of
     THIS call (reference: Student.__init__ calls self.train(), model_select.py:21)."""
     def tap(name, t):
         if taps is not None:
             taps[name] = t
-    x = _conv(x, sd["0.weight"], 2, 3)
+    x = _act(_conv(x, sd["0.weight"], 2, 3))
     tap("conv1", x)
     x = _relu(_bn(x, sd, "1", training, update_running))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = _act(F.max_pool2d(x, 3, 2, 1))
     tap("pool", x)
     for idx, cin, cout, stride in RESNET18_STAGES:
         for b in range(2):
             p = "%d.%d" % (idx, b)
             s = stride if b == 0 else 1
             idn = x
-            out = _conv(x, sd[p + ".conv1.weight"], s, 1)
-            out = _relu(_bn(out, sd, p + ".bn1", training, update_running))
-            out = _conv(out, sd[p + ".conv2.weight"], 1, 1)
+            out = _act(_conv(x, sd[p + ".conv1.weight"], s, 1))
+            out = _act(_relu(_bn(out, sd, p + ".bn1", training, update_running)))
+            out = _act(_conv(out, sd[p + ".conv2.weight"], 1, 1))
             out = _bn(out, sd, p + ".bn2", training, update_running)
             if (p + ".downsample.0.weight") in sd:
-                idn = _conv(x, sd[p + ".downsample.0.weight"], s, 0)
+                idn = _act(_conv(x, sd[p + ".downsample.0.weight"], s, 0))
                 idn = _bn(idn, sd, p + ".downsample.1", training, update_running)
-            x = _relu(out + idn)
+            x = _act(_relu(out + idn))
             tap(p, x)
     return x
 

@@ -1013,3 +1013,94 @@ def test_gpu_frame_transform_matches_reference_chain(dev):
         out = tf([torch.from_numpy(v) for v in vids], train=train)
         assert out.shape == (40, 224, 224, 4)
         assert torch.equal(out[..., :3].cpu(), ref) and float(out[..., 3].abs().max()) == 0.0
+
+
+@pytest.fixture
+def bf16_act():
+    from litemkd_amd import ops
+    ops.set_conv_compute_dtype("bf16")
+    ops.set_activation_dtype("bf16")
+    yield
+    ops.set_activation_dtype("fp32")
+    ops.set_conv_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("cfg", [(5, 64, 14, 14, 64, 3, 1, 1), (3, 128, 9, 11, 256, 3, 2, 1), (4, 256, 7, 7, 64, 1, 2, 0), (40, 128, 28, 28, 128, 3, 1, 1)])
+def test_bf16_activation_kernels_equal_rounded_fp32_kernels(dev, cfg):
+    """BASELINE configs[2] with bf16 tensors in HBM (lmkd_set_activation_dtype(1)): every kernel instance that reads / writes bf16
+    activations must give exactly the ROUNDED result of the fp32-activation instance on the same (bf16-representable) inputs -
+    the arithmetic in between is the same fp32 arithmetic; statistics are those of the stored (rounded) convolution output."""
+    from litemkd_amd import ops
+    N, C, H, W, Cout, K, s, p = cfg
+    r = lambda t: t.to(torch.bfloat16)                                        # noqa: E731
+    x32 = r(rnd(N, H, W, C, seed=60) * 1.5).float().to(dev)
+    w = (rnd(Cout, C, K, K, seed=61) * math.sqrt(2.0 / (Cout * K * K))).to(dev)
+    ops.set_conv_compute_dtype("bf16")
+    try:
+        wp, wd = ops._pack_weights(w, C, 0), ops._pack_weights(w, C, 1)
+        y32, p32 = ops.conv_fwd(x32, wp, Cout, K, K, s, p, True)
+        dy32 = r(rnd(*y32.shape, seed=62)).float().to(dev)
+        dx32 = ops.conv_bwd_data(dy32, wd, (N, H, W, C), Cout, K, K, s, p)
+        res32 = r(rnd(N, H, W, C, seed=63)).float().to(dev)
+        acc32 = res32.clone()
+        ops.conv_bwd_data(dy32, wd, (N, H, W, C), Cout, K, K, s, p, out=acc32, accumulate=True)
+        dw32 = ops.conv_bwd_weight(x32, dy32, (Cout, C, K, K), s, p)
+        # BatchNorm / pooling on a [N,H,W,C] activation
+        gamma, beta = (1 + 0.2 * rnd(C, seed=64)).to(dev), (0.3 * rnd(C, seed=65)).to(dev)
+        flat = x32.reshape(-1, C)
+        part = torch.stack([flat.sum(0, keepdim=True), (flat ** 2).sum(0, keepdim=True)], -1).contiguous()
+        st = ops.bn_stats_train(part, flat.shape[0], gamma, beta, None, None)
+        a32, bits32 = ops.bn_apply(x32, st, True, res32, want_bits=True)
+        g32 = r(rnd(N, H, W, C, seed=66)).float().to(dev)
+        b32 = ops.bn_backward(g32, x32, bits32, st, gamma, 3, want_g=True)
+        ops.set_activation_dtype("bf16")
+        x16, dy16, res16, g16 = r(x32), r(dy32), r(res32), r(g32)
+        y16, p16 = ops.conv_fwd(x16, wp, Cout, K, K, s, p, True)
+        assert y16.dtype == torch.bfloat16 and torch.equal(y16, r(y32))
+        yr = y16.float().reshape(-1, Cout).double()
+        sums = p16.double().sum(0)
+        assert torch.allclose(sums[:, 0], yr.sum(0), rtol=0, atol=2e-6 * float(yr.abs().sum(0).max())) and torch.allclose(sums[:, 1], (yr * yr).sum(0), rtol=1e-5)
+        assert torch.equal(ops.conv_bwd_data(dy16, wd, (N, H, W, C), Cout, K, K, s, p), r(dx32))
+        acc16 = res16.clone()
+        ops.conv_bwd_data(dy16, wd, (N, H, W, C), Cout, K, K, s, p, out=acc16, accumulate=True)
+        assert torch.equal(acc16, r(acc32))
+        assert torch.equal(ops.conv_bwd_weight(x16, dy16, (Cout, C, K, K), s, p), dw32)
+        a16, bits16 = ops.bn_apply(x16, st, True, res16, want_bits=True)
+        assert torch.equal(a16, r(a32)) and torch.equal(bits16, bits32)
+        b16 = ops.bn_backward(g16, x16, bits16, st, gamma, 3, want_g=True)
+        assert torch.equal(b16[0], r(b32[0])) and torch.equal(b16[1], r(b32[1])) and torch.equal(b16[2], b32[2]) and torch.equal(b16[3], b32[3])
+    finally:
+        ops.set_activation_dtype("fp32")
+        ops.set_conv_compute_dtype("fp32")
+
+
+def test_bf16_activation_stem_and_pooling(dev, bf16_act):
+    """stem (fp32 NHWC4 frames in, bf16 out), BatchNorm+ReLU+max-pool forward / backward and the pooled head on bf16 tensors vs the
+    fp32-tensor instances of the same kernels fed the same bf16-representable values"""
+    from litemkd_amd import ops
+    torch.manual_seed(2)
+    N, H = 4, 32
+    frames = torch.rand(N, 3, H, H, device=dev)
+    w = (torch.randn(64, 3, 7, 7, device=dev) * 0.1).requires_grad_()
+    gamma, beta = (1 + 0.1 * torch.randn(64, device=dev)).requires_grad_(), (0.1 * torch.randn(64, device=dev)).requires_grad_()
+    rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+
+    def run():
+        for t in (w, gamma, beta):
+            t.grad = None
+        y = ops.StemFn.apply(frames, w, gamma, beta, rm.clone(), rv.clone(), True)
+        f = ops.PoolHeadFn.apply(y)
+        f.backward(torch.linspace(-1, 1, f.numel(), device=dev).reshape(f.shape))
+        return y.detach().float(), f.detach(), w.grad.clone(), gamma.grad.clone()
+    y16, f16, dw16, dg16 = run()
+    assert float(y16.abs().max()) > 0
+    ops.set_activation_dtype("fp32")
+    y32, f32, dw32, dg32 = run()
+    # fp32 tensors keep the convolution output unrounded, so the two runs differ by bf16 rounding of the stored tensors (0.4 %)
+    assert float((y16 - y32).abs().max()) <= 1e-2 * float(y32.abs().max())
+    assert float((f16 - f32).abs().max()) <= 1e-2 * float(f32.abs().max())
+    # gradients: the BatchNorm backward is a residual of large cancelling terms (g - mean g - xhat mean(g xhat)); with the gradient
+    # tensors stored as bf16 (0.4 % per element) and 1 K samples per channel the weight gradient moves by several percent - the
+    # nature of bf16 training tensors, not a kernel property.  Sanity bound here; the arithmetic itself is pinned by
+    # test_episode_matches_oracle[...-bf16act] against the oracle that rounds the same tensors at the same places.
+    assert float((dw16 - dw32).norm() / dw32.norm()) < 0.25 and float((dg16 - dg32).norm() / dg32.norm()) < 0.25
