@@ -124,6 +124,27 @@ template <typename T> __device__ __forceinline__ void st1(T* __restrict__ p, lon
 template <> __device__ __forceinline__ void st1<float>(float* __restrict__ p, long i, float v) { p[i] = v; }
 template <> __device__ __forceinline__ void st1<lmkd_bf16_t>(lmkd_bf16_t* __restrict__ p, long i, float v) { p[i] = f32_to_bf16(v); }
 
+// U consecutive groups of 4 elements per thread: U = 1 for fp32 (one 16-byte access), U = 2 for bf16 (8 elements = one 16-byte access)
+template <typename T> struct ActU { static constexpr int U = 1; };
+template <> struct ActU<lmkd_bf16_t> { static constexpr int U = 2; };
+template <typename T, int U> __device__ __forceinline__ void ldv(const T* __restrict__ p, long iu, float4 (&v)[U]);
+template <> __device__ __forceinline__ void ldv<float, 1>(const float* __restrict__ p, long iu, float4 (&v)[1]) { v[0] = reinterpret_cast<const float4*>(p)[iu]; }
+template <> __device__ __forceinline__ void ldv<lmkd_bf16_t, 2>(const lmkd_bf16_t* __restrict__ p, long iu, float4 (&v)[2]) {
+  const uint4 u = reinterpret_cast<const uint4*>(p)[iu];
+  v[0] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  v[1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+}
+template <typename T, int U> __device__ __forceinline__ void stv(T* __restrict__ p, long iu, const float4 (&v)[U]);
+template <> __device__ __forceinline__ void stv<float, 1>(float* __restrict__ p, long iu, const float4 (&v)[1]) { reinterpret_cast<float4*>(p)[iu] = v[0]; }
+template <> __device__ __forceinline__ void stv<lmkd_bf16_t, 2>(lmkd_bf16_t* __restrict__ p, long iu, const float4 (&v)[2]) {
+  uint4 u;
+  u.x = (unsigned)f32_to_bf16(v[0].x) | ((unsigned)f32_to_bf16(v[0].y) << 16);
+  u.y = (unsigned)f32_to_bf16(v[0].z) | ((unsigned)f32_to_bf16(v[0].w) << 16);
+  u.z = (unsigned)f32_to_bf16(v[1].x) | ((unsigned)f32_to_bf16(v[1].y) << 16);
+  u.w = (unsigned)f32_to_bf16(v[1].z) | ((unsigned)f32_to_bf16(v[1].w) << 16);
+  reinterpret_cast<uint4*>(p)[iu] = u;
+}
+
 // launch the fp32 or the bf16-activation instance of a kernel template `K<T>` (first template argument = storage type)
 #define LMKD_ACT_DISPATCH(K, grid, block, shmem, stream, ...)                                                     \
   do {                                                                                                             \

@@ -298,37 +298,47 @@ extern "C" int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, 
 // res_mode: 0 none, 1 plain residual, 2 residual with its own BN affine (downsample branch)
 // ---------------------------------------------------------------------------------
 // mask_bits (nullable, training): bit e of the array = (y[e] > 0) for flat element e, i.e. the ReLU mask the BatchNorm backward
-// needs, at 1/32 of the bytes of y.  Lane i owns elements 4i..4i+3 = one nibble; 8 lanes assemble a word with three shuffles
-// (n4 % 8 == 0 because C % 32 == 0, so a group of 8 lanes is active or inactive as a whole).
+// needs, at 1/32 of the bytes of y.  A lane owns U groups of 4 consecutive elements (U = 1 fp32, 2 bf16: 16 bytes either way) = U
+// nibbles; 8 / U lanes assemble a word with shuffles (n4 % 8 == 0 because C % 32 == 0, so such a lane group is active or inactive
+// as a whole).
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const T* __restrict__ res,
                                 const float* __restrict__ rstats, T* __restrict__ y, long n4, int C, int relu, int res_mode,
                                 unsigned* __restrict__ mask_bits) {
+  constexpr int U = ActU<T>::U;
   const int C4 = C >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + c);
-    const float4 sh = *reinterpret_cast<const float4*>(stats + 3 * C + c);
-    float4 v = ld4<T>(x, i);
-    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-    if (res_mode == 1) {
-      const float4 r = ld4<T>(res, i);
-      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-    } else if (res_mode == 2) {
-      const float4 r = ld4<T>(res, i);
-      const float4 rs = *reinterpret_cast<const float4*>(rstats + 2 * C + c);
-      const float4 rh = *reinterpret_cast<const float4*>(rstats + 3 * C + c);
-      v.x += fmaf(r.x, rs.x, rh.x); v.y += fmaf(r.y, rs.y, rh.y); v.z += fmaf(r.z, rs.z, rh.z); v.w += fmaf(r.w, rs.w, rh.w);
+  const long nu = n4 / U;
+  for (long iu = (long)blockIdx.x * blockDim.x + threadIdx.x; iu < nu; iu += (long)gridDim.x * blockDim.x) {
+    float4 v[U], r[U];
+    ldv<T, U>(x, iu, v);
+    if (res_mode) ldv<T, U>(res, iu, r);
+    unsigned nibs = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = iu * U + u;
+      const int c = (int)(i % C4) * 4;
+      const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + c);
+      const float4 sh = *reinterpret_cast<const float4*>(stats + 3 * C + c);
+      float4& w = v[u];
+      w.x = fmaf(w.x, sc.x, sh.x); w.y = fmaf(w.y, sc.y, sh.y); w.z = fmaf(w.z, sc.z, sh.z); w.w = fmaf(w.w, sc.w, sh.w);
+      if (res_mode == 1) {
+        w.x += r[u].x; w.y += r[u].y; w.z += r[u].z; w.w += r[u].w;
+      } else if (res_mode == 2) {
+        const float4 rs = *reinterpret_cast<const float4*>(rstats + 2 * C + c);
+        const float4 rh = *reinterpret_cast<const float4*>(rstats + 3 * C + c);
+        w.x += fmaf(r[u].x, rs.x, rh.x); w.y += fmaf(r[u].y, rs.y, rh.y); w.z += fmaf(r[u].z, rs.z, rh.z); w.w += fmaf(r[u].w, rs.w, rh.w);
+      }
+      if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+      nibs |= ((w.x > 0.f ? 1u : 0u) | (w.y > 0.f ? 2u : 0u) | (w.z > 0.f ? 4u : 0u) | (w.w > 0.f ? 8u : 0u)) << (4 * u);
     }
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    st4<T>(y, i, v);      // bf16 storage: a positive value never rounds to zero, so the mask below equals (stored y > 0)
+    stv<T, U>(y, iu, v);      // bf16 storage: a positive value never rounds to zero, so the mask equals (stored y > 0)
     if (mask_bits) {
-      unsigned nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
-      unsigned wbits = nib << (4 * (threadIdx.x & 7));
+      constexpr int LPW = 8 / U;      // lanes per 32-bit word
+      unsigned wbits = nibs << (4 * U * (threadIdx.x & (LPW - 1)));
       wbits |= __shfl_xor(wbits, 1, 64);
       wbits |= __shfl_xor(wbits, 2, 64);
-      wbits |= __shfl_xor(wbits, 4, 64);
-      if ((threadIdx.x & 7) == 0) mask_bits[i >> 3] = wbits;
+      if (LPW == 8) wbits |= __shfl_xor(wbits, 4, 64);
+      if ((threadIdx.x & (LPW - 1)) == 0) mask_bits[iu / LPW] = wbits;
     }
   }
 }
@@ -339,6 +349,7 @@ extern "C" int lmkd_bn_apply(const float* x, const float* stats, const float* re
   LMKD_REQUIRE(res_mode == 0 || res, "lmkd_bn_apply: residual pointer missing");
   LMKD_REQUIRE(res_mode != 2 || rstats, "lmkd_bn_apply: residual stats missing");
   LMKD_REQUIRE(!mask_bits || C % 32 == 0, "lmkd_bn_apply: the ReLU bit mask needs C %% 32 == 0 (C=%d)", C);
+  LMKD_REQUIRE(!g_lmkd_act_bf16 || C % 8 == 0, "lmkd_bn_apply: bf16 tensors need C %% 8 == 0 (C=%d)", C);
   const long n4 = rows * C / 4;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_apply_kernel<lmkd_bf16_t>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)x, stats,
@@ -375,37 +386,56 @@ __device__ __forceinline__ float4 bn_masked_grad(const float4 dy, const float4 x
   return g;
 }
 
-// block: 256 threads = RL row lanes x CC4 channel-quads of one channel chunk (chunk = min(C, 1024) channels, blockIdx.y)
+// block: 256 threads = RL row lanes x (CC / 4U) channel groups of one channel chunk (chunk = min(C, 1024) channels, blockIdx.y);
+// a thread reads U groups of 4 consecutive channels (16 bytes) per row.  The rows are dealt to nbv "virtual blocks" of RL1 = 256 /
+// (CC / 4) row lanes whatever U is - a bf16 workgroup (U = 2) carries two of them - so that the partial sums, their order and with
+// them dgamma / dbeta are bit-identical between the fp32 and the bf16 tensor instances on the same values.
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
                                      const float* __restrict__ stats, float* __restrict__ partial, long rows, int C, int CC,
-                                     int mask_mode) {
+                                     int mask_mode, int nbv) {
   extern __shared__ float sm[];  // [RL][CC][2]
-  const int C4 = C >> 2, CC4 = CC >> 2;
-  const int RL = NP_THREADS / CC4;
-  const int cq = threadIdx.x % CC4, rl = threadIdx.x / CC4;
+  constexpr int U = ActU<T>::U;
+  const int C4 = C >> 2, CCV = CC / (4 * U);
+  const int RL = NP_THREADS / CCV, RL1 = RL / U;
+  const int cq = threadIdx.x % CCV, rl = threadIdx.x / CCV;
+  const int bv = blockIdx.x * U + rl / RL1, vl = rl % RL1;      // virtual block, lane in it
   const int c0 = blockIdx.y * CC;
-  const int c = c0 + cq * 4;
-  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-  {
-    const float4 mean = *reinterpret_cast<const float4*>(stats + c);
-    const float4 istd = *reinterpret_cast<const float4*>(stats + C + c);
-    for (long r = (long)blockIdx.x * RL + rl; r < rows; r += (long)gridDim.x * RL) {
-      const long i = r * C4 + (c >> 2);
-      const float4 xv = ld4<T>(x, i);
-      const float4 g = bn_masked_grad<T>(ld4<T>(dy, i), xv, yact, i, stats, C, c, mask_mode);
-      s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
-      s2.x = fmaf(g.x, (xv.x - mean.x) * istd.x, s2.x); s2.y = fmaf(g.y, (xv.y - mean.y) * istd.y, s2.y);
-      s2.z = fmaf(g.z, (xv.z - mean.z) * istd.z, s2.z); s2.w = fmaf(g.w, (xv.w - mean.w) * istd.w, s2.w);
+  const int c = c0 + cq * 4 * U;
+  float4 s1[U], s2[U], mean[U], istd[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    s1[u] = make_float4(0, 0, 0, 0); s2[u] = make_float4(0, 0, 0, 0);
+    mean[u] = *reinterpret_cast<const float4*>(stats + c + 4 * u);
+    istd[u] = *reinterpret_cast<const float4*>(stats + C + c + 4 * u);
+  }
+  for (long r = bv < nbv ? (long)bv * RL1 + vl : rows; r < rows; r += (long)nbv * RL1) {
+    const long i0 = r * C4 + (c >> 2);      // index of the first group of 4
+    float4 xv[U], dv[U];
+    ldv<T, U>(x, i0 / U, xv);
+    ldv<T, U>(dy, i0 / U, dv);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float4 g = bn_masked_grad<T>(dv[u], xv[u], yact, i0 + u, stats, C, c + 4 * u, mask_mode);
+      s1[u].x += g.x; s1[u].y += g.y; s1[u].z += g.z; s1[u].w += g.w;
+      s2[u].x = fmaf(g.x, (xv[u].x - mean[u].x) * istd[u].x, s2[u].x); s2[u].y = fmaf(g.y, (xv[u].y - mean[u].y) * istd[u].y, s2[u].y);
+      s2[u].z = fmaf(g.z, (xv[u].z - mean[u].z) * istd[u].z, s2[u].z); s2[u].w = fmaf(g.w, (xv[u].w - mean[u].w) * istd[u].w, s2[u].w);
     }
-    float* d = sm + ((long)rl * CC + cq * 4) * 2;
-    d[0] = s1.x; d[1] = s2.x; d[2] = s1.y; d[3] = s2.y; d[4] = s1.z; d[5] = s2.z; d[6] = s1.w; d[7] = s2.w;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float* d = sm + ((long)rl * CC + cq * 4 * U + 4 * u) * 2;
+    d[0] = s1[u].x; d[1] = s2[u].x; d[2] = s1[u].y; d[3] = s2[u].y; d[4] = s1[u].z; d[5] = s2[u].z; d[6] = s1[u].w; d[7] = s2[u].w;
   }
   __syncthreads();
   for (int j = threadIdx.x; j < 2 * CC; j += NP_THREADS) {
-    float s = 0.f;
-    for (int q = 0; q < RL; ++q) s += sm[(long)q * 2 * CC + j];
-    partial[(long)blockIdx.x * 2 * C + 2 * c0 + j] = s;
+#pragma unroll
+    for (int h = 0; h < U; ++h) {
+      if (blockIdx.x * U + h >= nbv) break;
+      float s = 0.f;
+      for (int q = h * RL1; q < (h + 1) * RL1; ++q) s += sm[(long)q * 2 * CC + j];
+      partial[(long)(blockIdx.x * U + h) * 2 * C + 2 * c0 + j] = s;
+    }
   }
 }
 
@@ -429,23 +459,31 @@ template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
                                     const float* __restrict__ stats, const float* __restrict__ coef, T* __restrict__ dx,
                                     T* __restrict__ g_out, long n4, int C, int mask_mode) {
+  constexpr int U = ActU<T>::U;
   const int C4 = C >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    const float4 xv = ld4<T>(x, i);
-    const float4 g = bn_masked_grad<T>(ld4<T>(dy, i), xv, yact, i, stats, C, c, mask_mode);
-    const float4 mean = *reinterpret_cast<const float4*>(stats + c);
-    const float4 istd = *reinterpret_cast<const float4*>(stats + C + c);
-    const float4 A = *reinterpret_cast<const float4*>(coef + c);
-    const float4 mg = *reinterpret_cast<const float4*>(coef + C + c);
-    const float4 mgx = *reinterpret_cast<const float4*>(coef + 2 * C + c);
-    float4 o;
-    o.x = A.x * (g.x - mg.x - (xv.x - mean.x) * istd.x * mgx.x);
-    o.y = A.y * (g.y - mg.y - (xv.y - mean.y) * istd.y * mgx.y);
-    o.z = A.z * (g.z - mg.z - (xv.z - mean.z) * istd.z * mgx.z);
-    o.w = A.w * (g.w - mg.w - (xv.w - mean.w) * istd.w * mgx.w);
-    st4<T>(dx, i, o);
-    if (g_out) st4<T>(g_out, i, g);
+  const long nu = n4 / U;
+  for (long iu = (long)blockIdx.x * blockDim.x + threadIdx.x; iu < nu; iu += (long)gridDim.x * blockDim.x) {
+    float4 xv[U], dv[U], o[U], gq[U];
+    ldv<T, U>(x, iu, xv);
+    ldv<T, U>(dy, iu, dv);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = iu * U + u;
+      const int c = (int)(i % C4) * 4;
+      const float4 g = bn_masked_grad<T>(dv[u], xv[u], yact, i, stats, C, c, mask_mode);
+      const float4 mean = *reinterpret_cast<const float4*>(stats + c);
+      const float4 istd = *reinterpret_cast<const float4*>(stats + C + c);
+      const float4 A = *reinterpret_cast<const float4*>(coef + c);
+      const float4 mg = *reinterpret_cast<const float4*>(coef + C + c);
+      const float4 mgx = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+      o[u].x = A.x * (g.x - mg.x - (xv[u].x - mean.x) * istd.x * mgx.x);
+      o[u].y = A.y * (g.y - mg.y - (xv[u].y - mean.y) * istd.y * mgx.y);
+      o[u].z = A.z * (g.z - mg.z - (xv[u].z - mean.z) * istd.z * mgx.z);
+      o[u].w = A.w * (g.w - mg.w - (xv[u].w - mean.w) * istd.w * mgx.w);
+      gq[u] = g;
+    }
+    stv<T, U>(dx, iu, o);
+    if (g_out) stv<T, U>(g_out, iu, gq);
   }
 }
 
@@ -458,22 +496,23 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
                                 int C, int mask_mode, void* stream) {
   LMKD_REQUIRE(dy && x && stats && dx && coef && workspace, "lmkd_bn_backward: null pointer");
   const int CC = C > 1024 ? 1024 : C;   // channel chunk handled by one workgroup column
-  LMKD_REQUIRE(C % 4 == 0 && C % CC == 0 && 256 % (CC / 4) == 0, "lmkd_bn_backward: unsupported channel count %d", C);
+  const int U = g_lmkd_act_bf16 ? 2 : 1;      // groups of 4 channels per thread (16-byte accesses)
+  LMKD_REQUIRE(C % (4 * U) == 0 && C % CC == 0 && 256 % (CC / 4) == 0, "lmkd_bn_backward: unsupported channel count %d", C);
   LMKD_REQUIRE((mask_mode != 1 && mask_mode != 3) || yact, "lmkd_bn_backward: mask_mode 1 / 3 needs the activation output / its bit mask");
   LMKD_REQUIRE(mask_mode != 3 || C % 32 == 0, "lmkd_bn_backward: bit masks need C %% 32 == 0");
   hipStream_t s = (hipStream_t)stream;
-  const int RL = NP_THREADS / (CC / 4);
-  int nb = cdiv(rows, (long)RL * 8);
+  const int RL1 = NP_THREADS / (CC / 4), RL = RL1 * U;
+  int nb = cdiv(rows, (long)RL1 * 8);      // virtual blocks of RL1 row lanes (U of them per workgroup)
   if (nb > 256 * g_ew_wg_per_cu) nb = 256 * g_ew_wg_per_cu;
   if (nb < 1) nb = 1;
   float* partial = (float*)workspace;
   double* dscr = (double*)((char*)workspace + (((long)2048 * 2 * C * sizeof(float) + 63) / 64) * 64);
   if (g_lmkd_act_bf16)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<lmkd_bf16_t>, dim3(nb, C / CC), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s,
-                       (const lmkd_bf16_t*)dy, (const lmkd_bf16_t*)x, (const lmkd_bf16_t*)yact, stats, partial, rows, C, CC, mask_mode);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<lmkd_bf16_t>, dim3(cdiv(nb, 2), C / CC), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s,
+                       (const lmkd_bf16_t*)dy, (const lmkd_bf16_t*)x, (const lmkd_bf16_t*)yact, stats, partial, rows, C, CC, mask_mode, nb);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb, C / CC), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s, dy, x, yact,
-                       stats, partial, rows, C, CC, mask_mode);
+                       stats, partial, rows, C, CC, mask_mode, nb);
   LMKD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
   const float* pf = partial;
   const double* pd = nullptr;
