@@ -26,6 +26,8 @@ struct ConvGemmArgs {
   int Ho, Wo, Co, omul;
   int Kp, cps, nclass;
   int n_rt, n_ct, xcd_mode;   // row tiles (all classes), column tiles, tile order (XCD-aware 1-D grid, see xcd_decode)
+  int same;    // same-size convolution (conv_same_size): the tile height may be one only the patch kernel has
+  int halo;    // conv_patch_x3_kernel: largest |dh * Ws + dw| over the taps (pixels either side of the tile's own range)
   int accum;   // epilogue: out = acc + out (residual-branch gradient already sits in the output buffer)
   // STATS == 2 (inference): out = relu?( acc * scale[c] + shift[c] (+ res) ), scale/shift = rows 2/3 of the [5][C] BatchNorm table
   const float* ep_stats;
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
 }
 
 #include "conv_x3.h"
+#include "conv_patch.h"
 
 // ---------------------------------------------------------------------------------
 // weight gradient: rows = co (dy, K-outer), cols = packed (tap, ci), K = pixels, split-K slabs
@@ -543,6 +546,8 @@ extern "C" int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout
 
 // ---- compute dtype of the convolutions: 0 = exact fp32 MFMA (default), 1 = bf16 MFMA inputs with fp32 accumulation ----
 static int g_conv_bf16 = 0;
+static int g_conv_patch = 1;   // same-size convolutions of the bf16-plane modes from an LDS-resident patch (conv_patch.h); 0 = im2col gather
+extern "C" int lmkd_conv_set_patch(int on) { g_conv_patch = on ? 1 : 0; return LMKD_OK; }
 static int g_conv_x3 = 0;   // 0 | 6 | 9 bf16 MFMA products per fp32 product (conv_x3.h)
 extern "C" int lmkd_conv_set_compute_dtype(int mode) {
   LMKD_REQUIRE(mode >= 0 && mode <= 3, "lmkd_conv_set_compute_dtype: 0 fp32 MFMA, 1 bf16, 2 fp32 as 3xbf16 (6 products), 3 (9 products)");
@@ -569,20 +574,37 @@ extern "C" int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, i
 // Workgroups per CU by LDS: 2 / 2 / 4 / 2 / 2.
 static int g_tile_override = 0;
 extern "C" int lmkd_conv_set_tile(int id) {
-  LMKD_REQUIRE(id >= 0 && id <= 9, "lmkd_conv_set_tile: id must be 0 (auto) .. 9");
+  LMKD_REQUIRE(id >= 0 && id <= 12, "lmkd_conv_set_tile: id must be 0 (auto) .. 12");
   g_tile_override = id;
   return LMKD_OK;
 }
-// 7..9: the 3xbf16 kernels (conv_x3.h), 8 waves: 7 = 256x64, 8 = 128x128, 9 = 128x64
-static inline int cfg_bm(int id) { return id == 7 ? 256 : ((id <= 2 || id >= 5) ? 128 : 64); }
-static inline int cfg_bn(int id) { return (id == 1 || id == 4 || id == 5 || id == 8) ? 128 : 64; }
+// 7..10: the bf16-plane kernels (conv_x3.h, conv_patch.h), 8 waves: 7 = 256x64, 8 = 128x128, 9 = 128x64, 10 = 256x128 (patch kernel only)
+// 11 / 12 (patch kernel only): 128x64 / 128x128 with FOUR waves, three / two workgroups per CU
+static inline int cfg_bm(int id) { return (id == 7 || id == 10) ? 256 : ((id <= 2 || id >= 5) ? 128 : 64); }
+static inline int cfg_bn(int id) { return (id == 1 || id == 4 || id == 5 || id == 8 || id == 10 || id == 12) ? 128 : 64; }
 static inline int cfg_wg_per_cu(int id) { return id == 1 ? 2 : (id == 3 ? 4 : 3); }
 
 // Pick the tile that minimises ceil(tiles / 256 CUs) * work per tile: at 64 cycles per fp32 MFMA every configuration is
 // matrix-pipe bound, so what differs is how evenly the launch's tiles divide over the CUs (the tail).
-static int pick_conv_cfg(long rows_per_class, int nclass, int ncols) {
+// same: same-size convolution served by the LDS-patch kernel (patch_eligible)
+static int pick_conv_cfg(long rows_per_class, int nclass, int ncols, bool same = false) {
   if (g_conv_x3 || g_conv_bf16) {
-    if (g_tile_override >= 7) return (ncols <= 64 && g_tile_override == 8) ? 9 : g_tile_override;
+    if (g_tile_override >= 7) {
+      int id = g_tile_override;
+      if (id == 10 && !same) id = 8;
+      if (id == 11 && !same) id = 9;
+      if (id == 12 && !same) id = 8;
+      if (ncols <= 64 && cfg_bn(id) == 128) id = id == 10 ? 7 : (id == 12 ? 11 : 9);
+      return id;
+    }
+    if (same) {
+      // patch kernel, measured at 200 frames (tools/patch_bench.py): four-wave workgroups, two or three per CU, beat one eight-wave
+      // workgroup - a workgroup's prologue / epilogue / chunk refill runs under the other workgroups' MFMAs.  128x128 (wave tile
+      // 64x64: half the LDS reads per MFMA) once it gives every CU at least two rounds of tiles, 128x64 otherwise.
+      if (ncols <= 64) return 11;
+      const long t128 = cdiv(rows_per_class, 128) * cdiv(ncols, 128);
+      return t128 >= (g_conv_x3 ? 1024 : 512) ? 12 : 11;
+    }
     if (ncols <= 64) return 9;
     // measured (tools/conv_bench_x3.py): 128x128 (one workgroup per CU) wins once the launch has a tile per CU
     return (long)nclass * cdiv(rows_per_class, 128) * cdiv(ncols, 128) >= 256 ? 8 : 9;
@@ -629,6 +651,57 @@ static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
   hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS, BF16>), grid, dim3(Cfg::THREADS), 0, s, a);
 }
 
+// Same-size convolutions (3x3 / stride 1 forward and data gradient, 1x1 / stride 1) of the bf16-plane modes read an LDS-resident
+// input patch (conv_patch.h).  Returns the halo (largest |dh * Ws + dw| over the taps), or -1 when the launch is not of that kind.
+static int patch_halo(const ConvGemmArgs& a) {
+  if (!g_conv_patch || !(g_conv_x3 || g_conv_bf16) || a.Cs % 32 != 0 || a.nclass != 1 || a.sh != 1 || a.Hs != a.Ho || a.Ws != a.Wo || a.ep_stats)
+    return -1;
+  int halo = 0;
+  for (int t = 0; t < a.ntap[0]; ++t) {
+    const int sft = a.taps[0][t].dh * a.Ws + a.taps[0][t].dw;
+    halo = std::max(halo, sft < 0 ? -sft : sft);
+  }
+  return halo <= PATCH_HALO_MAX ? halo : -1;
+}
+static inline bool conv_same_size(int H, int W, int KH, int KW, int stride, int pad) {
+  return g_conv_patch && stride == 1 && conv_out(H, KH, stride, pad) == H && conv_out(W, KW, stride, pad) == W && (KH / 2) * W + KW / 2 <= PATCH_HALO_MAX;
+}
+
+template <class Cfg>
+static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
+  a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
+  a.n_rt = a.tiles_per_class;
+  a.n_ct = cdiv(ncols, Cfg::BN);
+  a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
+  if (g_xcd_mode == 0) a.xcd_mode = 0;
+  const dim3 grid(xcd_grid(a.n_rt, a.n_ct, a.xcd_mode));
+  a.halo = halo;
+  const int npl = (g_conv_bf16 || g_lmkd_act_bf16) ? 1 : 3;
+  const size_t lds = patch_lds_bytes(Cfg::BM, halo, npl);
+#define LMKD_PATCH(NPROD, PRE, IO)                                                                                             \
+  do {                                                                                                                         \
+    static bool attr_set = false;                                                                                              \
+    if (!attr_set) {                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>),                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize,                                                   \
+                                (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, NPROD == 1 ? 1 : 3));                            \
+      attr_set = true;                                                                                                         \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>), grid, dim3(Cfg::THREADS), lds, s, a);                      \
+  } while (0)
+  if (g_lmkd_act_bf16) LMKD_PATCH(1, false, 3);
+  else if (a.pre_stats) {
+    if (g_conv_bf16) LMKD_PATCH(1, true, 0);
+    else if (g_conv_x3 == 9) LMKD_PATCH(9, true, 0);
+    else LMKD_PATCH(6, true, 0);
+  } else {
+    if (g_conv_bf16) LMKD_PATCH(1, false, 0);
+    else if (g_conv_x3 == 9) LMKD_PATCH(9, false, 0);
+    else LMKD_PATCH(6, false, 0);
+  }
+#undef LMKD_PATCH
+}
+
 template <class Cfg, bool SMALLC, bool STATS>
 static void launch_conv_x3(ConvGemmArgs a, int ncols, hipStream_t s) {
   a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
@@ -663,7 +736,24 @@ template <bool SMALLC, int STATS>
 static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
   if constexpr (STATS != 2) {
     if (g_conv_x3 || g_conv_bf16) {      // bf16 planes in LDS, weights in fragment order (conv_x3.h): 1, 6 or 9 products
-      switch (pick_conv_cfg(a.rows_per_class, a.nclass, ncols)) {
+      const int halo = SMALLC ? -1 : patch_halo(a);
+      int id = pick_conv_cfg(a.rows_per_class, a.nclass, ncols, a.same != 0);
+      if (halo < 0 && id == 10) id = 7;
+      if (halo < 0 && id == 11) id = 9;
+      if (halo < 0 && id == 12) id = 8;      // same tile height (the BatchNorm partials' row count) on the gather kernel
+      if (halo >= 0) {
+        switch (id) {
+          case 7: launch_conv_patch<X3Cfg<256, 64, 4, 2>>(a, ncols, halo, s); break;
+          case 8: launch_conv_patch<X3Cfg<128, 128, 2, 4>>(a, ncols, halo, s); break;
+          case 10: launch_conv_patch<X3Cfg<256, 128, 2, 4>>(a, ncols, halo, s); break;
+          case 11: launch_conv_patch<X3Cfg<128, 64, 2, 2, 3>>(a, ncols, halo, s); break;
+          case 12: launch_conv_patch<X3Cfg<128, 128, 2, 2, 2>>(a, ncols, halo, s); break;
+          default: launch_conv_patch<X3Cfg<128, 64, 4, 2>>(a, ncols, halo, s); break;
+        }
+        LMKD_CHECK_LAUNCH("conv_patch_x3_kernel");
+        return LMKD_OK;
+      }
+      switch (id) {
         case 7: launch_conv_x3<X3Cfg<256, 64, 4, 2>, SMALLC, STATS == 1>(a, ncols, s); break;
         case 8: launch_conv_x3<X3Cfg<128, 128, 2, 4>, SMALLC, STATS == 1>(a, ncols, s); break;
         default: launch_conv_x3<X3Cfg<128, 64, 4, 2>, SMALLC, STATS == 1>(a, ncols, s); break;
@@ -687,7 +777,7 @@ static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
 // number of row tiles (= rows of the BN partial-statistics buffer) of a forward conv
 extern "C" int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   const long M = (long)N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad);
-  return cdiv(M, cfg_bm(pick_conv_cfg(M, 1, Cout)));
+  return cdiv(M, cfg_bm(pick_conv_cfg(M, 1, Cout, conv_same_size(H, W, KH, KW, stride, pad))));
 }
 
 static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* stat_partial, const float* ep_stats,
@@ -717,6 +807,7 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
                "lmkd_conv2d_fwd: tensor exceeds 2^31 elements");
   a.Hr = a.Ho; a.Wr = a.Wo; a.rows_per_class = N * a.Ho * a.Wo; a.tiles_per_class = cdiv(a.rows_per_class, 128);
   a.sh = stride; a.omul = 1; a.nclass = 1;
+  a.same = conv_same_size(H, W, KH, KW, stride, pad) ? 1 : 0;      // as in lmkd_conv2d_fwd_row_tiles
   a.Kp = KH * KWp * Cs;
   a.div_hw = make_fastdiv(a.Hr * a.Wr); a.div_w = make_fastdiv(a.Wr);
   if (smallc) {
@@ -804,6 +895,7 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
   a.rows_per_class = N * a.Hr * a.Wr;
   a.tiles_per_class = cdiv(a.rows_per_class, 128);
   a.div_hw = make_fastdiv(a.Hr * a.Wr); a.div_w = make_fastdiv(a.Wr);
+  a.same = patch_halo(a) >= 0 ? 1 : 0;
   return launch_conv_gemm<false, 0>(a, Cin, (hipStream_t)stream);
 }
 
@@ -1011,7 +1103,9 @@ extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, 
     if (stride == 1) rows = (long)N * H * W;
     else { nclass = 4; rows = (long)N * ((H + 1) / 2) * ((W + 1) / 2); }
   }
-  const int id = pick_conv_cfg(rows, nclass, ncols);
+  const bool same = conv_same_size(H, W, KH, KW, stride, pad);
+  int id = pick_conv_cfg(rows, nclass, ncols, same);
+  if ((kind == 0 ? Cs : Cout) % 32 != 0) id = id == 10 ? 7 : (id == 11 ? 9 : (id == 12 ? 8 : id));
   const int n_rt = nclass * cdiv(rows, cfg_bm(id)), n_ct = cdiv(ncols, cfg_bn(id));
   int xm = (n_ct >= 8 && (n_ct & 7) == 0) ? 1 : 0;
   if (g_xcd_mode == 0) xm = 0;

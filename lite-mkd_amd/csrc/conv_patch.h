@@ -1,0 +1,235 @@
+// Same-size convolutions (3x3 / stride 1 / pad 1 forward and data gradient: 13 of the 20 convolutions of the ResNet-18 trunk,
+// 85 % of its FLOPs) from an LDS-resident input PATCH instead of an im2col gather.
+//
+// For a same-size convolution the input pixel of output pixel m (flattened n, h, w) under tap (dh, dw) is the flattened pixel
+// m + dh * W + dw.  A tile of BM consecutive output pixels therefore reads the CONTIGUOUS pixel range [m0 - halo, m0 + BM + halo),
+// halo = W + 1, and every tap's A operand is the same LDS image shifted by a whole number of rows.  Per 32-channel chunk a
+// workgroup loads that range once (BM + 2 halo rows instead of 9 x BM gathered rows: 1.1x - 1.9x the tile instead of 9x), splits
+// it into the bf16 planes once, and runs the nine taps' MFMAs against it: one pair of barriers per CHUNK, not one per K-step, and
+// 1/5 - 1/8 of the loader's global loads, split arithmetic and LDS writes.  Zero padding (and rows past the tensor) is an
+// address select per (row, tap): the read goes to an all-zero LDS row.
+//
+// LDS image: row j = pixel m0 - halo + j, ROWB bytes: [plane 0: 32 bf16][plane 1][plane 2][16 B pad] = 208 B in the three-plane
+// modes, [32 bf16][16 B pad] = 80 B in one-plane (bf16) mode - odd multiples of 16 B, so the 16 rows of each ds_read_b128 lane
+// group cover all 64 banks; plane and k-group offsets are instruction immediates.  Row P = BM + 2 halo is the zero row.
+// The weight operand comes from global memory in fragment order, straight into registers, exactly as in conv_gemm_x3_kernel.
+// The next chunk's patch is fetched into registers right after the current one is stored, i.e. a whole chunk (9 K-steps) ahead.
+#pragma once
+
+#define PATCH_HALO_MAX 57      // W <= 56
+
+template <int NPL> struct PatchRow { static constexpr int BYTES = NPL == 1 ? 80 : 208; };
+
+// dynamic LDS bytes of a launch
+static inline size_t patch_lds_bytes(int bm, int halo, int npl) { return (size_t)(bm + 2 * halo + 1) * (npl == 1 ? 80 : 208); }
+
+template <class Cfg, int NPROD, bool PRE, int IO>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(ConvGemmArgs a) {
+  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+  constexpr int NPL = NPROD == 1 ? 1 : 3;
+  static_assert((IO == 0 || NPROD == 1) && !(IN16 && PRE), "bf16 tensors: one-plane mode, no load-side arithmetic");
+  constexpr int ROWB = PatchRow<NPL>::BYTES;
+  constexpr int LPR = IN16 ? 4 : 8;                       // lanes per patch row (16 bytes each)
+  constexpr int RPP = Cfg::THREADS / LPR;                 // patch rows per pass
+  constexpr int NI = (Cfg::BM + 2 * PATCH_HALO_MAX + RPP - 1) / RPP;
+  using LB = X3FragB<Cfg::TN, NPL>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+  __shared__ int s_out[Cfg::BM];
+  __shared__ int s_tap_shift[LMKD_MAX_TAPS], s_tap_kofs[LMKD_MAX_TAPS];
+  __shared__ float s_red[Cfg::WM * Cfg::BN * 2];
+  const int tid = threadIdx.x;
+  int rt, ct;
+  if (!xcd_decode(blockIdx.x, a.n_rt, a.n_ct, a.xcd_mode, rt, ct)) return;
+  const int ntap = a.ntap[0];
+  const int halo = a.halo, P = Cfg::BM + 2 * halo;
+  const int M = a.rows_per_class;
+  const int row0 = rt * Cfg::BM, n0 = ct * Cfg::BN;
+  if (tid < ntap) {
+    const Tap tp = a.taps[0][tid];
+    s_tap_shift[tid] = (tp.dh * a.Ws + tp.dw) * ROWB;
+    s_tap_kofs[tid] = tp.kofs;
+  }
+  for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) s_out[r] = (row0 + r < M) ? (row0 + r) * a.Co : -1;
+  for (int j = tid; j < ROWB / 4; j += Cfg::THREADS) reinterpret_cast<unsigned*>(psm + (long)P * ROWB)[j] = 0u;   // the zero row
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int h = lane >> 5;
+  const int a_row = wm * (Cfg::TM * 32) + (lane & 31);
+  // per MFMA row of this lane: LDS byte address of its own pixel's row (tap shift 0) and one validity bit per tap
+  unsigned a_base[Cfg::TM], a_mask[Cfg::TM];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i) {
+    const int r = a_row + 32 * i, m = row0 + r;
+    a_base[i] = (unsigned)((r + halo) * ROWB + 16 * h);
+    unsigned mk = 0;
+    if (m < M) {
+      const int n = fdiv(m, a.div_hw);
+      const int rem = m - n * a.Hs * a.Ws;
+      const int hh = fdiv(rem, a.div_w), ww = rem - hh * a.Ws;
+      for (int tp = 0; tp < ntap; ++tp) {
+        const int y = hh + a.taps[0][tp].dh, x = ww + a.taps[0][tp].dw;
+        if ((unsigned)y < (unsigned)a.Hs && (unsigned)x < (unsigned)a.Ws) mk |= 1u << tp;
+      }
+    }
+    a_mask[i] = mk;
+  }
+  const unsigned zero_addr = (unsigned)(P * ROWB + 16 * h);
+  // patch loader: LPR lanes x 16 B per pixel row
+  constexpr int ESZ = IN16 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t prs = x3_rsrc(a.src, (long)a.N * a.Hs * a.Ws * a.Cs * ESZ);
+  const int pk = ((tid & (LPR - 1))) * (IN16 ? 8 : 4);            // first channel of this lane inside the 32-channel chunk
+  // byte offset of (patch row j = tid / LPR + RPP * i, channel pk) of chunk 0 is p_off0 + i * p_step where bit i of p_ok is set
+  // (row inside the patch and the tensor), else the load is sent out of range (returns zeros)
+  const long pix0 = (long)row0 - halo + tid / LPR;
+  const unsigned p_off0 = (unsigned)((pix0 * a.Cs + pk) * ESZ), p_step = (unsigned)(RPP * a.Cs * ESZ);
+  unsigned p_ok = 0;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const long pix = pix0 + RPP * i;
+    if (tid / LPR + RPP * i < P && pix >= 0 && pix < (long)a.N * a.Hs * a.Ws) p_ok |= 1u << i;
+  }
+  u32x4 rp[NI];
+  float4 psc = float4(), psh = float4();
+  auto issue_patch = [&](int cc) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (i * RPP < P) rp[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, ((p_ok >> i) & 1u) ? p_off0 + i * p_step + (unsigned)(cc * 32 * ESZ) : X3_OOB, 0, 0);
+    if (PRE) {
+      psc = *reinterpret_cast<const float4*>(a.pre_stats + 2 * a.Cs + cc * 32 + pk);
+      psh = *reinterpret_cast<const float4*>(a.pre_stats + 3 * a.Cs + cc * 32 + pk);
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int j = tid / LPR + RPP * i;
+      if (j >= P) continue;
+      unsigned char* d = psm + j * ROWB + pk * 2;
+      if constexpr (IN16) {
+        *reinterpret_cast<u32x4*>(d) = rp[i];
+      } else {
+        float4 v = make_float4(__uint_as_float(rp[i].x), __uint_as_float(rp[i].y), __uint_as_float(rp[i].z), __uint_as_float(rp[i].w));
+        if (PRE && ((p_ok >> i) & 1u)) {      // relu(BatchNorm(raw)), bit-identical to bn_apply_kernel; padding never reaches here
+          v.x = fmaxf(fmaf(v.x, psc.x, psh.x), 0.f); v.y = fmaxf(fmaf(v.y, psc.y, psh.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, psc.z, psh.z), 0.f); v.w = fmaxf(fmaf(v.w, psc.w, psh.w), 0.f);
+        }
+        if (NPL == 1) {
+          *reinterpret_cast<uint2*>(d) = x3_round4(v);
+        } else {
+          uint2 q0, q1, q2;
+          x3_split4(v, q0, q1, q2);
+          *reinterpret_cast<uint2*>(d) = q0;
+          *reinterpret_cast<uint2*>(d + 64) = q1;
+          *reinterpret_cast<uint2*>(d + 128) = q2;
+        }
+      }
+    }
+  };
+  LB lb;
+  lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane);
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int nk = ntap * a.cps;
+  u32x4 rb0[LB::NR], rb1[LB::NR];
+  int b_tp = 0, b_cc = 0;      // (tap, chunk) of the next B fragments to fetch
+  auto issue_b = [&](u32x4 (&rb)[LB::NR]) {
+    lb.load(s_tap_kofs[b_tp] + b_cc * LMKD_BK, rb);
+    if (++b_tp == ntap) { b_tp = 0; ++b_cc; }
+  };
+  int k_tp = 0, k_cc = 0;      // (tap, chunk) of the current K-step
+  // K-step t: MFMAs with the B set `rb`; afterwards the set fetched before them (`rbn`, step t+1) is landed - every load in flight
+  // is then one MFMA phase old - and `rb` is refilled with step t+2.  At a chunk boundary the patch is replaced first.
+  auto step = [&](int t, u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR]) {
+    if (k_tp == 0) {
+      __syncthreads();                       // every wave has finished reading the previous chunk
+      store_patch();
+      __syncthreads();
+      if (k_cc + 1 < a.cps) issue_patch(k_cc + 1);
+    }
+    const unsigned sh = (unsigned)s_tap_shift[k_tp];
+    unsigned ad[Cfg::TM];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) ad[i] = ((a_mask[i] >> k_tp) & 1u) ? a_base[i] + sh : zero_addr;
+    // both k-groups' A fragments are read up front (group 1 lands under group 0's MFMAs) unless that would be 96 registers
+    constexpr bool AHEAD = NPL * Cfg::TM < 12 && (Cfg::THREADS == 512 || NPL == 1);
+    bf16x8 av[2][NPL][Cfg::TM];
+    auto read_a = [&](int g) {
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i) av[AHEAD ? g : 0][p][i] = *reinterpret_cast<const bf16x8*>(psm + ad[i] + p * 64 + g * 32);
+    };
+    read_a(0);
+    if (AHEAD) read_a(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int ga = AHEAD ? g : 0;
+      if (!AHEAD && g == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        if constexpr (NPROD == 1) {
+          const bf16x8 b0 = x3_as_bf16(rb[j * 2 + g]);
+#pragma unroll
+          for (int i = 0; i < Cfg::TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][0][i], b0, acc[i][j], 0, 0, 0);
+        } else {
+          const bf16x8 b0 = x3_as_bf16(rb[j * 6 + g * 3 + 0]), b1 = x3_as_bf16(rb[j * 6 + g * 3 + 1]), b2 = x3_as_bf16(rb[j * 6 + g * 3 + 2]);
+#pragma unroll
+          for (int i = 0; i < Cfg::TM; ++i) {
+            f32x16 c = acc[i][j];
+            if (NPROD == 9) {
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][2][i], b2, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][1][i], b2, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][2][i], b1, c, 0, 0, 0);
+            }
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][1][i], b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][0][i], b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][2][i], b0, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][0][i], b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][1][i], b0, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][0][i], b0, c, 0, 0, 0);
+            acc[i][j] = c;
+          }
+        }
+      }
+    }
+    if (++k_tp == ntap) { k_tp = 0; ++k_cc; }
+    // unconditional: with the landing under `if (t + 1 < nk)` the compiler has to assume a path on which the sets are still in
+    // flight at the next step and puts s_waitcnt vmcnt(..0) between that step's MFMAs - behind the loads issued a moment ago
+    // The scheduling fences keep the wait where it is written: after this step's MFMAs and before the next loads are issued.
+    __builtin_amdgcn_sched_barrier(0);
+    x3_landed(rbn);
+    x3_landed(rp);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nk) issue_b(rb);
+  };
+  __syncthreads();      // tap tables, s_out, zero row
+  if (nk > 0) {
+    issue_patch(0);
+    issue_b(rb0);
+    if (nk > 1) issue_b(rb1);
+    x3_landed(rp);
+    x3_landed(rb0);
+    x3_landed(rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    // two steps per trip, the odd last step outside the loop: with `if (t + 1 < nk) step(t + 1, ..)` inside it the compiler sees a
+    // path (second step skipped, loop continues) on which the first step's B set was re-issued a moment ago, and guards the
+    // MFMAs with s_waitcnt vmcnt(5..0) - which on the real path wait for the loads issued just before them
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      step(t, rb0, rb1);
+      step(t + 1, rb1, rb0);
+    }
+    if (t < nk) step(t, rb0, rb1);
+  }
+  x3_epilogue<Cfg, true, OUT16>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid);
+}

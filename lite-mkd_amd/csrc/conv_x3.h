@@ -21,9 +21,10 @@
 
 #define X3_LD 40   // bf16 elements per LDS row
 
-template <int BM_, int BN_, int WM_, int WN_>
+// MINW: waves per SIMD the register allocation must leave room for (second __launch_bounds__ argument of hipcc)
+template <int BM_, int BN_, int WM_, int WN_, int MINW_ = 1>
 struct X3Cfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, MINW = MINW_;
   static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static constexpr int THREADS = 64 * WM * WN;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
@@ -274,6 +275,83 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* __restrict__ As, i
   }
 }
 
+// Shared epilogue of the bf16-plane convolution kernels: optional out += acc, store (fp32 or bf16 tensor), BatchNorm partial sums.
+// s_out[r] = element offset of tile row r's output pixel (channel 0), -1 for rows outside the tensor.
+template <class Cfg, bool STATS, bool OUT16>
+__device__ __forceinline__ void x3_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], const int* s_out, float* s_red, int rt,
+                                            int n0, int wm, int wn, int lane, int tid) {
+  const int cl0 = wn * (Cfg::TN * 32) + (lane & 31);
+  lmkd_bf16_t* out16 = reinterpret_cast<lmkd_bf16_t*>(a.out);
+  if (a.accum) {      // out += acc: all previous values first (loads in flight together), then the adds (conv_gemm_kernel)
+    float prev[Cfg::TM][Cfg::TN][16];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ob = s_out[wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane)];
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+          const int col = n0 + cl0 + j * 32;
+          prev[i][j][e] = (ob >= 0 && col < a.Co) ? (OUT16 ? bf16_to_f32(out16[(long)ob + col]) : a.out[(long)ob + col]) : 0.f;
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] + prev[i][j][e];
+  }
+  float s1[Cfg::TN], s2[Cfg::TN];
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane);
+      const int ob = s_out[rl];
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int col = n0 + cl0 + j * 32;
+        float v = acc[i][j][e];
+        if (OUT16) {      // the tensor in HBM is bf16: the BatchNorm statistics are those of the stored (rounded) values
+          const lmkd_bf16_t b = f32_to_bf16(v);
+          if (ob >= 0 && col < a.Co) out16[(long)ob + col] = b;
+          v = bf16_to_f32(b);
+        } else if (ob >= 0 && col < a.Co) {
+          a.out[(long)ob + col] = v;
+        }
+        if (STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (lane < 32) {
+        s_red[(wm * Cfg::BN + cl0 + j * 32) * 2 + 0] = t1;
+        s_red[(wm * Cfg::BN + cl0 + j * 32) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < Cfg::BN && n0 + tid < a.Co && a.stat_partial) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < Cfg::WM; ++w) {
+        t1 += s_red[(w * Cfg::BN + tid) * 2 + 0];
+        t2 += s_red[(w * Cfg::BN + tid) * 2 + 1];
+      }
+      float* p = a.stat_partial + ((long)rt * a.Co + n0 + tid) * 2;
+      p[0] = t1;
+      p[1] = t2;
+    }
+  }
+}
+
 // IO: bit 0 = the gathered tensor is stored as bf16, bit 1 = the output tensor is stored as bf16 (lmkd_set_activation_dtype(1))
 template <class Cfg, bool SMALLC, bool STATS, int NPROD, bool PRE = false, int IO = 0>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs a) {
@@ -427,76 +505,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
     }
   }
 
-  const int cl0 = wn * (Cfg::TN * 32) + (lane & 31);
-  lmkd_bf16_t* out16 = reinterpret_cast<lmkd_bf16_t*>(a.out);
-  if (a.accum) {      // out += acc: all previous values first (loads in flight together), then the adds (conv_gemm_kernel)
-    float prev[Cfg::TM][Cfg::TN][16];
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int ob = s_out[wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane)];
-#pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j) {
-          const int col = n0 + cl0 + j * 32;
-          prev[i][j][e] = (ob >= 0 && col < a.Co) ? (OUT16 ? bf16_to_f32(out16[(long)ob + col]) : a.out[(long)ob + col]) : 0.f;
-        }
-      }
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] + prev[i][j][e];
-  }
-  float s1[Cfg::TN], s2[Cfg::TN];
-#pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) s1[j] = s2[j] = 0.f;
-#pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int rl = wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane);
-      const int ob = s_out[rl];
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) {
-        const int col = n0 + cl0 + j * 32;
-        float v = acc[i][j][e];
-        if (OUT16) {      // the tensor in HBM is bf16: the BatchNorm statistics are those of the stored (rounded) values
-          const lmkd_bf16_t b = f32_to_bf16(v);
-          if (ob >= 0 && col < a.Co) out16[(long)ob + col] = b;
-          v = bf16_to_f32(b);
-        } else if (ob >= 0 && col < a.Co) {
-          a.out[(long)ob + col] = v;
-        }
-        if (STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (STATS) {
-#pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) {
-      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
-      const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
-      if (lane < 32) {
-        s_red[(wm * Cfg::BN + cl0 + j * 32) * 2 + 0] = t1;
-        s_red[(wm * Cfg::BN + cl0 + j * 32) * 2 + 1] = t2;
-      }
-    }
-    __syncthreads();
-    if (tid < Cfg::BN && n0 + tid < a.Co && a.stat_partial) {
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < Cfg::WM; ++w) {
-        t1 += s_red[(w * Cfg::BN + tid) * 2 + 0];
-        t2 += s_red[(w * Cfg::BN + tid) * 2 + 1];
-      }
-      float* p = a.stat_partial + ((long)rt * a.Co + n0 + tid) * 2;
-      p[0] = t1;
-      p[1] = t2;
-    }
-  }
+  x3_epilogue<Cfg, STATS, OUT16>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid);
 }
 
 // fp32 K-major packed weights Wp[col][Kp] -> fragment-order bf16 planes (layout: X3FragB); npl = 1: one RNE-rounded plane

@@ -1,0 +1,61 @@
+"""Same-size 3x3 convolutions of the trunk at 200 frames: LDS-patch kernel (conv_patch.h) against the im2col-gather kernel
+(conv_x3.h), forward and data gradient, per arithmetic mode, with a bit-for-bit comparison of the two kernels' outputs.
+`gpurun -- python tools/patch_bench.py [mode ...]`   modes: fp32x3 bf16 bf16act"""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import litemkd_amd  # noqa: F401
+from litemkd_amd import ops
+from litemkd_amd._lib import lib
+dev = torch.device("cuda", 0)
+
+
+def tm(f, reps=10):
+    f(); f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+N = 200
+shapes = [("l1", 64, 56, 64), ("l2", 128, 28, 128), ("l3", 256, 14, 256), ("l4", 512, 7, 512)]
+modes = sys.argv[1:] or ["fp32x3", "bf16", "bf16act"]
+for mode in modes:
+    ops.set_conv_compute_dtype("bf16" if mode.startswith("bf16") else mode)
+    ops.set_activation_dtype("bf16" if mode == "bf16act" else "fp32")
+    dt = torch.bfloat16 if mode == "bf16act" else torch.float32
+    for (name, C, H, Cout) in shapes:
+        x = torch.relu(torch.randn(N, H, H, C, device=dev)).to(dt)
+        w = torch.randn(Cout, C, 3, 3, device=dev) * 0.05
+        gy = torch.randn(N, H, H, Cout, device=dev).to(dt)
+        wp, wd = ops._pack_weights(w, C, 0), ops._pack_weights(w, C, 1)
+        fl = 2.0 * N * H * H * Cout * C * 9
+        res, best = {}, {}
+        cfgs = [(0, 0), (1, 0)] + [(1, t) for t in ((9, 7, 11) if Cout <= 64 else (8, 10, 11, 12))]
+        for rnd_ in range(3):      # interleaved rounds, best time per configuration: the clock the chip holds drifts between launches
+            for patch, tile in cfgs:
+                lib().call("lmkd_conv_set_patch", patch)
+                lib().call("lmkd_conv_set_tile", tile)
+                if rnd_ == 0:
+                    y, st = ops.conv_fwd(x, wp, Cout, 3, 3, 1, 1, True)
+                    dx = ops.conv_bwd_data(gy, wd, (N, H, H, C), Cout, 3, 3, 1, 1)
+                    # BatchNorm partial sums: per row tile, so compare their column totals (tile heights differ)
+                    res[(patch, tile)] = (y, st.double().sum(0), dx)
+                t1 = tm(lambda: ops.conv_fwd(x, wp, Cout, 3, 3, 1, 1, True), 6)
+                t2 = tm(lambda: ops.conv_bwd_data(gy, wd, (N, H, H, C), Cout, 3, 3, 1, 1), 6)
+                o = best.get((patch, tile), (1e9, 1e9))
+                best[(patch, tile)] = (min(o[0], t1), min(o[1], t2))
+        line = "%-8s %-3s" % (mode, name)
+        for (patch, tile) in cfgs:
+            t1, t2 = best[(patch, tile)]
+            line += " | %s%-2d %5.1f (%5.1f TF) dg %5.1f" % (("G", "P")[patch], tile, t1 * 1e3, fl / t1 / 1e9, t2 * 1e3)
+        ks = list(res)
+        same = all(torch.equal(res[ks[0]][0], res[k][0]) and torch.equal(res[ks[0]][2], res[k][2]) and
+                   torch.allclose(res[ks[0]][1], res[k][1], rtol=1e-6, atol=1e-3) for k in ks[1:])
+        print(line + " | identical %s" % same, flush=True)
+    lib().call("lmkd_conv_set_tile", 0)
+    lib().call("lmkd_conv_set_patch", 1)
+ops.set_activation_dtype("fp32")
+ops.set_conv_compute_dtype("fp32")
