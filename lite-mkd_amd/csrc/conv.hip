@@ -600,10 +600,10 @@ static int pick_conv_cfg(long rows_per_class, int nclass, int ncols, bool same =
     if (same) {
       // patch kernel, measured at 200 frames (tools/patch_bench.py): four-wave workgroups, two or three per CU, beat one eight-wave
       // workgroup - a workgroup's prologue / epilogue / chunk refill runs under the other workgroups' MFMAs.  128x128 (wave tile
-      // 64x64: half the LDS reads per MFMA) once it gives every CU at least two rounds of tiles, 128x64 otherwise.
+      // 64x64: half the LDS reads per MFMA) in the three-plane modes once it gives every CU at least two rounds of tiles, 128x64 otherwise.
       if (ncols <= 64) return 11;
       const long t128 = cdiv(rows_per_class, 128) * cdiv(ncols, 128);
-      return t128 >= (g_conv_x3 ? 1024 : 512) ? 12 : 11;
+      return (g_conv_x3 && t128 >= 1024) ? 12 : 11;      // one-plane modes: 128x64 throughout (three or four workgroups per CU)
     }
     if (ncols <= 64) return 9;
     // measured (tools/conv_bench_x3.py): 128x128 (one workgroup per CU) wins once the launch has a tile per CU
