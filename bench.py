@@ -194,7 +194,7 @@ def main():
     conv_flops_timed = sum(r[1] for r in timed_events)
     # the same HIP-event measurement inside the timed region: with two streams a launch's interval also contains the other
     # stream's kernels, so this is a lower bound of the kernel's own rate (reported next to the serialized figure)
-    cg_t = [(r[1], r[2].elapsed_time(r[3]) * 1e-3) for r in timed_events if r[0] == "conv_gemm_kernel"]
+    cg_t = [(r[1], r[2].elapsed_time(r[3]) * 1e-3) for r in timed_events if r[0] in ("conv_gemm_kernel", "conv_patch_kernel")]
     achieved_timed = (sum(f for f, _ in cg_t) / max(sum(t for _, t in cg_t), 1e-12) / 1e12) if cg_t else None
 
     # Per-kernel roofline.  In the timed region the two trunk calls run on two streams, so kernels overlap and a single
@@ -241,16 +241,31 @@ def main():
         for (name, flops, nbytes), (t, n) in sorted(shp.items(), key=lambda kv: -kv[1][0]):
             print("%-18s %7.2f %7.1f %4d %8.1f %6.1f %5.1f%%" % (name, flops / 1e9, nbytes / 1e6, n, t / n * 1e6, flops * n / t / 1e12,
                                                            100 * t / tot), file=sys.stderr)
-    cg = fam.get("conv_gemm_kernel", [0.0, 1.0, 1, 0.0])
-    wg = fam.get("conv_wgrad_kernel", [0.0, 1.0, 1, 0.0])
+    # Forward + data-gradient convolutions run on two kernel families: conv_patch_x3_kernel (same-size 3x3 convolutions of the
+    # bf16-plane modes, conv_patch.h) and the im2col-gather kernels (stride-2 / 1x1 / stem; every convolution in f32native).
+    # The roofline is that of whichever takes more time; the other one is reported beside it.
+    ZERO = [0.0, 1.0, 0, 0.0]
+
+    def conv_families(fm):
+        pk, gk = fm.get("conv_patch_kernel", ZERO), fm.get("conv_gemm_kernel", ZERO)
+        patch_dominant = pk[2] > 0 and pk[1] >= gk[1]
+        return (pk, gk, True) if patch_dominant else (gk, pk, False)
+    cg, cg_other, patch_dom = conv_families(fam)
+    wg = fam.get("conv_wgrad_kernel", ZERO)
     achieved = cg[0] / cg[1] / 1e12
     # dense MFMA peaks (MI355X_MICROARCH.md); the 3xbf16 arithmetic issues 6 bf16 MFMA flops per algorithmic fp32 flop
     PEAK = {"f32": 2500.0 / 6, "f32native": PEAK_FP32_MFMA_TFLOPS, "bf16": 2500.0, "bf16conv": 2500.0}
-    KERNEL = {"f32": "conv_gemm_x3_kernel (implicit-GEMM conv fwd + dgrad): v_mfma_f32_32x32x16_bf16 x6 per fp32 product, exact 3-way bf16 "
-                     "operand split, fp32 accumulate; peak = dense bf16 MFMA peak / 6",
-              "f32native": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad, v_mfma_f32_32x32x2_f32)",
-              "bf16": "conv_gemm_x3_kernel, one bf16 plane, bf16 tensors (implicit-GEMM conv fwd + dgrad, v_mfma_f32_32x32x16_bf16)",
-              "bf16conv": "conv_gemm_x3_kernel, one bf16 plane, fp32 tensors"}
+    ARITH = {"f32": "v_mfma_f32_32x32x16_bf16 x6 per fp32 product, exact 3-way bf16 operand split, fp32 accumulate; peak = dense bf16 MFMA peak / 6",
+             "f32native": "v_mfma_f32_32x32x2_f32",
+             "bf16": "one bf16 plane, bf16 tensors, v_mfma_f32_32x32x16_bf16",
+             "bf16conv": "one bf16 plane, fp32 tensors, v_mfma_f32_32x32x16_bf16"}
+
+    def kernel_name(mode, patch):
+        if patch:
+            return "conv_patch_x3_kernel (3x3 stride-1 conv fwd + dgrad from an LDS-resident input patch): " + ARITH[mode]
+        return ("conv_gemm_kernel" if mode == "f32native" else "conv_gemm_x3_kernel") + " (implicit-GEMM conv fwd + dgrad): " + ARITH[mode]
+    KERNEL = {a.dtype: kernel_name(a.dtype, patch_dom)}
+    PMC_KEY = "conv_patch_x3_kernel" if patch_dom else ("conv_gemm_kernel" if a.dtype == "f32native" else "conv_gemm_x3_kernel")
     peak = PEAK[a.dtype]
     # HBM-side traffic of the same kernel family: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950) of `bench.py --serial`,
@@ -264,8 +279,8 @@ def main():
         if a.dtype != "f32":
             traffic_note = "%s holds the PMC passes of the headline arithmetic only" % os.path.relpath(tfiles[-1], ROOT)
         elif tj.get("kernel_src_hash") == kernel_source_hash():
-            traffic = tj.get("conv_gemm_x3_kernel", {}).get("traffic_bytes_per_launch")
-            traffic_note = "rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch of conv_gemm_x3_kernel, %s" % os.path.relpath(tfiles[-1], ROOT)
+            traffic = tj.get(PMC_KEY, {}).get("traffic_bytes_per_launch")
+            traffic_note = "rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch of %s, %s" % (PMC_KEY, os.path.relpath(tfiles[-1], ROOT))
         else:
             traffic_note = "%s was measured on other kernel sources (hash %s, now %s): not reported" % (
                 os.path.relpath(tfiles[-1], ROOT), tj.get("kernel_src_hash"), kernel_source_hash())
@@ -296,6 +311,8 @@ def main():
                      "kernel_src_hash": kernel_source_hash(),
                      "algorithmic_bytes_per_launch": cg[3] / max(cg[2], 1),
                      "launches": cg[2], "avg_launch_ms": cg[1] / max(cg[2], 1) * 1e3,
+                     "other_conv_family": {"kernel": kernel_name(a.dtype, not patch_dom).split(":")[0], "launches": cg_other[2],
+                                           "tflops": cg_other[0] / cg_other[1] / 1e12, "avg_launch_ms": cg_other[1] / max(cg_other[2], 1) * 1e3},
                      "wgrad_kernel_tflops": wg[0] / wg[1] / 1e12, "wgrad_avg_launch_ms": wg[1] / max(wg[2], 1) * 1e3,
                      "measured_on": "timed region (--serial)" if a.serial else "%d extra serialized episodes after the timed region" % a.roofline_episodes,
                      "achieved_in_timed_region": achieved_timed,
@@ -317,10 +334,11 @@ def main():
             fence()
             v = 16 / (time.perf_counter() - t1)
             f2 = families(roofline_pass())
-            g2, w2 = f2.get("conv_gemm_kernel", [0.0, 1.0, 1, 0.0]), f2.get("conv_wgrad_kernel", [0.0, 1.0, 1, 0.0])
+            g2, _, pd2 = conv_families(f2)
+            w2 = f2.get("conv_wgrad_kernel", ZERO)
             ach = g2[0] / g2[1] / 1e12
             other[name] = {"value": v, "unit": "episodes/s", "steps": 16,
-                           "roofline": {"bound": "mfma", "kernel": KERNEL[name], "achieved": ach, "peak": PEAK[name], "unit": "TFLOP/s",
+                           "roofline": {"bound": "mfma", "kernel": kernel_name(name, pd2), "achieved": ach, "peak": PEAK[name], "unit": "TFLOP/s",
                                         "frac": ach / PEAK[name], "avg_launch_ms": g2[1] / max(g2[2], 1) * 1e3,
                                         "wgrad_kernel_tflops": w2[0] / w2[1] / 1e12}}
         set_mode("f32")

@@ -82,7 +82,8 @@ int lmkd_conv2d_bwd_weight_pre(const float* x_raw, const float* pre_stats, const
                                void* stream);
 
 /* launch plan (no launch) of lmkd_conv2d_fwd (kind 0) / _bwd_data (1) / _bwd_weight (2) for these shapes in the current mode:
-   info[4] (HOST) = tile id, XCD tile order, parity classes | pixel splits, workgroups.  Test/diagnostic aid. */
+   info[5] (HOST) = tile id, XCD tile order, parity classes | pixel splits, workgroups, 1 if the LDS-patch kernel runs it.
+   Test/diagnostic aid. */
 int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, int* info_host);
 
 /* dw_oihw += weight gradient (dw_oihw = the parameter's .grad; accumulation over trunk calls / episodes, trainwandb.py:141-143);

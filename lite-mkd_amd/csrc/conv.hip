@@ -1075,11 +1075,11 @@ extern "C" int lmkd_conv2d_bwd_weight_acc(const float* x, const float* pre_stats
 }
 
 // Launch plan of a convolution, without launching: which kernel instance and tile order the three entry points above would
-// pick for these shapes in the current arithmetic mode.  info[0] = tile id (lmkd_conv_set_tile numbering; the weight gradient
+// pick for these shapes in the current arithmetic mode (info: 5 ints).  info[0] = tile id (lmkd_conv_set_tile numbering; the weight gradient
 // reports 1 = 128x128/8 waves, 2 = 128x64, 3 = 64x64, 4 = 64x128), info[1] = XCD tile order (forward / data gradient: 0 row
 // bands, 1 column slices; weight gradient: 1 = all tiles of a pixel split on one XCD), info[2] = pixel splits (weight gradient)
 // or parity classes (data gradient), info[3] = workgroups launched.  Used by the parity tests to prove that the benchmark's
-// kernel instances are the ones under test.
+// kernel instances are the ones under test.  info[4] = 1 when the launch runs on the LDS-patch kernel (conv_patch.h).
 extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                 int* info) {
   LMKD_REQUIRE(info && kind >= 0 && kind <= 2, "lmkd_conv2d_plan: kind must be 0 (forward), 1 (data gradient) or 2 (weight gradient)");
@@ -1093,6 +1093,7 @@ extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, 
     info[1] = (g_xcd_mode != 0 && g_xcd_mode != 1 && splits >= 32) ? 1 : 0;
     info[2] = splits;
     info[3] = (info[1] ? 8 * cdiv(splits, 8) : splits) * cdiv(Cout, bm) * cdiv(Kp, bn);
+    info[4] = 0;
     return LMKD_OK;
   }
   long rows;
@@ -1105,10 +1106,11 @@ extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, 
   }
   const bool same = conv_same_size(H, W, KH, KW, stride, pad);
   int id = pick_conv_cfg(rows, nclass, ncols, same);
-  if ((kind == 0 ? Cs : Cout) % 32 != 0) id = id == 10 ? 7 : (id == 11 ? 9 : (id == 12 ? 8 : id));
+  const bool patch = same && (g_conv_x3 || g_conv_bf16) && (kind == 0 ? Cs : Cout) % 32 == 0;      // patch_halo() >= 0 for these launches
+  if (!patch) id = id == 10 ? 7 : (id == 11 ? 9 : (id == 12 ? 8 : id));
   const int n_rt = nclass * cdiv(rows, cfg_bm(id)), n_ct = cdiv(ncols, cfg_bn(id));
   int xm = (n_ct >= 8 && (n_ct & 7) == 0) ? 1 : 0;
   if (g_xcd_mode == 0) xm = 0;
-  info[0] = id; info[1] = xm; info[2] = nclass; info[3] = xcd_grid(n_rt, n_ct, xm);
+  info[0] = id; info[1] = xm; info[2] = nclass; info[3] = xcd_grid(n_rt, n_ct, xm); info[4] = patch ? 1 : 0;
   return LMKD_OK;
 }

@@ -229,6 +229,17 @@ class _timed:
             CONV_TIMING.append(self.rec)
 
 
+def _conv_family(kind, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad):
+    """name under which a forward (kind 0) / data-gradient (1) launch is timed: the LDS-patch kernel (conv_patch_x3_kernel: same-size
+    convolutions of the bf16-plane modes) or the im2col-gather kernels (conv_gemm_kernel / conv_gemm_x3_kernel)"""
+    if CONV_TIMING is None:
+        return "conv_gemm_kernel"
+    import ctypes
+    info = (ctypes.c_int * 5)()
+    lib().call("lmkd_conv2d_plan", kind, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, info)
+    return "conv_patch_kernel" if info[4] else "conv_gemm_kernel"
+
+
 def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None):
     """x NHWC [N,H,W,Cs] -> (y [N,Ho,Wo,Cout], stat partial [T,Cout,2] | None).  pre_stats: x is the RAW output of the previous
     convolution and the loader applies relu(BatchNorm(x)) with that layer's [5][Cs] table (lmkd_conv2d_fwd_pre)."""
@@ -241,7 +252,8 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None):
         T = lib().value("lmkd_conv2d_fwd_row_tiles", N, H, W, Cout, KH, KW, stride, pad)
         part = _empty((T, Cout, 2), x)
     cin = 3 if Cs == 4 else Cs
-    with _timed("conv_gemm_kernel", 2.0 * N * Ho * Wo * Cout * cin * KH * KW, 4 * (x.numel() + y.numel() + wp.numel())):
+    with _timed(_conv_family(0, N, H, W, Cs, cin, Cout, KH, KW, stride, pad), 2.0 * N * Ho * Wo * Cout * cin * KH * KW,
+                x.element_size() * x.numel() + y.element_size() * y.numel() + 4 * wp.numel()):
         if pre_stats is not None:
             lib().call("lmkd_conv2d_fwd_pre", _p(x), _p(pre_stats), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, _stream())
         else:
@@ -255,8 +267,8 @@ def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumula
     if accumulate and out is None:
         raise ValueError("accumulate needs an output buffer")
     dx = out if out is not None else _empty_act((N, H, W, Cin), dy)
-    with _timed("conv_gemm_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
-                4 * (dy.numel() + dx.numel() * (2 if accumulate else 1) + wd.numel())):
+    with _timed(_conv_family(1, N, H, W, Cin, Cin, Cout, KH, KW, stride, pad), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
+                dy.element_size() * dy.numel() + dx.element_size() * dx.numel() * (2 if accumulate else 1) + 4 * wd.numel()):
         lib().call("lmkd_conv2d_bwd_data", _p(dy), _p(wd), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, int(accumulate), _stream())
     return dx
 
@@ -271,7 +283,7 @@ def conv_bwd_weight(x, dy, w_shape, stride, pad, pre_stats=None, acc_into=None):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     dw = acc_into if acc_into is not None else _empty(w_shape, x)
     with _timed("conv_wgrad_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
-                4 * (x.numel() + dy.numel() + dw.numel())):
+                x.element_size() * x.numel() + dy.element_size() * dy.numel() + 4 * dw.numel()):
         if acc_into is not None:
             lib().call("lmkd_conv2d_bwd_weight_acc", _p(x), _p(pre_stats), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW,
                        stride, pad, _stream())
@@ -440,7 +452,8 @@ def conv_bn_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, relu, res=None):
     Ho, Wo = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
     y = _empty((N, Ho, Wo, Cout), x)
     cin = 3 if Cs == 4 else Cs
-    with _timed("conv_gemm_kernel", 2.0 * N * Ho * Wo * Cout * cin * KH * KW, 4 * (x.numel() + y.numel() + wp.numel())):
+    with _timed(_conv_family(0, N, H, W, Cs, cin, Cout, KH, KW, stride, pad), 2.0 * N * Ho * Wo * Cout * cin * KH * KW,
+                x.element_size() * x.numel() + y.element_size() * y.numel() + 4 * wp.numel()):
         lib().call("lmkd_conv2d_fwd_bn", _p(x), _p(wp), _p(y), _p(stats), _p(res), int(relu), N, H, W, Cs, Cout, KH, KW, stride, pad,
                    _stream())
     return y

@@ -32,7 +32,7 @@ SHAPES = [
     ("layer4.3x3", 7, 512, 512, 512, 3, 1, 1),
     ("layer4.ds", 14, 256, 256, 512, 1, 2, 0),
 ]
-SEEN = {"gemm": set(), "wgrad": set()}
+SEEN = {"gemm": set(), "wgrad": set(), "x3": set()}
 
 
 @pytest.fixture(scope="module")
@@ -47,7 +47,7 @@ def dev():
 
 def plan(kind, N, H, Cs, Cin, Cout, K, s, p):
     import litemkd_amd
-    info = (ctypes.c_int * 4)()
+    info = (ctypes.c_int * 5)()
     litemkd_amd.lib().call("lmkd_conv2d_plan", kind, N, H, H, Cs, Cin, Cout, K, K, s, p, info)
     return tuple(info)
 
@@ -84,6 +84,7 @@ def _run_shape(dev, name, H, Cs, Cin, Cout, K, s, p, N=FRAMES, check_wgrad=True)
     assert torch.allclose(sums[:, 0], yd.sum(0), rtol=0, atol=2e-6 * float(yd.abs().sum(0).max())), name + " BN sum"
     assert torch.allclose(sums[:, 1], (yd * yd).sum(0), rtol=1e-5), name + " BN sum of squares"
     SEEN["gemm"].add(plan(0, N, H, Cs, Cin, Cout, K, s, p)[:2])
+    SEEN["x3"].add(plan(0, N, H, Cs, Cin, Cout, K, s, p)[::4])      # (tile id, LDS-patch kernel?)
     # ---- data gradient (+ the accumulate epilogue at full size)
     if Cin != 3:
         wd = ops.pack_weights(w, Cin, 1)
@@ -127,9 +128,38 @@ def test_conv_benchmark_shapes_x3_mode_vs_fp64(dev, shape):
     criterion as the native fp32 MFMA kernels: fp32-class error, not reduced precision"""
     from litemkd_amd import ops
     ops.set_conv_compute_dtype("fp32x3")
+    SEEN["x3"].clear()
     try:
         _run_shape(dev, *shape)
+        SEEN.setdefault("x3_mode", set()).update(SEEN["x3"])
     finally:
+        ops.set_conv_compute_dtype("fp32")
+
+
+def test_x3_benchmark_instances_were_exercised(dev):
+    """in the headline arithmetic the shapes above must have run the LDS-patch kernel in both tiles the benchmark selects (11 =
+    128x64 / 4 waves, 12 = 128x128 / 4 waves) and the im2col-gather kernel (stem, stride 2, 1x1: tiles 8 / 9)"""
+    if not SEEN.get("x3_mode"):
+        pytest.skip("run together with test_conv_benchmark_shapes_x3_mode_vs_fp64")
+    assert {(11, 1), (12, 1)} <= SEEN["x3_mode"] and any(pt == 0 for _, pt in SEEN["x3_mode"]), SEEN["x3_mode"]
+
+
+@pytest.mark.parametrize("tile", [7, 8, 9, 10, 11, 12])
+def test_patch_tile_instances_at_full_size(dev, tile):
+    """every tile instance of conv_patch_x3_kernel (headline arithmetic) on a 200-frame layer (layer 1 for the 64-column tiles,
+    layer 2 for the 128-column ones) under the fp64-anchored criterion, forward and data gradient"""
+    import litemkd_amd
+    from litemkd_amd import ops
+    L = litemkd_amd.lib()
+    ops.set_conv_compute_dtype("fp32x3")
+    L.call("lmkd_conv_set_tile", tile)
+    try:
+        H, C = (56, 64) if tile in (7, 9, 11) else (28, 128)
+        pl = plan(0, FRAMES, H, C, C, C, 3, 1, 1)
+        assert pl[0] == tile and pl[4] == 1, pl
+        _run_shape(dev, "patch.tile%d" % tile, H, C, C, C, 3, 1, 1, check_wgrad=False)
+    finally:
+        L.call("lmkd_conv_set_tile", 0)
         ops.set_conv_compute_dtype("fp32")
 
 

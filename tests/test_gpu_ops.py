@@ -1104,3 +1104,67 @@ def test_bf16_activation_stem_and_pooling(dev, bf16_act):
     # nature of bf16 training tensors, not a kernel property.  Sanity bound here; the arithmetic itself is pinned by
     # test_episode_matches_oracle[...-bf16act] against the oracle that rounds the same tensors at the same places.
     assert float((dw16 - dw32).norm() / dw32.norm()) < 0.25 and float((dg16 - dg32).norm() / dg32.norm()) < 0.25
+
+
+# ------------------------------------------------------------------------------------------
+# same-size convolutions from an LDS-resident input patch (conv_patch.h)
+# ------------------------------------------------------------------------------------------
+PATCH_SHAPES = [  # N, C, H, W, Cout, K, pad
+    (3, 64, 9, 11, 64, 3, 1),        # ragged: 297 pixels (not a multiple of any tile), odd width
+    (2, 32, 5, 3, 96, 3, 1),         # fewer pixels than one tile, halo wider than a row, Cout not a multiple of the tile
+    (1, 64, 1, 1, 32, 3, 1),         # a single pixel: eight of the nine taps are padding
+    (5, 128, 14, 14, 256, 3, 1),     # several column tiles
+    (2, 64, 56, 56, 64, 3, 1),       # the widest row the kernel takes (halo 57)
+    (4, 256, 7, 7, 64, 1, 0),        # 1x1 / stride 1 (ResNet-50 bottleneck): halo 0
+]
+
+
+@pytest.mark.parametrize("tile", [0, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("mode", ["fp32x3", "fp32x3_9", "bf16", "bf16act"])
+def test_conv_patch_kernel_bit_identical_to_gather_kernel(dev, mode, tile):
+    """conv_patch_x3_kernel multiplies the same bf16 planes in the same order as conv_gemm_x3_kernel (channel chunk outer, tap inner,
+    one fp32 accumulator per output): forward, BatchNorm partial sums, data gradient, the accumulating data gradient and the fused
+    BatchNorm+ReLU loader must agree BIT FOR BIT with the im2col-gather kernel, for every tile instance, on ragged shapes (pixel
+    count below / not a multiple of the tile, one-pixel image, 1x1 convolution, widest supported row)."""
+    import ctypes
+    import litemkd_amd
+    from litemkd_amd import ops
+    L = litemkd_amd.lib()
+    act16 = mode == "bf16act"
+    ops.set_conv_compute_dtype("bf16" if mode.startswith("bf16") else mode)
+    ops.set_activation_dtype("bf16" if act16 else "fp32")
+    dt = torch.bfloat16 if act16 else torch.float32
+    try:
+        for (N, C, H, W, Cout, K, p) in PATCH_SHAPES:
+            x = (rnd(N, H, W, C, seed=70 + H) * 1.5).to(dev).to(dt)
+            w = (rnd(Cout, C, K, K, seed=71) * math.sqrt(2.0 / (Cout * K * K))).to(dev)
+            dy = rnd(N, H, W, Cout, seed=72).to(dev).to(dt)
+            r0 = rnd(N, H, W, C, seed=73).to(dev).to(dt)
+            st = torch.zeros(5, C, device=dev)
+            st[2], st[3] = (1 + 0.3 * rnd(C, seed=74)).to(dev), (0.2 * rnd(C, seed=75)).to(dev)
+            wp, wd = ops._pack_weights(w, C, 0), ops._pack_weights(w, C, 1)
+            out = {}
+            for patch in (0, 1):
+                L.call("lmkd_conv_set_patch", patch)
+                L.call("lmkd_conv_set_tile", tile)
+                info = (ctypes.c_int * 5)()
+                L.call("lmkd_conv2d_plan", 0, N, H, W, C, C, Cout, K, K, 1, p, info)
+                assert info[4] == patch and (tile == 0 or not patch or info[0] == (tile if Cout > 64 or tile in (7, 9, 11) else {8: 9, 10: 7, 12: 11}[tile])), list(info)
+                y, part = ops.conv_fwd(x, wp, Cout, K, K, 1, p, True)
+                dx = ops.conv_bwd_data(dy, wd, (N, H, W, C), Cout, K, K, 1, p)
+                acc = r0.clone()
+                ops.conv_bwd_data(dy, wd, (N, H, W, C), Cout, K, K, 1, p, out=acc, accumulate=True)
+                o = [y, part.double().sum(0), dx, acc]
+                if not act16:
+                    o.append(ops.conv_fwd(x, wp, Cout, K, K, 1, p, True, pre_stats=st)[0])
+                out[patch] = o
+            for i, (g_, p_) in enumerate(zip(out[0], out[1])):
+                if i == 1:      # per-row-tile partial sums (tile heights differ between instances): compare the column totals
+                    assert torch.allclose(g_, p_, rtol=1e-6, atol=1e-6 * float(g_.abs().max()) + 1e-12), (mode, tile, (N, C, H, W, Cout, K), "BN sums")
+                else:
+                    assert torch.equal(g_, p_), (mode, tile, (N, C, H, W, Cout, K), i, float((g_.float() - p_.float()).abs().max()))
+    finally:
+        L.call("lmkd_conv_set_patch", 1)
+        L.call("lmkd_conv_set_tile", 0)
+        ops.set_activation_dtype("fp32")
+        ops.set_conv_compute_dtype("fp32")

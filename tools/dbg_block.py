@@ -51,6 +51,6 @@ print("wgrad(conv1) from exact dc1: hip", rel_l2(dw, g64["conv1.weight"]))
 dw2 = ops.conv_bwd_weight(nhwc(t64["a1"].float()).to(dev), nhwc(t64["dc2"].float()).to(dev), (cout, cout, 3, 3), 1, 1)
 print("wgrad(conv2) from exact a1, dc2: hip", rel_l2(dw2, g64["conv2.weight"]))
 import ctypes
-info = (ctypes.c_int * 4)()
+info = (ctypes.c_int * 5)()
 litemkd_amd.lib().call("lmkd_conv2d_plan", 2, N, H, H, cin, cin, cout, 3, 3, stride, 1, info); print("wgrad plan conv1", list(info))
 litemkd_amd.lib().call("lmkd_conv2d_plan", 1, N, H, H, cin, cin, cout, 3, 3, stride, 1, info); print("dgrad plan conv1", list(info))
