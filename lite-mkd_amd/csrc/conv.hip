@@ -490,6 +490,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 }
 
 #include "wgrad_x3.h"
+#include "wgrad_win.h"
 
 // K-major packed weights (the GEMM's B operand: one row of K per output column):
 // mode 0 (forward): Wp[co][(kh*KWp+kw)*Cs + ci] = W[co][ci][kh][kw]   (zero for padded kw / ci)
@@ -904,6 +905,28 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
 // rounds of resident workgroups: an arbitrary count leaves a 1.5-round launch that runs as long as a 2-round one.
 static int g_wgrad_planes = 1;   // bf16 / 3xbf16 modes: weight gradient on the bf16-plane kernel (wgrad_x3.h); 0 = fp32-tile kernel
 extern "C" int lmkd_conv_set_wgrad_planes(int on) { g_wgrad_planes = on ? 1 : 0; return LMKD_OK; }
+// 3x3 / stride-1 weight gradients of the bf16-plane modes from a rolling LDS window of x (wgrad_win.h); 0 = im2col-gather kernel
+static int g_wgrad_window = 1;
+extern "C" int lmkd_conv_set_wgrad_window(int on) { g_wgrad_window = on ? 1 : 0; return LMKD_OK; }
+// With bf16 tensors in HBM the gather kernel copies its operands without conversion and its 128-wide tiles keep up with the window
+// kernel (91-103 vs 97-102 us per layer at 200 frames); only the 64x64 tiles of Cout <= 64 lose to it (115 vs 94 us).
+static inline bool wgrad_win_eligible(int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
+  return g_wgrad_window && g_wgrad_planes && (g_conv_x3 || g_conv_bf16) && KH == 3 && KW == 3 && stride == 1 && pad == 1 &&
+         Cs % 32 == 0 && 32 + 2 * (W + 1) <= 256 && (!g_lmkd_act_bf16 || Cout <= 64);
+}
+// pixel splits: about four workgroups per CU (two rounds at two resident workgroups per CU), but no slab shorter than 12 steps per
+// warm-up chunk of the window (the rows [k0 - halo, k0 + halo) are loaded before the first MFMA of a slab)
+static void wgrad_win_plan(int Mpix, int W, int Cs, int Cout, int* cob, int* splits, int* steps_per_split) {
+  *cob = Cout >= 128 ? 4 : 2;
+  const int tiles = cdiv(Cout, 32 * *cob) * (Cs / 32);
+  const int steps = cdiv(Mpix, LMKD_BK);
+  const int warm = cdiv(2 * (W + 1), LMKD_BK);
+  int sp = cdiv(1024, tiles);
+  const int cap = std::max(1, steps / (12 * warm));
+  if (sp > cap) sp = cap;
+  *steps_per_split = cdiv(steps, sp);
+  *splits = cdiv(steps, *steps_per_split);
+}
 static inline bool wgrad_uses_planes(int Cs) { (void)Cs; return (g_conv_x3 || g_conv_bf16) && g_wgrad_planes; }
 
 static void wgrad_plan(int Mpix, int Cout, int Kp, int* splits, int* steps_per_split, int* bm, int* bn, bool planes = false) {
@@ -950,6 +973,11 @@ extern "C" long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, in
   const int Kp = KH * kw_padded(Cs, KW) * Cs;
   int splits, sps, bm, bn;
   wgrad_plan(N * Ho * Wo, Cout, Kp, &splits, &sps, &bm, &bn, wgrad_uses_planes(Cs));
+  if (wgrad_win_eligible(W, Cs, Cout, KH, KW, stride, pad)) {
+    int cob, wsplits, wsps;
+    wgrad_win_plan(N * Ho * Wo, W, Cs, Cout, &cob, &wsplits, &wsps);
+    splits = std::max(splits, wsplits);
+  }
   return (long)splits * Cout * Kp * sizeof(float);
 }
 
@@ -973,13 +1001,52 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   a.Kp = KH * a.KWp * Cs;
   a.Mpix = N * a.Ho * a.Wo;
   LMKD_REQUIRE((long)N * H * W * Cs < 2147483647L && (long)a.Mpix * Cout < 2147483647L, "lmkd_conv2d_bwd_weight: tensor too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (wgrad_win_eligible(W, Cs, Cout, KH, KW, stride, pad)) {
+    WgradWinArgs w;
+    memset(&w, 0, sizeof(w));
+    w.dy = dy; w.x = x; w.slab = workspace; w.pre_stats = pre_stats;
+    w.N = N; w.H = H; w.W = W; w.Cs = Cs; w.Co = Cout; w.Kp = a.Kp; w.Mpix = a.Mpix;
+    w.steps_total = cdiv(a.Mpix, LMKD_BK);
+    int cob;
+    wgrad_win_plan(a.Mpix, W, Cs, Cout, &cob, &w.splits, &w.steps_per_split);
+    LMKD_REQUIRE(ws_bytes >= (long)w.splits * Cout * a.Kp * (long)sizeof(float), "lmkd_conv2d_bwd_weight: workspace too small");
+    LMKD_REQUIRE((long)a.Mpix * std::max(Cs, Cout) * 4 < 2147483647L, "lmkd_conv2d_bwd_weight: tensor too large for 32-bit byte offsets");
+    w.n_ct = cdiv(Cout, 32 * cob); w.n_it = Cs / 32;
+    w.div_hw = make_fastdiv(H * W); w.div_w = make_fastdiv(W);
+    const dim3 wgrid(8 * cdiv(w.splits, 8) * w.n_ct * w.n_it);
+    const bool big = 32 + 2 * (W + 1) > 128;      // ring of 256 pixel rows instead of 128
+#define LMKD_WIN(COB, NPROD, A16, PRE)                                                                                  \
+  do {                                                                                                                  \
+    if (big) hipLaunchKernelGGL((conv_wgrad_win_kernel<COB, NPROD, A16, 256, PRE>), wgrid, dim3(64 * COB), 0, s, w);    \
+    else hipLaunchKernelGGL((conv_wgrad_win_kernel<COB, NPROD, A16, 128, PRE>), wgrid, dim3(64 * COB), 0, s, w);        \
+  } while (0)
+#define LMKD_WIN_MODE(COB)                                                                                              \
+  do {                                                                                                                  \
+    if (g_lmkd_act_bf16) LMKD_WIN(COB, 1, true, false);                                                                 \
+    else if (g_conv_bf16) { if (pre_stats) LMKD_WIN(COB, 1, false, true); else LMKD_WIN(COB, 1, false, false); }        \
+    else if (g_conv_x3 == 9) { if (pre_stats) LMKD_WIN(COB, 9, false, true); else LMKD_WIN(COB, 9, false, false); }     \
+    else { if (pre_stats) LMKD_WIN(COB, 6, false, true); else LMKD_WIN(COB, 6, false, false); }                         \
+  } while (0)
+    if (cob == 4) LMKD_WIN_MODE(4);
+    else LMKD_WIN_MODE(2);
+#undef LMKD_WIN_MODE
+#undef LMKD_WIN
+    LMKD_CHECK_LAUNCH("conv_wgrad_win_kernel");
+    const long total = (long)Cout * KH * KW * Cin;
+    int rg = cdiv(total, 256);
+    if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, s, (const float*)workspace, dw_oihw, w.splits, Cout, Cin, Cs, KH, KW,
+                       a.KWp, a.Kp, accumulate);
+    LMKD_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return LMKD_OK;
+  }
   int splits, bm, bn;
   const bool planes = wgrad_uses_planes(Cs);
   wgrad_plan(a.Mpix, Cout, a.Kp, &splits, &a.steps_per_split, &bm, &bn, planes);
   a.steps_total = cdiv(a.Mpix, LMKD_BK);
   LMKD_REQUIRE(ws_bytes >= (long)splits * Cout * a.Kp * (long)sizeof(float), "lmkd_conv2d_bwd_weight: workspace too small");
   a.div_hw = make_fastdiv(a.Ho * a.Wo); a.div_w = make_fastdiv(a.Wo);
-  hipStream_t s = (hipStream_t)stream;
   a.n_mt = cdiv(Cout, bm); a.n_jt = cdiv(a.Kp, bn); a.splits = splits;
   // all column tiles of one pixel split read the same x / dy rows: with >= 32 splits they are dealt to ONE XCD (ids congruent
   // mod 8), whose L2 then serves the re-reads.  PMC: FETCH_SIZE 1053 -> 279 MB per launch (algorithmic 160-320 MB); the kernel
@@ -1079,7 +1146,8 @@ extern "C" int lmkd_conv2d_bwd_weight_acc(const float* x, const float* pre_stats
 // reports 1 = 128x128/8 waves, 2 = 128x64, 3 = 64x64, 4 = 64x128), info[1] = XCD tile order (forward / data gradient: 0 row
 // bands, 1 column slices; weight gradient: 1 = all tiles of a pixel split on one XCD), info[2] = pixel splits (weight gradient)
 // or parity classes (data gradient), info[3] = workgroups launched.  Used by the parity tests to prove that the benchmark's
-// kernel instances are the ones under test.  info[4] = 1 when the launch runs on the LDS-patch kernel (conv_patch.h).
+// kernel instances are the ones under test.  info[4] = 1 when the launch runs on the LDS-patch kernel (conv_patch.h) or, for the
+// weight gradient, on the rolling-window kernel (wgrad_win.h; it reports tile id 5 = 128 output channels per workgroup, 6 = 64).
 extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                 int* info) {
   LMKD_REQUIRE(info && kind >= 0 && kind <= 2, "lmkd_conv2d_plan: kind must be 0 (forward), 1 (data gradient) or 2 (weight gradient)");
@@ -1094,6 +1162,13 @@ extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, 
     info[2] = splits;
     info[3] = (info[1] ? 8 * cdiv(splits, 8) : splits) * cdiv(Cout, bm) * cdiv(Kp, bn);
     info[4] = 0;
+    if (wgrad_win_eligible(W, Cs, Cout, KH, KW, stride, pad)) {      // rolling-window kernel (wgrad_win.h): tile id 5 / 6 = 128 / 64 output channels
+      int cob, wsplits, wsps;
+      wgrad_win_plan(N * Ho * Wo, W, Cs, Cout, &cob, &wsplits, &wsps);
+      info[0] = cob == 4 ? 5 : 6; info[1] = 1; info[2] = wsplits;
+      info[3] = 8 * cdiv(wsplits, 8) * cdiv(Cout, 32 * cob) * (Cs / 32);
+      info[4] = 1;
+    }
     return LMKD_OK;
   }
   long rows;

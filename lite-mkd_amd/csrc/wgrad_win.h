@@ -1,0 +1,233 @@
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution from an LDS-resident, rolling WINDOW of x pixels (bf16-plane modes).
+//
+//   dW[co][(tap, ci)] = sum_m dy[m][co] * x[m + dh * W + dw][ci]        (m = flattened pixel, masked at the image borders)
+//
+// conv_wgrad_x3_kernel (wgrad_x3.h) treats this as a GEMM whose B operand is an im2col gather: every column tile (one or two taps
+// of 64-128 channels) loads its own shifted copy of x, and every workgroup converts / splits its own copies of both operands:
+// 8.7 VALU instructions per MFMA (16 in the 64x64 tiles) on a SIMD that issues one instruction at a time - the kernel is bound by
+// the instruction issue of its operand handling, not by the matrix pipe (PMC: VALU 61 %, MFMA 42 %).
+//
+// Here a workgroup owns 32 input channels x (32 * COB) output channels x ALL NINE taps.  The pixel axis is walked in steps of 32;
+// the x rows [k0 - halo, k0 + 32 + halo), halo = W + 1, live in a ring of R pixel rows in LDS (R = 128 or 256, a power of two
+// > 63 + 2 halo, so the 32 rows that enter at step t + 1 land on slots whose rows left the window before step t: no barrier
+// between the reads of step t and those writes is needed beyond the two per step that the single-buffered dy tile takes anyway).
+// Each x row is loaded and split ONCE and then serves the nine taps of 32 + 2 halo steps' worth of MFMAs; the dy tile is split once
+// per step and serves nine taps.  A tap is a row shift of the window: the transposed LDS read (ds_read_b64_tr_b16, wgrad_x3.h) takes
+// its row address per lane, so the shift is an add + wrap on that address, and the image-border mask of (pixel, tap) is an address
+// select to an all-zero row - the lane that supplies row q of a 4 x 16 block applies the mask of ITS pixel.
+// Wave w multiplies output-channel block w (32 rows) with the nine shifted 32-channel blocks: 9 accumulator tiles, every dy fragment
+// shared by nine taps.  (Three taps per wave - six waves instead of two where Cout = 64 leaves two channel blocks - was 15-50 % slower:
+// three times the dy-fragment reads and a six-wave barrier.)
+// Output: split-K slabs in the layout of conv_wgrad_kernel ([split][Cout][Kp], column = tap * Cs + ci), reduced by wgrad_reduce_kernel.
+#pragma once
+
+struct WgradWinArgs {
+  const float* dy;
+  const float* x;
+  float* slab;
+  const float* pre_stats;      // PRE: x is a raw conv output; relu(BatchNorm(x)) is applied when a row enters the window (ConvGemmArgs)
+  int N, H, W, Cs, Co, Kp;
+  int Mpix, steps_total, steps_per_split, splits;
+  int n_ct, n_it;      // output-channel tiles, input-channel tiles (32 channels each)
+  FastDiv div_hw, div_w;
+};
+
+template <int COB, int NPROD, bool ACT16, int R, bool PRE = false>
+__global__ __launch_bounds__(64 * COB) void conv_wgrad_win_kernel(WgradWinArgs a) {
+  constexpr int NPL = NPROD == 1 ? 1 : 3;
+  static_assert(!ACT16 || (NPROD == 1 && !PRE), "bf16 tensors: one plane, no store-side arithmetic");
+  constexpr int THREADS = 64 * COB, BM = 32 * COB;
+  constexpr int LDA = BM * 2 + 64, A_PLANE = LMKD_BK * LDA;      // dy image [k][co], bytes (odd multiple of 64: wgrad_x3.h)
+  constexpr int LDX = 64, X_PLANE = (R + 1) * LDX;               // x ring [slot][32 ci]; slot R = the zero row
+  constexpr int ESZ = ACT16 ? 2 : 4, EPL = ACT16 ? 8 : 4;        // element size, elements per 16-byte lane access
+  constexpr int A_LPR = BM / EPL, A_RPP = THREADS / A_LPR, A_NI = (LMKD_BK + A_RPP - 1) / A_RPP;      // dy loader: lanes per row, rows per pass
+  constexpr int X_LPR = 32 / EPL, X_RPP = THREADS / X_LPR, X_NI = (LMKD_BK + X_RPP - 1) / X_RPP;
+  static_assert(THREADS % A_LPR == 0 && THREADS % X_LPR == 0 && (LDA / 64) % 2 == 1, "tile layout");
+  __shared__ __attribute__((aligned(16))) unsigned char s_dy[NPL * A_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char s_x[NPL * X_PLANE];
+  __shared__ unsigned s_mask[2][LMKD_BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // all tiles of one pixel split run on one XCD (block ids congruent mod 8): its L2 serves their re-reads of the same x / dy rows
+  const int tiles = a.n_ct * a.n_it;
+  const int xj = blockIdx.x >> 3;
+  const int z = (blockIdx.x & 7) + 8 * (xj / tiles);
+  if (z >= a.splits) return;
+  const int tz = xj - (xj / tiles) * tiles;
+  const int co0 = (tz % a.n_ct) * BM, ci0 = (tz / a.n_ct) * 32;
+  const int s0 = z * a.steps_per_split;
+  int nk = a.steps_total - s0;
+  if (nk > a.steps_per_split) nk = a.steps_per_split;
+  const int halo = a.W + 1;
+
+  const __amdgpu_buffer_rsrc_t rs_dy = x3_rsrc(a.dy, (long)a.Mpix * a.Co * ESZ);
+  const __amdgpu_buffer_rsrc_t rs_x = x3_rsrc(a.x, (long)a.Mpix * a.Cs * ESZ);
+  // dy loader: row = pixel of the step, EPL consecutive output channels per lane
+  const int a_c = (tid % A_LPR) * EPL, a_r = tid / A_LPR;
+  const bool a_cin = co0 + a_c < a.Co;
+  // x loader: one 16-byte piece of one pixel row
+  const int x_c = (tid % X_LPR) * EPL, x_r = tid / X_LPR;
+  u32x4 ra[A_NI], rx[X_NI];
+  unsigned x_ok = 0;      // PRE: which of the prefetched x rows are real pixels (rows outside the tensor stay zero)
+  float4 psc = float4(), psh = float4();
+  if (PRE) {
+    psc = *reinterpret_cast<const float4*>(a.pre_stats + 2 * a.Cs + ci0 + x_c);
+    psh = *reinterpret_cast<const float4*>(a.pre_stats + 3 * a.Cs + ci0 + x_c);
+  }
+  auto load_dy = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_NI; ++i) {
+      const int p = k0 + a_r + A_RPP * i;
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (a_cin && a_r + A_RPP * i < LMKD_BK && p < a.Mpix) ? (unsigned)((p * a.Co + co0 + a_c) * ESZ) : X3_OOB, 0, 0);
+    }
+  };
+  auto load_x = [&](int q0) {      // the 32 pixel rows q0 .. q0 + 31 (rows outside the tensor read as zeros)
+#pragma unroll
+    for (int i = 0; i < X_NI; ++i) {
+      const int q = q0 + x_r + X_RPP * i;
+      const bool ok = x_r + X_RPP * i < LMKD_BK && q >= 0 && q < a.Mpix;
+      rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)((q * a.Cs + ci0 + x_c) * ESZ) : X3_OOB, 0, 0);
+      if (PRE) x_ok = ok ? (x_ok | (1u << i)) : (x_ok & ~(1u << i));
+    }
+  };
+  auto as_f4 = [](const u32x4& r) { return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)); };
+  auto store_dy = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_NI; ++i) {
+      if (a_r + A_RPP * i >= LMKD_BK) continue;
+      if constexpr (ACT16) tr_store8(s_dy, LDA, a_r + A_RPP * i, a_c, ra[i]);
+      else tr_store4<NPL, LDA, A_PLANE>(s_dy, a_r + A_RPP * i, a_c, as_f4(ra[i]));
+    }
+  };
+  auto store_x = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < X_NI; ++i) {
+      if (x_r + X_RPP * i >= LMKD_BK) continue;
+      const int slot = (q0 + x_r + X_RPP * i) & (R - 1);
+      if constexpr (ACT16) {
+        tr_store8(s_x, LDX, slot, x_c, rx[i]);
+      } else {
+        float4 v = as_f4(rx[i]);
+        if (PRE && ((x_ok >> i) & 1u)) {      // bit-identical to bn_apply_kernel
+          v.x = fmaxf(fmaf(v.x, psc.x, psh.x), 0.f); v.y = fmaxf(fmaf(v.y, psc.y, psh.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, psc.z, psh.z), 0.f); v.w = fmaxf(fmaf(v.w, psc.w, psh.w), 0.f);
+        }
+        tr_store4<NPL, LDX, X_PLANE>(s_x, slot, x_c, v);
+      }
+    }
+  };
+  // lanes 0..31: validity of the nine taps for each pixel of a step (bit tap = the tap's input pixel lies inside the image)
+  auto fill_mask = [&](unsigned* m, int k0) {
+    const int p = k0 + tid;
+    unsigned bits = 0;
+    if (p < a.Mpix) {
+      const int n = fdiv(p, a.div_hw);
+      const int rem = p - n * a.H * a.W;
+      const int h = fdiv(rem, a.div_w), w = rem - h * a.W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int y = h + t / 3 - 1, x = w + t % 3 - 1;
+        if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) bits |= 1u << t;
+      }
+    }
+    m[tid] = bits;
+  };
+
+  // transposed-read lane geometry (wgrad_x3.h): this lane supplies row 8h + q (and + 4) of each 16-row k-group, 4 columns at cb
+  const int hq = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int cb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int offA = tr_lane_off(LDA, lane) + wave * 32 * 2;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  if (nk > 0) {
+    const int kfirst = s0 * LMKD_BK;
+    for (int j = tid; j < NPL * LDX / 4; j += THREADS)      // the zero row of every plane
+      reinterpret_cast<unsigned*>(s_x + (j / (LDX / 4)) * X_PLANE + R * LDX)[j % (LDX / 4)] = 0u;
+    // warm-up: rows [k0 - halo, k0 + halo) in chunks of 32 (a chunk may run into the rows of step 0: rewritten with the same data)
+    for (int q0 = kfirst - halo; q0 < kfirst + halo; q0 += LMKD_BK) {
+      load_x(q0);
+      store_x(q0);
+    }
+    if (tid < LMKD_BK) fill_mask(s_mask[0], kfirst);
+    load_dy(kfirst);
+    load_x(kfirst + halo);
+    for (int t = 0; t < nk; ++t) {
+      const int k0 = kfirst + t * LMKD_BK;
+      store_dy();                             // waits for the prefetched registers of step t
+      store_x(k0 + halo);
+      __syncthreads();
+      if (t + 1 < nk) {
+        load_dy(k0 + LMKD_BK);
+        load_x(k0 + LMKD_BK + halo);
+        if (tid < LMKD_BK) fill_mask(s_mask[(t + 1) & 1], k0 + LMKD_BK);
+      }
+      // ---- MFMAs of step t
+      bf16x8 fa[2][NPL];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) fa[g][p] = tr_frag<LDA>(s_dy, offA + p * A_PLANE + g * 16 * LDA);
+      // [k-group][lo / hi row]: tap validity of the pixel whose row this lane supplies, and that row's byte offset in the ring at
+      // tap shift 0; a tap adds its shift and wraps (the wrap keeps the column bits: cb < LDX)
+      unsigned mk[2][2], rb[2][2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          mk[g][j] = s_mask[t & 1][16 * g + hq + 4 * j];
+          rb[g][j] = (unsigned)(((k0 + hq + 16 * g + 4 * j) & (R - 1)) * LDX + cb);
+        }
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const unsigned shb = (unsigned)(((tp / 3 - 1) * a.W + (tp % 3 - 1)) * LDX);
+        f32x16 c = acc[tp];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          unsigned ad[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) ad[j] = ((mk[g][j] >> tp) & 1u) ? ((rb[g][j] + shb) & (unsigned)(R * LDX - 1)) : (unsigned)(R * LDX + cb);
+          bf16x8 fb[NPL];
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) {
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(s_x + p * X_PLANE + ad[0]));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(s_x + p * X_PLANE + ad[1]));
+            union { s16x4_t s[2]; bf16x8 b; } u;
+            u.s[0] = lo; u.s[1] = hi;
+            fb[p] = u.b;
+          }
+          if constexpr (NPROD == 1) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0], fb[0], c, 0, 0, 0);
+          } else {
+            if (NPROD == 9) {
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][2], fb[2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][1], fb[2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][2], fb[1], c, 0, 0, 0);
+            }
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][1], fb[1], c, 0, 0, 0);     // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0], fb[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][2], fb[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0], fb[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][1], fb[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0], fb[0], c, 0, 0, 0);
+          }
+        }
+        acc[tp] = c;
+      }
+      __syncthreads();                        // every wave has read the dy tile (and this step's window) before they are overwritten
+    }
+  }
+
+  float* C = a.slab + (long)z * a.Co * a.Kp;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    const int col = tp * a.Cs + ci0 + (lane & 31);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = co0 + wave * 32 + acc_row(e, lane);
+      if (row < a.Co) C[(long)row * a.Kp + col] = acc[tp][e];
+    }
+  }
+}

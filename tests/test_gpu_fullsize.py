@@ -32,7 +32,7 @@ SHAPES = [
     ("layer4.3x3", 7, 512, 512, 512, 3, 1, 1),
     ("layer4.ds", 14, 256, 256, 512, 1, 2, 0),
 ]
-SEEN = {"gemm": set(), "wgrad": set(), "x3": set()}
+SEEN = {"gemm": set(), "wgrad": set(), "x3": set(), "x3w": set()}
 
 
 @pytest.fixture(scope="module")
@@ -112,6 +112,7 @@ def _run_shape(dev, name, H, Cs, Cin, Cout, K, s, p, N=FRAMES, check_wgrad=True)
         F.conv2d(x64.float(), wr32, None, s, p).backward(dy64.float())
         res["wgrad"] = anchored(name + " wgrad", dw, wr32.grad, wr.grad)
         SEEN["wgrad"].add(plan(2, N, H, Cs, Cin, Cout, K, s, p)[:2])
+        SEEN["x3w"].add(plan(2, N, H, Cs, Cin, Cout, K, s, p)[::4])      # (tile id, rolling-window kernel?)
     print(name, {k: "hip %.2e cpu %.2e" % v for k, v in res.items()})
     return res
 
@@ -129,9 +130,11 @@ def test_conv_benchmark_shapes_x3_mode_vs_fp64(dev, shape):
     from litemkd_amd import ops
     ops.set_conv_compute_dtype("fp32x3")
     SEEN["x3"].clear()
+    SEEN["x3w"].clear()
     try:
         _run_shape(dev, *shape)
         SEEN.setdefault("x3_mode", set()).update(SEEN["x3"])
+        SEEN.setdefault("x3w_mode", set()).update(SEEN["x3w"])
     finally:
         ops.set_conv_compute_dtype("fp32")
 
@@ -142,6 +145,8 @@ def test_x3_benchmark_instances_were_exercised(dev):
     if not SEEN.get("x3_mode"):
         pytest.skip("run together with test_conv_benchmark_shapes_x3_mode_vs_fp64")
     assert {(11, 1), (12, 1)} <= SEEN["x3_mode"] and any(pt == 0 for _, pt in SEEN["x3_mode"]), SEEN["x3_mode"]
+    # weight gradient: the rolling-window kernel with 128 (id 5) and 64 (id 6) output channels per workgroup, and the gather kernel
+    assert {(5, 1), (6, 1)} <= SEEN["x3w_mode"] and any(w == 0 for _, w in SEEN["x3w_mode"]), SEEN["x3w_mode"]
 
 
 @pytest.mark.parametrize("tile", [7, 8, 9, 10, 11, 12])
