@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64 * COB) void conv_wgrad_win_kernel(WgradWinArgs a
   static_assert(THREADS % A_LPR == 0 && THREADS % X_LPR == 0 && (LDA / 64) % 2 == 1, "tile layout");
   __shared__ __attribute__((aligned(16))) unsigned char s_dy[NPL * A_PLANE];
   __shared__ __attribute__((aligned(16))) unsigned char s_x[NPL * X_PLANE];
-  __shared__ unsigned s_mask[2][LMKD_BK];
+  __shared__ __attribute__((aligned(16))) unsigned s_adr[2][9 * LMKD_BK];      // per step: ring byte offset of (tap, pixel row), see fill_adr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // all tiles of one pixel split run on one XCD (block ids congruent mod 8): its L2 serves their re-reads of the same x / dy rows
   const int tiles = a.n_ct * a.n_it;
@@ -115,25 +115,28 @@ __global__ __launch_bounds__(64 * COB) void conv_wgrad_win_kernel(WgradWinArgs a
       }
     }
   };
-  // lanes 0..31: validity of the nine taps for each pixel of a step (bit tap = the tap's input pixel lies inside the image)
-  auto fill_mask = [&](unsigned* m, int k0) {
-    const int p = k0 + tid;
-    unsigned bits = 0;
-    if (p < a.Mpix) {
-      const int n = fdiv(p, a.div_hw);
-      const int rem = p - n * a.H * a.W;
-      const int h = fdiv(rem, a.div_w), w = rem - h * a.W;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int y = h + t / 3 - 1, x = w + t % 3 - 1;
-        if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) bits |= 1u << t;
+  // Address table of a step: for each tap and each of the step's 32 pixel rows, the byte offset (plane 0, column 0) of the ring row
+  // the tap reads for that pixel - (pixel + tap shift) wrapped - or of the zero row when the tap's input pixel lies outside the image
+  // (or the pixel past the tensor).  288 entries, computed ONCE per workgroup and step (every wave and 16 lanes of each wave need the
+  // same row address; computing it per lane cost 2 VALU instructions per MFMA).  Entry order: a lane's four rows of a step
+  // (k-group g, lo / hi read j; row = 16 g + 8 h + 4 j + q) are adjacent, so one ds_read_b128 per tap fetches them.
+  auto fill_adr = [&](unsigned* tab, int k0) {
+    for (int e = tid; e < 9 * LMKD_BK; e += THREADS) {
+      const int tp = e >> 5, r = e & 31;
+      const int p = k0 + r;
+      unsigned adr = (unsigned)(R * LDX);
+      if (p < a.Mpix) {
+        const int n = fdiv(p, a.div_hw);
+        const int rem = p - n * a.H * a.W;
+        const int h = fdiv(rem, a.div_w), w = rem - h * a.W;
+        const int dh = tp / 3 - 1, dw = tp - (tp / 3) * 3 - 1;
+        if ((unsigned)(h + dh) < (unsigned)a.H && (unsigned)(w + dw) < (unsigned)a.W) adr = (unsigned)(((p + dh * a.W + dw) & (R - 1)) * LDX);
       }
+      tab[tp * LMKD_BK + ((((r >> 3) & 1) * 4 + (r & 3)) * 4 + ((r >> 4) * 2 + ((r >> 2) & 1)))] = adr;
     }
-    m[tid] = bits;
   };
 
   // transposed-read lane geometry (wgrad_x3.h): this lane supplies row 8h + q (and + 4) of each 16-row k-group, 4 columns at cb
-  const int hq = 8 * (lane >> 5) + ((lane & 15) >> 2);
   const int cb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
   const int offA = tr_lane_off(LDA, lane) + wave * 32 * 2;
   f32x16 acc[9];
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(64 * COB) void conv_wgrad_win_kernel(WgradWinArgs a
       load_x(q0);
       store_x(q0);
     }
-    if (tid < LMKD_BK) fill_mask(s_mask[0], kfirst);
+    fill_adr(s_adr[0], kfirst);
     load_dy(kfirst);
     load_x(kfirst + halo);
     for (int t = 0; t < nk; ++t) {
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(64 * COB) void conv_wgrad_win_kernel(WgradWinArgs a
       if (t + 1 < nk) {
         load_dy(k0 + LMKD_BK);
         load_x(k0 + LMKD_BK + halo);
-        if (tid < LMKD_BK) fill_mask(s_mask[(t + 1) & 1], k0 + LMKD_BK);
+        fill_adr(s_adr[(t + 1) & 1], k0 + LMKD_BK);
       }
       // ---- MFMAs of step t
       bf16x8 fa[2][NPL];
@@ -170,25 +173,14 @@ __global__ __launch_bounds__(64 * COB) void conv_wgrad_win_kernel(WgradWinArgs a
       for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int p = 0; p < NPL; ++p) fa[g][p] = tr_frag<LDA>(s_dy, offA + p * A_PLANE + g * 16 * LDA);
-      // [k-group][lo / hi row]: tap validity of the pixel whose row this lane supplies, and that row's byte offset in the ring at
-      // tap shift 0; a tap adds its shift and wraps (the wrap keeps the column bits: cb < LDX)
-      unsigned mk[2][2], rb[2][2];
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          mk[g][j] = s_mask[t & 1][16 * g + hq + 4 * j];
-          rb[g][j] = (unsigned)(((k0 + hq + 16 * g + 4 * j) & (R - 1)) * LDX + cb);
-        }
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) {
-        const unsigned shb = (unsigned)(((tp / 3 - 1) * a.W + (tp % 3 - 1)) * LDX);
+        // this lane's four ring rows under tap tp: [k-group 0 lo, hi, k-group 1 lo, hi]
+        const u32x4 a4 = *reinterpret_cast<const u32x4*>(&s_adr[t & 1][tp * LMKD_BK + ((lane >> 5) * 4 + ((lane & 15) >> 2)) * 4]);
         f32x16 c = acc[tp];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          unsigned ad[2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) ad[j] = ((mk[g][j] >> tp) & 1u) ? ((rb[g][j] + shb) & (unsigned)(R * LDX - 1)) : (unsigned)(R * LDX + cb);
+          const unsigned ad[2] = {(g ? a4.z : a4.x) + (unsigned)cb, (g ? a4.w : a4.y) + (unsigned)cb};
           bf16x8 fb[NPL];
 #pragma unroll
           for (int p = 0; p < NPL; ++p) {
