@@ -907,21 +907,22 @@ static int g_wgrad_planes = 1;   // bf16 / 3xbf16 modes: weight gradient on the 
 extern "C" int lmkd_conv_set_wgrad_planes(int on) { g_wgrad_planes = on ? 1 : 0; return LMKD_OK; }
 // 3x3 / stride-1 weight gradients of the bf16-plane modes from a rolling LDS window of x (wgrad_win.h); 0 = im2col-gather kernel
 static int g_wgrad_window = 1;
-extern "C" int lmkd_conv_set_wgrad_window(int on) { g_wgrad_window = on ? 1 : 0; return LMKD_OK; }
-// With bf16 tensors in HBM the gather kernel copies its operands without conversion and its 128-wide tiles keep up with the window
-// kernel (91-103 vs 97-102 us per layer at 200 frames); only the 64x64 tiles of Cout <= 64 lose to it (115 vs 94 us).
+extern "C" int lmkd_conv_set_wgrad_window(int on) { g_wgrad_window = on < 0 ? 0 : on; return LMKD_OK; }      // > 1: workgroup target of the split plan
 static inline bool wgrad_win_eligible(int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
   return g_wgrad_window && g_wgrad_planes && (g_conv_x3 || g_conv_bf16) && KH == 3 && KW == 3 && stride == 1 && pad == 1 &&
-         Cs % 32 == 0 && 32 + 2 * (W + 1) <= 256 && (!g_lmkd_act_bf16 || Cout <= 64);
+         Cs % 32 == 0 && 32 + 2 * (W + 1) <= 256;
 }
-// pixel splits: about four workgroups per CU (two rounds at two resident workgroups per CU), but no slab shorter than 12 steps per
-// warm-up chunk of the window (the rows [k0 - halo, k0 + halo) are loaded before the first MFMA of a slab)
+// pixel splits: ONE round of resident workgroups (two per CU; four of the two-wave workgroups of the one-plane modes - registers
+// allow two waves per SIMD, one for the three-plane Cout = 64 instance) - measured at 200 frames (tools/wgrad_bench.py): 277 / 228 /
+// 225 / 229 us per layer against 348 / 273 / 244 / 246 with twice as many, shorter slabs (the window warm-up and the slab traffic
+// double) - but no slab shorter than 12 steps per warm-up chunk of the window (rows [k0 - halo, k0 + halo) precede the first MFMA)
 static void wgrad_win_plan(int Mpix, int W, int Cs, int Cout, int* cob, int* splits, int* steps_per_split) {
   *cob = Cout >= 128 ? 4 : 2;
   const int tiles = cdiv(Cout, 32 * *cob) * (Cs / 32);
   const int steps = cdiv(Mpix, LMKD_BK);
   const int warm = cdiv(2 * (W + 1), LMKD_BK);
-  int sp = cdiv(1024, tiles);
+  const int resident = 256 * ((g_conv_x3 && *cob == 2) ? 2 : 8 / *cob);
+  int sp = cdiv(g_wgrad_window > 1 ? g_wgrad_window : resident, tiles);
   const int cap = std::max(1, steps / (12 * warm));
   if (sp > cap) sp = cap;
   *steps_per_split = cdiv(steps, sp);

@@ -1048,8 +1048,7 @@ def test_bf16_activation_kernels_equal_rounded_fp32_kernels(dev, cfg):
         res32 = r(rnd(N, H, W, C, seed=63)).float().to(dev)
         acc32 = res32.clone()
         ops.conv_bwd_data(dy32, wd, (N, H, W, C), Cout, K, K, s, p, out=acc32, accumulate=True)
-        # weight gradient: by either kernel family (rolling window / im2col gather); with bf16 tensors the window kernel serves only
-        # Cout <= 64, so the two settings are compared family by family
+        # weight gradient: by either kernel family (rolling window for 3x3 / stride 1, im2col gather), compared family by family
         import ctypes
         import litemkd_amd
         L = litemkd_amd.lib()
@@ -1229,7 +1228,7 @@ def test_wgrad_window_kernel_matches_gather_kernel_and_fp64(dev, mode):
                 L.call("lmkd_conv_set_wgrad_window", win)
                 info = (ctypes.c_int * 5)()
                 L.call("lmkd_conv2d_plan", 2, N, H, W, C, C, Cout, 3, 3, 1, 1, info)
-                assert info[4] == (win if (not act16 or Cout <= 64) else 0), list(info)
+                assert info[4] == win, list(info)
                 out[win] = ops.conv_bwd_weight(x, dy, (Cout, C, 3, 3), 1, 1)
             x64 = x.float().permute(0, 3, 1, 2).cpu().double()
             dy64 = dy.float().permute(0, 3, 1, 2).cpu().double()

@@ -19,7 +19,7 @@ def kernel_source_hash():
 
 
 def family(n):
-    for k in ("conv_patch_x3_kernel", "conv_gemm_x3_kernel", "conv_wgrad_x3_kernel", "conv_gemm_kernel", "conv_wgrad_kernel"):
+    for k in ("conv_patch_x3_kernel", "conv_gemm_x3_kernel", "conv_wgrad_win_kernel", "conv_wgrad_x3_kernel", "conv_gemm_kernel", "conv_wgrad_kernel"):
         if k in n:
             return k
     return n.replace("void ", "").split("(")[0].split("<")[0][:48]

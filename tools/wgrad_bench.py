@@ -21,6 +21,7 @@ def tm(f, reps=6):
 
 N = int(os.environ.get("FRAMES", "200"))
 shapes = [("l1", 64, 56, 64), ("l2", 128, 28, 128), ("l3", 256, 14, 256), ("l4", 512, 7, 512)]
+WINS = [int(v) for v in os.environ.get("WINS", "0,1").split(",")]
 modes = sys.argv[1:] or ["fp32x3", "bf16", "bf16act"]
 for mode in modes:
     ops.set_conv_compute_dtype("bf16" if mode.startswith("bf16") else mode)
@@ -32,16 +33,15 @@ for mode in modes:
         fl = 2.0 * N * H * H * Cout * C * 9
         res, best = {}, {}
         for rnd_ in range(3):
-            for win in (0, 1):
+            for win in WINS:
                 lib().call("lmkd_conv_set_wgrad_window", win)
                 if rnd_ == 0:
                     res[win] = ops.conv_bwd_weight(x, gy, (Cout, C, 3, 3), 1, 1)
                 t = tm(lambda: ops.conv_bwd_weight(x, gy, (Cout, C, 3, 3), 1, 1))
                 best[win] = min(best.get(win, 1e9), t)
         ref = torch.nn.functional.conv2d(x.float().permute(3, 0, 1, 2).double()[:, :8], gy.float().permute(3, 0, 1, 2).double()[:, :8], padding=1).permute(1, 0, 2, 3) if False else None
-        d = float((res[0].double() - res[1].double()).norm() / res[0].double().norm())
-        print("%-8s %-3s gather %6.1f us (%5.1f TF) | window %6.1f us (%5.1f TF) | rel diff %.2e" % (
-            mode, name, best[0] * 1e3, fl / best[0] / 1e9, best[1] * 1e3, fl / best[1] / 1e9, d), flush=True)
+        d = float((res[WINS[0]].double() - res[WINS[-1]].double()).norm() / res[WINS[0]].double().norm())
+        print("%-8s %-3s " % (mode, name) + " | ".join("%s %6.1f us (%5.1f TF)" % ("gather" if w_ == 0 else "window(%d)" % w_, best[w_] * 1e3, fl / best[w_] / 1e9) for w_ in WINS) + " | rel diff %.2e" % d, flush=True)
     lib().call("lmkd_conv_set_wgrad_window", 1)
 ops.set_activation_dtype("fp32")
 ops.set_conv_compute_dtype("fp32")
