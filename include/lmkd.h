@@ -43,6 +43,8 @@ long lmkd_conv2d_packed_weight_elems(int Cout, int Cin, int Cs, int KH, int KW, 
 int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout, int Cin, int Cs, int KH, int KW, int mode /*0 fwd, 1 dgrad*/,
                              void* stream);
 int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, int KW, int stride, int pad);
+/* the same with the input's channel count (4 = the padded stem input, whose launch may use a tile of its own) */
+int lmkd_conv2d_fwd_row_tiles_cs(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad);
 int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound kernels, workgroups per CU (default 4) */
 /* arithmetic of the convolutions: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16 MFMA inputs + fp32 accumulation
    (BASELINE configs[2]), 2 = fp32 operands split exactly into three bf16 planes, six bf16 MFMA products per fp32 product,
@@ -55,6 +57,7 @@ int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, int Kp, void
 int lmkd_conv_get_compute_dtype(void);
 int lmkd_conv_set_wgrad_planes(int on); /* tuning (modes 1-3): 1 = weight gradient on the bf16-plane kernel with transposed LDS reads (default), 0 = fp32-tile kernel */
 int lmkd_conv_set_patch(int on); /* tuning (modes 1-3): 1 = same-size convolutions (3x3 / stride 1 forward and data gradient) read an LDS-resident input patch (default), 0 = im2col gather */
+int lmkd_conv_set_stem_patch(int on); /* tuning (modes 1-3): 1 = the 7x7 / stride-2 stem convolution reads an LDS-resident patch of input rows (default), 0 = im2col gather */
 int lmkd_conv_set_wgrad_window(int on); /* tuning (modes 1-3): 1 = 3x3 / stride-1 weight gradients read a rolling LDS window of x, all nine taps per workgroup (default), 0 = im2col-gather kernel */
 int lmkd_conv_set_xcd_mode(int mode); /* tuning: -1 auto (XCD-aware tile order + XCD-grouped weight-gradient splits), 0 plain orders, 1 auto without the weight-gradient grouping */
 int lmkd_conv_set_tile(int id); /* tuning: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 64x128 */
@@ -83,7 +86,7 @@ int lmkd_conv2d_bwd_weight_pre(const float* x_raw, const float* pre_stats, const
                                void* stream);
 
 /* launch plan (no launch) of lmkd_conv2d_fwd (kind 0) / _bwd_data (1) / _bwd_weight (2) for these shapes in the current mode:
-   info[5] (HOST) = tile id, XCD tile order, parity classes | pixel splits, workgroups, 1 if the LDS-patch kernel runs it.
+   info[5] (HOST) = tile id, XCD tile order, parity classes | pixel splits, workgroups, 1 if the LDS-patch / rolling-window kernel runs it (2: the stem's input-row patch kernel).
    Test/diagnostic aid. */
 int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, int* info_host);
 

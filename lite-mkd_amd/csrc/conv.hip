@@ -324,6 +324,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
 
 #include "conv_x3.h"
 #include "conv_patch.h"
+#include "conv_stem.h"
 
 // ---------------------------------------------------------------------------------
 // weight gradient: rows = co (dy, K-outer), cols = packed (tap, ci), K = pixels, split-K slabs
@@ -775,10 +776,26 @@ static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
   return LMKD_OK;
 }
 
+// The stem (7x7 / stride 2 / pad 3 on the NHWC4 input, Cout <= 64) of the bf16-plane modes runs conv_stem_patch_kernel (conv_stem.h):
+// one workgroup per pair of output rows.  Returns the patch row pitch in pixels, or 0 when the launch is not of that kind.
+static int g_conv_stem_patch = 1;
+extern "C" int lmkd_conv_set_stem_patch(int on) { g_conv_stem_patch = on ? 1 : 0; return LMKD_OK; }
+static int stem_patch_pitch(int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
+  if (!g_conv_stem_patch || !(g_conv_x3 || g_conv_bf16) || Cs != 4 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || Cout > 64) return 0;
+  const int Wo = conv_out(W, KW, stride, pad);
+  int wp = std::max(2 * Wo + 6, W + 3);
+  wp += wp & 1;
+  return (2 * Wo <= 256 && wp <= STEM_MAX_WP) ? wp : 0;
+}
+
 // number of row tiles (= rows of the BN partial-statistics buffer) of a forward conv
-extern "C" int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
+extern "C" int lmkd_conv2d_fwd_row_tiles_cs(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
+  if (stem_patch_pitch(W, Cs, Cout, KH, KW, stride, pad)) return N * cdiv(conv_out(H, KH, stride, pad), 2);
   const long M = (long)N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad);
   return cdiv(M, cfg_bm(pick_conv_cfg(M, 1, Cout, conv_same_size(H, W, KH, KW, stride, pad))));
+}
+extern "C" int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
+  return lmkd_conv2d_fwd_row_tiles_cs(N, H, W, 32, Cout, KH, KW, stride, pad);
 }
 
 static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* stat_partial, const float* ep_stats,
@@ -822,6 +839,24 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
       for (int kw = 0; kw < KW; ++kw) a.taps[0][kh * KW + kw] = Tap{kh - pad, kw - pad, (kh * KWp + kw) * Cs};
   }
   hipStream_t s = (hipStream_t)stream;
+  if (const int wp = ep_stats ? 0 : stem_patch_pitch(W, Cs, Cout, KH, KW, stride, pad)) {
+    a.halo = wp;      // row pitch of the input-row patch
+    a.n_rt = N * cdiv(a.Ho, 2); a.n_ct = 1;
+    const int npl = (g_conv_bf16 || g_lmkd_act_bf16) ? 1 : 3;
+    const size_t lds = (size_t)npl * 9 * wp * 8;
+    const dim3 grid(a.n_rt), block(512);
+#define LMKD_STEM(OR)                                                                                                  \
+  do {                                                                                                                 \
+    if (g_lmkd_act_bf16) hipLaunchKernelGGL((conv_stem_patch_kernel<1, true, OR>), grid, block, lds, s, a);            \
+    else if (g_conv_bf16) hipLaunchKernelGGL((conv_stem_patch_kernel<1, false, OR>), grid, block, lds, s, a);          \
+    else if (g_conv_x3 == 9) hipLaunchKernelGGL((conv_stem_patch_kernel<9, false, OR>), grid, block, lds, s, a);       \
+    else hipLaunchKernelGGL((conv_stem_patch_kernel<6, false, OR>), grid, block, lds, s, a);                           \
+  } while (0)
+    LMKD_STEM(2);      // two output rows per workgroup (one row, four waves: 557 vs 447 us at 200 frames)
+#undef LMKD_STEM
+    LMKD_CHECK_LAUNCH("conv_stem_patch_kernel");
+    return LMKD_OK;
+  }
   if (ep_stats) return smallc ? launch_conv_gemm<true, 2>(a, Cout, s) : launch_conv_gemm<false, 2>(a, Cout, s);
   if (smallc) return stat_partial ? launch_conv_gemm<true, 1>(a, Cout, s) : launch_conv_gemm<true, 0>(a, Cout, s);
   return stat_partial ? launch_conv_gemm<false, 1>(a, Cout, s) : launch_conv_gemm<false, 0>(a, Cout, s);
@@ -1148,7 +1183,8 @@ extern "C" int lmkd_conv2d_bwd_weight_acc(const float* x, const float* pre_stats
 // bands, 1 column slices; weight gradient: 1 = all tiles of a pixel split on one XCD), info[2] = pixel splits (weight gradient)
 // or parity classes (data gradient), info[3] = workgroups launched.  Used by the parity tests to prove that the benchmark's
 // kernel instances are the ones under test.  info[4] = 1 when the launch runs on the LDS-patch kernel (conv_patch.h) or, for the
-// weight gradient, on the rolling-window kernel (wgrad_win.h; it reports tile id 5 = 128 output channels per workgroup, 6 = 64).
+// weight gradient, on the rolling-window kernel (wgrad_win.h; it reports tile id 5 = 128 output channels per workgroup, 6 = 64);
+// info[4] = 2: the stem's input-row patch kernel (conv_stem.h).
 extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                 int* info) {
   LMKD_REQUIRE(info && kind >= 0 && kind <= 2, "lmkd_conv2d_plan: kind must be 0 (forward), 1 (data gradient) or 2 (weight gradient)");
@@ -1170,6 +1206,10 @@ extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, 
       info[3] = 8 * cdiv(wsplits, 8) * cdiv(Cout, 32 * cob) * (Cs / 32);
       info[4] = 1;
     }
+    return LMKD_OK;
+  }
+  if (kind == 0 && stem_patch_pitch(W, Cs, Cout, KH, KW, stride, pad)) {      // conv_stem_patch_kernel: tile id 14, one workgroup per output row pair
+    info[0] = 14; info[1] = 0; info[2] = 1; info[3] = N * cdiv(Ho, 2); info[4] = 2;
     return LMKD_OK;
   }
   long rows;

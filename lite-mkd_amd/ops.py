@@ -237,7 +237,7 @@ def _conv_family(kind, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad):
     import ctypes
     info = (ctypes.c_int * 5)()
     lib().call("lmkd_conv2d_plan", kind, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, info)
-    return "conv_patch_kernel" if info[4] else "conv_gemm_kernel"
+    return "conv_patch_kernel" if info[4] == 1 else "conv_gemm_kernel"
 
 
 def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None):
@@ -249,7 +249,7 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None):
     y = _empty_act((N, Ho, Wo, Cout), x)
     part = None
     if want_stats:
-        T = lib().value("lmkd_conv2d_fwd_row_tiles", N, H, W, Cout, KH, KW, stride, pad)
+        T = lib().value("lmkd_conv2d_fwd_row_tiles_cs", N, H, W, Cs, Cout, KH, KW, stride, pad)
         part = _empty((T, Cout, 2), x)
     cin = 3 if Cs == 4 else Cs
     with _timed(_conv_family(0, N, H, W, Cs, cin, Cout, KH, KW, stride, pad), 2.0 * N * Ho * Wo * Cout * cin * KH * KW,

@@ -1247,3 +1247,39 @@ def test_wgrad_window_kernel_matches_gather_kernel_and_fp64(dev, mode):
         L.call("lmkd_conv_set_wgrad_window", 1)
         ops.set_activation_dtype("fp32")
         ops.set_conv_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("mode", ["fp32x3", "fp32x3_9", "bf16", "bf16act"])
+def test_stem_patch_kernel_bit_identical_to_gather_kernel(dev, mode):
+    """conv_stem_patch_kernel (7x7 / stride 2 from an LDS-resident patch of nine input rows, zero padding stored in the patch) sums the
+    same products in the same order as the gather kernel (kernel row outer, (kw, c) inner): output and BatchNorm sums must agree bit
+    for bit, also for an odd number of output rows (the last row pair is half empty), widths whose row pairs are not a whole number
+    of 32-pixel blocks, and fewer than 64 output channels."""
+    import ctypes
+    import litemkd_amd
+    from litemkd_amd import ops
+    L = litemkd_amd.lib()
+    act16 = mode == "bf16act"
+    ops.set_conv_compute_dtype("bf16" if mode.startswith("bf16") else mode)
+    ops.set_activation_dtype("bf16" if act16 else "fp32")
+    try:
+        for (N, H, W, Cout) in [(3, 64, 64, 64), (2, 58, 40, 64), (1, 21, 30, 32), (2, 224, 224, 64)]:
+            x = torch.zeros(N, H, W, 4)
+            x[..., :3] = rnd(N, H, W, 3, seed=90 + H)
+            x = x.to(dev)
+            w = (rnd(Cout, 3, 7, 7, seed=91) * math.sqrt(2.0 / (Cout * 49))).to(dev)
+            wp = ops._pack_weights(w, 4, 0)
+            out = {}
+            for on in (0, 1):
+                L.call("lmkd_conv_set_stem_patch", on)
+                info = (ctypes.c_int * 5)()
+                L.call("lmkd_conv2d_plan", 0, N, H, W, 4, 3, Cout, 7, 7, 2, 3, info)
+                assert (info[4] == 2) == bool(on), list(info)
+                y, part = ops.conv_fwd(x, wp, Cout, 7, 7, 2, 3, True)
+                out[on] = (y, part.double().sum(0))
+            assert torch.equal(out[0][0], out[1][0]), (mode, (N, H, W, Cout), float((out[0][0].float() - out[1][0].float()).abs().max()))
+            assert torch.allclose(out[0][1], out[1][1], rtol=1e-6, atol=1e-6 * float(out[0][1].abs().max())), (mode, (N, H, W, Cout))
+    finally:
+        L.call("lmkd_conv_set_stem_patch", 1)
+        ops.set_activation_dtype("fp32")
+        ops.set_conv_compute_dtype("fp32")

@@ -21,10 +21,10 @@ for mode in ("fp32x3", "bf16"):
     gy = torch.randn(N, 112, 112, 64, device=dev)
     best = {}
     for r in range(3):
-        for t in (9, 7):
-            lib().call("lmkd_conv_set_tile", t)
+        for t in ("gather", "rows"):
+            lib().call("lmkd_conv_set_stem_patch", int(t == "rows"))
             best[t] = min(best.get(t, 1e9), tm(lambda: ops.conv_fwd(x, wp, 64, 7, 7, 2, 3, True)))
-    lib().call("lmkd_conv_set_tile", 0)
+    lib().call("lmkd_conv_set_stem_patch", 1)
     tw = tm(lambda: ops.conv_bwd_weight(x, gy, (64, 3, 7, 7), 2, 3))
     print(mode, {k: "%.0f us (%.0f TF)" % (v * 1e3, fl / v / 1e9) for k, v in best.items()}, "wgrad %.0f us (%.0f TF)" % (tw * 1e3, fl / tw / 1e9))
     # stride-2 3x3 and downsample shapes
