@@ -35,22 +35,35 @@ __global__ __launch_bounds__(256 * OR) void conv_stem_patch_kernel(ConvGemmArgs 
   const int WP = a.halo;                           // row pitch of the patch in pixels (host: even, >= 2 (Wo - 1) + 8)
   const int plane_bytes = PR * WP * 8;
   const int ih0 = 2 * oh0 - 3;
-  // ---- patch: input rows ih0 .. ih0 + 8, columns -3 .. WP - 4, zero outside the image
-  for (int i = tid; i < PR * WP; i += NTHR) {
-    const int pr = i / WP, pc = i - pr * WP;
-    const int ih = ih0 + pr, iw = pc - 3;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((unsigned)ih < (unsigned)a.Hs && (unsigned)iw < (unsigned)a.Ws)
-      v = *reinterpret_cast<const float4*>(a.src + ((long)(n * a.Hs + ih) * a.Ws + iw) * 4);
-    unsigned char* d = psm + i * 8;
-    if (NPL == 1) {
-      *reinterpret_cast<uint2*>(d) = x3_round4(v);
-    } else {
-      uint2 q0, q1, q2;
-      x3_split4(v, q0, q1, q2);
-      *reinterpret_cast<uint2*>(d) = q0;
-      *reinterpret_cast<uint2*>(d + plane_bytes) = q1;
-      *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = q2;
+  // ---- patch: input rows ih0 .. ih0 + PR - 1, columns -3 .. WP - 4, zero outside the image.  Thread -> (column, row parity);
+  // every thread's loads are issued before the first one is split (a load -> split -> store loop waits one memory latency per trip)
+  {
+    static_assert(STEM_MAX_WP <= 256, "one thread per patch column");
+    constexpr int RSTEP = NTHR / 256, NIT = (PR + RSTEP - 1) / RSTEP;
+    const __amdgpu_buffer_rsrc_t rs = x3_rsrc(a.src, (long)a.N * a.Hs * a.Ws * 16);
+    const int pc = tid & 255, iw = pc - 3;
+    u32x4 rp[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pr = (tid >> 8) + RSTEP * it, ih = ih0 + pr;
+      const bool ok = pr < PR && (unsigned)ih < (unsigned)a.Hs && (unsigned)iw < (unsigned)a.Ws;
+      rp[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(((n * a.Hs + ih) * a.Ws + iw) * 16) : X3_OOB, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pr = (tid >> 8) + RSTEP * it;
+      if (pr >= PR || pc >= WP) continue;
+      const float4 v = make_float4(__uint_as_float(rp[it].x), __uint_as_float(rp[it].y), __uint_as_float(rp[it].z), __uint_as_float(rp[it].w));
+      unsigned char* d = psm + (pr * WP + pc) * 8;
+      if (NPL == 1) {
+        *reinterpret_cast<uint2*>(d) = x3_round4(v);
+      } else {
+        uint2 q0, q1, q2;
+        x3_split4(v, q0, q1, q2);
+        *reinterpret_cast<uint2*>(d) = q0;
+        *reinterpret_cast<uint2*>(d + plane_bytes) = q1;
+        *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = q2;
+      }
     }
   }
   const int npix = OR * a.Wo;                      // output pixels of the tile (a second row may lie below the image)
