@@ -19,7 +19,7 @@ def kernel_source_hash():
 
 
 def family(n):
-    for k in ("conv_patch_x3_kernel", "conv_gemm_x3_kernel", "conv_wgrad_win_kernel", "conv_wgrad_x3_kernel", "conv_gemm_kernel", "conv_wgrad_kernel"):
+    for k in ("conv_patch_x3_kernel", "conv_stem_patch_kernel", "conv_gemm_x3_kernel", "conv_wgrad_win_kernel", "conv_wgrad_x3_kernel", "conv_gemm_kernel", "conv_wgrad_kernel"):
         if k in n:
             return k
     return n.replace("void ", "").split("(")[0].split("<")[0][:48]
@@ -64,7 +64,7 @@ if tr:
     g = collections.defaultdict(list)
     for r in csv.DictReader(open(tr)):
         n = r["Kernel_Name"]
-        if "conv_gemm" in n or "conv_wgrad" in n or "conv_patch" in n:
+        if "conv_gemm" in n or "conv_wgrad" in n or "conv_patch" in n or "conv_stem" in n:
             key = (n.replace("void ", "").split("(")[0], int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["LDS_Block_Size"], r["VGPR_Count"])
             g[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open("profiles/%s_conv_by_shape.txt" % tag, "w") as fo:
