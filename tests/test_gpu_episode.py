@@ -28,6 +28,7 @@ def _rel(a, b):
                                                              (1, 1, 64, "TRX_2fcsup", "fc_2_sup_dist", "resnet50_2fc", "fp32"),
                                                              (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3"),
                                                              (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3"),
+                                                             (1, 1, 64, "TRX_2fcsup", "fc_2_sup_dist", "resnet50_2fc", "fp32x3"),
                                                              (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "bf16"),
                                                              (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "bf16act")])
 def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode):
