@@ -656,13 +656,17 @@ static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
 // Same-size convolutions (3x3 / stride 1 forward and data gradient, 1x1 / stride 1) of the bf16-plane modes read an LDS-resident
 // input patch (conv_patch.h).  Returns the halo (largest |dh * Ws + dw| over the taps), or -1 when the launch is not of that kind.
 static int patch_halo(const ConvGemmArgs& a) {
-  if (!g_conv_patch || !(g_conv_x3 || g_conv_bf16) || a.Cs % 32 != 0 || a.nclass != 1 || a.sh != 1 || a.Hs != a.Ho || a.Ws != a.Wo || a.ep_stats)
-    return -1;
+  if (!g_conv_patch || !(g_conv_x3 || g_conv_bf16) || a.Cs % 32 != 0 || a.sh != 1 || a.ep_stats) return -1;
+  // one class: output grid = input grid; four parity classes (stride-2 data gradient): each class runs on the dy grid
+  const bool plain = a.nclass == 1 && a.Hs == a.Ho && a.Ws == a.Wo;
+  const bool classes = a.nclass == 4 && a.Hr == a.Hs && a.Wr == a.Ws;
+  if (!plain && !classes) return -1;
   int halo = 0;
-  for (int t = 0; t < a.ntap[0]; ++t) {
-    const int sft = a.taps[0][t].dh * a.Ws + a.taps[0][t].dw;
-    halo = std::max(halo, sft < 0 ? -sft : sft);
-  }
+  for (int c = 0; c < a.nclass; ++c)
+    for (int t = 0; t < a.ntap[c]; ++t) {
+      const int sft = a.taps[c][t].dh * a.Ws + a.taps[c][t].dw;
+      halo = std::max(halo, sft < 0 ? -sft : sft);
+    }
   return halo <= PATCH_HALO_MAX ? halo : -1;
 }
 static inline bool conv_same_size(int H, int W, int KH, int KW, int stride, int pad) {
@@ -672,7 +676,7 @@ static inline bool conv_same_size(int H, int W, int KH, int KW, int stride, int 
 template <class Cfg>
 static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
   a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
-  a.n_rt = a.tiles_per_class;
+  a.n_rt = a.nclass * a.tiles_per_class;
   a.n_ct = cdiv(ncols, Cfg::BN);
   a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
   if (g_xcd_mode == 0) a.xcd_mode = 0;
@@ -1177,6 +1181,24 @@ extern "C" int lmkd_conv2d_bwd_weight_acc(const float* x, const float* pre_stats
   return conv2d_bwd_weight_impl(x, pre_stats, dy, dw_oihw, workspace, ws_bytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, stream, 1);
 }
 
+
+// stride-2 data gradient: does the LDS-patch kernel run its four parity classes (patch_halo() of the launch's arguments >= 0)?
+static bool dgrad_s2_patch_ok(int H, int W, int Cout, int KH, int KW, int pad) {
+  if (!g_conv_patch || !(g_conv_x3 || g_conv_bf16) || Cout % 32 != 0) return false;
+  const int Hr = (H + 1) / 2, Wr = (W + 1) / 2;
+  if (conv_out(H, KH, 2, pad) != Hr || conv_out(W, KW, 2, pad) != Wr) return false;
+  int halo = 0;
+  for (int c = 0; c < 4; ++c)
+    for (int kh = 0; kh < KH; ++kh)
+      for (int kw = 0; kw < KW; ++kw) {
+        const int nh = (c >> 1) + pad - kh, nw = (c & 1) + pad - kw;
+        if ((nh & 1) || (nw & 1)) continue;
+        const int sft = (nh >= 0 ? nh / 2 : -((-nh) / 2)) * Wr + (nw >= 0 ? nw / 2 : -((-nw) / 2));
+        halo = std::max(halo, sft < 0 ? -sft : sft);
+      }
+  return halo <= PATCH_HALO_MAX;
+}
+
 // Launch plan of a convolution, without launching: which kernel instance and tile order the three entry points above would
 // pick for these shapes in the current arithmetic mode (info: 5 ints).  info[0] = tile id (lmkd_conv_set_tile numbering; the weight gradient
 // reports 1 = 128x128/8 waves, 2 = 128x64, 3 = 64x64, 4 = 64x128), info[1] = XCD tile order (forward / data gradient: 0 row
@@ -1220,7 +1242,8 @@ extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, 
     if (stride == 1) rows = (long)N * H * W;
     else { nclass = 4; rows = (long)N * ((H + 1) / 2) * ((W + 1) / 2); }
   }
-  const bool same = conv_same_size(H, W, KH, KW, stride, pad);
+  const bool s2patch = kind == 1 && stride == 2 && dgrad_s2_patch_ok(H, W, Cout, KH, KW, pad);
+  const bool same = conv_same_size(H, W, KH, KW, stride, pad) || s2patch;
   int id = pick_conv_cfg(rows, nclass, ncols, same);
   const bool patch = same && (g_conv_x3 || g_conv_bf16) && (kind == 0 ? Cs : Cout) % 32 == 0;      // patch_halo() >= 0 for these launches
   if (!patch) id = id == 10 ? 7 : (id == 11 ? 9 : (id == 12 ? 8 : id));

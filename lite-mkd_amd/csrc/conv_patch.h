@@ -40,16 +40,38 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
   const int tid = threadIdx.x;
   int rt, ct;
   if (!xcd_decode(blockIdx.x, a.n_rt, a.n_ct, a.xcd_mode, rt, ct)) return;
-  const int ntap = a.ntap[0];
+  // parity classes of a stride-2 data gradient (conv.hip): each class is a same-size convolution over the dy grid with its own 1-4
+  // taps, its outputs scattered to the pixels (2a + ph, 2b + pw); a.nclass == 1: plain same-size convolution (omul 1, ph = pw = 0)
+  const int tile = rt / a.nclass;
+  const int cls = rt - tile * a.nclass;
+  const int ph = cls >> 1, pw = cls & 1;
+  const int ntap = a.ntap[cls];
+  if (a.accum && ntap == 0) return;      // out += 0
+  const Tap* taps = a.taps[cls];
   const int halo = a.halo, P = Cfg::BM + 2 * halo;
   const int M = a.rows_per_class;
-  const int row0 = rt * Cfg::BM, n0 = ct * Cfg::BN;
+  const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
   if (tid < ntap) {
-    const Tap tp = a.taps[0][tid];
+    const Tap tp = taps[tid];
     s_tap_shift[tid] = (tp.dh * a.Ws + tp.dw) * ROWB;
     s_tap_kofs[tid] = tp.kofs;
   }
-  for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) s_out[r] = (row0 + r < M) ? (row0 + r) * a.Co : -1;
+  for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
+    const int m = row0 + r;
+    int ob = -1;
+    if (m < M) {
+      if (a.nclass == 1) {
+        ob = m * a.Co;
+      } else {
+        const int n = fdiv(m, a.div_hw);
+        const int rem = m - n * a.Hs * a.Ws;
+        const int aa = fdiv(rem, a.div_w), bb = rem - aa * a.Ws;
+        const int oh = aa * a.omul + ph, ow = bb * a.omul + pw;
+        if (oh < a.Ho && ow < a.Wo) ob = ((n * a.Ho + oh) * a.Wo + ow) * a.Co;
+      }
+    }
+    s_out[r] = ob;
+  }
   for (int j = tid; j < ROWB / 4; j += Cfg::THREADS) reinterpret_cast<unsigned*>(psm + (long)P * ROWB)[j] = 0u;   // the zero row
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -67,7 +89,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
       const int rem = m - n * a.Hs * a.Ws;
       const int hh = fdiv(rem, a.div_w), ww = rem - hh * a.Ws;
       for (int tp = 0; tp < ntap; ++tp) {
-        const int y = hh + a.taps[0][tp].dh, x = ww + a.taps[0][tp].dw;
+        const int y = hh + taps[tp].dh, x = ww + taps[tp].dw;
         if ((unsigned)y < (unsigned)a.Hs && (unsigned)x < (unsigned)a.Ws) mk |= 1u << tp;
       }
     }

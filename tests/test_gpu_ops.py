@@ -1283,3 +1283,43 @@ def test_stem_patch_kernel_bit_identical_to_gather_kernel(dev, mode):
         L.call("lmkd_conv_set_stem_patch", 1)
         ops.set_activation_dtype("fp32")
         ops.set_conv_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("mode", ["fp32x3", "bf16", "bf16act"])
+def test_stride2_data_gradient_on_patch_kernel_bit_identical(dev, mode):
+    """a stride-2 data gradient is four same-size convolutions over the dy grid (one per input parity, 1-4 taps each) whose outputs
+    are scattered to the pixels of their parity: the patch kernel runs them (plan info[4] == 1), bit-identical to the gather kernel,
+    also through the accumulating epilogue, for the 1x1 / stride-2 downsample (three of its four classes have no tap) and for odd
+    H, W (the last row / column of a class falls outside the image and is not stored)."""
+    import ctypes
+    import litemkd_amd
+    from litemkd_amd import ops
+    L = litemkd_amd.lib()
+    act16 = mode == "bf16act"
+    ops.set_conv_compute_dtype("bf16" if mode.startswith("bf16") else mode)
+    ops.set_activation_dtype("bf16" if act16 else "fp32")
+    dt = torch.bfloat16 if act16 else torch.float32
+    try:
+        for (N, Cin, H, W, Cout, K, p) in [(3, 64, 12, 20, 128, 3, 1), (2, 32, 56, 56, 64, 3, 1), (2, 64, 10, 6, 96, 1, 0), (5, 128, 14, 14, 256, 3, 1),
+                                           (2, 64, 9, 11, 128, 3, 1)]:
+            Ho, Wo = (H + 2 * p - K) // 2 + 1, (W + 2 * p - K) // 2 + 1
+            w = (rnd(Cout, Cin, K, K, seed=95) * math.sqrt(2.0 / (Cout * K * K))).to(dev)
+            dy = rnd(N, Ho, Wo, Cout, seed=96).to(dev).to(dt)
+            r0 = rnd(N, H, W, Cin, seed=97).to(dev).to(dt)
+            wd = ops._pack_weights(w, Cin, 1)
+            out = {}
+            for patch in (0, 1):
+                L.call("lmkd_conv_set_patch", patch)
+                info = (ctypes.c_int * 5)()
+                L.call("lmkd_conv2d_plan", 1, N, H, W, Cin, Cin, Cout, K, K, 2, p, info)
+                assert info[4] == patch and info[2] == 4, list(info)
+                dx = ops.conv_bwd_data(dy, wd, (N, H, W, Cin), Cout, K, K, 2, p)
+                acc = r0.clone()
+                ops.conv_bwd_data(dy, wd, (N, H, W, Cin), Cout, K, K, 2, p, out=acc, accumulate=True)
+                out[patch] = (dx, acc)
+            for i in range(2):
+                assert torch.equal(out[0][i], out[1][i]), (mode, (N, Cin, H, W, Cout, K), i, float((out[0][i].float() - out[1][i].float()).abs().max()))
+    finally:
+        L.call("lmkd_conv_set_patch", 1)
+        ops.set_activation_dtype("fp32")
+        ops.set_conv_compute_dtype("fp32")
