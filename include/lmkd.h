@@ -42,8 +42,11 @@ int lmkd_gemm_f32(char layA, char layB, int M, int N, int K, float alpha, const 
 long lmkd_conv2d_packed_weight_elems(int Cout, int Cin, int Cs, int KH, int KW, int mode);
 int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout, int Cin, int Cs, int KH, int KW, int mode /*0 fwd, 1 dgrad*/,
                              void* stream);
+/* rows T of the [T][Cout][2] BatchNorm partial-sum buffer a forward launch fills (one row per row tile), for an input with Cs % 32 == 0;
+   evaluate it in the arithmetic mode the launch will run in */
 int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, int KW, int stride, int pad);
-/* the same with the input's channel count (4 = the padded stem input, whose launch may use a tile of its own) */
+/* the same for any input channel count: REQUIRED for the padded stem input (Cs = 4), whose launch uses a tiling of its own in the
+   bf16-plane modes (one row per pair of output rows) */
 int lmkd_conv2d_fwd_row_tiles_cs(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad);
 int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound kernels, workgroups per CU (default 4) */
 /* arithmetic of the convolutions: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16 MFMA inputs + fp32 accumulation
