@@ -1058,8 +1058,12 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
     const bool big = 32 + 2 * (W + 1) > 128;      // ring of 256 pixel rows instead of 128
 #define LMKD_WIN(COB, NPROD, A16, PRE)                                                                                  \
   do {                                                                                                                  \
-    if (big) hipLaunchKernelGGL((conv_wgrad_win_kernel<COB, NPROD, A16, 256, PRE>), wgrid, dim3(64 * COB), 0, s, w);    \
-    else hipLaunchKernelGGL((conv_wgrad_win_kernel<COB, NPROD, A16, 128, PRE>), wgrid, dim3(64 * COB), 0, s, w);        \
+    /* Cout = 64 leaves two channel blocks: in the three-plane modes the nine taps are dealt 5 + 4 to two wave groups (four    \
+       waves instead of two: 262 vs 318 us at 200 frames); with one plane the extra dy-fragment reads cost more (119 vs 94) */ \
+    constexpr int TPW = (COB == 2 && NPROD != 1) ? 5 : 9;                                                               \
+    constexpr int NT = 64 * COB * ((9 + TPW - 1) / TPW);                                                                \
+    if (big) hipLaunchKernelGGL((conv_wgrad_win_kernel<COB, NPROD, A16, 256, PRE, TPW>), wgrid, dim3(NT), 0, s, w);     \
+    else hipLaunchKernelGGL((conv_wgrad_win_kernel<COB, NPROD, A16, 128, PRE, TPW>), wgrid, dim3(NT), 0, s, w);         \
   } while (0)
 #define LMKD_WIN_MODE(COB)                                                                                              \
   do {                                                                                                                  \

@@ -15,9 +15,10 @@
 // per step and serves nine taps.  A tap is a row shift of the window: the transposed LDS read (ds_read_b64_tr_b16, wgrad_x3.h) takes
 // its row address per lane, so the shift is an add + wrap on that address, and the image-border mask of (pixel, tap) is an address
 // select to an all-zero row - the lane that supplies row q of a 4 x 16 block applies the mask of ITS pixel.
-// Wave w multiplies output-channel block w (32 rows) with the nine shifted 32-channel blocks: 9 accumulator tiles, every dy fragment
-// shared by nine taps.  (Three taps per wave - six waves instead of two where Cout = 64 leaves two channel blocks - was 15-50 % slower:
-// three times the dy-fragment reads and a six-wave barrier.)
+// A wave multiplies one output-channel block (32 rows) with TPW of the nine shifted 32-channel blocks (TPW accumulator tiles).  TPW = 9:
+// COB waves, every dy fragment shared by nine taps.  Where Cout = 64 leaves two channel blocks (two waves per workgroup, one per
+// SIMD) the three-plane modes deal the taps 5 + 4 to two wave groups (four waves; three taps per wave, six waves, was slower than
+// either: three times the dy-fragment reads and a six-wave barrier).
 // Output: split-K slabs in the layout of conv_wgrad_kernel ([split][Cout][Kp], column = tap * Cs + ci), reduced by wgrad_reduce_kernel.
 #pragma once
 
@@ -32,11 +33,11 @@ struct WgradWinArgs {
   FastDiv div_hw, div_w;
 };
 
-template <int COB, int NPROD, bool ACT16, int R, bool PRE = false>
-__global__ __launch_bounds__(64 * COB) void conv_wgrad_win_kernel(WgradWinArgs a) {
+template <int COB, int NPROD, bool ACT16, int R, bool PRE = false, int TPW = 9>
+__global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_win_kernel(WgradWinArgs a) {
   constexpr int NPL = NPROD == 1 ? 1 : 3;
   static_assert(!ACT16 || (NPROD == 1 && !PRE), "bf16 tensors: one plane, no store-side arithmetic");
-  constexpr int THREADS = 64 * COB, BM = 32 * COB;
+  constexpr int THREADS = 64 * COB * ((9 + TPW - 1) / TPW), BM = 32 * COB;
   constexpr int LDA = BM * 2 + 64, A_PLANE = LMKD_BK * LDA;      // dy image [k][co], bytes (odd multiple of 64: wgrad_x3.h)
   constexpr int LDX = 64, X_PLANE = (R + 1) * LDX;               // x ring [slot][32 ci]; slot R = the zero row
   constexpr int ESZ = ACT16 ? 2 : 4, EPL = ACT16 ? 8 : 4;        // element size, elements per 16-byte lane access
@@ -138,10 +139,11 @@ __global__ __launch_bounds__(64 * COB) void conv_wgrad_win_kernel(WgradWinArgs a
 
   // transposed-read lane geometry (wgrad_x3.h): this lane supplies row 8h + q (and + 4) of each 16-row k-group, 4 columns at cb
   const int cb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-  const int offA = tr_lane_off(LDA, lane) + wave * 32 * 2;
-  f32x16 acc[9];
+  const int cw = wave % COB, tap0 = (wave / COB) * TPW;
+  const int offA = tr_lane_off(LDA, lane) + cw * 32 * 2;
+  f32x16 acc[TPW];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
@@ -174,10 +176,12 @@ __global__ __launch_bounds__(64 * COB) void conv_wgrad_win_kernel(WgradWinArgs a
 #pragma unroll
         for (int p = 0; p < NPL; ++p) fa[g][p] = tr_frag<LDA>(s_dy, offA + p * A_PLANE + g * 16 * LDA);
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
+      for (int ti = 0; ti < TPW; ++ti) {
+        const int tp = tap0 + ti;
+        if (9 % TPW != 0 && ti >= 9 - TPW * (9 / TPW) && tp >= 9) break;      // only the last wave group's trailing taps can be missing
         // this lane's four ring rows under tap tp: [k-group 0 lo, hi, k-group 1 lo, hi]
         const u32x4 a4 = *reinterpret_cast<const u32x4*>(&s_adr[t & 1][tp * LMKD_BK + ((lane >> 5) * 4 + ((lane & 15) >> 2)) * 4]);
-        f32x16 c = acc[tp];
+        f32x16 c = acc[ti];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           const unsigned ad[2] = {(g ? a4.z : a4.x) + (unsigned)cb, (g ? a4.w : a4.y) + (unsigned)cb};
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(64 * COB) void conv_wgrad_win_kernel(WgradWinArgs a
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0], fb[0], c, 0, 0, 0);
           }
         }
-        acc[tp] = c;
+        acc[ti] = c;
       }
       __syncthreads();                        // every wave has read the dy tile (and this step's window) before they are overwritten
     }
@@ -214,12 +218,13 @@ __global__ __launch_bounds__(64 * COB) void conv_wgrad_win_kernel(WgradWinArgs a
 
   float* C = a.slab + (long)z * a.Co * a.Kp;
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp) {
-    const int col = tp * a.Cs + ci0 + (lane & 31);
+  for (int ti = 0; ti < TPW; ++ti) {
+    if (9 % TPW != 0 && tap0 + ti >= 9) break;
+    const int col = (tap0 + ti) * a.Cs + ci0 + (lane & 31);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = co0 + wave * 32 + acc_row(e, lane);
-      if (row < a.Co) C[(long)row * a.Kp + col] = acc[tp][e];
+      const int row = co0 + cw * 32 + acc_row(e, lane);
+      if (row < a.Co) C[(long)row * a.Kp + col] = acc[ti][e];
     }
   }
 }
