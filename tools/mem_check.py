@@ -1,5 +1,5 @@
 """Long-run check: memory stays flat and throughput steady over many training episodes (three-stream schedule, caching
-allocator + record_stream).  `gpurun -- python tools/mem_check.py [episodes]`"""
+allocator + record_stream).  `gpurun -- python tools/mem_check.py [episodes] [fp32x3|bf16]`"""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import litemkd_amd
@@ -10,6 +10,9 @@ from litemkd_amd.options import default_args
 from litemkd_amd.utils import aggregate_accuracy
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+if len(sys.argv) > 2:      # arithmetic mode of the convolutions (default fp32 MFMA); "fp32x3" = the benchmark's headline
+    ops.set_conv_compute_dtype(sys.argv[2])
+ops.SIDE_WGRAD = True
 cfg = default_args(shot=5, device=dev, training_iterations=10 ** 9, print_freq=10 ** 9)
 torch.manual_seed(0)
 student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
