@@ -180,8 +180,30 @@ __device__ __forceinline__ double colsum_inline(const Tin* __restrict__ in, int 
   return (s0 + s1) + (s2 + s3);
 }
 
-// Stage 1 of a tall reduction (T > 256 rows): in[T][CV] floats -> scratch[64][CV] doubles.  The consumer kernel (finalize /
-// coef) sums the remaining <= 256 rows itself, so a BatchNorm forward costs 1-2 launches and a backward 3-4.
+// The same for a (64 columns) x NP_RLANES (row lanes) thread block: row lane ty sums the rows t = ty (mod NP_RLANES), the lanes'
+// sums are added in lane order through LDS; every thread of the block must call it, the result is valid on row lane 0.
+#define NP_RLANES 8
+#define NP_DIRECT_ROWS 2048      // tallest partial-sum buffer finalize / coef reduce themselves (256 rows per thread)
+template <typename Tin>
+__device__ __forceinline__ double colsum_block(const Tin* __restrict__ in, int T, int CV, int col, bool active, double (*sm)[64]) {
+  const int ty = threadIdx.y;
+  double s = 0.0;
+  if (active) {
+    const int rows = (T - ty + NP_RLANES - 1) / NP_RLANES;      // rows ty, ty + NP_RLANES, ...
+    s = rows > 0 ? colsum_inline(in + (long)ty * CV, rows, CV * NP_RLANES, col) : 0.0;
+  }
+  sm[ty][threadIdx.x] = s;
+  __syncthreads();
+  double tot = 0.0;
+  if (ty == 0)
+    for (int q = 0; q < NP_RLANES; ++q) tot += sm[q][threadIdx.x];
+  __syncthreads();
+  return tot;
+}
+
+// Stage 1 of a tall reduction (T > NP_DIRECT_ROWS rows): in[T][CV] floats -> scratch[64][CV] doubles.  The consumer kernel
+// (finalize / coef: 64 channels x 8 row lanes per block) sums up to 2048 rows itself, so a BatchNorm forward costs 1 launch
+// (2 for the 4900- and 11200-row partial buffers of layer 1 and the stem) and a backward 3.
 static int colsum_stage1(const float* in, int T, int CV, double* scratch, hipStream_t s);
 
 // reduce in[T][CV] floats to out[CV] doubles using scratch (>= 64*CV doubles)
@@ -211,10 +233,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ pf, const double* _
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
                                    float* __restrict__ stats) {
+  __shared__ double sm[NP_RLANES][64];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double s1 = pf ? colsum_inline(pf, T, 2 * C, 2 * c) : colsum_inline(pd, T, 2 * C, 2 * c);
-  const double s2 = pf ? colsum_inline(pf, T, 2 * C, 2 * c + 1) : colsum_inline(pd, T, 2 * C, 2 * c + 1);
+  const bool act = c < C;
+  const double s1 = pf ? colsum_block(pf, T, 2 * C, 2 * c, act, sm) : colsum_block(pd, T, 2 * C, 2 * c, act, sm);
+  const double s2 = pf ? colsum_block(pf, T, 2 * C, 2 * c + 1, act, sm) : colsum_block(pd, T, 2 * C, 2 * c + 1, act, sm);
+  if (!act || threadIdx.y != 0) return;
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -273,12 +297,12 @@ extern "C" int lmkd_bn_finalize(const float* partial, int T, int C, long count, 
   hipStream_t s = (hipStream_t)stream;
   const float* pf = partial;
   const double* pd = nullptr;
-  if (T > 256) {
+  if (T > NP_DIRECT_ROWS) {
     int rc = colsum_stage1(partial, T, 2 * C, scratch, s);
     if (rc) return rc;
     pf = nullptr; pd = scratch; T = 64;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, pf, pd, T, C, (double)count, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64, NP_RLANES), 0, s, pf, pd, T, C, (double)count, gamma, beta,
                      running_mean, running_var, momentum, eps, stats);
   LMKD_CHECK_LAUNCH("bn_finalize_kernel");
   return LMKD_OK;
@@ -442,10 +466,12 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
 __global__ void bn_bwd_coef_kernel(const float* __restrict__ pf, const double* __restrict__ pd, int T, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ stats, float* __restrict__ coef,
                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double sm[NP_RLANES][64];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double sg = pf ? colsum_inline(pf, T, 2 * C, 2 * c) : colsum_inline(pd, T, 2 * C, 2 * c);
-  const double sgx = pf ? colsum_inline(pf, T, 2 * C, 2 * c + 1) : colsum_inline(pd, T, 2 * C, 2 * c + 1);
+  const bool act = c < C;
+  const double sg = pf ? colsum_block(pf, T, 2 * C, 2 * c, act, sm) : colsum_block(pd, T, 2 * C, 2 * c, act, sm);
+  const double sgx = pf ? colsum_block(pf, T, 2 * C, 2 * c + 1, act, sm) : colsum_block(pd, T, 2 * C, 2 * c + 1, act, sm);
+  if (!act || threadIdx.y != 0) return;
   const float g = gamma ? gamma[c] : 1.f;
   const float invstd = stats[C + c];
   coef[c] = g * invstd;                        // A
@@ -517,12 +543,12 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
   const float* pf = partial;
   const double* pd = nullptr;
   int T = nb;
-  if (T > 256) {
+  if (T > NP_DIRECT_ROWS) {
     int rc = colsum_stage1(partial, T, 2 * C, dscr, s);
     if (rc) return rc;
     pf = nullptr; pd = dscr; T = 64;
   }
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, pf, pd, T, C, (double)rows, gamma, stats, coef, dgamma,
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 64)), dim3(64, NP_RLANES), 0, s, pf, pd, T, C, (double)rows, gamma, stats, coef, dgamma,
                      dbeta);
   const long n4 = rows * C / 4;
   if (g_lmkd_act_bf16)
