@@ -49,10 +49,12 @@ int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, int KW, int
    bf16-plane modes (one row per pair of output rows) */
 int lmkd_conv2d_fwd_row_tiles_cs(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad);
 int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound kernels, workgroups per CU (default 4) */
-/* arithmetic of the convolutions: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16 MFMA inputs + fp32 accumulation
-   (BASELINE configs[2]), 2 = fp32 operands split exactly into three bf16 planes, six bf16 MFMA products per fp32 product,
-   fp32 accumulation (csrc/conv_x3.h), 3 = the same with all nine products.  In modes 1/2/3 the packed-weight arguments of
-   lmkd_conv2d_fwd / lmkd_conv2d_bwd_data point at the buffer written by lmkd_conv2d_split_weights (in that mode). */
+/* arithmetic of the convolutions (process-wide setting, not thread safe: set it before the first launch, one process per GPU):
+   2 (DEFAULT) = fp32 operands split exactly into three bf16 planes, six bf16 MFMA products per fp32 product, fp32
+   accumulation (csrc/conv_x3.h; fp32-class error, the arithmetic of the benchmark's headline line), 3 = the same with all nine
+   products, 0 = native fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16 MFMA inputs + fp32 accumulation (BASELINE configs[2]).
+   In modes 1/2/3 the packed-weight arguments of lmkd_conv2d_fwd / lmkd_conv2d_bwd_data point at the buffer written by
+   lmkd_conv2d_split_weights (in that mode). */
 int lmkd_conv_set_compute_dtype(int mode);
 /* wp: fp32 K-major packed weights [ncols][Kp] (lmkd_conv2d_pack_weights; ncols = Cout forward, Cin data gradient)
    -> wf: P * ncols * Kp bf16 in MFMA fragment order, P = 1 (mode 1: one round-to-nearest plane) or 3 (modes 2/3) */

@@ -546,11 +546,12 @@ extern "C" int lmkd_conv2d_pack_weights(const float* w_oihw, float* wp, int Cout
   return LMKD_OK;
 }
 
-// ---- compute dtype of the convolutions: 0 = exact fp32 MFMA (default), 1 = bf16 MFMA inputs with fp32 accumulation ----
+// ---- compute dtype of the convolutions: 0 = exact fp32 MFMA, 1 = bf16 MFMA inputs with fp32 accumulation, 2 (DEFAULT since round 3:
+// the arithmetic bench.py's headline line runs) = fp32 as three bf16 planes, six products, 3 = nine products ----
 static int g_conv_bf16 = 0;
 static int g_conv_patch = 1;   // same-size convolutions of the bf16-plane modes from an LDS-resident patch (conv_patch.h); 0 = im2col gather
 extern "C" int lmkd_conv_set_patch(int on) { g_conv_patch = on ? 1 : 0; return LMKD_OK; }
-static int g_conv_x3 = 0;   // 0 | 6 | 9 bf16 MFMA products per fp32 product (conv_x3.h)
+static int g_conv_x3 = 6;   // 0 | 6 | 9 bf16 MFMA products per fp32 product (conv_x3.h); library default: 6
 extern "C" int lmkd_conv_set_compute_dtype(int mode) {
   LMKD_REQUIRE(mode >= 0 && mode <= 3, "lmkd_conv_set_compute_dtype: 0 fp32 MFMA, 1 bf16, 2 fp32 as 3xbf16 (6 products), 3 (9 products)");
   g_conv_bf16 = mode == 1;
@@ -656,7 +657,7 @@ static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
 // Same-size convolutions (3x3 / stride 1 forward and data gradient, 1x1 / stride 1) of the bf16-plane modes read an LDS-resident
 // input patch (conv_patch.h).  Returns the halo (largest |dh * Ws + dw| over the taps), or -1 when the launch is not of that kind.
 static int patch_halo(const ConvGemmArgs& a) {
-  if (!g_conv_patch || !(g_conv_x3 || g_conv_bf16) || a.Cs % 32 != 0 || a.sh != 1 || a.ep_stats) return -1;
+  if (!g_conv_patch || !(g_conv_x3 || g_conv_bf16) || a.Cs % 32 != 0 || a.sh != 1) return -1;
   // one class: output grid = input grid; four parity classes (stride-2 data gradient): each class runs on the dy grid
   const bool plain = a.nclass == 1 && a.Hs == a.Ho && a.Ws == a.Wo;
   const bool classes = a.nclass == 4 && a.Hr == a.Hs && a.Wr == a.Ws;
@@ -695,7 +696,11 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
     }                                                                                                                          \
     hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>), grid, dim3(Cfg::THREADS), lds, s, a);                      \
   } while (0)
-  if (g_lmkd_act_bf16) LMKD_PATCH(1, false, 3);
+  if (a.ep_stats) {      // inference: BatchNorm affine (+ residual, ReLU) in the epilogue, fp32 tensors
+    if (g_conv_bf16) LMKD_PATCH(1, false, 4);
+    else if (g_conv_x3 == 9) LMKD_PATCH(9, false, 4);
+    else LMKD_PATCH(6, false, 4);
+  } else if (g_lmkd_act_bf16) LMKD_PATCH(1, false, 3);
   else if (a.pre_stats) {
     if (g_conv_bf16) LMKD_PATCH(1, true, 0);
     else if (g_conv_x3 == 9) LMKD_PATCH(9, true, 0);
@@ -720,6 +725,14 @@ static void launch_conv_x3(ConvGemmArgs a, int ncols, hipStream_t s) {
   // main loop of the instance without the statistics epilogue worse (register copies in front of the MFMAs: 105 vs 148 TFLOP/s
   // on the same layer), so that instance is not built
   (void)STATS;
+  if constexpr (!SMALLC) {
+    if (a.ep_stats) {      // inference epilogue (x3_epilogue EP): stride-2 / 1x1-downsample convolutions of an eval forward
+      if (g_conv_bf16) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, false, true, 1, false, 4>), grid, dim3(Cfg::THREADS), 0, s, a);
+      else if (g_conv_x3 == 9) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, false, true, 9, false, 4>), grid, dim3(Cfg::THREADS), 0, s, a);
+      else hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, false, true, 6, false, 4>), grid, dim3(Cfg::THREADS), 0, s, a);
+      return;
+    }
+  }
   if (g_lmkd_act_bf16) {      // bf16 tensors in HBM (one-plane mode): the loader copies, the epilogue rounds; the stem input stays fp32
     if constexpr (SMALLC) hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, true, true, 1, false, 2>), grid, dim3(Cfg::THREADS), 0, s, a);
     else hipLaunchKernelGGL((conv_gemm_x3_kernel<Cfg, false, true, 1, false, 3>), grid, dim3(Cfg::THREADS), 0, s, a);
@@ -740,7 +753,7 @@ static void launch_conv_x3(ConvGemmArgs a, int ncols, hipStream_t s) {
 
 template <bool SMALLC, int STATS>
 static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
-  if constexpr (STATS != 2) {
+  if constexpr (STATS != 2 || !SMALLC) {      // STATS == 2 (inference epilogue) exists on the bf16-plane kernels for Cs % 32 == 0
     if (g_conv_x3 || g_conv_bf16) {      // bf16 planes in LDS, weights in fragment order (conv_x3.h): 1, 6 or 9 products
       const int halo = SMALLC ? -1 : patch_halo(a);
       int id = pick_conv_cfg(a.rows_per_class, a.nclass, ncols, a.same != 0);
@@ -827,6 +840,9 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
   LMKD_REQUIRE(a.Ho > 0 && a.Wo > 0, "lmkd_conv2d_fwd: empty output");
   LMKD_REQUIRE((long)N * H * W * Cs < 2147483647L && (long)N * a.Ho * a.Wo * Cout < 2147483647L,
                "lmkd_conv2d_fwd: tensor exceeds 2^31 elements");
+  // the bf16-plane kernels (patch / stem / gather) address the gathered tensor with 32-bit BYTE offsets through a buffer resource
+  LMKD_REQUIRE(!(g_conv_x3 || g_conv_bf16) || (long)N * H * W * Cs * (g_lmkd_act_bf16 && Cs != 4 ? 2 : 4) < 0xffffffe0L,
+               "lmkd_conv2d_fwd: input tensor exceeds the 4 GiB buffer range of the bf16-plane kernels");
   a.Hr = a.Ho; a.Wr = a.Wo; a.rows_per_class = N * a.Ho * a.Wo; a.tiles_per_class = cdiv(a.rows_per_class, 128);
   a.sh = stride; a.omul = 1; a.nclass = 1;
   a.same = conv_same_size(H, W, KH, KW, stride, pad) ? 1 : 0;      // as in lmkd_conv2d_fwd_row_tiles
@@ -885,7 +901,8 @@ extern "C" int lmkd_conv2d_fwd_pre(const float* x_raw, const float* pre_stats, c
 extern "C" int lmkd_conv2d_fwd_bn(const float* x, const float* wp, float* y, const float* bn_stats, const float* res, int relu,
                                   int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, void* stream) {
   LMKD_REQUIRE(bn_stats, "lmkd_conv2d_fwd_bn: BatchNorm table missing");
-  LMKD_REQUIRE(!g_conv_x3 && !g_conv_bf16, "lmkd_conv2d_fwd_bn: fp32 MFMA mode only (the bf16 modes use fragment-order weights)");
+  LMKD_REQUIRE(!g_lmkd_act_bf16, "lmkd_conv2d_fwd_bn: fp32 tensors only (with bf16 tensors run lmkd_conv2d_fwd + lmkd_bn_apply)");
+  LMKD_REQUIRE(!(g_conv_x3 || g_conv_bf16) || Cs % 32 == 0, "lmkd_conv2d_fwd_bn: the bf16-plane modes need Cs %% 32 == 0 (Cs=%d)", Cs);
   return conv2d_fwd_impl(x, wp, y, nullptr, bn_stats, res, relu, N, H, W, Cs, Cout, KH, KW, stride, pad, stream);
 }
 
@@ -901,6 +918,8 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
   const int Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
   LMKD_REQUIRE((long)N * H * W * Cin < 2147483647L && (long)N * Ho * Wo * Cout < 2147483647L,
                "lmkd_conv2d_bwd_data: tensor exceeds 2^31 elements");
+  LMKD_REQUIRE(!(g_conv_x3 || g_conv_bf16) || (long)N * Ho * Wo * Cout * (g_lmkd_act_bf16 ? 2 : 4) < 0xffffffe0L,
+               "lmkd_conv2d_bwd_data: dy exceeds the 4 GiB buffer range of the bf16-plane kernels");
   ConvGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.src = dy; a.wpk = wd; a.out = dx; a.stat_partial = nullptr; a.accum = accumulate;

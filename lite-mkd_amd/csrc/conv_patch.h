@@ -25,9 +25,9 @@ static inline size_t patch_lds_bytes(int bm, int halo, int npl) { return (size_t
 
 template <class Cfg, int NPROD, bool PRE, int IO>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(ConvGemmArgs a) {
-  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0, EP = (IO & 4) != 0;      // IO bits: conv_gemm_x3_kernel
   constexpr int NPL = NPROD == 1 ? 1 : 3;
-  static_assert((IO == 0 || NPROD == 1) && !(IN16 && PRE), "bf16 tensors: one-plane mode, no load-side arithmetic");
+  static_assert(((IO & 3) == 0 || NPROD == 1) && !(IN16 && PRE), "bf16 tensors: one-plane mode, no load-side arithmetic");
   constexpr int ROWB = PatchRow<NPL>::BYTES;
   constexpr int LPR = IN16 ? 4 : 8;                       // lanes per patch row (16 bytes each)
   constexpr int RPP = Cfg::THREADS / LPR;                 // patch rows per pass
@@ -253,5 +253,5 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     }
     if (t < nk) step(t, rb0, rb1);
   }
-  x3_epilogue<Cfg, true, OUT16>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid);
+  x3_epilogue<Cfg, true, OUT16, EP>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid);
 }

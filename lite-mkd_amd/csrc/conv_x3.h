@@ -277,11 +277,43 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* __restrict__ As, i
 
 // Shared epilogue of the bf16-plane convolution kernels: optional out += acc, store (fp32 or bf16 tensor), BatchNorm partial sums.
 // s_out[r] = element offset of tile row r's output pixel (channel 0), -1 for rows outside the tensor.
-template <class Cfg, bool STATS, bool OUT16>
+// EP (inference, lmkd_conv2d_fwd_bn): out = relu?( acc * scale[c] + shift[c] (+ res) ) with scale / shift = rows 2 / 3 of the [5][C]
+// BatchNorm table a.ep_stats - the operations of bn_apply_kernel in its order, so the fused forward is bit-identical to the
+// two-pass form (conv_gemm_kernel's STATS == 2 epilogue does the same for the native fp32 mode).
+template <class Cfg, bool STATS, bool OUT16, bool EP = false>
 __device__ __forceinline__ void x3_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], const int* s_out, float* s_red, int rt,
                                             int n0, int wm, int wn, int lane, int tid) {
+  static_assert(!(EP && OUT16), "the BatchNorm epilogue writes fp32 tensors");
   const int cl0 = wn * (Cfg::TN * 32) + (lane & 31);
   lmkd_bf16_t* out16 = reinterpret_cast<lmkd_bf16_t*>(a.out);
+  if constexpr (EP) {
+    float esc[Cfg::TN], esh[Cfg::TN];
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = n0 + cl0 + j * 32;
+      esc[j] = col < a.Co ? a.ep_stats[2 * a.Co + col] : 0.f;
+      esh[j] = col < a.Co ? a.ep_stats[3 * a.Co + col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ob = s_out[wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane)];
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+          const int col = n0 + cl0 + j * 32;
+          if (ob >= 0 && col < a.Co) {
+            float v = fmaf(acc[i][j][e], esc[j], esh[j]);
+            if (a.ep_res) v += a.ep_res[(long)ob + col];
+            if (a.ep_relu) v = fmaxf(v, 0.f);
+            a.out[(long)ob + col] = v;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   if (a.accum) {      // out += acc: all previous values first (loads in flight together), then the adds (conv_gemm_kernel)
     float prev[Cfg::TM][Cfg::TN][16];
 #pragma unroll
@@ -352,11 +384,12 @@ __device__ __forceinline__ void x3_epilogue(const ConvGemmArgs& a, f32x16 (&acc)
   }
 }
 
-// IO: bit 0 = the gathered tensor is stored as bf16, bit 1 = the output tensor is stored as bf16 (lmkd_set_activation_dtype(1))
+// IO: bit 0 = the gathered tensor is stored as bf16, bit 1 = the output tensor is stored as bf16 (lmkd_set_activation_dtype(1)),
+// bit 2 = inference epilogue (BatchNorm affine + residual + ReLU, x3_epilogue EP)
 template <class Cfg, bool SMALLC, bool STATS, int NPROD, bool PRE = false, int IO = 0>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs a) {
-  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
-  static_assert(!(IN16 && SMALLC) && (IO == 0 || NPROD == 1), "bf16 activations: one-plane mode; the stem input stays fp32");
+  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0, EP = (IO & 4) != 0;
+  static_assert(!(IN16 && SMALLC) && ((IO & 3) == 0 || NPROD == 1), "bf16 activations: one-plane mode; the stem input stays fp32");
   using LA = typename std::conditional<IN16, X3GatherA16<Cfg::BM, Cfg::THREADS>, X3GatherA<Cfg::BM, SMALLC, Cfg::THREADS>>::type;
   constexpr int NPL = NPROD == 1 ? 1 : 3;                 // NPROD == 1: plain bf16 (one RNE-rounded plane, one product)
   constexpr int A_BYTES = NPL * Cfg::BM * X3_LD * 2;
@@ -505,7 +538,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
     }
   }
 
-  x3_epilogue<Cfg, STATS, OUT16>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid);
+  x3_epilogue<Cfg, STATS, OUT16, EP>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid);
 }
 
 // fp32 K-major packed weights Wp[col][Kp] -> fragment-order bf16 planes (layout: X3FragB); npl = 1: one RNE-rounded plane

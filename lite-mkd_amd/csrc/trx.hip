@@ -368,16 +368,16 @@ __global__ void supportdk_partial_kernel(const float* __restrict__ sup, float* _
   }
 }
 __global__ void supportdk_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int way, int nblk, float inv_len) {
-  const int npair = way * (way - 1) / 2;
-  int p = threadIdx.x;
-  if (p >= npair) return;
-  float v = 0.f;
-  for (int b = 0; b < nblk; ++b) v += partial[(long)b * npair + p];
-  int i = 0, rem = p;                               // pair index -> (i, j), i < j
-  while (rem >= way - 1 - i) { rem -= way - 1 - i; ++i; }
-  const int j = i + 1 + rem;
-  out[i * (way - 1) + (j - 1)] = -v * inv_len;      // row i lists j != i ascending: column j-1 for j > i
-  out[j * (way - 1) + i] = -v * inv_len;            // row j: column i for i < j
+  const int npair = way * (way - 1) / 2;            // up to 120 pairs (way <= LMKD_MAX_SEG = 16): every pair is visited whatever the block size
+  for (int p = threadIdx.x; p < npair; p += blockDim.x) {
+    float v = 0.f;
+    for (int b = 0; b < nblk; ++b) v += partial[(long)b * npair + p];
+    int i = 0, rem = p;                               // pair index -> (i, j), i < j
+    while (rem >= way - 1 - i) { rem -= way - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    out[i * (way - 1) + (j - 1)] = -v * inv_len;      // row i lists j != i ascending: column j-1 for j > i
+    out[j * (way - 1) + i] = -v * inv_len;            // row j: column i for i < j
+  }
 }
 // dsup[i*shot+s, e] = sum_{j != i} (G[i][j] + G[j][i]) * (-2/L) * (P_i - P_j) / shot
 __global__ void supportdk_bwd_kernel(const float* __restrict__ sup, const float* __restrict__ g, float* __restrict__ dsup, int way,
@@ -411,7 +411,7 @@ extern "C" int lmkd_supportdk_fwd(const float* support, float* out, int way, int
   if (nblk > 256) nblk = 256;
   if (way == 5) hipLaunchKernelGGL(supportdk_partial_kernel<5>, dim3(nblk), dim3(TX_THREADS), 0, (hipStream_t)stream, support, (float*)workspace, way, shot, E);
   else hipLaunchKernelGGL(supportdk_partial_kernel<0>, dim3(nblk), dim3(TX_THREADS), 0, (hipStream_t)stream, support, (float*)workspace, way, shot, E);
-  hipLaunchKernelGGL(supportdk_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, out, way, nblk,
+  hipLaunchKernelGGL(supportdk_finish_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, (const float*)workspace, out, way, nblk,
                      1.f / (float)seq_len);
   LMKD_CHECK_LAUNCH("supportdk kernels");
   return LMKD_OK;

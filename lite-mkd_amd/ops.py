@@ -188,9 +188,16 @@ def _pack_weights(w, Cs, mode):
     return wp
 
 
+# Library default (also the default of liblmkd_hip.so itself): the arithmetic of the benchmark's headline line
+DEFAULT_CONV_DTYPE = "fp32x3"
+
+
 def set_conv_compute_dtype(dtype):
-    """'fp32' (default): exact-fp32 MFMA.  'bf16' (BASELINE configs[2]): the convolutions round their operands to bf16 when
-    the MFMA fragments are read and accumulate in fp32; everything else (activations in HBM, BatchNorm, loss) stays fp32."""
+    """Process-wide arithmetic of the convolutions (lmkd_conv_set_compute_dtype; one process per GPU, set before launching):
+    'fp32x3' (DEFAULT): fp32 tensors and accumulation, each fp32 product formed on the bf16 matrix pipe from an exact 3-way
+    bf16 split of both operands (6 of the 9 cross products; 'fp32x3_9': all nine) - fp32-class error (tests/test_gpu_fullsize.py).
+    'fp32': native fp32 MFMA (v_mfma_f32_32x32x2_f32).  'bf16' (BASELINE configs[2]): operands rounded to bf16, fp32 accumulation;
+    with set_activation_dtype('bf16') the trunk's tensors in HBM are bf16 as well."""
     modes = {"fp32": 0, "bf16": 1, "fp32x3": 2, "fp32x3_9": 3}
     if dtype not in modes:
         raise ValueError(dtype)
@@ -202,6 +209,28 @@ def set_conv_compute_dtype(dtype):
 
 def get_conv_compute_dtype():
     return ("fp32", "bf16", "fp32x3", "fp32x3_9")[lib().value("lmkd_conv_get_compute_dtype")]
+
+
+def reset_compute_dtypes():
+    """back to the library defaults: fp32x3 convolutions, fp32 tensors"""
+    set_conv_compute_dtype(DEFAULT_CONV_DTYPE)
+    set_activation_dtype("fp32")
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def compute_dtypes(conv, act="fp32"):
+    """with ops.compute_dtypes('bf16', 'bf16'): ...  - switch the process-wide arithmetic for a block and restore it afterwards"""
+    prev = (get_conv_compute_dtype(), get_activation_dtype())
+    set_conv_compute_dtype(conv)
+    set_activation_dtype(act)
+    try:
+        yield
+    finally:
+        set_conv_compute_dtype(prev[0])
+        set_activation_dtype(prev[1])
 
 
 def conv_out_size(H, K, s, p):
@@ -439,7 +468,9 @@ FUSE_EVAL_BN = True      # eval mode: BatchNorm (+ residual, ReLU) in the convol
 
 
 def _eval_fused():
-    return FUSE_EVAL_BN and not torch.is_grad_enabled() and lib().value("lmkd_conv_get_compute_dtype") == 0
+    """every arithmetic mode has the epilogue (conv_gemm_kernel STATS == 2, x3_epilogue EP); with bf16 tensors in HBM the eval
+    forward stays two-pass (the stored convolution output is rounded before the BatchNorm there)"""
+    return FUSE_EVAL_BN and not torch.is_grad_enabled() and _ACT_DTYPE[0] is torch.float32
 
 
 def conv_bn_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, relu, res=None):
@@ -475,8 +506,9 @@ def _train_fused():
 
 
 def _train_pre():
-    """inner BatchNorm + ReLU in the consumers' loaders"""
-    return FUSE_TRAIN_BN and (FUSE_PRE_ALL_MODES or lib().value("lmkd_conv_get_compute_dtype") == 0)
+    """inner BatchNorm + ReLU in the consumers' loaders (the loaders exist for fp32 tensors only)"""
+    return (FUSE_TRAIN_BN and _ACT_DTYPE[0] is torch.float32
+            and (FUSE_PRE_ALL_MODES or lib().value("lmkd_conv_get_compute_dtype") == 0))
 
 
 def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training, pre_stats=None):

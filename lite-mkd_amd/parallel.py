@@ -45,23 +45,32 @@ def world_size():
 ALLREDUCE_TIMING = None
 
 
-def averaged_bn_running_stats(module):
-    """{state_dict key: tensor} of every BatchNorm running_mean / running_var of `module`, averaged over the ranks (SURVEY 8e:
-    each rank's BatchNorm sees only its own episodes; the estimates are averaged when a checkpoint is written).  ONE
-    all-reduce of the concatenated buffers; collective: every rank must call it.  The live buffers are not modified."""
-    keys = [k for k in module.state_dict() if k.endswith("running_mean") or k.endswith("running_var")]
+def sync_bn_running_stats(module):
+    """COLLECTIVE (every rank must call it): {state_dict key: tensor} of every BatchNorm running_mean / running_var of `module`
+    pooled over the ranks (each rank's BatchNorm sees only its own episodes; the estimates are pooled when a
+    checkpoint is written).  running_mean = mean over the ranks; running_var = the variance of the pooled population,
+    mean_r(var_r) + mean_r(mean_r^2) - (mean_r mean_r)^2, i.e. the ranks' own variances plus the spread of their means.
+    ONE all-reduce of the concatenated buffers on the current stream.  The live buffers are not modified."""
     sd = module.state_dict()
-    if not keys:
+    mkeys = [k for k in sd if k.endswith("running_mean")]
+    if not mkeys:
         return {}
-    flat = torch.cat([sd[k].detach().reshape(-1).float() for k in keys])
+    vkeys = [k[:-len("running_mean")] + "running_var" for k in mkeys]
+    means = torch.cat([sd[k].detach().reshape(-1).float() for k in mkeys])
+    varis = torch.cat([sd[k].detach().reshape(-1).float() for k in vkeys])
+    flat = torch.cat([means, varis, means * means])
     if world_size() > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat /= world_size()
+    n = means.numel()
+    m, v, m2 = flat[:n], flat[n:2 * n], flat[2 * n:]
+    v = v + (m2 - m * m).clamp_min(0.0)
     out, o = {}, 0
-    for k in keys:
-        n = sd[k].numel()
-        out[k] = flat[o:o + n].reshape(sd[k].shape).clone()
-        o += n
+    for km, kv in zip(mkeys, vkeys):
+        c = sd[km].numel()
+        out[km] = m[o:o + c].reshape(sd[km].shape).clone()
+        out[kv] = v[o:o + c].reshape(sd[kv].shape).clone()
+        o += c
     return out
 
 

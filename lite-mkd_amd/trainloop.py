@@ -110,30 +110,51 @@ def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
     return task_loss.detach(), task_accuracy, {"accuracy": task_accuracy}
 
 
-def save_checkpoint(student, iteration, config):
+def save_checkpoint(student, iteration, config, bn_stats=None):
     """trainwandb.py:171-180: {'iteration', 'model_state_dict'} -> <save_dir>/<yyyymmddHHMM><mode><iteration>.pt (the
-    file load_student / the reference's test.py read).  The replicas hold identical weights; their BatchNorm running
-    statistics (each rank saw its own episodes) are averaged over the ranks into the saved copy (collective: every rank
-    calls this), then rank 0 writes the file."""
+    file load_student / the reference's test.py read).  RANK-LOCAL: writes a file from this process's weights, no collective
+    (a caller that follows the reference's `if rank == 0: save_checkpoint(...)` pattern cannot deadlock).  bn_stats: optional
+    {key: tensor} replacing the BatchNorm running statistics in the saved copy - under episode parallelism the loop passes
+    parallel.sync_bn_running_stats(student), the statistics pooled over the ranks (that call IS collective)."""
     import os
     import time
-    from .parallel import rank as _rank, averaged_bn_running_stats
-    avg = averaged_bn_running_stats(student)
-    if _rank() != 0:
-        return None
     os.makedirs(config.save_dir, exist_ok=True)
     path = os.path.join(config.save_dir, "%s%s%d.pt" % (time.strftime("%Y%m%d%H%M", time.localtime(time.time())), config.mode, iteration))
-    sd = {k: (avg[k] if k in avg else v).detach().cpu() for k, v in student.state_dict().items()}
+    bn_stats = bn_stats or {}
+    sd = {k: (bn_stats[k] if k in bn_stats else v).detach().cpu() for k, v in student.state_dict().items()}
     torch.save({"iteration": iteration, "model_state_dict": sd}, path)
     return path
 
 
+def checkpoint_all_ranks(student, iteration, config):
+    """COLLECTIVE: pool the BatchNorm running statistics over the ranks (one all-reduce), then rank 0 writes the checkpoint.
+    -> path on rank 0, None elsewhere"""
+    from .parallel import rank as _rank, sync_bn_running_stats
+    pooled = sync_bn_running_stats(student)
+    return save_checkpoint(student, iteration, config, pooled) if _rank() == 0 else None
+
+
+def _crossed(n_before, n_after, period):
+    """did the count of processed GLOBAL episodes pass a multiple of `period` between n_before and n_after?"""
+    return period > 0 and n_after // period > n_before // period
+
+
 def train(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log=None):
     """trainwandb.py:111-188 (optimizer cadence, print, checkpoint every save_freq, test at test_iters).
-    Returns (losses, accuracies) as python floats."""
+    Returns (losses, accuracies) as python floats.
+
+    Under episode parallelism (world W > 1) every rank runs this loop over its own episodes and EVERY counter of the reference
+    stays in GLOBAL episodes: the loop ends after ceil(training_iterations / W) local iterations, the optimizer fires every
+    tasks_per_batch / W local iterations (tasks_per_batch global episodes; W must divide it), MultiStepLR advances by W per
+    local iteration, and print_freq / save_freq / test_iters trigger when the global count (local iteration x W) passes them.
+    At W = 1 all of this reduces to the reference's conditions literally."""
     losses, accuracies = [], []
-    total_iterations = config.training_iterations
-    every = max(1, config.tasks_per_batch // world_size())
+    world = world_size()
+    if config.tasks_per_batch % world != 0:
+        raise ValueError("tasks_per_batch = %d is not divisible by the world size %d: the optimizer step could not keep the reference's "
+                         "%d-episode gradient accumulation" % (config.tasks_per_batch, world, config.tasks_per_batch))
+    total_iterations = -(-config.training_iterations // world)
+    every = max(1, config.tasks_per_batch // world)
     iteration = 0
     # FusedOptimizer waits for the side-stream weight gradients itself (step / zero_grad), so backward() need not: the next
     # episode's forward then overlaps the tail of the previous episode's weight gradients
@@ -142,14 +163,14 @@ def train(student, teacher, video_loader, distiller, optimizer, scheduler, accur
     ops.SIDE_WGRAD = getattr(config, "side_wgrad", True)      # this loop owns the optimizer: weight gradients on their own stream
     try:
         return _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log, losses,
-                           accuracies, total_iterations, every, iteration)
+                           accuracies, total_iterations, every, iteration, world)
     finally:
         ops.wait_weight_grads()
         ops.SYNC_WGRAD_AT_BACKWARD_END, ops.SIDE_WGRAD = sync_prev, side_prev
 
 
 def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log, losses, accuracies,
-                total_iterations, every, iteration):
+                total_iterations, every, iteration, world=1):
     for task_dict in video_loader:
         if iteration >= total_iterations:
             break
@@ -162,12 +183,15 @@ def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler,
             optimizer.step()
             optimizer.zero_grad()
         scheduler.step()
-        if log is not None and (iteration + 1) % config.print_freq == 0:
-            log(iteration, float(torch.stack(losses[-config.print_freq:]).mean()),
-                float(torch.stack(accuracies[-config.print_freq:]).mean()))
-        if ((iteration + 1) % config.save_freq == 0) and (iteration + 1) != total_iterations:
-            save_checkpoint(student, iteration, config)
-        if ((iteration + 1) in getattr(config, "test_iters", ())) and (iteration + 1) != total_iterations:
+        # the reference's (iteration + 1) % period == 0 tests, on the global episode count g = (iteration + 1) * world
+        g0, g1 = iteration * world, (iteration + 1) * world
+        last = (iteration + 1) == total_iterations
+        if log is not None and _crossed(g0, g1, config.print_freq):
+            n = max(1, config.print_freq // world)
+            log(iteration, float(torch.stack(losses[-n:]).mean()), float(torch.stack(accuracies[-n:]).mean()))
+        if _crossed(g0, g1, config.save_freq) and not last:
+            checkpoint_all_ranks(student, iteration, config)
+        if any(g0 < t <= g1 for t in getattr(config, "test_iters", ())) and not last:
             accuracy_dict = test(student, video_loader, accuracy_fn, config)
             if log is not None:
                 log(iteration, accuracy_dict, None)

@@ -12,6 +12,10 @@ Reference modules imported (by file path):
       `torchvision.models` stub for a dead import (TRX_2fcsup.py:12) and
       `Tensor.cuda = identity` for the tuple-index tensors (TRX_2fcsup.py:71)
 
+  model/backbone/resnet18_2fc.py, model/model_select.py (A3 pooled head + fc1/fc2, A1 Student.forward dict plumbing)
+      -- `torchvision.models.resnet18` is a test-only stub whose children()[:-2] is an identity, so the tensors fed in ARE the
+      trunk's output maps; every line after `self.resnet(...)` is the reference's own (gen_head)
+
   teacher/code/model.py (MFM fusion)                -- test-only stubs for dead imports: `turtle`, `timm`,
       `torchvision.models` (matplotlib, einops and the local `transformer` / `utils` modules import as they are);
       `Tensor.cuda = identity` for extract_feature's `.cuda()` calls (model.py:1649-1651)
@@ -361,6 +365,73 @@ def gen_mfm(mods):
     return out
 
 
+def head_case_inputs(seed, ns, nq, hw=7):
+    """Re-creates the exact inputs / weights of gen_head (used by tests; no reference needed): trunk output maps [F, 512, hw, hw]
+    for the support and the query frames (post-ReLU: non-negative, many exact zeros, ties for the max pooling), labels, upstream
+    weights for the scalar that is differentiated, and the seeded student parameters (fc1, fc2, TRX heads)."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    fm_s = torch.relu(torch.randn(ns * 8, 512, hw, hw, generator=g))
+    fm_q = torch.relu(torch.randn(nq * 8, 512, hw, hw, generator=g))
+    lab = torch.arange(5).repeat_interleave(ns // 5)[torch.randperm(ns, generator=g)].float()
+    params = O.make_student_params(7100 + seed)
+    params = {k: v for k, v in params.items() if not k.startswith("backbone.resnet.")}
+    return fm_s, fm_q, lab, params
+
+
+def gen_head(mods):
+    """A3 + A1: the reference's OWN resnet18_2fc.forward (model/backbone/resnet18_2fc.py:37-77: adaptive max pool 4x4, patch mean,
+    fc1 / fc2, reshape) and Student.forward (model/model_select.py:26-36: backbone -> classifier -> dict) run here.  torchvision is
+    absent from this image and from the reference tree, so `torchvision.models.resnet18` is a test-only stub whose children()[:-2]
+    is an identity: the 'frames' handed to the reference ARE trunk output maps [F, 512, h, w] (seeded, head_case_inputs) - every
+    line after `self.resnet(...)` is the reference's code.  7x7 maps (224^2 frames) and 3x3 maps (96^2: adaptive windows that
+    overlap)."""
+    import torch.nn as nn
+    tvm = sys.modules["torchvision.models"]
+
+    class _StubResNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.trunk = nn.Identity()
+            self.avgpool = nn.Identity()      # children()[-2:], dropped by resnet18_2fc.py:30-33
+            self.fc = nn.Identity()
+    tvm.resnet18 = lambda pretrained=True: _StubResNet()
+    MS = _load("ref_model_select", os.path.join(REF, "model/model_select.py"))
+    out = {}
+    for case, (seed, ns, nq, hw) in enumerate([(1, 5, 5, 7), (2, 10, 5, 3)]):
+        args = argparse.Namespace(way=5, shot=ns // 5, query_per_class=nq // 5, seq_len=8, trans_linear_out_dim=1152,
+                                  trans_linear_in_dim=2048, trans_dropout=0.0, num_gpus=1, model_backbone="resnet18_2fc",
+                                  model_classifier="TRX_2fcsup", temp_set=[2])
+        student = MS.Student(args)
+        fm_s, fm_q, lab, params = head_case_inputs(seed, ns, nq, hw)
+        sd = student.state_dict()
+        for k, v in params.items():
+            sd[k].copy_(v)
+        fm_s.requires_grad_()
+        fm_q.requires_grad_()
+        r = student(fm_s, lab, fm_q)
+        cf, tf, lg = r["context_features"], r["target_features"], r["logits"]
+        w = torch.linspace(-1, 1, nq * 5).reshape(nq, 5)
+        wf = torch.linspace(-1, 1, 2048)
+        scalar = ((lg["kl"] * w).sum() * 1e-2 + (lg["ce"] * w.flip(0)).sum() * 1e-2 + (lg["sup"] * torch.linspace(1, -1, 20).reshape(5, 4)).sum() * 1e-3
+                  + (cf["context_features_1"] * wf).sum() * 1e-3 + (tf["target_features_2"] * wf.flip(0)).sum() * 1e-3)
+        scalar.backward()
+        pre = "c%d_" % case
+        bb = student.backbone
+        out.update({pre + "seed": seed, pre + "ns": ns, pre + "nq": nq, pre + "hw": hw,
+                    # [N, 8, 2048] features as 64-wide chunk sums + the first video in full (keeps the fixture small)
+                    pre + "cf1": gsum(cf["context_features_1"]), pre + "cf2": gsum(cf["context_features_2"]),
+                    pre + "tf1": gsum(tf["target_features_1"]), pre + "tf2": gsum(tf["target_features_2"]),
+                    pre + "cf1_v0": cf["context_features_1"][0].clone(), pre + "tf2_v0": tf["target_features_2"][0].clone(),
+                    pre + "kl": lg["kl"], pre + "ce": lg["ce"], pre + "sup": lg["sup"],
+                    # gradients: the trunk-output maps as per-frame / per-channel sums + the first frame in full, fc parameters as row sums
+                    pre + "g_fm_s_fc": fm_s.grad.sum((2, 3)), pre + "g_fm_q_fc": fm_q.grad.sum((2, 3)),
+                    pre + "g_fm_s_f0": fm_s.grad[0].clone(), pre + "g_fm_q_f0": fm_q.grad[0].clone(),
+                    pre + "g_fc1_w": bb.fc1.weight.grad.sum(1), pre + "g_fc1_b": bb.fc1.bias.grad,
+                    pre + "g_fc2_w": bb.fc2.weight.grad.sum(1), pre + "g_fc2_b": bb.fc2.bias.grad,
+                    pre + "keys": np.array(sorted(r.keys()) + sorted(cf.keys()) + sorted(tf.keys()) + sorted(lg.keys()))})
+    return out
+
+
 def trx_case_inputs(seed, ns, nq, shuffle):
     """Re-creates the exact inputs/weights of gen_trx (used by tests; no reference needed)."""
     g = torch.Generator().manual_seed(1000 + seed)
@@ -382,7 +453,8 @@ def main():
     mods = load_reference()
     os.makedirs(GOLD, exist_ok=True)
     for name, fn in (("distill", gen_distill), ("distill_methods", gen_distill_methods), ("edist", gen_edist), ("trx", gen_trx),
-                     ("trx_sup", gen_trx_sup), ("resize", gen_resize), ("mfm", gen_mfm), ("kl_feature", gen_kl_feature)):
+                     ("trx_sup", gen_trx_sup), ("resize", gen_resize), ("mfm", gen_mfm), ("kl_feature", gen_kl_feature),
+                     ("head", gen_head)):
         data = fn(mods)
         data = t2n(data) if name != "resize" else data
         path = os.path.join(GOLD, name + ".npz")

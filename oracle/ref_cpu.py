@@ -274,8 +274,15 @@ def pooled_frame_features(fmap):
 def backbone_resnet18_2fc(ctx_imgs, tgt_imgs, params, seq_len=8, training=True, update_running=True):
     """resnet18_2fc.forward (resnet18_2fc.py:37-77). params: 'resnet.<k>', 'fc1.*', 'fc2.*'."""
     sd = {k[len("resnet."):]: v for k, v in params.items() if k.startswith("resnet.")}
-    cf = pooled_frame_features(resnet18_trunk(ctx_imgs, sd, training, update_running))
-    tf = pooled_frame_features(resnet18_trunk(tgt_imgs, sd, training, update_running))
+    return head_2fc(resnet18_trunk(ctx_imgs, sd, training, update_running), resnet18_trunk(tgt_imgs, sd, training, update_running),
+                    params, seq_len)
+
+
+def head_2fc(fm_ctx, fm_tgt, params, seq_len=8):
+    """everything of resnet18_2fc.forward after the two trunk calls (resnet18_2fc.py:44-77): pooled frame features, fc1 / fc2,
+    reshape to [videos, seq_len, 2048], the two dicts.  Pinned by tests/golden/head.npz, which the reference's own forward produced
+    from trunk output maps (oracle/gen_golden.py gen_head)."""
+    cf, tf = pooled_frame_features(fm_ctx), pooled_frame_features(fm_tgt)
     out_c, out_t = {}, {}
     for h in (1, 2):
         w, b = params["fc%d.weight" % h], params["fc%d.bias" % h]

@@ -37,3 +37,15 @@ def anchored_dict(hip, cpu32, ref64, factor=3.0, floor=2e-6, zero_scale=1e-7):
         if ratio > worst[0]:
             worst = (ratio, k, e_hip, e_cpu)
     return worst
+
+
+def record(name, pairs):
+    """append the measured (HIP-vs-fp64, torch-CPU-fp32-vs-fp64) relative-L2 error pairs of an anchored test to the file named
+    by $LMKD_PARITY_LOG (the GPU run that produces profiles/rNN_parity_errors.txt sets it), so the fp32-class claim of the
+    arithmetic modes can be audited from a tracked file"""
+    import os
+    path = os.environ.get("LMKD_PARITY_LOG")
+    if not path:
+        return
+    with open(path, "a") as f:
+        f.write("%-64s %s\n" % (name, "  ".join("%s: hip %.3e cpu %.3e" % (k, v[0], v[1]) for k, v in pairs.items())))

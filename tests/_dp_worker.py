@@ -2,7 +2,7 @@
 the one GPU of the test box over gloo).  G global episodes are dealt round-robin to the ranks; every rank accumulates the
 gradients of its share (weight gradients on the side stream, as in the training loop), then ONE FusedOptimizer.step()
 all-reduces the flat bucket and applies SGD.  Rank 0 writes the flat weights; every rank writes its BatchNorm running
-statistics; save_checkpoint() writes the rank-averaged ones."""
+statistics; checkpoint_all_ranks() (collective) writes the rank-pooled ones."""
 import os
 import sys
 
@@ -41,7 +41,7 @@ def main():
     torch.save(bn, os.path.join(out_dir, "bn_w%d_r%d.pt" % (world, rank)))
     if rank == 0:
         torch.save({"w0": w0.cpu(), "w1": opt.bucket.flat.detach().cpu()}, os.path.join(out_dir, "flat_w%d.pt" % world))
-    TL.save_checkpoint(student, 1, cfg)
+    TL.checkpoint_all_ranks(student, 1, cfg)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -30,9 +30,12 @@ def _rel(a, b):
                                                              (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3"),
                                                              (1, 1, 64, "TRX_2fcsup", "fc_2_sup_dist", "resnet50_2fc", "fp32x3"),
                                                              (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "bf16"),
-                                                             (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "bf16act")])
+                                                             (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "bf16act"),
+                                                             # BASELINE configs[1] at FULL SIZE in the benchmark's arithmetic: 400 frames of
+                                                             # 224^2, forward, loss and every parameter gradient (three oracle runs, ~2 min)
+                                                             (5, 5, 224, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3")])
 def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode):
-    """mode fp32x3: the convolutions (forward, data and weight gradient) in the 3xbf16 arithmetic, under the same fp32 criteria.
+    """mode fp32x3 (the library default and bench.py's headline arithmetic): the convolutions (forward, data and weight gradient) in the 3xbf16 arithmetic, under the same fp32 criteria.
     mode bf16 (BASELINE configs[2]): against the ORACLE RUN ON BF16-ROUNDED CONVOLUTION OPERANDS (oracle.CONV_BF16: forward
     conv(r(x), r(w)), data gradient from r(dy), r(w), weight gradient from r(x), r(dy), fp32 everywhere else) - the same
     arithmetic on the CPU, not the GPU's own fp32 run."""
@@ -47,7 +50,7 @@ def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode):
     finally:
         O.ACT_BF16 = False
         ops.set_activation_dtype("fp32")
-        ops.set_conv_compute_dtype("fp32")
+        ops.reset_compute_dtypes()
 
 
 class _MaskedReLU(torch.autograd.Function):
@@ -195,6 +198,10 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
             e_hip, e_cpu = anchored(k, pg[k].grad, sp32[k].grad, sp64[k].grad, factor, 5e-5, 1e-7 * gmax)
             worst = max(worst, (e_hip / (e_cpu + 1e-6), k, e_hip, e_cpu))
     print("worst HIP/CPU gradient error ratio vs fp64:", worst, "loss", loss.item(), ol.item(), ol64.item(), "mask flips vs fp64:", flips)
+    from _anchor import record
+    record("episode %d-shot %d-query %dpx %s %s [%s%s]" % (shot, query, img, clf, bb, ops.get_conv_compute_dtype(),
+                                                          ", bf16 tensors" if ops.get_activation_dtype() == "bf16" else ""),
+           {"worst parameter gradient (%s)" % worst[1]: worst[2:], "loss (hip, oracle fp32) vs fp64 abs": (abs(loss.item() - ol64.item()), abs(ol.item() - ol64.item()))})
 
 
 def test_train_loop_runs_and_steps(dev):
@@ -393,14 +400,18 @@ def test_packed_weight_cache_follows_optimizer(dev):
     assert torch.equal(trunk(x), fresh(x))
 
 
-def test_full_size_episode_matches_oracle(dev):
+@pytest.mark.parametrize("mode", ["fp32x3", "fp32"])
+def test_full_size_episode_matches_oracle(dev, mode):
     """BASELINE configs[1] at full size (5-way 5-shot, 5 queries/class, 400 frames of 224x224): logits, loss and class
-    predictions of the HIP path against the CPU oracle on the same episode and weights (~10 s of oracle time)."""
+    predictions of the HIP path against the CPU oracle on the same episode and weights (~10 s of oracle time), in the library
+    default arithmetic (fp32x3 = what bench.py times) and in the native fp32 MFMA mode.  (The gradients at this size:
+    test_episode_matches_oracle[5-5-224-...-fp32x3].)"""
     from litemkd_amd.model.model_select import Student, Teacher
     from litemkd_amd.distillers import Distiller
     from litemkd_amd.options import default_args
     from litemkd_amd import ops
     from oracle import ref_cpu as O
+    ops.set_conv_compute_dtype(mode)
     args = default_args(trans_dropout=0.0, device=dev)
     torch.manual_seed(11)
     student, teacher = Student(args).to(dev), Teacher(args).to(dev)

@@ -211,7 +211,7 @@ def test_data_parallel_world2_equals_world1(dev, tmp_path):
     """Episode parallelism (parallel.py): 16 global episodes dealt to 2 ranks (two processes on this one GPU, gloo
     — the bucket / all-reduce / optimizer code is the one RCCL runs), one all-reduce of the flat gradient bucket, one SGD
     step: the updated weights equal the 1-process run over the same 16 episodes to fp32 rounding (different summation
-    order of the 16 episode gradients only).  The checkpoint holds the rank-averaged BatchNorm running statistics."""
+    order of the 16 episode gradients only).  The checkpoint holds the rank-pooled BatchNorm running statistics."""
     import glob
     import os
     import socket
@@ -242,6 +242,9 @@ def test_data_parallel_world2_equals_world1(dev, tmp_path):
     r0, r1 = torch.load(str(tmp_path / "bn_w2_r0.pt")), torch.load(str(tmp_path / "bn_w2_r1.pt"))
     ck = torch.load(glob.glob(str(tmp_path / "*w2_1.pt"))[0])["model_state_dict"]
     for k in r0:
-        if k.endswith("running_mean") or k.endswith("running_var"):
+        if k.endswith("running_mean"):
             assert torch.allclose(ck[k], (r0[k] + r1[k]) / 2, rtol=1e-6, atol=1e-7), k
+            kv = k[:-len("running_mean")] + "running_var"      # pooled variance: mean of the variances + spread of the means
+            pooled = (r0[kv] + r1[kv]) / 2 + (r0[k] ** 2 + r1[k] ** 2) / 2 - ((r0[k] + r1[k]) / 2) ** 2
+            assert torch.allclose(ck[kv], pooled, rtol=1e-5, atol=1e-6), kv
     assert not torch.equal(r0["backbone.resnet.1.running_mean"], r1["backbone.resnet.1.running_mean"])

@@ -146,13 +146,13 @@ def _gloo_worker(rank, world, port, q):
     local = fp.grad.clone()
     fp.allreduce_grads()
     # checkpoint-time BatchNorm averaging (one collective) and the scheduler's global-episode count
-    from litemkd_amd.parallel import averaged_bn_running_stats
+    from litemkd_amd.parallel import sync_bn_running_stats
     from litemkd_amd.trainloop import MultiStepLR
     bn = torch.nn.Sequential(torch.nn.BatchNorm1d(3), torch.nn.BatchNorm1d(2))
     with torch.no_grad():
         bn[0].running_mean.fill_(float(rank + 1))
         bn[1].running_var.fill_(10.0 * (rank + 1))
-    avg = averaged_bn_running_stats(bn)
+    avg = sync_bn_running_stats(bn)
 
     class _O:
         lr = 1.0
@@ -184,6 +184,8 @@ def test_flat_bucket_allreduce_gloo_world2():
     # BatchNorm running statistics averaged over the ranks for the checkpoint; the live buffers stay per-rank
     assert set(avg0) == {"0.running_mean", "0.running_var", "1.running_mean", "1.running_var"}
     assert torch.allclose(avg0["0.running_mean"], torch.full((3,), 1.5)) and torch.allclose(avg1["1.running_var"], torch.full((2,), 15.0))
+    # pooled variance = mean of the ranks' variances (1, 1) + the spread of their means (1, 2): 1 + (2.5 - 1.5^2)
+    assert torch.allclose(avg0["0.running_var"], torch.full((3,), 1.25))
     assert float(live0[0]) == 1.0 and float(live1[0]) == 2.0
     # MultiStepLR counts GLOBAL episodes: at world 2 the milestone 4 is reached after 2 local episodes
     assert lrs0 == (1.0, 0.1) or abs(lrs0[1] - 0.1) < 1e-12 and lrs0[0] == 1.0
@@ -232,7 +234,7 @@ def test_cabi_argument_errors_return_codes_not_crashes():
     # the shim
     with pytest.raises(RuntimeError, match="lmkd_conv_set_tile"):
         L.call("lmkd_conv_set_tile", 99)
-    assert cd.lmkd_conv_set_tile(0) == 0 and cd.lmkd_conv_set_compute_dtype(0) == 0
+    assert cd.lmkd_conv_set_tile(0) == 0 and cd.lmkd_conv_set_compute_dtype(2) == 0
 
 
 def test_bench_self_launch_command(monkeypatch):

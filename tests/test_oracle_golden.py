@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from oracle import ref_cpu as O
-from oracle.gen_golden import feature_case, gsum, trx_case_inputs
+from oracle.gen_golden import feature_case, gsum, head_case_inputs, trx_case_inputs
 
 RTOL, ATOL = 2e-5, 2e-5     # fp32, same library (torch CPU) on both sides
 
@@ -235,3 +235,50 @@ def test_mfm_oracle_matches_torch_transformer_encoder():
         ref = f1(enc(h))
         out = O.mfm_three_fusion(xs[0], xs[1], xs[2], p)
     close(out, ref, 1e-4, 1e-5)
+
+
+def _close(a, b, rtol, atol, msg=""):
+    np.testing.assert_allclose(a.detach().numpy() if torch.is_tensor(a) else a, np.asarray(b), rtol=rtol, atol=atol, err_msg=msg)
+
+
+def _head_case(G, case):
+    pre = "c%d_" % case
+    return pre, head_case_inputs(int(G[pre + "seed"]), int(G[pre + "ns"]), int(G[pre + "nq"]), int(G[pre + "hw"]))
+
+
+def test_head_golden(golden_dir):
+    """A3 + A1 pinned by the reference itself: tests/golden/head.npz holds what the reference's resnet18_2fc.forward
+    (resnet18_2fc.py:44-77) and Student.forward (model_select.py:26-36) return for seeded trunk OUTPUT maps (torchvision's trunk
+    stubbed by an identity, oracle/gen_golden.py gen_head).  The oracle's head_2fc + clf_TRX_2fcsup + the dict plumbing of
+    student_forward must reproduce features, logits and the gradients w.r.t. the maps and the fc parameters."""
+    G = np.load(os.path.join(golden_dir, "head.npz"))
+    for case in (0, 1):
+        pre, (fm_s, fm_q, lab, params) = _head_case(G, case)
+        ns, nq = int(G[pre + "ns"]), int(G[pre + "nq"])
+        fm_s.requires_grad_()
+        fm_q.requires_grad_()
+        p = {k: v.clone().requires_grad_() if v.is_floating_point() and not k.endswith("pe.pe") else v for k, v in params.items()}
+        bp = {k[len("backbone."):]: v for k, v in p.items() if k.startswith("backbone.")}
+        cp = {k[len("classifier.transformers."):]: v for k, v in p.items() if k.startswith("classifier.transformers.")}
+        cf, tf = O.head_2fc(fm_s, fm_q, bp)
+        lg = O.clf_TRX_2fcsup(cf, lab, tf, cp, 5, ns // 5)
+        out = {"logits": lg, "context_features": cf, "target_features": tf}
+        assert sorted(out.keys()) + sorted(cf.keys()) + sorted(tf.keys()) + sorted(lg.keys()) == list(G[pre + "keys"])
+        for k, t in (("cf1", cf["context_features_1"]), ("cf2", cf["context_features_2"]), ("tf1", tf["target_features_1"]),
+                     ("tf2", tf["target_features_2"])):
+            _close(gsum(t), G[pre + k], 2e-5, 1e-5, k)
+        _close(cf["context_features_1"][0], G[pre + "cf1_v0"], 2e-5, 1e-6, "cf1_v0")
+        _close(tf["target_features_2"][0], G[pre + "tf2_v0"], 2e-5, 1e-6, "tf2_v0")
+        for k in ("kl", "ce", "sup"):
+            _close(lg[k], G[pre + k], 2e-5, 1e-3, k)
+        w = torch.linspace(-1, 1, nq * 5).reshape(nq, 5)
+        wf = torch.linspace(-1, 1, 2048)
+        ((lg["kl"] * w).sum() * 1e-2 + (lg["ce"] * w.flip(0)).sum() * 1e-2 + (lg["sup"] * torch.linspace(1, -1, 20).reshape(5, 4)).sum() * 1e-3
+         + (cf["context_features_1"] * wf).sum() * 1e-3 + (tf["target_features_2"] * wf.flip(0)).sum() * 1e-3).backward()
+        _close(fm_s.grad.sum((2, 3)), G[pre + "g_fm_s_fc"], 1e-4, 1e-6, "g_fm_s")
+        _close(fm_q.grad.sum((2, 3)), G[pre + "g_fm_q_fc"], 1e-4, 1e-6, "g_fm_q")
+        _close(fm_s.grad[0], G[pre + "g_fm_s_f0"], 1e-4, 1e-7, "g_fm_s_f0")
+        _close(fm_q.grad[0], G[pre + "g_fm_q_f0"], 1e-4, 1e-7, "g_fm_q_f0")
+        for h in (1, 2):
+            _close(p["backbone.fc%d.weight" % h].grad.sum(1), G[pre + "g_fc%d_w" % h], 1e-4, 1e-5, "fc%d.weight" % h)
+            _close(p["backbone.fc%d.bias" % h].grad, G[pre + "g_fc%d_b" % h], 1e-4, 1e-6, "fc%d.bias" % h)
