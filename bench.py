@@ -99,6 +99,7 @@ def main():
     R.OVERLAP_TRUNK_CALLS = not a.serial
     ops.SIDE_WGRAD = (not a.serial) and os.environ.get("LMKD_SIDE_WGRAD", "1") != "0"   # weight gradients on a third stream
     ops.SYNC_WGRAD_AT_BACKWARD_END = os.environ.get("LMKD_SYNC_WG", "0") == "1"           # FusedOptimizer waits for them itself
+    ops.DIRECT_PARAM_GRAD = os.environ.get("LMKD_DIRECT_GRAD", "1") != "0"               # BatchNorm / Linear / TRX parameter gradients added into .grad by the kernels
 
     from litemkd_amd import parallel as PAR
     rank, world, dev = init_distributed()

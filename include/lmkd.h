@@ -112,10 +112,14 @@ int lmkd_resize_plan(int in_size, int out_size, int* bounds_host, int* coeffs_ho
 int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst, const int* bounds_dev, const int* coeffs_dev, int ksize, long outer,
                         int n_in, int n_out, long inner, void* stream);
 int lmkd_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int N, int H, int W, void* stream);
-/* stats: [5][C] = mean, invstd, scale, shift, unbiased batch variance.  scratch: >= 65*2*C doubles.
+/* Ticket words: the single-launch column reductions (lmkd_bn_finalize, lmkd_bn_backward, lmkd_colsum) elect their finishing workgroup
+ * through counters in a caller-owned buffer of lmkd_ticket_words() 32-bit words that must be ZERO on entry and is zero again when
+ * the launch has finished; launches that may run concurrently (different streams) need different buffers. */
+long lmkd_ticket_words(void);
+/* stats: [5][C] = mean, invstd, scale, shift, unbiased batch variance.  scratch: >= 64*2*C doubles.
  * running_mean/var may be NULL (update deferred to lmkd_bn_running_update) */
 int lmkd_bn_finalize(const float* partial, int T, int C, long count, const float* gamma, const float* beta, float* running_mean,
-                     float* running_var, float momentum, float eps, float* stats, double* scratch, void* stream);
+                     float* running_var, float momentum, float eps, float* stats, double* scratch, unsigned* tickets, void* stream);
 int lmkd_bn_running_update(float* running_mean, float* running_var, const float* stats, int C, float momentum, void* stream);
 int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                        float* stats, void* stream);
@@ -125,10 +129,11 @@ int lmkd_bn_apply(const float* x, const float* stats, const float* res, const fl
                   int res_mode, unsigned* mask_bits, void* stream);
 long lmkd_bn_bwd_workspace(int C);
 /* mask_mode 0 none, 1 (yact>0), 2 (x*scale+shift>0), 3 (yact = the bit mask of lmkd_bn_apply); coef: [3][C] scratch;
-   g_out (nullable) = masked dy */
+   g_out (nullable) = masked dy; accumulate_param_grads != 0: dgamma / dbeta += (they point at the parameters' .grad: gradient
+   accumulation over trunk calls and episodes, trainwandb.py:141-143, without a separate add) */
 int lmkd_bn_backward(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dx,
-                     float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, long rows, int C, int mask_mode,
-                     void* stream);
+                     float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, int C,
+                     int mask_mode, int accumulate_param_grads, void* stream);
 int lmkd_relu_backward(const float* dy, const float* y, float* g, long n, void* stream);
 int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, float* y, unsigned char* idx, int N, int H, int W, int C, void* stream);
 int lmkd_maxpool_bwd(const float* dy, const unsigned char* idx, float* g, int N, int H, int W, int C, void* stream);
@@ -136,7 +141,8 @@ int lmkd_maxpool_bwd(const float* dy, const unsigned char* idx, float* g, int N,
 int lmkd_adaptive_maxpool_mean_fwd(const float* x, float* y, int F, int H, int W, int C, void* stream);
 int lmkd_adaptive_maxpool_mean_bwd(const float* x, const float* dy, float* dx, int F, int H, int W, int C, void* stream);
 long lmkd_colsum_workspace(int C);
-int lmkd_colsum(const float* a, const float* b, float* out, long rows, int C, int accumulate, void* workspace, void* stream);
+int lmkd_colsum(const float* a, const float* b, float* out, long rows, int C, int accumulate, void* workspace, unsigned* tickets,
+                void* stream);
 
 /* ---- matchers: TemporalCrossTransformer (TRX_2fcsup.py:74-148), SupportDK (:162-189), e_dist (e_dist_fc2.py:52-91) ---- */
 int lmkd_dropout_mask(float* mask, long n, float p, unsigned long long seed, void* stream);

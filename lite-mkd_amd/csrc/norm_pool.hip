@@ -6,6 +6,7 @@
 #include "common.h"
 #include <vector>
 #include <cmath>
+#include <algorithm>
 
 #define NP_THREADS 256
 static int g_ew_wg_per_cu = 4;
@@ -145,100 +146,92 @@ extern "C" int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst,
 }
 
 // ---------------------------------------------------------------------------------
-// column reduction of per-tile partials:  in[T][C][V] (float) -> out[C][V] (double)
-// grid = (ceil(C*V/64), TS): stage 1 writes TS x (C*V) doubles, stage 2 (TS==1 grid.y) finishes
+// Column sums of a tall partial-sum buffer in ONE launch (round 3; before: a 64-slice stage-1 kernel for buffers taller than
+// 2048 rows plus a finishing kernel in which ONE workgroup per 64 channels walked up to 2048 rows: 11 - 19 us per BatchNorm).
+// grid = (column groups of CS_COLS, S row slices), block = CS_COLS columns x CS_LANES row lanes.  Every block sums its slice of
+// rows for its columns in fp64 (fixed order: row lane q takes rows q, q + 8, ... with four interleaved accumulators, lanes added
+// in lane order) and writes one fp64 row of scratch[S][CV]; a ticket counter per column group tells the block that arrives last,
+// which adds the S slices in slice order - the result does not depend on the arrival order - and goes on to the consumer's
+// arithmetic (BatchNorm finalize / backward coefficients).  tickets[] must be zero on entry and is zero again on exit; launches
+// that may run concurrently (two HIP streams) need separate ticket and scratch buffers.
 // ---------------------------------------------------------------------------------
-template <typename Tin>
-__global__ void colsum_partials_kernel(const Tin* __restrict__ in, double* __restrict__ out, int T, int CV) {
-  __shared__ double red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int tg = threadIdx.x >> 6;
-  const int per = (T + gridDim.y - 1) / gridDim.y;
+#define CS_COLS 32
+#define CS_LANES 8
+#define CS_MAX_SLICES 64
+#define LMKD_TICKET_WORDS 256      // >= cdiv(2 C, CS_COLS): C <= 4096
+extern "C" long lmkd_ticket_words(void) { return LMKD_TICKET_WORDS; }
+static inline int cs_slices(int T) { return T <= 64 ? 1 : std::min(CS_MAX_SLICES, cdiv(T, 64)); }
+
+// -> true in the block that holds the totals of its CS_COLS columns in tot[] (every thread of the block gets the same answer)
+template <bool PROD = false>      // PROD: sum in[r][c] * in2[r][c] (the float product, as a separate multiply)
+__device__ __forceinline__ bool colsum_ticket(const float* __restrict__ in, int T, int CV, double* __restrict__ scratch,
+                                              unsigned* __restrict__ tickets, double (*sm)[CS_COLS], double* tot, int* s_last,
+                                              const float* __restrict__ in2 = nullptr) {
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int col = blockIdx.x * CS_COLS + tx;
+  const bool act = col < CV;
+  const int S = gridDim.y;
+  const int per = (T + S - 1) / S;
   const int t0 = blockIdx.y * per;
-  int t1 = t0 + per;
-  if (t1 > T) t1 = T;
-  double s = 0.0;
-  if (c < CV)
-    for (int t = t0 + tg; t < t1; t += 4) s += (double)in[(long)t * CV + c];
-  red[tg][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (tg == 0 && c < CV) out[(long)blockIdx.y * CV + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
-// sum of column `col` over T rows of in[T][CV] (4 independent accumulators: the loads of a thread are in flight together)
-template <typename Tin>
-__device__ __forceinline__ double colsum_inline(const Tin* __restrict__ in, int T, int CV, int col) {
+  const int t1 = t0 + per < T ? t0 + per : T;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int t = 0;
-  for (; t + 4 <= T; t += 4) {
-    s0 += (double)in[(long)(t + 0) * CV + col];
-    s1 += (double)in[(long)(t + 1) * CV + col];
-    s2 += (double)in[(long)(t + 2) * CV + col];
-    s3 += (double)in[(long)(t + 3) * CV + col];
+  if (act) {
+    int t = t0 + ty;
+    auto at = [&](int r) -> double {
+      const long i = (long)r * CV + col;
+      return PROD ? (double)(in[i] * in2[i]) : (double)in[i];
+    };
+    for (; t + 3 * CS_LANES < t1; t += 4 * CS_LANES) {
+      s0 += at(t);
+      s1 += at(t + CS_LANES);
+      s2 += at(t + 2 * CS_LANES);
+      s3 += at(t + 3 * CS_LANES);
+    }
+    for (; t < t1; t += CS_LANES) s0 += at(t);
   }
-  for (; t < T; ++t) s0 += (double)in[(long)t * CV + col];
-  return (s0 + s1) + (s2 + s3);
-}
-
-// The same for a (64 columns) x NP_RLANES (row lanes) thread block: row lane ty sums the rows t = ty (mod NP_RLANES), the lanes'
-// sums are added in lane order through LDS; every thread of the block must call it, the result is valid on row lane 0.
-#define NP_RLANES 8
-#define NP_DIRECT_ROWS 2048      // tallest partial-sum buffer finalize / coef reduce themselves (256 rows per thread)
-template <typename Tin>
-__device__ __forceinline__ double colsum_block(const Tin* __restrict__ in, int T, int CV, int col, bool active, double (*sm)[64]) {
-  const int ty = threadIdx.y;
-  double s = 0.0;
-  if (active) {
-    const int rows = (T - ty + NP_RLANES - 1) / NP_RLANES;      // rows ty, ty + NP_RLANES, ...
-    s = rows > 0 ? colsum_inline(in + (long)ty * CV, rows, CV * NP_RLANES, col) : 0.0;
-  }
-  sm[ty][threadIdx.x] = s;
+  sm[ty][tx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  double tot = 0.0;
+  double v = 0.0;
   if (ty == 0)
-    for (int q = 0; q < NP_RLANES; ++q) tot += sm[q][threadIdx.x];
-  __syncthreads();
-  return tot;
-}
-
-// Stage 1 of a tall reduction (T > NP_DIRECT_ROWS rows): in[T][CV] floats -> scratch[64][CV] doubles.  The consumer kernel
-// (finalize / coef: 64 channels x 8 row lanes per block) sums up to 2048 rows itself, so a BatchNorm forward costs 1 launch
-// (2 for the 4900- and 11200-row partial buffers of layer 1 and the stem) and a backward 3.
-static int colsum_stage1(const float* in, int T, int CV, double* scratch, hipStream_t s);
-
-// reduce in[T][CV] floats to out[CV] doubles using scratch (>= 64*CV doubles)
-static int colsum_to_double(const float* in, int T, int CV, double* out, double* scratch, hipStream_t s) {
-  const int gx = cdiv(CV, 64);
-  if (T > 256) {
-    const int TS = 64;
-    hipLaunchKernelGGL(colsum_partials_kernel<float>, dim3(gx, TS), dim3(256), 0, s, in, scratch, T, CV);
-    hipLaunchKernelGGL(colsum_partials_kernel<double>, dim3(gx, 1), dim3(256), 0, s, (const double*)scratch, out, TS, CV);
-  } else {
-    hipLaunchKernelGGL(colsum_partials_kernel<float>, dim3(gx, 1), dim3(256), 0, s, in, out, T, CV);
+    for (int q = 0; q < CS_LANES; ++q) v += sm[q][tx];
+  if (S == 1) {
+    if (ty == 0) tot[tx] = v;
+    __syncthreads();
+    return true;
   }
-  LMKD_CHECK_LAUNCH("colsum_partials_kernel");
-  return LMKD_OK;
-}
-static int colsum_stage1(const float* in, int T, int CV, double* scratch, hipStream_t s) {
-  hipLaunchKernelGGL(colsum_partials_kernel<float>, dim3(cdiv(CV, 64), 64), dim3(256), 0, s, in, scratch, T, CV);
-  LMKD_CHECK_LAUNCH("colsum_partials_kernel");
-  return LMKD_OK;
+  if (ty == 0 && act) scratch[(long)blockIdx.y * CV + col] = v;
+  __threadfence();                                   // release: this block's slice row is visible device-wide before its ticket
+  __syncthreads();
+  if (tx == 0 && ty == 0) *s_last = atomicAdd(&tickets[blockIdx.x], 1u) == (unsigned)(S - 1);
+  __syncthreads();
+  if (!*s_last) return false;
+  __threadfence();                                   // acquire: the other blocks' slice rows
+  if (ty == 0) {
+    double a = 0.0;
+    if (act)
+      for (int q = 0; q < S; ++q) a += __hip_atomic_load(&scratch[(long)q * CV + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot[tx] = a;
+  }
+  if (tx == 0 && ty == 0) tickets[blockIdx.x] = 0u;   // zero again for the next launch that uses this ticket buffer
+  __syncthreads();
+  return true;
 }
 
 // ---------------------------------------------------------------------------------
 // BatchNorm finalize: sums -> mean / invstd / fused scale+shift, running-stat update
 //   stats layout out: [5][C] = mean, invstd, scale (= gamma*invstd), shift (= beta - mean*scale), unbiased variance
 // ---------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ pf, const double* __restrict__ pd, int T, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
-                                   float* __restrict__ stats) {
-  __shared__ double sm[NP_RLANES][64];
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool act = c < C;
-  const double s1 = pf ? colsum_block(pf, T, 2 * C, 2 * c, act, sm) : colsum_block(pd, T, 2 * C, 2 * c, act, sm);
-  const double s2 = pf ? colsum_block(pf, T, 2 * C, 2 * c + 1, act, sm) : colsum_block(pd, T, 2 * C, 2 * c + 1, act, sm);
-  if (!act || threadIdx.y != 0) return;
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int T, int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, float* __restrict__ stats, double* __restrict__ scratch,
+                                   unsigned* __restrict__ tickets) {
+  __shared__ double sm[CS_LANES][CS_COLS];
+  __shared__ double tot[CS_COLS];
+  __shared__ int s_last;
+  if (!colsum_ticket(part, T, 2 * C, scratch, tickets, sm, tot, &s_last)) return;
+  const int c = blockIdx.x * (CS_COLS / 2) + threadIdx.x;
+  if (threadIdx.y != 0 || threadIdx.x >= CS_COLS / 2 || c >= C) return;
+  const double s1 = tot[2 * threadIdx.x], s2 = tot[2 * threadIdx.x + 1];
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -289,21 +282,14 @@ __global__ void bn_eval_stats_kernel(int C, const float* __restrict__ gamma, con
   stats[4 * C + c] = running_var[c];
 }
 
-// partial: [T][C][2] (sum, sumsq) from the conv epilogue; scratch: >= (64+1)*2*C doubles
+// partial: [T][C][2] (sum, sumsq) from the conv epilogue; scratch: >= 64*2*C doubles; tickets: lmkd_ticket_words() zeroed words
 extern "C" int lmkd_bn_finalize(const float* partial, int T, int C, long count, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* stats,
-                                double* scratch, void* stream) {
-  LMKD_REQUIRE(partial && stats && scratch && T > 0 && C > 0 && count > 0, "lmkd_bn_finalize: bad arguments");
-  hipStream_t s = (hipStream_t)stream;
-  const float* pf = partial;
-  const double* pd = nullptr;
-  if (T > NP_DIRECT_ROWS) {
-    int rc = colsum_stage1(partial, T, 2 * C, scratch, s);
-    if (rc) return rc;
-    pf = nullptr; pd = scratch; T = 64;
-  }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64, NP_RLANES), 0, s, pf, pd, T, C, (double)count, gamma, beta,
-                     running_mean, running_var, momentum, eps, stats);
+                                double* scratch, unsigned* tickets, void* stream) {
+  LMKD_REQUIRE(partial && stats && scratch && tickets && T > 0 && C > 0 && count > 0, "lmkd_bn_finalize: bad arguments");
+  LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS, "lmkd_bn_finalize: C=%d exceeds the ticket buffer", C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(2 * C, CS_COLS), cs_slices(T)), dim3(CS_COLS, CS_LANES), 0, (hipStream_t)stream, partial, T,
+                     C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, stats, scratch, tickets);
   LMKD_CHECK_LAUNCH("bn_finalize_kernel");
   return LMKD_OK;
 }
@@ -463,22 +449,25 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
   }
 }
 
-__global__ void bn_bwd_coef_kernel(const float* __restrict__ pf, const double* __restrict__ pd, int T, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ stats, float* __restrict__ coef,
-                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double sm[NP_RLANES][64];
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool act = c < C;
-  const double sg = pf ? colsum_block(pf, T, 2 * C, 2 * c, act, sm) : colsum_block(pd, T, 2 * C, 2 * c, act, sm);
-  const double sgx = pf ? colsum_block(pf, T, 2 * C, 2 * c + 1, act, sm) : colsum_block(pd, T, 2 * C, 2 * c + 1, act, sm);
-  if (!act || threadIdx.y != 0) return;
+// accumulate != 0: dgamma / dbeta point at the parameters' .grad (or at a per-stream shadow of it): += instead of = (gradient
+// accumulation over trunk calls / episodes without an ATen add per BatchNorm parameter)
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ part, int T, int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ stats, float* __restrict__ coef, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta, int accumulate, double* __restrict__ scratch, unsigned* __restrict__ tickets) {
+  __shared__ double sm[CS_LANES][CS_COLS];
+  __shared__ double tot[CS_COLS];
+  __shared__ int s_last;
+  if (!colsum_ticket(part, T, 2 * C, scratch, tickets, sm, tot, &s_last)) return;
+  const int c = blockIdx.x * (CS_COLS / 2) + threadIdx.x;
+  if (threadIdx.y != 0 || threadIdx.x >= CS_COLS / 2 || c >= C) return;
+  const double sg = tot[2 * threadIdx.x], sgx = tot[2 * threadIdx.x + 1];
   const float g = gamma ? gamma[c] : 1.f;
   const float invstd = stats[C + c];
   coef[c] = g * invstd;                        // A
   coef[C + c] = (float)(sg / count);           // mean(g)
   coef[2 * C + c] = (float)(sgx / count);      // mean(g*xhat)
-  if (dgamma) dgamma[c] = (float)sgx;
-  if (dbeta) dbeta[c] = (float)sg;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
 }
 
 template <typename T>
@@ -516,16 +505,18 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
 extern "C" long lmkd_bn_bwd_workspace(int C) { return (long)(2048 * 2 * C) * sizeof(float) + (long)(66 * 2 * C) * sizeof(double) + 64; }
 
 // dy, x, (yact) : [rows, C];  stats from the forward;  outputs dx (may alias dy), g_out (optional), dgamma, dbeta
-// coef: [3][C] floats scratch;  workspace: lmkd_bn_bwd_workspace(C) bytes
+// coef: [3][C] floats scratch;  workspace: lmkd_bn_bwd_workspace(C) bytes;  tickets: lmkd_ticket_words() zeroed words (zero again on
+// return; one buffer per stream that may run this concurrently);  accumulate_param_grads: dgamma / dbeta += (see bn_bwd_coef_kernel)
 extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma,
-                                float* dx, float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, long rows,
-                                int C, int mask_mode, void* stream) {
-  LMKD_REQUIRE(dy && x && stats && dx && coef && workspace, "lmkd_bn_backward: null pointer");
+                                float* dx, float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets,
+                                long rows, int C, int mask_mode, int accumulate_param_grads, void* stream) {
+  LMKD_REQUIRE(dy && x && stats && dx && coef && workspace && tickets, "lmkd_bn_backward: null pointer");
   const int CC = C > 1024 ? 1024 : C;   // channel chunk handled by one workgroup column
   const int U = g_lmkd_act_bf16 ? 2 : 1;      // groups of 4 channels per thread (16-byte accesses)
   LMKD_REQUIRE(C % (4 * U) == 0 && C % CC == 0 && 256 % (CC / 4) == 0, "lmkd_bn_backward: unsupported channel count %d", C);
   LMKD_REQUIRE((mask_mode != 1 && mask_mode != 3) || yact, "lmkd_bn_backward: mask_mode 1 / 3 needs the activation output / its bit mask");
   LMKD_REQUIRE(mask_mode != 3 || C % 32 == 0, "lmkd_bn_backward: bit masks need C %% 32 == 0");
+  LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS, "lmkd_bn_backward: C=%d exceeds the ticket buffer", C);
   hipStream_t s = (hipStream_t)stream;
   const int RL1 = NP_THREADS / (CC / 4), RL = RL1 * U;
   int nb = cdiv(rows, (long)RL1 * 8);      // virtual blocks of RL1 row lanes (U of them per workgroup)
@@ -540,16 +531,9 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb, C / CC), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s, dy, x, yact,
                        stats, partial, rows, C, CC, mask_mode, nb);
   LMKD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-  const float* pf = partial;
-  const double* pd = nullptr;
-  int T = nb;
-  if (T > NP_DIRECT_ROWS) {
-    int rc = colsum_stage1(partial, T, 2 * C, dscr, s);
-    if (rc) return rc;
-    pf = nullptr; pd = dscr; T = 64;
-  }
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 64)), dim3(64, NP_RLANES), 0, s, pf, pd, T, C, (double)rows, gamma, stats, coef, dgamma,
-                     dbeta);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(2 * C, CS_COLS), cs_slices(nb)), dim3(CS_COLS, CS_LANES), 0, s, (const float*)partial, nb, C,
+                     (double)rows, gamma, stats, coef, dgamma, dbeta, accumulate_param_grads, dscr, tickets);
+  LMKD_CHECK_LAUNCH("bn_bwd_coef_kernel");
   const long n4 = rows * C / 4;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<lmkd_bf16_t>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, (const lmkd_bf16_t*)dy, (const lmkd_bf16_t*)x,
@@ -778,36 +762,27 @@ extern "C" int lmkd_adaptive_maxpool_mean_bwd(const float* x, const float* dy, f
 // column sums of a [rows, C] matrix (Linear bias grads, LayerNorm parameter grads):
 //   out[c] = sum_r a[r,c] * (b ? b[r,c] : 1)
 // ---------------------------------------------------------------------------------
-__global__ void colsum_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partial, long rows, int C) {
-  // grid.x over column chunks of 256, grid.y over row slices
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const long per = (rows + gridDim.y - 1) / gridDim.y;
-  const long r0 = (long)blockIdx.y * per;
-  long r1 = r0 + per;
-  if (r1 > rows) r1 = rows;
-  float s = 0.f;
-  for (long r = r0; r < r1; ++r) s += b ? a[r * C + c] * b[r * C + c] : a[r * C + c];
-  partial[(long)blockIdx.y * C + c] = s;
-}
-__global__ void colsum_finish_kernel(const double* __restrict__ sums, float* __restrict__ out, int C, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) out[c] = (accumulate ? out[c] : 0.f) + (float)sums[c];
+template <bool PROD>
+__global__ void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int rows, int C,
+                              int accumulate, double* __restrict__ scratch, unsigned* __restrict__ tickets) {
+  __shared__ double sm[CS_LANES][CS_COLS];
+  __shared__ double tot[CS_COLS];
+  __shared__ int s_last;
+  if (!colsum_ticket<PROD>(a, rows, C, scratch, tickets, sm, tot, &s_last, b)) return;
+  const int c = blockIdx.x * CS_COLS + threadIdx.x;
+  if (threadIdx.y == 0 && c < C) out[c] = (accumulate ? out[c] : 0.f) + (float)tot[threadIdx.x];
 }
 
-extern "C" long lmkd_colsum_workspace(int C) { return (long)64 * C * sizeof(float) + (long)66 * C * sizeof(double) + 64; }
+extern "C" long lmkd_colsum_workspace(int C) { return (long)CS_MAX_SLICES * C * sizeof(double) + 64; }
 
-extern "C" int lmkd_colsum(const float* a, const float* b, float* out, long rows, int C, int accumulate, void* workspace, void* stream) {
-  LMKD_REQUIRE(a && out && workspace && rows > 0 && C > 0, "lmkd_colsum: bad arguments");
-  hipStream_t s = (hipStream_t)stream;
-  int slices = (int)(rows < 64 ? rows : 64);
-  float* partial = (float*)workspace;
-  double* dscr = (double*)((char*)workspace + (((long)64 * C * sizeof(float) + 63) / 64) * 64);
-  hipLaunchKernelGGL(colsum_rows_kernel, dim3(cdiv(C, 256), slices), dim3(256), 0, s, a, b, partial, rows, C);
-  LMKD_CHECK_LAUNCH("colsum_rows_kernel");
-  int rc = colsum_to_double(partial, slices, C, dscr, dscr + C, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)dscr, out, C, accumulate);
-  LMKD_CHECK_LAUNCH("colsum_finish_kernel");
+// ONE launch (round 3; before: row slices, a reduction of the slices and a finishing kernel).  tickets: as lmkd_bn_finalize
+extern "C" int lmkd_colsum(const float* a, const float* b, float* out, long rows, int C, int accumulate, void* workspace, unsigned* tickets,
+                           void* stream) {
+  LMKD_REQUIRE(a && out && workspace && tickets && rows > 0 && rows < 2147483647L && C > 0, "lmkd_colsum: bad arguments");
+  LMKD_REQUIRE(cdiv(C, CS_COLS) <= LMKD_TICKET_WORDS, "lmkd_colsum: C=%d exceeds the ticket buffer", C);
+  const dim3 grid(cdiv(C, CS_COLS), cs_slices((int)rows)), block(CS_COLS, CS_LANES);
+  if (b) hipLaunchKernelGGL(colsum_kernel<true>, grid, block, 0, (hipStream_t)stream, a, b, out, (int)rows, C, accumulate, (double*)workspace, tickets);
+  else hipLaunchKernelGGL(colsum_kernel<false>, grid, block, 0, (hipStream_t)stream, a, b, out, (int)rows, C, accumulate, (double*)workspace, tickets);
+  LMKD_CHECK_LAUNCH("colsum_kernel");
   return LMKD_OK;
 }

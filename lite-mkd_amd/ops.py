@@ -94,6 +94,20 @@ def linear_fwd(x, w, b):
     return gemm("K", "K", M, N, K, x, K, w, K, y, N, bias=b)
 
 
+# Ticket buffers of the single-launch column reductions (lmkd_ticket_words() zeroed int32 words, left zeroed by every launch): one
+# per (device, stream), because launches of two streams may run at the same time.
+_TICKETS = {}
+
+
+def _tickets(like):
+    cur = torch.cuda.current_stream(like.device)
+    key = (like.device.index, cur.cuda_stream)
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(lib().value("lmkd_ticket_words"), dtype=torch.int32, device=like.device)
+    return t
+
+
 def colsum(a, b=None, out=None, accumulate=False):
     rows, C = a.shape
     if out is None:
@@ -101,8 +115,37 @@ def colsum(a, b=None, out=None, accumulate=False):
         accumulate = False
     _chk(a, b, out)
     ws = torch.empty(lib().value("lmkd_colsum_workspace", C), dtype=torch.uint8, device=a.device)
-    lib().call("lmkd_colsum", _p(a), _p(b), _p(out), rows, C, int(accumulate), _p(ws), _stream())
+    lib().call("lmkd_colsum", _p(a), _p(b), _p(out), rows, C, int(accumulate), _p(ws), _p(_tickets(a)), _stream())
     return out
+
+
+# Direct gradient accumulation (DIRECT_PARAM_GRAD, switched on by the loops that own a FusedOptimizer, like SIDE_WGRAD): the fused
+# Functions add the gradients of BatchNorm / Linear / TRX parameters INTO the parameters' .grad inside their own kernels (the
+# BatchNorm coefficient kernel, the GEMM's beta = 1 epilogue, the column-sum kernel) and hand autograd None - ~100 ATen add launches
+# per episode less on the critical stream.  The two trunk calls of an episode run on two streams and meet the same BatchNorm
+# parameters: the call on the side stream accumulates into a SHADOW of the gradient buffer (FlatParams.shadow, registered here per
+# parameter), which the optimizer adds to the real one before it steps - no two streams ever add to the same address.
+DIRECT_PARAM_GRAD = False
+_GRAD_SLOT = {}
+
+
+def register_grad_slot(param, shadow_view):
+    """param.grad (a view into the flat gradient buffer) may be accumulated into directly; shadow_view: the same view of the
+    shadow buffer for kernels that run on the side stream"""
+    _GRAD_SLOT[param.data_ptr()] = (weakref.ref(param), shadow_view)
+
+
+def _grad_target(param):
+    """-> tensor to accumulate this parameter's gradient into, or None (autograd path)"""
+    if not DIRECT_PARAM_GRAD or param is None or not param.requires_grad:
+        return None
+    e = _GRAD_SLOT.get(param.data_ptr())
+    if e is None or e[0]() is not param or param.grad is None or _has_hooks(param):
+        return None
+    side = _side_streams.get((param.device.type, param.device.index))
+    if side is not None and torch.cuda.current_stream(param.device).cuda_stream == side.cuda_stream:
+        return e[1]
+    return param.grad
 
 
 class LinearFn(torch.autograd.Function):
@@ -113,6 +156,7 @@ class LinearFn(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.bias = b
         return linear_fwd(x, w.contiguous(), b)
 
     @staticmethod
@@ -126,10 +170,18 @@ class LinearFn(torch.autograd.Function):
             dx = _empty((M, K), x)
             gemm("K", "N", M, K, N, dy, N, w, K, dx, K)          # dx = dy @ W
         if ctx.needs_input_grad[1]:
-            dw = _empty((N, K), x)
-            gemm("M", "N", N, K, M, dy, N, x, K, dw, K)          # dW = dy^T @ x
+            tw = _grad_target(w)
+            if tw is not None:      # w.grad += dy^T @ x in the GEMM's epilogue (beta = 1)
+                gemm("M", "N", N, K, M, dy, N, x, K, tw, K, beta=1.0)
+            else:
+                dw = _empty((N, K), x)
+                gemm("M", "N", N, K, M, dy, N, x, K, dw, K)          # dW = dy^T @ x
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy)
+            tb = _grad_target(ctx.bias)
+            if tb is not None:
+                colsum(dy, out=tb, accumulate=True)
+            else:
+                db = colsum(dy)
         return dx, dw, db
 
 
@@ -394,9 +446,9 @@ BN_MOMENTUM = 0.1
 def bn_stats_train(part, count, gamma, beta, running_mean, running_var):
     T, C, _ = part.shape
     stats = _empty((5, C), part)
-    scratch = torch.empty(66 * 2 * C, dtype=torch.float64, device=part.device)
+    scratch = torch.empty(64 * 2 * C, dtype=torch.float64, device=part.device)
     lib().call("lmkd_bn_finalize", _p(part), T, C, count, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-               _f32(BN_MOMENTUM), _f32(BN_EPS), _p(stats), _p(scratch), _stream())
+               _f32(BN_MOMENTUM), _f32(BN_EPS), _p(stats), _p(scratch), _p(_tickets(part)), _stream())
     return stats
 
 
@@ -419,19 +471,24 @@ def bn_apply(x, stats, relu, res=None, rstats=None, want_bits=False):
     return (y, bits) if want_bits else y
 
 
-def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None):
-    """-> dx, g (masked dy) | None, dgamma, dbeta.  mask_mode 1: yact = the activation output; 3: yact = its packed bit mask"""
+def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None, beta=None):
+    """-> dx, g (masked dy) | None, dgamma, dbeta.  mask_mode 1: yact = the activation output; 3: yact = its packed bit mask.
+    beta (the BatchNorm bias parameter) given and DIRECT_PARAM_GRAD on: dgamma / dbeta are added into gamma.grad / beta.grad (or
+    their side-stream shadows) by the coefficient kernel and None is returned for both."""
     C = x.shape[-1]
     rows = x.numel() // C
     _chk(dy, x, yact, stats, gamma)
     dx = dx_out if dx_out is not None else torch.empty_like(x)
     g = torch.empty_like(x) if want_g else None
-    dgamma, dbeta = _empty((C,), x), _empty((C,), x)
+    tg = _grad_target(gamma) if beta is not None else None
+    tb = _grad_target(beta) if tg is not None else None
+    direct = tg is not None and tb is not None
+    dgamma, dbeta = (tg, tb) if direct else (_empty((C,), x), _empty((C,), x))
     coef = _empty((3, C), x)
     ws = torch.empty(lib().value("lmkd_bn_bwd_workspace", C), dtype=torch.uint8, device=x.device)
     lib().call("lmkd_bn_backward", _p(dy), _p(x), _p(yact), _p(stats), _p(gamma), _p(dx), _p(g), _p(dgamma), _p(dbeta),
-               _p(coef), _p(ws), rows, C, mask_mode, _stream())
-    return dx, g, dgamma, dbeta
+               _p(coef), _p(ws), _p(_tickets(x)), rows, C, mask_mode, int(direct), _stream())
+    return (dx, g, None, None) if direct else (dx, g, dgamma, dbeta)
 
 
 # When the two trunk calls of an episode run on two HIP streams (backbone: overlap_trunk_calls), the running-statistics
@@ -462,6 +519,17 @@ def side_stream(device):
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]
+
+
+_aux_streams = {}
+
+
+def aux_stream(device):
+    """a third forward stream: the frozen teacher head of an episode runs there beside the student's trunk (trainloop.train_task)"""
+    key = (device.type, device.index)
+    if key not in _aux_streams:
+        _aux_streams[key] = torch.cuda.Stream(device=device)
+    return _aux_streams[key]
 
 
 FUSE_EVAL_BN = True      # eval mode: BatchNorm (+ residual, ReLU) in the convolution epilogue (lmkd_conv2d_fwd_bn)
@@ -552,6 +620,7 @@ class StemFn(torch.autograd.Function):
             BLOCK_TAPS.append({"stem_c": c, "stem_st": stats})
         if training:
             ctx.save_for_backward(x4, c, stats, idx, gamma, w)
+            ctx.beta = beta
         ctx.training = training
         return y
 
@@ -564,7 +633,7 @@ class StemFn(torch.autograd.Function):
         N, Hc, Wc, C = c.shape
         g = torch.empty_like(c)
         lib().call("lmkd_maxpool_bwd", _p(dy), _p(idx), _p(g), N, Hc, Wc, C, _stream())
-        dc, _, dgamma, dbeta = bn_backward(g, c, None, stats, gamma, 2, dx_out=g)
+        dc, _, dgamma, dbeta = bn_backward(g, c, None, stats, gamma, 2, dx_out=g, beta=ctx.beta)
         dw = weight_grad(w, x4, dc, 2, 3)
         return None, dw, dgamma, dbeta, None, None, None
 
@@ -673,6 +742,7 @@ class BasicBlockFn(torch.autograd.Function):
         ctx.stride = stride
         ctx.has_ds = wd is not None
         ctx.fused = fused
+        ctx.betas = (b1, b2, bd)      # BatchNorm biases: the backward may add their gradients straight into .grad (DIRECT_PARAM_GRAD)
         if BLOCK_TAPS is not None:
             BLOCK_TAPS.append({"c1": c1, "st1": st1, "y": y})
         if training:
@@ -689,19 +759,19 @@ class BasicBlockFn(torch.autograd.Function):
         stride = ctx.stride
         Cmid = w1.shape[0]
         # bn2 (+ReLU mask from y, or from its bits); g = masked dy = gradient of both residual branches
-        dc2, g, dg2, db2 = bn_backward(dy, c2, y, st2, g2, 3 if ctx.fused else 1, want_g=True)
+        dc2, g, dg2, db2 = bn_backward(dy, c2, y, st2, g2, 3 if ctx.fused else 1, want_g=True, beta=ctx.betas[1])
         wd2 = pack_weights(w2, Cmid, 1)
         # first: its stream then waits for the BatchNorm backward only, not for the data gradient
         dw2 = weight_grad(w2, c1, dc2, 1, 1, st1) if a1 is None else weight_grad(w2, a1, dc2, 1, 1)
         da1 = conv_bwd_data(dc2, wd2, c1.shape, Cmid, 3, 3, 1, 1)
         del dc2
-        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)    # mask from c1*scale+shift > 0
+        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1, beta=ctx.betas[0])    # mask from c1*scale+shift > 0
         dw1 = weight_grad(w1, x, dc1, stride, 1)
         dwd = dgd = dbd = None
         need_dx = ctx.needs_input_grad[0]
         dx = None
         if ctx.has_ds:
-            dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g)
+            dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g, beta=ctx.betas[2])
             dwd = weight_grad(wd, x, dcd, stride, 0)
             if need_dx:
                 # the 3x3 gradient writes every input pixel; the 1x1 stride-2 one then accumulates onto the quarter of the
@@ -755,6 +825,7 @@ class BottleneckFn(torch.autograd.Function):
         else:
             y, ybits = bn_apply(c3, st3, True, res, rst), None
         ctx.training, ctx.stride, ctx.has_ds, ctx.fused = training, stride, wd is not None, fused
+        ctx.betas = (b1, b2, b3, bd)
         if training:
             ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, a2, w3, g3, c3, st3, ybits if fused else y, wd, gd, cd, std)
         return y
@@ -768,21 +839,21 @@ class BottleneckFn(torch.autograd.Function):
         stride = ctx.stride
         fused = ctx.fused
         Cm, Co = w1.shape[0], w3.shape[0]
-        dc3, g, dg3, db3 = bn_backward(dy, c3, y, st3, g3, 3 if fused else 1, want_g=True)
+        dc3, g, dg3, db3 = bn_backward(dy, c3, y, st3, g3, 3 if fused else 1, want_g=True, beta=ctx.betas[2])
         dw3 = weight_grad(w3, c2, dc3, 1, 0, st2) if a2 is None else weight_grad(w3, a2, dc3, 1, 0)       # weight gradients first (BasicBlockFn)
         da2 = conv_bwd_data(dc3, pack_weights(w3, Cm, 1), c2.shape, Co, 1, 1, 1, 0)
         del dc3
-        dc2, _, dg2, db2 = bn_backward(da2, c2, None, st2, g2, 2, dx_out=da2)
+        dc2, _, dg2, db2 = bn_backward(da2, c2, None, st2, g2, 2, dx_out=da2, beta=ctx.betas[1])
         dw2 = weight_grad(w2, c1, dc2, stride, 1, st1) if a1 is None else weight_grad(w2, a1, dc2, stride, 1)
         da1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), c1.shape, Cm, 3, 3, stride, 1)
         del dc2, da2
-        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1)
+        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1, beta=ctx.betas[0])
         dw1 = weight_grad(w1, x, dc1, 1, 0)
         dwd = dgd = dbd = None
         need_dx = ctx.needs_input_grad[0]
         dx = None
         if ctx.has_ds:
-            dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g)
+            dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g, beta=ctx.betas[3])
             dwd = weight_grad(wd, x, dcd, stride, 0)
             if need_dx:      # conv1's gradient first (writes every pixel), the strided downsample one accumulates (BasicBlockFn)
                 dx = conv_bwd_data(dc1, pack_weights(w1, x.shape[-1], 1), x.shape, Cm, 1, 1, 1, 0)
@@ -909,6 +980,7 @@ class TRXLogitsFn(torch.autograd.Function):
         ctx.save_for_backward(Xp, Kn, V, Khat, rstd, S, proto, rowmap, wk, wv, gamma, mask)
         ctx.plan, ctx.seg_off, ctx.seg_cnt = plan, seg_off, seg_cnt
         ctx.shapes = (sup.shape, qry.shape)
+        ctx.biases = (bk, bv, beta)
         return logits
 
     @staticmethod
@@ -953,19 +1025,30 @@ def _trx_backward(ctx, g, gsim=None, gram=None):
         sc = 1.0 / math.sqrt(D)
         gemm("K", "N", Rq, D, Rs, dS, Rs, Sk, D, dQk, D, alpha=sc)                                        # dQk = sc * dS @ Sk
         gemm("M", "N", Rs, D, Rq, dS, Rs, Qk, D, dSk, D, alpha=sc)                                        # dSk = sc * dS^T @ Qk
+        # parameter gradients: returned to autograd, or (DIRECT_PARAM_GRAD) added into the parameters' .grad by the kernels themselves
+        bk_, bv_, beta_ = getattr(ctx, "biases", (None, None, None))
+
+        def colsum_into(param, a, b=None):
+            t = _grad_target(param)
+            if t is None:
+                return colsum(a, b)
+            colsum(a, b, out=t, accumulate=True)
+            return None
         # LayerNorm parameter grads, then dKn -> dKraw in place
-        dgamma = colsum(dKn, Khat)
-        dbeta = colsum(dKn)
+        dgamma = colsum_into(gamma, dKn, Khat)
+        dbeta = colsum_into(beta_, dKn)
         lib().call("lmkd_layernorm_bwd_rows", _p(dKn), _p(Khat), _p(rstd), _p(gamma), NV * T, D, _stream())
-        dbk = colsum(dKn)
-        dbv = colsum(dV)
+        dbk = colsum_into(bk_, dKn)
+        dbv = colsum_into(bv_, dV)
         dP = _empty((NV * L, 4 * D), Xp)
         lib().call("lmkd_trx_tuple_bwd_gather", _p(dKn), _p(dV), _p(rowmap), _p(dP), NV, L, D, _stream())
         # weight grads: dW[:, half] = dP[:, blk]^T @ Xp
-        dwk = _empty((D, 2 * Din), Xp)
-        dwv = _empty((D, 2 * Din), Xp)
-        gemm("M", "N", D, Din, NV * L, dP, 4 * D, Xp, Din, dwk, 2 * Din, batch=2, sA=D, sC=Din)
-        gemm("M", "N", D, Din, NV * L, dP, 4 * D, Xp, Din, dwv, 2 * Din, batch=2, sA=D, sC=Din, A_off=2 * D)
+        tk, tv = _grad_target(wk), _grad_target(wv)
+        dwk = _empty((D, 2 * Din), Xp) if tk is None else None
+        dwv = _empty((D, 2 * Din), Xp) if tv is None else None
+        gemm("M", "N", D, Din, NV * L, dP, 4 * D, Xp, Din, dwk if tk is None else tk, 2 * Din, batch=2, sA=D, sC=Din, beta=0.0 if tk is None else 1.0)
+        gemm("M", "N", D, Din, NV * L, dP, 4 * D, Xp, Din, dwv if tv is None else tv, 2 * Din, batch=2, sA=D, sC=Din, A_off=2 * D,
+             beta=0.0 if tv is None else 1.0)
         # input grads: dXp = sum_blk dP[:, blk] @ W[:, half]
         dX = _empty((NV * L, Din), Xp)
         gemm("K", "N", NV * L, Din, D, dP, 4 * D, wk, 2 * Din, dX, Din)
@@ -1001,6 +1084,7 @@ class TRXSupFn(torch.autograd.Function):
         ctx.save_for_backward(Xp, Kn, V, Khat, rstd, S, proto, rowmap, wk, wv, gamma, mask, gram)
         ctx.plan, ctx.seg_off, ctx.seg_cnt = plan, seg_off, seg_cnt
         ctx.shapes = (sup.shape, qry.shape)
+        ctx.biases = (bk, bv, beta)
         return logits, sim
 
     @staticmethod

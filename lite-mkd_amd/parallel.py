@@ -92,16 +92,31 @@ class FlatParams:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.params, self.offsets = params, offs
+        # second gradient buffer for kernels that accumulate parameter gradients directly from the side stream (ops.DIRECT_PARAM_GRAD:
+        # the query-frame trunk call's BatchNorm backward); folded into `grad` before every use of it (fold_shadow)
+        self.shadow = torch.zeros(total, dtype=torch.float32, device=dev) if dev.type == "cuda" else None
+        self.shadow_dirty = False
         with torch.no_grad():
             for p, o in zip(params, offs):
                 v = self.flat[o:o + p.numel()].view_as(p)
                 v.copy_(p.data)
                 p.data = v
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
+                if self.shadow is not None:
+                    from . import ops
+                    ops.register_grad_slot(p, self.shadow[o:o + p.numel()].view_as(p))
         self.numel = total
 
     def zero_grad(self):
         self.grad.zero_()
+        if self.shadow is not None:
+            self.shadow.zero_()
+
+    def fold_shadow(self):
+        """grad += shadow; shadow = 0 (call on the stream that owns the gradient buffer, after the side streams have been joined)"""
+        if self.shadow is not None:
+            self.grad.add_(self.shadow)
+            self.shadow.zero_()
 
     def allreduce_grads(self):
         """One all-reduce(sum) of the whole bucket.  No-op on a single process.  With ALLREDUCE_TIMING set to a list, the

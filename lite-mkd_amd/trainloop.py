@@ -33,6 +33,8 @@ class FusedOptimizer:
     def step(self):
         b = self.bucket
         ops.wait_weight_grads()
+        if ops.DIRECT_PARAM_GRAD:
+            b.fold_shadow()                 # gradients the side stream's kernels accumulated directly (ops.DIRECT_PARAM_GRAD)
         b.allreduce_grads()
         self.steps += 1
         ops.WEIGHT_EPOCH[0] += 1            # invalidates the packed-weight cache (raw-pointer update below)
@@ -83,12 +85,48 @@ def prepare_task(task_dict, device, images_to_device=True):
             target_labels, real_target_labels, batch_class_list)
 
 
+# The frozen teacher head needs only the teacher features of the episode: it is queued on a stream of its own BEFORE the student's
+# forward, so its ~40 small kernels run beside the student's trunk instead of after it (the loss waits for both).
+TEACHER_STREAM = True
+
+
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors(v)
+
+
+def _teacher_forward(teacher, ctf, labels, ttf, way):
+    """-> (teacher output dict, stream to join before the outputs are used | None)"""
+    if not (TEACHER_STREAM and ctf.is_cuda) or torch.is_grad_enabled() and any(p.requires_grad for p in teacher.parameters()):
+        return teacher(ctf, labels, ttf), None
+    main, aux = torch.cuda.current_stream(ctf.device), ops.aux_stream(ctf.device)
+    # per-episode tensors both heads share are created on the main stream first (class plan: small H2D copies + one cat)
+    if labels.dim() == 1 and ctf.dim() == 3:
+        ops.get_plan(labels, way).full_rowmap(ctf.shape[0] + ttf.shape[0])
+    aux.wait_stream(main)
+    with torch.cuda.stream(aux):
+        out = teacher(ctf, labels, ttf)
+    for t in (ctf, ttf, labels):
+        t.record_stream(aux)
+    for t in _tensors(out):
+        t.record_stream(main)
+    return out, aux
+
+
 def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
     """trainwandb.py:190-287 for the logits-based distillers."""
     (context_images, target_images, context_teacher_feature, target_teacher_feature, context_labels,
      target_labels, _, _) = prepare_task(task_dict, config.device)
+    teacher_model_dict, joined = _teacher_forward(teacher, context_teacher_feature, context_labels, target_teacher_feature, config.way)
     model_dict = student(context_images, context_labels, target_images)
-    teacher_model_dict = teacher(context_teacher_feature, context_labels, target_teacher_feature)
+    if joined is not None:
+        torch.cuda.current_stream(config.device).wait_stream(joined)
     target_logits = model_dict["logits"]
     teacher_logits = teacher_model_dict["logits"]
     if config.distill_name == "KL_feature":         # trainwandb.py:209-226: the features travel inside the logits dicts
@@ -158,15 +196,19 @@ def train(student, teacher, video_loader, distiller, optimizer, scheduler, accur
     iteration = 0
     # FusedOptimizer waits for the side-stream weight gradients itself (step / zero_grad), so backward() need not: the next
     # episode's forward then overlaps the tail of the previous episode's weight gradients
-    sync_prev, side_prev = ops.SYNC_WGRAD_AT_BACKWARD_END, ops.SIDE_WGRAD
+    sync_prev, side_prev, direct_prev = ops.SYNC_WGRAD_AT_BACKWARD_END, ops.SIDE_WGRAD, ops.DIRECT_PARAM_GRAD
     ops.SYNC_WGRAD_AT_BACKWARD_END = not isinstance(optimizer, FusedOptimizer)
     ops.SIDE_WGRAD = getattr(config, "side_wgrad", True)      # this loop owns the optimizer: weight gradients on their own stream
+    # ... and BatchNorm / Linear / TRX parameter gradients added into .grad by the kernels themselves (the optimizer folds the shadow)
+    ops.DIRECT_PARAM_GRAD = isinstance(optimizer, FusedOptimizer) and getattr(config, "direct_param_grad", True)
     try:
         return _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log, losses,
                            accuracies, total_iterations, every, iteration, world)
     finally:
         ops.wait_weight_grads()
-        ops.SYNC_WGRAD_AT_BACKWARD_END, ops.SIDE_WGRAD = sync_prev, side_prev
+        if ops.DIRECT_PARAM_GRAD and isinstance(optimizer, FusedOptimizer):
+            optimizer.bucket.fold_shadow()          # leave complete gradients in .grad for whoever reads them next
+        ops.SYNC_WGRAD_AT_BACKWARD_END, ops.SIDE_WGRAD, ops.DIRECT_PARAM_GRAD = sync_prev, side_prev, direct_prev
 
 
 def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log, losses, accuracies,

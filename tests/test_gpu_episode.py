@@ -513,3 +513,47 @@ def test_side_stream_weight_gradients_identical(dev):
                         assert float((got[n] - ref[n]).abs().max()) <= 2e-6 * float(ref[n].abs().max()) + 1e-12, (n, sync)
     finally:
         ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END = False, True
+
+
+def test_direct_param_grads_match_autograd_path(dev):
+    """ops.DIRECT_PARAM_GRAD: BatchNorm / Linear / TRX parameter gradients added into .grad inside the HIP kernels (the side stream's
+    share into FlatParams.shadow, folded by the optimizer) instead of returned to autograd.  After two accumulated episodes the
+    flat gradient buffer equals the autograd path's to fp32 rounding (the same per-call gradients, added in a different order);
+    the teacher head on its own stream (trainloop.TEACHER_STREAM) is exercised on the way."""
+    from litemkd_amd import ops, trainloop as TL
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd.utils import aggregate_accuracy
+    cfg = default_args(shot=1, query_per_class=1, img_size=64, trans_dropout=0.0, device=dev)
+    torch.manual_seed(21)
+    student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
+    opt = TL.FusedOptimizer(student, "sgd", 1e-3)
+    distiller = Distiller(cfg.distill_name, cfg.cfg, dev)
+    src = TL.SyntheticEpisodes(cfg, base_seed=31, device=dev)
+    eps = [src.episode(e) for e in range(2)]
+
+    def grads(direct, teacher_stream):
+        prev = (ops.DIRECT_PARAM_GRAD, ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, TL.TEACHER_STREAM)
+        ops.DIRECT_PARAM_GRAD, ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, TL.TEACHER_STREAM = direct, True, False, teacher_stream
+        try:
+            opt.zero_grad()
+            losses = [TL.train_task(ep, student, teacher, distiller, aggregate_accuracy, cfg)[0] for ep in eps]
+            ops.wait_weight_grads()
+            if direct:
+                assert float(opt.bucket.shadow.abs().max()) > 0          # the side stream's BatchNorm gradients went to the shadow
+                opt.bucket.fold_shadow()
+            torch.cuda.synchronize()
+            return opt.bucket.grad.clone(), torch.stack(losses)
+        finally:
+            ops.DIRECT_PARAM_GRAD, ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, TL.TEACHER_STREAM = prev
+    g_ref, l_ref = grads(False, False)
+    g_dir, l_dir = grads(True, True)
+    assert torch.equal(l_ref, l_dir)                                   # the forward does not change
+    assert float(g_ref.abs().max()) > 0
+    scale = float(g_ref.abs().max())
+    assert float((g_dir - g_ref).abs().max()) <= 2e-6 * scale, float((g_dir - g_ref).abs().max()) / scale
+    # per parameter: relative L2
+    for p, o in zip(opt.bucket.params, opt.bucket.offsets):
+        a, b = g_dir[o:o + p.numel()].double(), g_ref[o:o + p.numel()].double()
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9 * scale, (o, float((a - b).norm() / (b.norm() + 1e-30)))

@@ -397,7 +397,9 @@ def test_block_isolated(dev, N, cin, cout, H, stride, mode):
         finally:
             O.CONV_BF16, O.ACT_BF16 = False, False
         g = {k: v.grad for k, v in ref.items()}
-        g["x"] = x.grad
+        # bf16 tensors: the block-input gradient is itself a stored tensor (the previous block's output gradient): the fp32 run
+        # rounds it where the HIP path does, the fp64 run stays exact
+        g["x"] = O._r16(x.grad) if (b16 and dt == torch.float32) else x.grad
         return y.detach(), g, (pre1.detach(), pre2.detach())
     y64n, _, (p1, p2) = ref_run(torch.float64, None)
     flips = 0
@@ -1071,8 +1073,10 @@ def test_eval_bn_fused_in_conv_epilogue(dev, arch, frames, img, mode):
         ref = (O.resnet18_trunk if arch == "resnet18" else O.resnet50_trunk)(x, sd, training=False)
     finally:
         O.CONV_BF16 = False
-    tol = 2e-3 if mode == "bf16" else 1e-4      # bf16: same operand rounding on both sides, fp32 accumulation order differs
-    close(nchw(y_fused), ref, 10 * tol, tol * float(ref.abs().max()), "eval trunk vs oracle")
+    # bf16: the same operand rounding on both sides, but an activation within accumulation noise of a bf16 rounding boundary rounds
+    # the other way (0.4 % of that operand) and the difference travels through the remaining layers: percent-level on single elements
+    tol = 2e-2 if mode == "bf16" else 1e-4
+    close(nchw(y_fused), ref, 5 * tol, tol * float(ref.abs().max()), "eval trunk vs oracle")
 
 
 def test_resize_frames_matches_pillow(dev, golden_dir):
