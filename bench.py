@@ -83,6 +83,12 @@ def main():
     ap.add_argument("--live-mfm", action="store_true", help="fuse rgb/depth/flow teacher features with the MFM transformer "
                     "inside every episode (BASELINE configs[4]) instead of using precomputed fused features")
     ap.add_argument("--cpu-episodes", type=int, default=3, help="episodes of the bounded cpu_baseline sample")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=os.environ.get("LMKD_GRAPH", "1") != "0",
+                    help="replay each resident episode as a captured hipGraph (trainloop.GraphedEpisode; default, LMKD_GRAPH=0 or --no-graph: "
+                         "eager launches).  Same kernels, same results; the ~600 launches of an episode leave the host path")
+    ap.add_argument("--no-graph", dest="graph", action="store_false")
+    ap.add_argument("--emulate-world", type=int, default=0, help="single-GPU rehearsal of the per-rank cadence of a W-rank run: the optimizer "
+                    "step (+ weight re-pack) every tasks_per_batch / W episodes; no collective runs, `value` stays the 1-GPU figure of that cadence")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(a.gpus))
@@ -137,7 +143,17 @@ def main():
         nv = cfg.way * (cfg.shot + cfg.query_per_class)
         mods = [{k: torch.randn(nv, cfg.seq_len, 2048, generator=g, device=dev).abs() for k in ("rgb", "depth", "flow")}
                 for _ in range(a.pool)]
-    every = max(1, cfg.tasks_per_batch // world)
+    every = max(1, cfg.tasks_per_batch // (a.emulate_world if a.emulate_world > 0 else world))
+    use_graph = a.graph and not a.serial and mfm is None
+    runners = {}      # one GraphedEpisode per arithmetic mode: a captured graph holds that mode's kernels and packed-weight buffers
+    state = {"mode": a.dtype}
+
+    def graph_runner():
+        if not use_graph:
+            return None
+        if state["mode"] not in runners:
+            runners[state["mode"]] = TL.GraphedEpisode(student, teacher, distiller, aggregate_accuracy, cfg, max_graphs=max(4, a.pool))
+        return runners[state["mode"]]
 
     def run(n, it0):
         it = it0
@@ -148,7 +164,11 @@ def main():
                 fused = mfm.extract_feature(mods[i % len(pool)])
                 ns = cfg.way * cfg.shot
                 ep = dict(ep, support_set_feature_teacher=fused[:ns].unsqueeze(0), target_set_feature_teacher=fused[ns:].unsqueeze(0))
-            TL.train_task(ep, student, teacher, distiller, aggregate_accuracy, cfg)
+            graphed = graph_runner()
+            if graphed is not None:
+                graphed(ep)
+            else:
+                TL.train_task(ep, student, teacher, distiller, aggregate_accuracy, cfg)
             if (it + 1) % every == 0:
                 opt.step()
                 opt.zero_grad()
@@ -161,16 +181,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    it = run(a.warmup, 0)
+    # warm-up: with graphs every resident episode has to be seen twice before it replays (first eager, then captured)
+    it = run(max(a.warmup, 2 * len(pool) + 1) if use_graph else a.warmup, 0)
     fence()
-    ops.CONV_TIMING = []
+    ops.CONV_TIMING = None if use_graph else []      # per-launch HIP events cannot be recorded into a captured graph (roofline_pass below times them)
     PAR.ALLREDUCE_TIMING = []
     steps0 = opt.steps
     t0 = time.perf_counter()
     it = run(a.steps, it)
+    t_enq = time.perf_counter() - t0                 # host time to enqueue the timed region (before the fence)
     fence()
     dt = time.perf_counter() - t0
-    timed_events, ops.CONV_TIMING = ops.CONV_TIMING, None
+    timed_events, ops.CONV_TIMING = (ops.CONV_TIMING or []), None
     ar_events, PAR.ALLREDUCE_TIMING = PAR.ALLREDUCE_TIMING, None
     opt_steps_timed = opt.steps - steps0
     dist_info = {"backend": None, "world": world, "devices": [torch.cuda.get_device_name(dev)], "allreduce_ms_per_optimizer_step": None,
@@ -206,6 +228,7 @@ def main():
         """`--roofline-episodes` extra episodes with the stream overlap switched off -> per-launch HIP-event records"""
         R.OVERLAP_TRUNK_CALLS = False
         ops.SIDE_WGRAD = False
+        ops.wait_weight_grads()
         ops.CONV_TIMING = []
         # optimizer steps are excluded here on purpose: this pass only prices kernels
         for i in range(a.roofline_episodes):
@@ -320,7 +343,16 @@ def main():
                      "timed_region_conv_tflops_per_gpu": conv_flops_timed / dt / 1e12,
                      "episode_model_tflops": step_tflop * world * a.steps / dt},
         "distributed": dist_info,
+        # host side of the timed region: time the Python loop needed to ENQUEUE the K episodes (it then waits in the fence); with
+        # hipGraph replay this is the true host cost per episode, eagerly the host is throttled by the full launch queue
+        "host_enqueue_ms_per_episode": t_enq / a.steps * 1e3,
+        "hipgraph": {"enabled": bool(use_graph), "replays": runners[a.dtype].replays if use_graph else 0,
+                     "eager_episodes": runners[a.dtype].eager if use_graph else None, "graphs": len(runners[a.dtype].graphs) if use_graph else 0},
     }
+    if a.emulate_world > 0:
+        out["emulated_world"] = {"world": a.emulate_world, "episodes_per_optimizer_step": every,
+                                 "note": "per-rank cadence of a %d-rank run rehearsed on ONE GPU (optimizer step + weight re-pack every %d episodes, "
+                                         "no collective): value x %d would be the job's rate at perfect scaling" % (a.emulate_world, every, a.emulate_world)}
     if world == 1 and a.dtype == "f32" and not a.no_other_modes:
         # the same job in the two other arithmetic modes of the convolutions, for the record (never part of `value`):
         # short timed regions right here, same process, same resident episodes, each with its own per-kernel roofline pass
@@ -328,7 +360,8 @@ def main():
         ALG_BYTES_PER_EPISODE = 3 * 12.9e6 * frames      # 12.9 MB of bf16 activation traffic per frame forward, x3 for a step
         for name in ("f32native", "bf16"):
             set_mode(name)
-            it = run(2, it)
+            state["mode"] = name
+            it = run(2 * len(pool) + 1 if use_graph else 2, it)
             fence()
             t1 = time.perf_counter()
             it = run(16, it)      # 16 consecutive episodes always contain exactly one optimizer step
@@ -343,6 +376,7 @@ def main():
                                         "frac": ach / PEAK[name], "avg_launch_ms": g2[1] / max(g2[2], 1) * 1e3,
                                         "wgrad_kernel_tflops": w2[0] / w2[1] / 1e12}}
         set_mode("f32")
+        state["mode"] = "f32"
         other["f32native"]["what"] = "round 1's headline arithmetic: every convolution on the fp32 MFMA (157.3 TFLOP/s peak)"
         other["bf16"]["what"] = "BASELINE configs[2]: bf16 tensors in HBM (activations and their gradients), bf16 MFMA, fp32 accumulate / statistics / weights"
         # configs[2] sits at the ridge of the bf16 roofline: report the HBM side as well, on algorithmic bytes

@@ -57,7 +57,8 @@ int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound 
    lmkd_conv2d_split_weights (in that mode). */
 int lmkd_conv_set_compute_dtype(int mode);
 /* wp: fp32 K-major packed weights [ncols][Kp] (lmkd_conv2d_pack_weights; ncols = Cout forward, Cin data gradient)
-   -> wf: P * ncols * Kp bf16 in MFMA fragment order, P = 1 (mode 1: one round-to-nearest plane) or 3 (modes 2/3) */
+   -> wf: bf16 in MFMA fragment order: mode 1: ncols * Kp (one round-to-nearest plane); modes 2/3: 6 * ncols * Kp (the three planes
+   of W followed by the three planes of -W: odd row tiles accumulate -y, csrc/conv_x3.h X3FragB) */
 int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, int Kp, void* stream);
 int lmkd_conv_get_compute_dtype(void);
 int lmkd_conv_set_wgrad_planes(int on); /* tuning (modes 1-3): 1 = weight gradient on the bf16-plane kernel with transposed LDS reads (default), 0 = fp32-tile kernel */
@@ -146,6 +147,8 @@ int lmkd_colsum(const float* a, const float* b, float* out, long rows, int C, in
 
 /* ---- matchers: TemporalCrossTransformer (TRX_2fcsup.py:74-148), SupportDK (:162-189), e_dist (e_dist_fc2.py:52-91) ---- */
 int lmkd_dropout_mask(float* mask, long n, float p, unsigned long long seed, void* stream);
+/* the same mask with the seed read from device memory when the kernel runs (hipGraph replays draw new masks) */
+int lmkd_dropout_mask_dev(float* mask, long n, float p, const unsigned long long* seed_dev, void* stream);
 int lmkd_add_pe(const float* x, const float* pe, const float* mask, float* y, long rows, int D, int L, void* stream); /* :44-48,79-80 */
 int lmkd_mul(const float* a, const float* b, float* out, long n, void* stream);
 int lmkd_axpby(const float* x, float* y, float alpha, float beta, long n, void* stream);

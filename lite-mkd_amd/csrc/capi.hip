@@ -13,7 +13,7 @@ extern "C" void lmkd_set_error(const char* fmt, ...) {
 
 extern "C" const char* lmkd_last_error(void) { return g_err; }
 
-extern "C" int lmkd_abi_version(void) { return 1; }
+extern "C" int lmkd_abi_version(void) { return 3; }      // 3 (round 3): ticket words in the BatchNorm / column-sum entry points, lmkd_dropout_mask_dev
 
 // 0 when a gfx950 device is visible, negative otherwise (message in lmkd_last_error()).
 extern "C" int lmkd_device_check(int device) {

@@ -563,7 +563,7 @@ extern "C" int lmkd_conv_get_compute_dtype(void) { return g_conv_bf16 ? 1 : (g_c
 extern "C" int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, int Kp, void* stream) {
   LMKD_REQUIRE(wp && wf, "lmkd_conv2d_split_weights: null pointer");
   LMKD_REQUIRE(ncols > 0 && ncols % 32 == 0 && Kp > 0 && Kp % 32 == 0, "lmkd_conv2d_split_weights: ncols=%d and Kp=%d must be multiples of 32", ncols, Kp);
-  LMKD_REQUIRE((long)ncols * Kp * 6 < 0xffffffe0L, "lmkd_conv2d_split_weights: weights exceed the 4 GiB buffer range");
+  LMKD_REQUIRE((long)ncols * Kp * 12 < 0xffffffe0L, "lmkd_conv2d_split_weights: weights exceed the 4 GiB buffer range");
   int grid = cdiv((long)ncols * Kp, 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(split_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wp, (unsigned short*)wf, ncols, Kp,

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     }
   };
   LB lb;
-  lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane);
+  const bool neg = NPL == 3 && (tile & 1);      // odd row tiles accumulate -y: X3FragB::init
+  lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, neg);
   f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
@@ -253,5 +254,5 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     }
     if (t < nk) step(t, rb0, rb1);
   }
-  x3_epilogue<Cfg, true, OUT16, EP>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid);
+  x3_epilogue<Cfg, true, OUT16, EP>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid, neg);
 }

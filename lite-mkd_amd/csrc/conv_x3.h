@@ -75,8 +75,15 @@ struct X3FragB {
   static constexpr int NR = TN * 2 * NPL;
   __amdgpu_buffer_rsrc_t rs;
   unsigned off[TN];     // byte offset of (n-tile, k-group 0, plane 0, this lane)
-  __device__ __forceinline__ void init(const void* wf, int ncols, int Kp, int col0 /* of this wave */, int lane) {
-    rs = x3_rsrc(wf, (long)ncols * Kp * 2 * NPL);
+  // neg: fetch the NEGATED copy of the planes (three-plane modes: lmkd_conv2d_split_weights writes it behind the plain copy).
+  // The MFMA's addition of products 2^-8 ... 2^-16 smaller than its accumulator truncates toward -inf (measured: a mean error of
+  // -4e-11 x K x rms per element in the three-plane modes, none with one plane, none on the fp32 pipe: tools/x3_bias_probe.py) - half an
+  // fp32 ulp at most, but of ONE sign, so the per-channel sums over 10^5 .. 10^6 pixels of the BatchNorm backward pick it up
+  // coherently.  Workgroups of odd row tiles therefore accumulate -y (negated weights) and flip the sign in the epilogue: the bias
+  // alternates from tile to tile and cancels in every sum over pixels.
+  __device__ __forceinline__ void init(const void* wf, int ncols, int Kp, int col0 /* of this wave */, int lane, bool neg = false) {
+    const long copy_bytes = (long)ncols * Kp * 2 * NPL;
+    rs = x3_rsrc(reinterpret_cast<const unsigned char*>(wf) + (neg ? copy_bytes : 0), copy_bytes);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nt = (col0 >> 5) + j;
@@ -282,8 +289,16 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* __restrict__ As, i
 // two-pass form (conv_gemm_kernel's STATS == 2 epilogue does the same for the native fp32 mode).
 template <class Cfg, bool STATS, bool OUT16, bool EP = false>
 __device__ __forceinline__ void x3_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], const int* s_out, float* s_red, int rt,
-                                            int n0, int wm, int wn, int lane, int tid) {
+                                            int n0, int wm, int wn, int lane, int tid, bool neg = false) {
   static_assert(!(EP && OUT16), "the BatchNorm epilogue writes fp32 tensors");
+  if (neg) {      // this workgroup accumulated -y (X3FragB::init)
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = -acc[i][j][e];
+  }
   const int cl0 = wn * (Cfg::TN * 32) + (lane & 31);
   lmkd_bf16_t* out16 = reinterpret_cast<lmkd_bf16_t*>(a.out);
   if constexpr (EP) {
@@ -442,7 +457,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   LA la;
   LB lb;
   la.init(a.src, (long)a.N * a.Hs * a.Ws * a.Cs, a.Hs, a.Ws, s_src, s_hw, taps, a.ntap[cls]);
-  lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane);
+  const bool neg = NPL == 3 && !SMALLC && (tile & 1);      // odd row tiles accumulate -y (X3FragB::init); the stem (K = 224) does not
+  lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, neg);
   f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
@@ -538,10 +554,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
     }
   }
 
-  x3_epilogue<Cfg, STATS, OUT16, EP>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid);
+  x3_epilogue<Cfg, STATS, OUT16, EP>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid, neg);
 }
 
-// fp32 K-major packed weights Wp[col][Kp] -> fragment-order bf16 planes (layout: X3FragB); npl = 1: one RNE-rounded plane
+// fp32 K-major packed weights Wp[col][Kp] -> fragment-order bf16 planes (layout: X3FragB); npl = 1: one RNE-rounded plane;
+// npl = 3: the three planes of W followed by the three planes of -W (2 x 3 x ncols x Kp bf16)
 __global__ void split_weights_kernel(const float* __restrict__ wp, unsigned short* __restrict__ wf, int ncols, int Kp, int npl) {
   const long total = (long)ncols * Kp;
   const int G = Kp >> 4;
@@ -559,9 +576,15 @@ __global__ void split_weights_kernel(const float* __restrict__ wp, unsigned shor
       const float r1 = x - __uint_as_float(b0 & 0xffff0000u);
       const unsigned b1 = __float_as_uint(r1);
       const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
-      wf[o] = (unsigned short)(b0 >> 16);
-      wf[o + 512] = (unsigned short)(b1 >> 16);
-      wf[o + 1024] = (unsigned short)(__float_as_uint(r2) >> 16);
+      const unsigned short p0 = (unsigned short)(b0 >> 16), p1 = (unsigned short)(b1 >> 16), p2 = (unsigned short)(__float_as_uint(r2) >> 16);
+      wf[o] = p0;
+      wf[o + 512] = p1;
+      wf[o + 1024] = p2;
+      // second copy: the planes of -W (sign bit flipped: the truncation split is symmetric), read by the odd row tiles (X3FragB::init)
+      const long o2 = o + total * 3;
+      wf[o2] = p0 ^ 0x8000u;
+      wf[o2 + 512] = p1 ^ 0x8000u;
+      wf[o2 + 1024] = p2 ^ 0x8000u;
     }
   }
 }

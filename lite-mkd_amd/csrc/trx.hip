@@ -38,6 +38,22 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, long n, float p, u
     mask[i] = u >= p ? keep : 0.f;
   }
 }
+// the same mask with the seed read from DEVICE memory at run time: a launch captured into a hipGraph draws a new mask on every replay
+// once the host has written that replay's seed into *seed_dev (trainloop.GraphedEpisode)
+__global__ void dropout_mask_dev_kernel(float* __restrict__ mask, long n, float p, const unsigned long long* __restrict__ seed_dev) {
+  const uint64_t seed = *seed_dev;
+  const float keep = 1.f / (1.f - p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float u = (float)(hash_u32(seed * 0x9E3779B97F4A7C15ULL + (uint64_t)i) >> 8) * (1.f / 16777216.f);
+    mask[i] = u >= p ? keep : 0.f;
+  }
+}
+extern "C" int lmkd_dropout_mask_dev(float* mask, long n, float p, const unsigned long long* seed_dev, void* stream) {
+  LMKD_REQUIRE(mask && seed_dev && n > 0 && p >= 0.f && p < 1.f, "lmkd_dropout_mask_dev: bad arguments");
+  hipLaunchKernelGGL(dropout_mask_dev_kernel, dim3(tx_grid(n)), dim3(TX_THREADS), 0, (hipStream_t)stream, mask, n, p, seed_dev);
+  LMKD_CHECK_LAUNCH("dropout_mask_dev_kernel");
+  return LMKD_OK;
+}
 extern "C" int lmkd_dropout_mask(float* mask, long n, float p, unsigned long long seed, void* stream) {
   LMKD_REQUIRE(mask && n > 0 && p >= 0.f && p < 1.f, "lmkd_dropout_mask: bad arguments");
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(tx_grid(n)), dim3(TX_THREADS), 0, (hipStream_t)stream, mask, n, p, (uint64_t)seed);

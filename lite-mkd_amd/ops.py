@@ -212,32 +212,65 @@ def pack_weights(w, Cs, mode):
     if owner is None or owner.data_ptr() != w.data_ptr() or owner.shape != w.shape:
         return _pack_weights(w, Cs, mode)
     tag = (owner._version, WEIGHT_EPOCH[0])
+    key = (Cs, mode, lib().value("lmkd_conv_get_compute_dtype"))      # one persistent buffer per arithmetic mode
     cur = torch.cuda.current_stream()
-    hit = e["packs"].get((Cs, mode))
+    hit = e["packs"].get(key)
     if hit is not None and hit[0] == tag:
-        if hit[3] != cur.cuda_stream:
+        if hit[3] is not None and hit[3] != cur.cuda_stream:
             cur.wait_event(hit[2])            # packed on the other stream: order this stream behind the pack kernel
         return hit[1]
-    wp = _pack_weights(w, Cs, mode)
+    # stale or missing: (re)pack - into the SAME buffer when there is one, so that its address stays valid for a captured hipGraph
+    # (trainloop.GraphedEpisode) and the allocator is left alone
+    wp = _pack_weights(w, Cs, mode, out=hit[1] if hit is not None else None)
     ev = torch.cuda.Event()
     ev.record(cur)
-    e["packs"][(Cs, mode)] = (tag, wp, ev, cur.cuda_stream)
+    e["packs"][key] = (tag, wp, ev, cur.cuda_stream)
     return wp
 
 
-def _pack_weights(w, Cs, mode):
+def refresh_packs(streams=()):
+    """Re-pack, on the current stream and IN PLACE, every cached pack of the current arithmetic mode whose weights have changed since
+    (optimizer step, in-place update), make `streams` wait for it and mark the packs as visible everywhere.  A captured episode
+    calls pack_weights() during capture and must find every pack valid (no pack kernel inside the graph): GraphedEpisode calls this
+    before capture and before every replay."""
+    cur = torch.cuda.current_stream()
+    cd = lib().value("lmkd_conv_get_compute_dtype")
+    n = 0
+    for e in _pack_cache.values():
+        owner = e["ref"]()
+        if owner is None:
+            continue
+        tag = (owner._version, WEIGHT_EPOCH[0])
+        for key, hit in e["packs"].items():
+            if key[2] != cd:
+                continue
+            if hit[0] != tag:
+                _pack_weights(owner, key[0], key[1], out=hit[1])
+                n += 1
+            if hit[0] != tag or hit[3] is not None:
+                e["packs"][key] = (tag, hit[1], hit[2], None)
+    for s in streams:
+        s.wait_stream(cur)
+    return n
+
+
+def _pack_weights(w, Cs, mode, out=None):
     Cout, Cin, KH, KW = w.shape
     n = lib().value("lmkd_conv2d_packed_weight_elems", Cout, Cin, Cs, KH, KW, mode)
-    wp = _empty((n,), w)
-    _chk(w)
-    lib().call("lmkd_conv2d_pack_weights", _p(w), _p(wp), Cout, Cin, Cs, KH, KW, mode, _stream())
     cd = lib().value("lmkd_conv_get_compute_dtype")
-    if cd >= 1:      # bf16 (one RNE plane) / fp32-as-3xbf16 (three planes): weights in MFMA fragment order, fetched into registers
-        ncols = Cout if mode == 0 else Cin
-        planes = torch.empty(((1 if cd == 1 else 3) * n,), dtype=torch.int16, device=w.device)
-        lib().call("lmkd_conv2d_split_weights", _p(wp), planes.data_ptr(), ncols, n // ncols, _stream())
-        return planes
-    return wp
+    _chk(w)
+    if cd == 0:
+        wp = out if out is not None else _empty((n,), w)
+        lib().call("lmkd_conv2d_pack_weights", _p(w), _p(wp), Cout, Cin, Cs, KH, KW, mode, _stream())
+        return wp
+    # bf16 (one RNE plane) / fp32-as-3xbf16 (three planes): weights in MFMA fragment order, fetched into registers
+    wp = _empty((n,), w)
+    lib().call("lmkd_conv2d_pack_weights", _p(w), _p(wp), Cout, Cin, Cs, KH, KW, mode, _stream())
+    ncols = Cout if mode == 0 else Cin
+    # one RNE plane, or the three planes of W followed by the three planes of -W (lmkd_conv2d_split_weights)
+    planes = out if out is not None else torch.empty(((1 if cd == 1 else 6) * n,), dtype=torch.int16, device=w.device)
+    lib().call("lmkd_conv2d_split_weights", _p(wp), planes.data_ptr(), ncols, n // ncols, _stream())
+    return planes
 
 
 # Library default (also the default of liblmkd_hip.so itself): the arithmetic of the benchmark's headline line
@@ -253,8 +286,7 @@ def set_conv_compute_dtype(dtype):
     modes = {"fp32": 0, "bf16": 1, "fp32x3": 2, "fp32x3_9": 3}
     if dtype not in modes:
         raise ValueError(dtype)
-    WEIGHT_EPOCH[0] += 1                                     # packed-weight caches hold the other mode's layout
-    lib().call("lmkd_conv_set_compute_dtype", modes[dtype])
+    lib().call("lmkd_conv_set_compute_dtype", modes[dtype])   # (the packed-weight cache keeps one buffer per mode)
     if dtype != "bf16" and _ACT_DTYPE[0] is not torch.float32:
         set_activation_dtype("fp32")                         # bf16 tensors exist in the one-plane mode only
 
@@ -397,7 +429,8 @@ def wait_weight_grads():
     """make the current (and the default) stream wait for every weight gradient launched on the side stream"""
     for dev, sw in _WG_STREAM.items():
         torch.cuda.current_stream(dev).wait_stream(sw)
-        torch.cuda.default_stream(dev).wait_stream(sw)
+        if not torch.cuda.is_current_stream_capturing():      # a wait on a capturing stream's event would pull the default stream into the capture
+            torch.cuda.default_stream(dev).wait_stream(sw)
 
 
 def _end_of_backward():
@@ -1104,9 +1137,39 @@ def trx_logits_nograd(sup, qry, plan, wk, bk, wv, bv, gamma, beta, pe, mask=None
     return _trx_forward(sup.contiguous(), qry.contiguous(), plan, wk, bk, wv, bv, gamma, beta, pe, mask, False)[0]
 
 
+# While SEED_SLOTS is a SeedSlots object (a hipGraph is being captured), every dropout mask takes its seed from the next slot of a
+# device buffer instead of a kernel argument; the replay loop writes fresh seeds into the slots before each replay.
+SEED_SLOTS = None
+
+
+class SeedSlots:
+    def __init__(self, device, n=16):
+        self.dev = torch.zeros(n, dtype=torch.int64, device=device)
+        self.used = 0
+
+    def next_ptr(self):
+        if self.used >= self.dev.numel():
+            raise RuntimeError("more than %d dropout calls in one captured episode" % self.dev.numel())
+        self.used += 1
+        return self.dev.data_ptr() + 8 * (self.used - 1)
+
+    def stage(self, seeds):
+        """seeds of the next replay (one per slot used during capture, in call order) -> device, on the current stream.  A fresh
+        pinned block per call (torch's pinned allocator does not recycle it before the copy has run): the host may be many replays
+        ahead of the device"""
+        if not seeds:
+            return
+        h = torch.zeros(self.dev.numel(), dtype=torch.int64)
+        h[:len(seeds)] = torch.tensor(seeds, dtype=torch.int64)
+        self.dev.copy_(h.pin_memory(), non_blocking=True)
+
+
 def dropout_mask(shape, p, seed, device):
     m = torch.empty(shape, dtype=torch.float32, device=device)
-    lib().call("lmkd_dropout_mask", _p(m), m.numel(), _f32(p), ctypes.c_ulonglong(seed), _stream())
+    if SEED_SLOTS is not None:      # capture: `seed` is ignored, the slot is filled before every replay
+        lib().call("lmkd_dropout_mask_dev", _p(m), m.numel(), _f32(p), ctypes.c_void_p(SEED_SLOTS.next_ptr()), _stream())
+    else:
+        lib().call("lmkd_dropout_mask", _p(m), m.numel(), _f32(p), ctypes.c_ulonglong(seed), _stream())
     return m
 
 

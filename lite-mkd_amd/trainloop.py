@@ -121,8 +121,12 @@ def _teacher_forward(teacher, ctf, labels, ttf, way):
 
 def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
     """trainwandb.py:190-287 for the logits-based distillers."""
+    return _train_task_prepared(prepare_task(task_dict, config.device), student, teacher, distiller, accuracy_fn, config)
+
+
+def _train_task_prepared(prepared, student, teacher, distiller, accuracy_fn, config):
     (context_images, target_images, context_teacher_feature, target_teacher_feature, context_labels,
-     target_labels, _, _) = prepare_task(task_dict, config.device)
+     target_labels, _, _) = prepared
     teacher_model_dict, joined = _teacher_forward(teacher, context_teacher_feature, context_labels, target_teacher_feature, config.way)
     model_dict = student(context_images, context_labels, target_images)
     if joined is not None:
@@ -146,6 +150,127 @@ def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
         task_accuracy = accuracy_fn(target_logits, target_labels)
     task_loss.backward(retain_graph=False)
     return task_loss.detach(), task_accuracy, {"accuracy": task_accuracy}
+
+
+class GraphedEpisode:
+    """train_task as a captured hipGraph (torch.cuda.CUDAGraph): forward + loss + backward of one episode on the three HIP streams
+    become ONE graph launch - ~600 kernel launches, their Python glue and the autograd engine leave the per-episode host path
+    (10-13 ms of host time per episode eagerly: profiles/r02_host_bound.txt; bf16 tensors ran host-bound).
+
+    What changes from episode to episode has to live in device memory the graph reads:
+      * frames, teacher features, labels: the graph is captured on the episode's OWN device tensors and cached by their addresses
+        (a resident pool of episodes, as in bench.py, replays without any copy); episodes that arrive in new tensors are copied
+        into the static tensors of one generic graph;
+      * the class plan (support labels -> class-sorted row map) is a device tensor built before the capture / refreshed in place;
+        its STRUCTURE (shots per class) is baked into the graph, an episode with another structure runs eagerly;
+      * dropout seeds: ops.SeedSlots - the mask kernels read their seeds from device memory, the host stages the seeds of the next
+        replay (the same draws from torch's generator, in the same order, as the eager path: results are bit-identical);
+      * packed weights: re-packed IN PLACE after every optimizer step (ops.refresh_packs), outside the graph.
+    The first episode with a new key runs eagerly (warm-up: allocator, kernel attributes), the second is captured and replayed.
+    Gradients accumulate into the same flat buffers as in the eager path; optimizer, scheduler and all-reduce stay outside."""
+
+    KEYS = ("support_set", "target_set", "support_set_feature_teacher", "target_set_feature_teacher", "support_labels", "target_labels")
+
+    def __init__(self, student, teacher, distiller, accuracy_fn, config, max_graphs=4):
+        self.student, self.teacher, self.distiller, self.accuracy_fn, self.config = student, teacher, distiller, accuracy_fn, config
+        self.max_graphs = max_graphs
+        self.graphs = {}        # key -> entry dict
+        self.seen = set()
+        self.replays = self.eager = 0
+
+    def _key(self, task_dict):
+        ts = [task_dict[k] for k in self.KEYS]
+        if not all(t.is_cuda for t in ts):
+            return None
+        return tuple(t.data_ptr() for t in ts) + tuple(tuple(t.shape) for t in ts)
+
+    def _seeds(self, n):
+        from .model.classifiers.TRX_2fcsup import TemporalCrossTransformer as T
+        return [T.draw_dropout_seed() for _ in range(n)]
+
+    def _capture(self, task_dict, key):
+        cfg = self.config
+        prepared = prepare_task(task_dict, cfg.device)
+        labels = prepared[4]
+        plan = ops.get_plan(labels, cfg.way)                       # built (H2D copies) outside the capture; the capture finds it cached
+        plan.full_rowmap(prepared[2].shape[0] + prepared[3].shape[0])
+        plan.full_rowmap(prepared[0].shape[0] // cfg.seq_len + prepared[1].shape[0] // cfg.seq_len)
+        streams = [ops.side_stream(cfg.device), ops.aux_stream(cfg.device)] + list(ops._WG_STREAM.values())
+        ops.refresh_packs(streams)
+        slots = ops.SeedSlots(cfg.device)
+        g = torch.cuda.CUDAGraph()
+        prev_sync = ops.SYNC_WGRAD_AT_BACKWARD_END
+        torch.cuda.synchronize()
+        ops.SEED_SLOTS = slots
+        ops.SYNC_WGRAD_AT_BACKWARD_END = True                      # every forked stream joins the capture stream before it ends
+        try:
+            with torch.cuda.graph(g):
+                loss, acc, _ = _train_task_prepared(prepared, self.student, self.teacher, self.distiller, self.accuracy_fn, cfg)
+                ops.wait_weight_grads()
+        finally:
+            ops.SEED_SLOTS = None
+            ops.SYNC_WGRAD_AT_BACKWARD_END = prev_sync
+        ent = {"graph": g, "slots": slots, "loss": loss, "acc": acc, "prepared": prepared, "plan": plan, "counts": tuple(plan.counts),
+               "task": task_dict}
+        self.graphs[key] = ent
+        return ent
+
+    def _eager(self, task_dict):
+        self.eager += 1
+        return train_task(task_dict, self.student, self.teacher, self.distiller, self.accuracy_fn, self.config)
+
+    def _replay(self, ent):
+        ops.wait_weight_grads()                                        # an eager episode's weight gradients may still be in flight
+        ops.refresh_packs()
+        ent["slots"].stage(self._seeds(ent["slots"].used))
+        ent["graph"].replay()
+        self.replays += 1
+        return ent["loss"], ent["acc"], {"accuracy": ent["acc"]}
+
+    def _generic(self, task_dict):
+        """episodes that arrive in NEW tensors (a data loader): one graph on static copies of the inputs; the new episode's tensors are
+        copied in, its class plan (computed on the host from the labels, as ops.ClassPlan does) overwrites the static plan's device
+        tensors.  An episode whose class structure differs from the captured one runs eagerly."""
+        cfg = self.config
+        shapes = tuple(tuple(task_dict[k].shape) for k in self.KEYS)
+        ent = self.graphs.get(("generic",) + shapes)
+        lab = task_dict["support_labels"][0]
+        plan = ops.ClassPlan(lab, cfg.way, lab.detach().to("cpu"))
+        if ent is None:
+            if ("generic",) + shapes not in self.seen:
+                self.seen.add(("generic",) + shapes)
+                return self._eager(task_dict)
+            static = {k: v.detach().to(cfg.device).clone() if k in self.KEYS else v for k, v in task_dict.items()}
+            ent = self._capture(static, ("generic",) + shapes)
+            return self._replay(ent)
+        if tuple(plan.counts) != ent["counts"] or plan.classes != ent["plan"].classes:
+            return self._eager(task_dict)
+        for k in self.KEYS:
+            ent["task"][k].copy_(task_dict[k], non_blocking=True)
+        sp = ent["plan"]
+        sp.rowmap.copy_(plan.rowmap)
+        sp.cls.copy_(plan.cls)
+        for nv, full in sp._full.items():
+            full[:sp.ns].copy_(plan.rowmap)
+        # prepare_task's derived tensor (target labels as int64) lives in the static `prepared` tuple
+        ent["prepared"][5].copy_(ent["task"]["target_labels"][0].long())
+        return self._replay(ent)
+
+    def __call__(self, task_dict):
+        key = self._key(task_dict)
+        if key is None:
+            return self._generic(task_dict)
+        ent = self.graphs.get(key)
+        if ent is None:
+            if key not in self.seen:                                   # first sight: eager (also the warm-up of the capture)
+                if len(self.seen) > 64:
+                    return self._generic(task_dict)                    # device tensors, but new ones every time
+                self.seen.add(key)
+                return self._eager(task_dict)
+            if sum(1 for k in self.graphs if k[0] != "generic") >= self.max_graphs:
+                return self._generic(task_dict)
+            ent = self._capture(task_dict, key)
+        return self._replay(ent)
 
 
 def save_checkpoint(student, iteration, config, bn_stats=None):

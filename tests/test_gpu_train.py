@@ -248,3 +248,56 @@ def test_data_parallel_world2_equals_world1(dev, tmp_path):
             pooled = (r0[kv] + r1[kv]) / 2 + (r0[k] ** 2 + r1[k] ** 2) / 2 - ((r0[k] + r1[k]) / 2) ** 2
             assert torch.allclose(ck[kv], pooled, rtol=1e-5, atol=1e-6), kv
     assert not torch.equal(r0["backbone.resnet.1.running_mean"], r1["backbone.resnet.1.running_mean"])
+
+
+def test_graphed_episode_bit_identical_to_eager(dev):
+    """trainloop.GraphedEpisode: the episode captured into a hipGraph (forward + loss + backward on three streams, dropout seeds and
+    class plan in device memory, packed weights refreshed in place) replays the SAME kernels on the same data: losses, accuracies,
+    accumulated gradients, BatchNorm running statistics and the weights after an optimizer step are bit-identical to the eager loop
+    over the same episodes with the same RNG state (dropout 0.1 active)."""
+    from litemkd_amd import ops, trainloop as TL
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd.utils import aggregate_accuracy
+    cfg = default_args(shot=1, query_per_class=1, img_size=64, trans_dropout=0.1, device=dev, learning_rate=1e-2)
+    src = TL.SyntheticEpisodes(cfg, base_seed=77, device=dev)
+    pool = [src.episode(e) for e in range(2)]
+    order = [0, 1, 0, 1, 0, 1, 1, 0]
+
+    def run(graph):
+        torch.manual_seed(91)
+        student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
+        opt = TL.FusedOptimizer(student, "sgd", cfg.learning_rate)
+        distiller = Distiller(cfg.distill_name, cfg.cfg, dev)
+        runner = TL.GraphedEpisode(student, teacher, distiller, aggregate_accuracy, cfg) if graph else None
+        prev = (ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD)
+        ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD = True, False, True
+        out = []
+        try:
+            torch.manual_seed(5)                      # the dropout seeds are drawn from the CPU generator, one per head and episode
+            for i, e in enumerate(order):
+                if graph:
+                    loss, acc, _ = runner(pool[e])
+                else:
+                    loss, acc, _ = TL.train_task(pool[e], student, teacher, distiller, aggregate_accuracy, cfg)
+                out.append((float(loss), float(acc)))
+                if i == 4:                              # an optimizer step in the middle: the packed weights must follow
+                    opt.step()
+                    opt.zero_grad()
+            ops.wait_weight_grads()
+            opt.bucket.fold_shadow()
+            torch.cuda.synchronize()
+        finally:
+            ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD = prev
+        stats = {k: v.clone() for k, v in student.state_dict().items() if "running" in k or "num_batches" in k}
+        return out, opt.bucket.grad.clone(), opt.bucket.flat.clone(), stats, runner
+    o_e, g_e, w_e, s_e, _ = run(False)
+    o_g, g_g, w_g, s_g, runner = run(True)
+    assert runner.replays == len(order) - 2 and runner.eager == 2 and len(runner.graphs) == 2, (runner.replays, runner.eager)
+    assert o_e == o_g, (o_e, o_g)
+    assert torch.equal(w_e, w_g)
+    assert torch.equal(g_e, g_g), float((g_e - g_g).abs().max())
+    for k in s_e:
+        assert torch.equal(s_e[k], s_g[k]), k
+    assert len({l for l, _ in o_e}) > 4                 # the episodes really differ (dropout masks, optimizer step)

@@ -17,7 +17,7 @@ def test_cabi_exports_every_declared_symbol():
     protos = parse_header()
     assert len(protos) >= 40
     L = litemkd_amd.lib()                      # binding fails if any declared symbol is missing
-    assert L.value("lmkd_abi_version") == 1
+    assert L.value("lmkd_abi_version") == 3
     out = subprocess.check_output(["nm", "-D", LIB_PATH]).decode()
     for name in protos:
         assert (" T " + name) in out, name
