@@ -136,8 +136,19 @@ int lmkd_bn_backward(const float* dy, const float* x, const float* yact, const f
                      float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, int C,
                      int mask_mode, int accumulate_param_grads, void* stream);
 int lmkd_relu_backward(const float* dy, const float* y, float* g, long n, void* stream);
-int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, float* y, unsigned char* idx, int N, int H, int W, int C, void* stream);
+/* stem: y = maxpool3x3/2/1(relu(x * scale + shift)), idx = arg-max byte (0..8) per output element, cmax (nullable) = x at the arg-max
+   (torchvision resnet children 1-3, resnet18_2fc.py:33) */
+int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int H, int W, int C,
+                             void* stream);
 int lmkd_maxpool_bwd(const float* dy, const unsigned char* idx, float* g, int N, int H, int W, int C, void* stream);
+/* the stem's BatchNorm backward without the pre-pooling gradient tensor: (1) reduce + coefficient launches over the POOLED tensors
+   (dy, cmax: [pooled_rows, C]; count = N*H*W of the pre-pooling tensor) -> coef [3][C], dgamma, dbeta (+= when accumulate_param_grads);
+   (2) max-pool backward + BatchNorm backward apply in one pass -> dc [N,H,W,C], the gradient w.r.t. the convolution output c */
+int lmkd_bn_backward_stats(const float* dy, const float* cmax, const float* stats, const float* gamma, float* dgamma, float* dbeta,
+                           float* coef, void* workspace, unsigned* tickets, long pooled_rows, long count, int C, int accumulate_param_grads,
+                           void* stream);
+int lmkd_stem_unpool_bn_bwd(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef, float* dc,
+                            int N, int H, int W, int C, void* stream);
 /* AdaptiveMaxPool2d((4,4)) + mean over the 16 patches: resnet18_2fc.py:44-54 */
 int lmkd_adaptive_maxpool_mean_fwd(const float* x, float* y, int F, int H, int W, int C, void* stream);
 int lmkd_adaptive_maxpool_mean_bwd(const float* x, const float* dy, float* dx, int F, int H, int W, int C, void* stream);

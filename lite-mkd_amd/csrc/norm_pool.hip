@@ -504,20 +504,19 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
 
 extern "C" long lmkd_bn_bwd_workspace(int C) { return (long)(2048 * 2 * C) * sizeof(float) + (long)(66 * 2 * C) * sizeof(double) + 64; }
 
-// dy, x, (yact) : [rows, C];  stats from the forward;  outputs dx (may alias dy), g_out (optional), dgamma, dbeta
-// coef: [3][C] floats scratch;  workspace: lmkd_bn_bwd_workspace(C) bytes;  tickets: lmkd_ticket_words() zeroed words (zero again on
-// return; one buffer per stream that may run this concurrently);  accumulate_param_grads: dgamma / dbeta += (see bn_bwd_coef_kernel)
-extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma,
-                                float* dx, float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets,
-                                long rows, int C, int mask_mode, int accumulate_param_grads, void* stream) {
-  LMKD_REQUIRE(dy && x && stats && dx && coef && workspace && tickets, "lmkd_bn_backward: null pointer");
+// reduce + coefficient launches of the BatchNorm backward: partial sums of (g, g * xhat) over `rows` rows of (dy, x), then
+// coef[3][C] = A, mean(g), mean(g * xhat) with the means taken over `count` elements per channel (count = rows except for the stem,
+// whose sums run over the POOLED tensor while the BatchNorm normalised the pre-pooling one: lmkd_bn_backward_stats)
+static int bn_bwd_stats_impl(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dgamma,
+                             float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, long count, int C, int mask_mode,
+                             int accumulate_param_grads, hipStream_t s, const char* who) {
+  LMKD_REQUIRE(dy && x && stats && coef && workspace && tickets, "%s: null pointer", who);
   const int CC = C > 1024 ? 1024 : C;   // channel chunk handled by one workgroup column
   const int U = g_lmkd_act_bf16 ? 2 : 1;      // groups of 4 channels per thread (16-byte accesses)
-  LMKD_REQUIRE(C % (4 * U) == 0 && C % CC == 0 && 256 % (CC / 4) == 0, "lmkd_bn_backward: unsupported channel count %d", C);
-  LMKD_REQUIRE((mask_mode != 1 && mask_mode != 3) || yact, "lmkd_bn_backward: mask_mode 1 / 3 needs the activation output / its bit mask");
-  LMKD_REQUIRE(mask_mode != 3 || C % 32 == 0, "lmkd_bn_backward: bit masks need C %% 32 == 0");
-  LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS, "lmkd_bn_backward: C=%d exceeds the ticket buffer", C);
-  hipStream_t s = (hipStream_t)stream;
+  LMKD_REQUIRE(C % (4 * U) == 0 && C % CC == 0 && 256 % (CC / 4) == 0, "%s: unsupported channel count %d", who, C);
+  LMKD_REQUIRE((mask_mode != 1 && mask_mode != 3) || yact, "%s: mask_mode 1 / 3 needs the activation output / its bit mask", who);
+  LMKD_REQUIRE(mask_mode != 3 || C % 32 == 0, "%s: bit masks need C %% 32 == 0", who);
+  LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS, "%s: C=%d exceeds the ticket buffer", who, C);
   const int RL1 = NP_THREADS / (CC / 4), RL = RL1 * U;
   int nb = cdiv(rows, (long)RL1 * 8);      // virtual blocks of RL1 row lanes (U of them per workgroup)
   if (nb > 256 * g_ew_wg_per_cu) nb = 256 * g_ew_wg_per_cu;
@@ -532,8 +531,22 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
                        stats, partial, rows, C, CC, mask_mode, nb);
   LMKD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(2 * C, CS_COLS), cs_slices(nb)), dim3(CS_COLS, CS_LANES), 0, s, (const float*)partial, nb, C,
-                     (double)rows, gamma, stats, coef, dgamma, dbeta, accumulate_param_grads, dscr, tickets);
+                     (double)count, gamma, stats, coef, dgamma, dbeta, accumulate_param_grads, dscr, tickets);
   LMKD_CHECK_LAUNCH("bn_bwd_coef_kernel");
+  return LMKD_OK;
+}
+
+// dy, x, (yact) : [rows, C];  stats from the forward;  outputs dx (may alias dy), g_out (optional), dgamma, dbeta
+// coef: [3][C] floats scratch;  workspace: lmkd_bn_bwd_workspace(C) bytes;  tickets: lmkd_ticket_words() zeroed words (zero again on
+// return; one buffer per stream that may run this concurrently);  accumulate_param_grads: dgamma / dbeta += (see bn_bwd_coef_kernel)
+extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma,
+                                float* dx, float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets,
+                                long rows, int C, int mask_mode, int accumulate_param_grads, void* stream) {
+  LMKD_REQUIRE(dx, "lmkd_bn_backward: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = bn_bwd_stats_impl(dy, x, yact, stats, gamma, dgamma, dbeta, coef, workspace, tickets, rows, rows, C, mask_mode,
+                                   accumulate_param_grads, s, "lmkd_bn_backward");
+  if (rc) return rc;
   const long n4 = rows * C / 4;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<lmkd_bf16_t>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, (const lmkd_bf16_t*)dy, (const lmkd_bf16_t*)x,
@@ -543,6 +556,20 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
                        n4, C, mask_mode);
   LMKD_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return LMKD_OK;
+}
+
+// The stem's BatchNorm backward statistics from the POOLED side (round 3).  The gradient that reaches the stem's BatchNorm is the
+// max-pool backward of dy: non-zero only at the arg-max position of each pooling window, so
+//   sum g = sum over windows of dy * [bn(c_max) > 0],   sum g * xhat = sum over windows of dy * [..] * xhat(c_max)
+// with c_max = the convolution output at the window's arg-max (saved by lmkd_bn_relu_maxpool_fwd).  One pass over two 160 MB tensors
+// instead of materialising the 642 MB pre-pooling gradient and reducing it together with the 642 MB convolution output.
+//   dy, cmax: [pooled_rows, C];  count = N * H * W of the pre-pooling tensor (the means of the BatchNorm backward run over it)
+extern "C" int lmkd_bn_backward_stats(const float* dy, const float* cmax, const float* stats, const float* gamma, float* dgamma, float* dbeta,
+                                      float* coef, void* workspace, unsigned* tickets, long pooled_rows, long count, int C,
+                                      int accumulate_param_grads, void* stream) {
+  LMKD_REQUIRE(pooled_rows > 0 && count >= pooled_rows, "lmkd_bn_backward_stats: bad row counts");
+  return bn_bwd_stats_impl(dy, cmax, nullptr, stats, gamma, dgamma, dbeta, coef, workspace, tickets, pooled_rows, count, C, 2,
+                           accumulate_param_grads, (hipStream_t)stream, "lmkd_bn_backward_stats");
 }
 
 // plain ReLU backward (eval-mode / no-BN paths): g = dy * (y > 0)
@@ -569,7 +596,7 @@ extern "C" int lmkd_relu_backward(const float* dy, const float* y, float* g, lon
 // ---------------------------------------------------------------------------------
 template <typename T>
 __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ stats, T* __restrict__ y,
-                                       uchar4* __restrict__ idx, int N, int H, int W, int C, int OH, int OW) {
+                                       uchar4* __restrict__ idx, T* __restrict__ cmax, int N, int H, int W, int C, int OH, int OW) {
   const int C4 = C >> 2;
   const long total = (long)N * OH * OW * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -581,6 +608,7 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __r
     const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + cq * 4);
     const float4 sh = *reinterpret_cast<const float4*>(stats + 3 * C + cq * 4);
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    float4 cm = make_float4(0.f, 0.f, 0.f, 0.f);      // the raw convolution output at the arg-max (backward: lmkd_bn_backward_stats)
     uchar4 am = make_uchar4(255, 255, 255, 255);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
@@ -590,32 +618,34 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __r
       for (int kw = 0; kw < 3; ++kw) {
         const int w = ow * 2 - 1 + kw;
         if ((unsigned)w >= (unsigned)W) continue;
-        float4 v = ld4<T>(x, ((long)(n * H + h) * W + w) * C4 + cq);
-        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+        const float4 r = ld4<T>(x, ((long)(n * H + h) * W + w) * C4 + cq);
+        float4 v;
+        v.x = fmaxf(fmaf(r.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(r.y, sc.y, sh.y), 0.f);
+        v.z = fmaxf(fmaf(r.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(r.w, sc.w, sh.w), 0.f);
         const unsigned char t = (unsigned char)(kh * 3 + kw);
-        if (v.x > m.x || am.x == 255) { m.x = v.x; am.x = t; }
-        if (v.y > m.y || am.y == 255) { m.y = v.y; am.y = t; }
-        if (v.z > m.z || am.z == 255) { m.z = v.z; am.z = t; }
-        if (v.w > m.w || am.w == 255) { m.w = v.w; am.w = t; }
+        if (v.x > m.x || am.x == 255) { m.x = v.x; am.x = t; cm.x = r.x; }
+        if (v.y > m.y || am.y == 255) { m.y = v.y; am.y = t; cm.y = r.y; }
+        if (v.z > m.z || am.z == 255) { m.z = v.z; am.z = t; cm.z = r.z; }
+        if (v.w > m.w || am.w == 255) { m.w = v.w; am.w = t; cm.w = r.w; }
       }
     }
     st4<T>(y, i, m);
     idx[i] = am;
+    if (cmax) st4<T>(cmax, i, cm);
   }
 }
 
-extern "C" int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, float* y, unsigned char* idx, int N, int H, int W, int C,
-                                        void* stream) {
+extern "C" int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int H, int W,
+                                        int C, void* stream) {
   LMKD_REQUIRE(x && stats && y && idx && C % 4 == 0, "lmkd_bn_relu_maxpool_fwd: bad arguments");
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long total = (long)N * OH * OW * C / 4;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<lmkd_bf16_t>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)x,
-                       stats, (lmkd_bf16_t*)y, (uchar4*)idx, N, H, W, C, OH, OW);
+                       stats, (lmkd_bf16_t*)y, (uchar4*)idx, (lmkd_bf16_t*)cmax, N, H, W, C, OH, OW);
   else
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, stats, y, (uchar4*)idx,
-                       N, H, W, C, OH, OW);
+                       cmax, N, H, W, C, OH, OW);
   LMKD_CHECK_LAUNCH("bn_relu_maxpool_kernel");
   return LMKD_OK;
 }
@@ -654,6 +684,106 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uchar4* __res
     }
     st4<T>(g, i, acc);
   }
+}
+
+// Max-pool backward + BatchNorm backward apply of the stem in ONE pass (round 3; before: maxpool_bwd wrote the 642 MB pre-pooling
+// gradient g, bn_bwd_apply read g and c and wrote dc).  A thread owns a 2 x 2 block of pre-pooling pixels (rows 2a, 2a + 1, columns
+// 2b, 2b + 1) x 4 channels: exactly the pixels the four windows (a .. a + 1, b .. b + 1) can select in that block - even rows /
+// columns belong to one window, odd ones to two - so it loads four (dy, arg-max) pairs instead of up to four per PIXEL (the
+// gather form above), forms g for its four pixels in the order of maxpool_bwd_kernel (window row, then window column) and writes
+//   dc = A * (m * g - mean(g) - xhat * mean(g * xhat)),   m = (c * scale + shift > 0),   xhat = (c - mean) * invstd
+// - the arithmetic of bn_bwd_apply_kernel with mask_mode 2.
+template <typename T>
+__global__ void stem_unpool_bn_bwd_kernel(const T* __restrict__ dy, const uchar4* __restrict__ idx, const T* __restrict__ c,
+                                          const float* __restrict__ stats, const float* __restrict__ coef, T* __restrict__ dc, int N,
+                                          int H, int W, int C, int OH, int OW) {
+  const int C4 = C >> 2;
+  const int HB = (H + 1) >> 1, WB = (W + 1) >> 1;
+  const long total = (long)N * HB * WB * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % C4);
+    long r = i / C4;
+    const int b = (int)(r % WB); r /= WB;
+    const int a = (int)(r % HB);
+    const int n = (int)(r / HB);
+    const int ch = cq * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + ch);
+    const float4 sh = *reinterpret_cast<const float4*>(stats + 3 * C + ch);
+    const float4 mean = *reinterpret_cast<const float4*>(stats + ch);
+    const float4 istd = *reinterpret_cast<const float4*>(stats + C + ch);
+    const float4 A = *reinterpret_cast<const float4*>(coef + ch);
+    const float4 mg = *reinterpret_cast<const float4*>(coef + C + ch);
+    const float4 mgx = *reinterpret_cast<const float4*>(coef + 2 * C + ch);
+    // the four windows (a + i, b + j)
+    float4 d[2][2];
+    uchar4 am[2][2];
+#pragma unroll
+    for (int wi = 0; wi < 2; ++wi)
+#pragma unroll
+      for (int wj = 0; wj < 2; ++wj) {
+        const int oh = a + wi, ow = b + wj;
+        if (oh < OH && ow < OW) {
+          const long o = ((long)(n * OH + oh) * OW + ow) * C4 + cq;
+          d[wi][wj] = ld4<T>(dy, o);
+          am[wi][wj] = idx[o];
+        } else {
+          d[wi][wj] = make_float4(0.f, 0.f, 0.f, 0.f);
+          am[wi][wj] = make_uchar4(254, 254, 254, 254);
+        }
+      }
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const int h = 2 * a + pi;
+      if (h >= H) continue;
+#pragma unroll
+      for (int pj = 0; pj < 2; ++pj) {
+        const int w = 2 * b + pj;
+        if (w >= W) continue;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        // windows that contain (h, w): rows oh = a (kh = pi + 1) and, for the odd row, oh = a + 1 (kh = 0); columns likewise
+#pragma unroll
+        for (int wi = 0; wi <= pi; ++wi) {
+          const int kh = wi == 0 ? pi + 1 : 0;
+#pragma unroll
+          for (int wj = 0; wj <= pj; ++wj) {
+            const int kw = wj == 0 ? pj + 1 : 0;
+            const unsigned char t = (unsigned char)(kh * 3 + kw);
+            if (am[wi][wj].x == t) g.x += d[wi][wj].x;
+            if (am[wi][wj].y == t) g.y += d[wi][wj].y;
+            if (am[wi][wj].z == t) g.z += d[wi][wj].z;
+            if (am[wi][wj].w == t) g.w += d[wi][wj].w;
+          }
+        }
+        const long p = ((long)(n * H + h) * W + w) * C4 + cq;
+        const float4 xv = ld4<T>(c, p);
+        g.x = fmaf(xv.x, sc.x, sh.x) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
+        g.z = fmaf(xv.z, sc.z, sh.z) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, sc.w, sh.w) > 0.f ? g.w : 0.f;
+        float4 o;
+        o.x = A.x * (g.x - mg.x - (xv.x - mean.x) * istd.x * mgx.x);
+        o.y = A.y * (g.y - mg.y - (xv.y - mean.y) * istd.y * mgx.y);
+        o.z = A.z * (g.z - mg.z - (xv.z - mean.z) * istd.z * mgx.z);
+        o.w = A.w * (g.w - mg.w - (xv.w - mean.w) * istd.w * mgx.w);
+        st4<T>(dc, p, o);
+      }
+    }
+  }
+}
+
+// dy, idx: [N, OH, OW, C] (pooled gradient, arg-max bytes of lmkd_bn_relu_maxpool_fwd); c: [N, H, W, C] convolution output;
+// stats: its [5][C] table; coef: [3][C] from lmkd_bn_backward_stats; dc: [N, H, W, C] gradient w.r.t. the convolution output
+extern "C" int lmkd_stem_unpool_bn_bwd(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef,
+                                       float* dc, int N, int H, int W, int C, void* stream) {
+  LMKD_REQUIRE(dy && idx && c && stats && coef && dc && C % 4 == 0 && N > 0 && H > 0 && W > 0, "lmkd_stem_unpool_bn_bwd: bad arguments");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * C / 4;
+  if (g_lmkd_act_bf16)
+    hipLaunchKernelGGL(stem_unpool_bn_bwd_kernel<lmkd_bf16_t>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream,
+                       (const lmkd_bf16_t*)dy, (const uchar4*)idx, (const lmkd_bf16_t*)c, stats, coef, (lmkd_bf16_t*)dc, N, H, W, C, OH, OW);
+  else
+    hipLaunchKernelGGL(stem_unpool_bn_bwd_kernel<float>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, dy, (const uchar4*)idx, c,
+                       stats, coef, dc, N, H, W, C, OH, OW);
+  LMKD_CHECK_LAUNCH("stem_unpool_bn_bwd_kernel");
+  return LMKD_OK;
 }
 
 extern "C" int lmkd_maxpool_bwd(const float* dy, const unsigned char* idx, float* g, int N, int H, int W, int C, void* stream) {

@@ -106,9 +106,26 @@ class TRX_2fcsup(nn.Module):
         self.supportKD = SupportDK(args)
 
     def forward(self, context_feature, context_labels, target_feature):
-        l1 = self.transformers(context_feature["context_features_1"], context_labels, target_feature["target_features_1"])["logits"]
-        l2 = self.transformers(context_feature["context_features_2"], context_labels, target_feature["target_features_2"])["logits"]
-        l3 = self.supportKD(context_feature["context_features_2"], context_labels, target_feature["target_features_2"])["logits"]
+        c1, t1 = context_feature["context_features_1"], target_feature["target_features_1"]
+        c2, t2 = context_feature["context_features_2"], target_feature["target_features_2"]
+        l1 = self.transformers(c1, context_labels, t1)["logits"]
+        if ops.HEADS_ON_TWO_STREAMS and c2.is_cuda:
+            # the 'ce' head does not depend on the 'kl' head: its ~20 small GEMM / softmax launches (126 workgroups each on a 256-CU
+            # chip) run on the auxiliary stream beside the first head's, forward and - autograd replays a node on the stream of its
+            # forward - backward
+            main, aux = torch.cuda.current_stream(c2.device), ops.aux_stream(c2.device)
+            ops.get_plan(context_labels, self.args.way).full_rowmap(c2.shape[0] + t2.shape[0])      # shared per-episode tensors: made on main
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                l2 = self.transformers(c2, context_labels, t2)["logits"]
+            for t in (c2, t2):
+                t.record_stream(aux)
+            l3 = self.supportKD(c2, context_labels, t2)["logits"]
+            main.wait_stream(aux)
+            l2.record_stream(main)
+        else:
+            l2 = self.transformers(c2, context_labels, t2)["logits"]
+            l3 = self.supportKD(c2, context_labels, t2)["logits"]
         return {"logits": {"kl": l1, "ce": l2, "sup": l3}}
 
 

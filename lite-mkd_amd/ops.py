@@ -142,9 +142,13 @@ def _grad_target(param):
     e = _GRAD_SLOT.get(param.data_ptr())
     if e is None or e[0]() is not param or param.grad is None or _has_hooks(param):
         return None
-    side = _side_streams.get((param.device.type, param.device.index))
-    if side is not None and torch.cuda.current_stream(param.device).cuda_stream == side.cuda_stream:
-        return e[1]
+    # kernels of the side stream (query-frame trunk call: BatchNorm parameters) and of the auxiliary stream (second TRX head: TRX
+    # parameters) add to the shadow buffer, everything on the caller's stream to .grad: no address is ever added to from two streams
+    cur = torch.cuda.current_stream(param.device).cuda_stream
+    key = (param.device.type, param.device.index)
+    for other in (_side_streams.get(key), _aux_streams.get(key)):
+        if other is not None and cur == other.cuda_stream:
+            return e[1]
     return param.grad
 
 
@@ -554,6 +558,7 @@ def side_stream(device):
     return _side_streams[key]
 
 
+HEADS_ON_TWO_STREAMS = True      # TRX_2fcsup: the 'ce' head on the auxiliary stream beside the 'kl' head
 _aux_streams = {}
 
 
@@ -627,6 +632,9 @@ def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training,
     return y, stats
 
 
+STEM_POOLED_BWD = True      # the stem's BatchNorm backward from the pooled side (lmkd_bn_backward_stats + lmkd_stem_unpool_bn_bwd); False: round-2 path
+
+
 class StemFn(torch.autograd.Function):
     """conv7x7/2 + BN + ReLU + maxpool3x3/2 (torchvision resnet children 0-3, resnet18_2fc.py:33).
     Input NCHW [F,3,H,W] (the reference's frame layout), output NHWC [F,H/4,W/4,64]."""
@@ -648,11 +656,14 @@ class StemFn(torch.autograd.Function):
         Ho, Wo = conv_out_size(Hc, 3, 2, 1), conv_out_size(Wc, 3, 2, 1)
         y = _empty_act((N, Ho, Wo, C), x)
         idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
-        lib().call("lmkd_bn_relu_maxpool_fwd", _p(c), _p(stats), _p(y), _p(idx), N, Hc, Wc, C, _stream())
+        # training: also the raw convolution output at each window's arg-max - the BatchNorm backward then takes its sums from the
+        # pooled tensors (lmkd_bn_backward_stats) instead of the 4x larger pre-pooling ones
+        cmax = torch.empty_like(y) if (training and STEM_POOLED_BWD) else None
+        lib().call("lmkd_bn_relu_maxpool_fwd", _p(c), _p(stats), _p(y), _p(idx), _p(cmax), N, Hc, Wc, C, _stream())
         if BLOCK_TAPS is not None:
             BLOCK_TAPS.append({"stem_c": c, "stem_st": stats})
         if training:
-            ctx.save_for_backward(x4, c, stats, idx, gamma, w)
+            ctx.save_for_backward(x4, c, stats, idx, gamma, w, cmax)
             ctx.beta = beta
         ctx.training = training
         return y
@@ -661,12 +672,28 @@ class StemFn(torch.autograd.Function):
     def backward(ctx, dy):
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
-        x4, c, stats, idx, gamma, w = ctx.saved_tensors
+        x4, c, stats, idx, gamma, w, cmax = ctx.saved_tensors
         dy = dy.contiguous()
         N, Hc, Wc, C = c.shape
-        g = torch.empty_like(c)
-        lib().call("lmkd_maxpool_bwd", _p(dy), _p(idx), _p(g), N, Hc, Wc, C, _stream())
-        dc, _, dgamma, dbeta = bn_backward(g, c, None, stats, gamma, 2, dx_out=g, beta=ctx.beta)
+        if cmax is not None:
+            # sums of the BatchNorm backward over the pooled tensors, then max-pool backward + BatchNorm backward apply in one pass:
+            # the 642 MB pre-pooling gradient is never written
+            tg = _grad_target(gamma)
+            tb = _grad_target(ctx.beta) if tg is not None else None
+            direct = tg is not None and tb is not None
+            dgamma, dbeta = (tg, tb) if direct else (_empty((C,), c), _empty((C,), c))
+            coef = _empty((3, C), c)
+            ws = torch.empty(lib().value("lmkd_bn_bwd_workspace", C), dtype=torch.uint8, device=c.device)
+            lib().call("lmkd_bn_backward_stats", _p(dy), _p(cmax), _p(stats), _p(gamma), _p(dgamma), _p(dbeta), _p(coef), _p(ws),
+                       _p(_tickets(c)), dy.numel() // C, c.numel() // C, C, int(direct), _stream())
+            dc = torch.empty_like(c)
+            lib().call("lmkd_stem_unpool_bn_bwd", _p(dy), _p(idx), _p(c), _p(stats), _p(coef), _p(dc), N, Hc, Wc, C, _stream())
+            if direct:
+                dgamma = dbeta = None
+        else:
+            g = torch.empty_like(c)
+            lib().call("lmkd_maxpool_bwd", _p(dy), _p(idx), _p(g), N, Hc, Wc, C, _stream())
+            dc, _, dgamma, dbeta = bn_backward(g, c, None, stats, gamma, 2, dx_out=g, beta=ctx.beta)
         dw = weight_grad(w, x4, dc, 2, 3)
         return None, dw, dgamma, dbeta, None, None, None
 
