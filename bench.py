@@ -108,6 +108,7 @@ def main():
     TL.TEACHER_STREAM = os.environ.get("LMKD_TEACHER_STREAM", "1") != "0"                  # tuning switches of the round-3 schedule changes
     ops.HEADS_ON_TWO_STREAMS = os.environ.get("LMKD_HEADS2", "1") != "0"
     ops.STEM_POOLED_BWD = os.environ.get("LMKD_STEM_POOLED", "1") != "0"
+    ops.FUSE_PRE_ALL_MODES = os.environ.get("LMKD_FUSE_PRE", "0") == "1"                   # inner BatchNorm + ReLU in the consumers' loaders also in the plane modes
     ops.DIRECT_PARAM_GRAD = os.environ.get("LMKD_DIRECT_GRAD", "1") != "0"               # BatchNorm / Linear / TRX parameter gradients added into .grad by the kernels
 
     from litemkd_amd import parallel as PAR
@@ -130,12 +131,8 @@ def main():
     cfg = default_args(shot=a.shot, device=dev, trans_dropout=a.dropout, training_iterations=10 ** 9, print_freq=10 ** 9,
                        model_backbone=a.backbone)
     torch.manual_seed(1234)                                  # identical initial weights on every rank
-    student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
-    opt = TL.FusedOptimizer(student, cfg.opt, cfg.learning_rate)
-    opt.bucket.broadcast_params(0)
-    sch = TL.MultiStepLR(opt, cfg.sch)
-    distiller = Distiller(cfg.distill_name, cfg.cfg, dev)
-    src = TL.SyntheticEpisodes(cfg, base_seed=2024, rank=rank, device=dev)
+    # the reference's make() (trainwandb.py:78-109): models, episode source, distiller, accuracy function, optimizer, scheduler
+    student, teacher, src, distiller, aggregate_accuracy, _, opt, sch = TL.make(cfg, base_seed=2024)
     pool = [src.episode(e) for e in range(a.pool)]           # resident in HBM before the timed region
     mfm = None
     if a.live_mfm:
@@ -196,6 +193,16 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timed_events, ops.CONV_TIMING = (ops.CONV_TIMING or []), None
+    # host cost of ONE episode's enqueue on an idle queue (nothing to wait for): what the Python / launch side needs per episode
+    # when it is not throttled by a full launch queue
+    host_idle = 0.0
+    for _ in range(4):
+        fence()
+        th = time.perf_counter()
+        it = run(1, it)
+        host_idle += time.perf_counter() - th
+    fence()
+    host_idle /= 4
     ar_events, PAR.ALLREDUCE_TIMING = PAR.ALLREDUCE_TIMING, None
     opt_steps_timed = opt.steps - steps0
     dist_info = {"backend": None, "world": world, "devices": [torch.cuda.get_device_name(dev)], "allreduce_ms_per_optimizer_step": None,
@@ -346,9 +353,11 @@ def main():
                      "timed_region_conv_tflops_per_gpu": conv_flops_timed / dt / 1e12,
                      "episode_model_tflops": step_tflop * world * a.steps / dt},
         "distributed": dist_info,
-        # host side of the timed region: time the Python loop needed to ENQUEUE the K episodes (it then waits in the fence); with
-        # hipGraph replay this is the true host cost per episode, eagerly the host is throttled by the full launch queue
-        "host_enqueue_ms_per_episode": t_enq / a.steps * 1e3,
+        # host side: time to ENQUEUE one episode on an idle queue (4 samples after the timed region; an optimizer step may fall on one
+        # of them), and the time the Python loop spent enqueueing the timed region - there the host is throttled by the full launch
+        # queue whenever the GPU is the bottleneck
+        "host_enqueue_ms_per_episode": host_idle * 1e3,
+        "host_loop_ms_per_episode_in_timed_region": t_enq / a.steps * 1e3,
         "hipgraph": {"enabled": bool(use_graph), "replays": runners[a.dtype].replays if use_graph else 0,
                      "eager_episodes": runners[a.dtype].eager if use_graph else None, "graphs": len(runners[a.dtype].graphs) if use_graph else 0},
     }

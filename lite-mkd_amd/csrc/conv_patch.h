@@ -148,7 +148,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     }
   };
   LB lb;
-  const bool neg = NPL == 3 && (tile & 1);      // odd row tiles accumulate -y: X3FragB::init
+  const bool neg = NPL == 3 && x3_neg_tile(tile, a.tiles_per_class);      // half the row tiles accumulate -y: X3FragB::init
   lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, neg);
   f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll

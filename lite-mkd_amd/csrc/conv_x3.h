@@ -66,6 +66,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const void* base, long
   return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long)hi << 32) | lo), 0, n, 0x00020000);
 }
 
+// which row tiles accumulate -y (X3FragB::init): the second half of the launch's row tiles.  Per-channel sums over the pixels of a
+// launch then see the MFMA's directional truncation with both signs in equal measure; and because a workgroup's XCD walks its row
+// tiles in order (xcd_decode), every XCD reads ONE copy of the weight planes at a time (alternating the sign from tile to tile
+// doubled the weight working set of each 4 MiB L2)
+__device__ __forceinline__ bool x3_neg_tile(int tile, int tiles_per_class) { return 2 * tile >= tiles_per_class && tiles_per_class > 1; }
+
 // Weight operand: split once per optimizer step into MFMA FRAGMENT order (lmkd_conv2d_split_weights)
 //   Wf[n-tile = col/32][k-group = k/16][plane][lane = col%32 + 32*h][8]  holds plane(W[col][16*kgroup + 8*h + j]), j = 0..7,
 // so the B fragments of one K-step (2 k-groups x 3 planes) of one 32-column tile are 6 KiB contiguous and each lane's 16 bytes
@@ -79,8 +85,8 @@ struct X3FragB {
   // The MFMA's addition of products 2^-8 ... 2^-16 smaller than its accumulator truncates toward -inf (measured: a mean error of
   // -4e-11 x K x rms per element in the three-plane modes, none with one plane, none on the fp32 pipe: tools/x3_bias_probe.py) - half an
   // fp32 ulp at most, but of ONE sign, so the per-channel sums over 10^5 .. 10^6 pixels of the BatchNorm backward pick it up
-  // coherently.  Workgroups of odd row tiles therefore accumulate -y (negated weights) and flip the sign in the epilogue: the bias
-  // alternates from tile to tile and cancels in every sum over pixels.
+  // coherently.  The workgroups of half the row tiles (x3_neg_tile) therefore accumulate -y (negated weights) and flip the sign in the
+  // epilogue: the bias has either sign on half the pixels and cancels in every sum over pixels.
   __device__ __forceinline__ void init(const void* wf, int ncols, int Kp, int col0 /* of this wave */, int lane, bool neg = false) {
     const long copy_bytes = (long)ncols * Kp * 2 * NPL;
     rs = x3_rsrc(reinterpret_cast<const unsigned char*>(wf) + (neg ? copy_bytes : 0), copy_bytes);
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   LA la;
   LB lb;
   la.init(a.src, (long)a.N * a.Hs * a.Ws * a.Cs, a.Hs, a.Ws, s_src, s_hw, taps, a.ntap[cls]);
-  const bool neg = NPL == 3 && !SMALLC && (tile & 1);      // odd row tiles accumulate -y (X3FragB::init); the stem (K = 224) does not
+  const bool neg = NPL == 3 && !SMALLC && x3_neg_tile(tile, a.tiles_per_class);      // the second half of the row tiles accumulates -y (X3FragB::init); the stem (K = 224) does not
   lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, neg);
   f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll

@@ -205,11 +205,26 @@ __device__ __forceinline__ bool colsum_ticket(const float* __restrict__ in, int 
   if (tx == 0 && ty == 0) *s_last = atomicAdd(&tickets[blockIdx.x], 1u) == (unsigned)(S - 1);
   __syncthreads();
   if (!*s_last) return false;
-  __threadfence();                                   // acquire: the other blocks' slice rows
+  __threadfence();                                   // acquire: the other blocks' slice rows (plain loads below: after the fence they
+                                                     // miss the non-coherent caches; device-scope atomic loads here serialised at ~1 us each)
+  // row lane q adds the slices q, q + 8, ... (all loads of a lane in flight together), the lanes are added in lane order
+  {
+    double a0 = 0.0, a1 = 0.0;
+    if (act) {
+      const double* sp = scratch + col;
+      int q = ty;
+      for (; q + CS_LANES < S; q += 2 * CS_LANES) {
+        a0 += sp[(long)q * CV];
+        a1 += sp[(long)(q + CS_LANES) * CV];
+      }
+      if (q < S) a0 += sp[(long)q * CV];
+    }
+    sm[ty][tx] = a0 + a1;
+  }
+  __syncthreads();
   if (ty == 0) {
     double a = 0.0;
-    if (act)
-      for (int q = 0; q < S; ++q) a += __hip_atomic_load(&scratch[(long)q * CV + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q = 0; q < CS_LANES; ++q) a += sm[q][tx];
     tot[tx] = a;
   }
   if (tx == 0 && ty == 0) tickets[blockIdx.x] = 0u;   // zero again for the next launch that uses this ticket buffer

@@ -59,7 +59,6 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
   int nk = a.steps_total - s0;
   if (nk > a.steps_per_split) nk = a.steps_per_split;
   const int halo = a.W + 1;
-  const bool neg = NPL == 3 && (z & 1);      // odd pixel splits accumulate -dW (wgrad_x3.h: the MFMA's directional truncation cancels in the slab sum)
 
   const __amdgpu_buffer_rsrc_t rs_dy = x3_rsrc(a.dy, (long)a.Mpix * a.Co * ESZ);
   const __amdgpu_buffer_rsrc_t rs_x = x3_rsrc(a.x, (long)a.Mpix * a.Cs * ESZ);
@@ -97,11 +96,7 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
     for (int i = 0; i < A_NI; ++i) {
       if (a_r + A_RPP * i >= LMKD_BK) continue;
       if constexpr (ACT16) tr_store8(s_dy, LDA, a_r + A_RPP * i, a_c, ra[i]);
-      else {
-        float4 v = as_f4(ra[i]);
-        if (neg) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
-        tr_store4<NPL, LDA, A_PLANE>(s_dy, a_r + A_RPP * i, a_c, v);
-      }
+      else tr_store4<NPL, LDA, A_PLANE>(s_dy, a_r + A_RPP * i, a_c, as_f4(ra[i]));
     }
   };
   auto store_x = [&](int q0) {
@@ -229,7 +224,7 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = co0 + cw * 32 + acc_row(e, lane);
-      if (row < a.Co) C[(long)row * a.Kp + col] = neg ? -acc[ti][e] : acc[ti][e];
+      if (row < a.Co) C[(long)row * a.Kp + col] = acc[ti][e];
     }
   }
 }

@@ -173,10 +173,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
   const int s0 = z * a.steps_per_split;
   int nk = a.steps_total - s0;
   if (nk > a.steps_per_split) nk = a.steps_per_split;
-  // three-plane modes: odd pixel splits accumulate -dW (dy negated when its tile is split) and store -acc: the directional
-  // truncation of the MFMA's mixed-magnitude additions (conv_x3.h, X3FragB::init) alternates in sign from slab to slab and cancels
-  // in the slab sum
-  const bool neg = NPL == 3 && (z & 1);
+  // (The directional truncation of the MFMA's mixed-magnitude additions - conv_x3.h, X3FragB::init - is left alone here: a slab is a
+  // sum over ~2.5 K pixels, the bias of a weight-gradient element is ~1e-6 of the tensor's rms and nothing sums weight gradients
+  // coherently over 10^5 terms afterwards.  Alternating the accumulation sign per pixel split was measured: it removes the bias, but
+  // the negation of dy at store time cost the rolling-window kernel 25 % - its register allocation - and was not kept.)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -194,11 +194,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
 #pragma unroll
     for (int i = 0; i < LA::NI; ++i) {
       if constexpr (ACT16) tr_store8(sa, IA::LDB, tid / LA::CPR + LA::KPP * i, la.r4, la.reg[i]);
-      else {
-        float4 v = la.reg[i];
-        if (neg) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
-        tr_store4<NPL, IA::LDB, IA::PLANE>(sa, tid / LA::CPR + LA::KPP * i, la.r4, v);
-      }
+      else tr_store4<NPL, IA::LDB, IA::PLANE>(sa, tid / LA::CPR + LA::KPP * i, la.r4, la.reg[i]);
     }
     if constexpr (B16) {
 #pragma unroll
@@ -285,7 +281,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane);
-        if (row < a.Co) C[(long)row * a.Kp + col] = neg ? -acc[i][j][e] : acc[i][j][e];
+        if (row < a.Co) C[(long)row * a.Kp + col] = acc[i][j][e];
       }
   }
 }

@@ -152,6 +152,46 @@ def _train_task_prepared(prepared, student, teacher, distiller, accuracy_fn, con
     return task_loss.detach(), task_accuracy, {"accuracy": task_accuracy}
 
 
+def init_model(config):
+    """trainwandb.py:53-68: Student / Teacher from the registry names in `config`, moved to config.device"""
+    from .model.model_select import Student, Teacher
+    student, teacher = Student(config), Teacher(config)
+    return student.to(config.device), teacher.to(config.device)
+
+
+class TestAccuracies:
+    """utils.TestAccuracies of the reference as far as make() uses it: the list of test sets a test run reports on"""
+
+    def __init__(self, test_sets):
+        self.datasets = list(test_sets)
+
+
+def make(config, video_loader=None, base_seed=0):
+    """trainwandb.py:78-109: everything the training loop needs, built from the reference's args namespace in the reference's order -
+    -> (student, teacher, video_loader, distillers, accuracy_fn, test_accuracies, optimizer, scheduler), the reference's tuple.
+    Differences that are the point of this build: the optimizer is FusedOptimizer (SGD / Adam kernels on the flat parameter and
+    gradient buffers; under torch.distributed its step() all-reduces the gradient bucket) and, because the dataset / video I/O layer
+    is outside the hot path (video_reader.VideoDataset: host JPEG decoding), the default `video_loader` is SyntheticEpisodes with the
+    dataset's shapes and dtypes - pass the real DataLoader to train on data.  The replicas' initial weights are broadcast from rank 0."""
+    from .distillers import Distiller
+    from .parallel import rank as _rank
+    from .utils import aggregate_accuracy
+    student, teacher = init_model(config)
+    test_set = [config.dataset]
+    if video_loader is None:
+        video_loader = SyntheticEpisodes(config, base_seed=base_seed, rank=_rank(), device=config.device)
+    distillers = Distiller(config.distill_name, config.cfg, config.device)
+    accuracy_fn = aggregate_accuracy
+    test_accuracies = TestAccuracies(test_set)
+    if config.opt not in ("adam", "sgd"):
+        raise KeyError(config.opt)
+    optimizer = FusedOptimizer(student, config.opt, config.learning_rate)
+    optimizer.bucket.broadcast_params(0)
+    scheduler = MultiStepLR(optimizer, milestones=config.sch, gamma=0.1)
+    optimizer.zero_grad()
+    return student, teacher, video_loader, distillers, accuracy_fn, test_accuracies, optimizer, scheduler
+
+
 class GraphedEpisode:
     """train_task as a captured hipGraph (torch.cuda.CUDAGraph): forward + loss + backward of one episode on the three HIP streams
     become ONE graph launch - ~600 kernel launches, their Python glue and the autograd engine leave the per-episode host path

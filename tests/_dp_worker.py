@@ -25,11 +25,8 @@ def main():
     cfg = default_args(shot=1, query_per_class=1, img_size=64, trans_dropout=0.0, device=dev, learning_rate=1e-2, save_dir=out_dir,
                        mode="w%d_" % world)
     torch.manual_seed(33)
-    student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
-    opt = TL.FusedOptimizer(student, "sgd", cfg.learning_rate)
-    opt.bucket.broadcast_params(0)
+    student, teacher, _, distiller, aggregate_accuracy, _, opt, _ = TL.make(cfg)      # trainwandb.py:78-109
     w0 = opt.bucket.flat.clone()
-    distiller = Distiller(cfg.distill_name, cfg.cfg, dev)
     src = TL.SyntheticEpisodes(cfg, base_seed=808, rank=0, device=dev)          # ONE global stream, dealt round-robin
     ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END = True, False
     for e in range(G):

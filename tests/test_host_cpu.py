@@ -257,3 +257,23 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "8", "--warmup", "2"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert len(bench.kernel_source_hash()) == 16
+
+
+def test_make_returns_the_reference_tuple():
+    """trainloop.make mirrors trainwandb.py:78-109: (student, teacher, video_loader, distillers, accuracy_fn, test_accuracies,
+    optimizer, scheduler) from the reference's args namespace; runs on the CPU (construction only, no kernel is launched)."""
+    import litemkd_amd  # noqa: F401
+    from litemkd_amd import trainloop as TL
+    from litemkd_amd.options import default_args
+    cfg = default_args(device=torch.device("cpu"), shot=1, query_per_class=1, img_size=32, opt="adam", learning_rate=3e-4, sch=[7, 9])
+    student, teacher, loader, distillers, accuracy_fn, test_acc, optimizer, scheduler = TL.make(cfg, base_seed=3)
+    assert type(student).__name__ == "Student" and type(teacher).__name__ == "Teacher"
+    assert optimizer.opt == "adam" and optimizer.lr == 3e-4 and scheduler.milestones == [7, 9] and test_acc.datasets == ["hmdb"]
+    assert callable(accuracy_fn) and hasattr(distillers, cfg.distill_name)
+    ep = next(iter(loader))
+    assert ep["support_set"].shape == (1, 40, 3, 32, 32) and ep["support_labels"].shape == (1, 5)
+    # every trainable parameter is a view into the optimizer's flat buffer, gradients zeroed
+    p0 = next(student.parameters())
+    assert p0.data_ptr() == optimizer.bucket.flat.data_ptr() and float(optimizer.bucket.grad.abs().max()) == 0.0
+    with pytest.raises(KeyError):
+        TL.make(default_args(device=torch.device("cpu"), opt="rmsprop"))
