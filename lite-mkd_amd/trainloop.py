@@ -219,8 +219,10 @@ class GraphedEpisode:
         self.replays = self.eager = 0
 
     def _key(self, task_dict):
+        """identity of the episode's tensors (the frames and teacher features must already be device tensors; the small label tensors
+        may live on the host - prepare_task moves them before the capture)"""
         ts = [task_dict[k] for k in self.KEYS]
-        if not all(t.is_cuda for t in ts):
+        if not all(t.is_cuda for t in ts[:4]):
             return None
         return tuple(t.data_ptr() for t in ts) + tuple(tuple(t.shape) for t in ts)
 
@@ -303,8 +305,8 @@ class GraphedEpisode:
         ent = self.graphs.get(key)
         if ent is None:
             if key not in self.seen:                                   # first sight: eager (also the warm-up of the capture)
-                if len(self.seen) > 64:
-                    return self._generic(task_dict)                    # device tensors, but new ones every time
+                if sum(1 for k in self.seen if k[0] != "generic") >= self.max_graphs:
+                    return self._generic(task_dict)                    # device tensors, but new ones every time (a data loader)
                 self.seen.add(key)
                 return self._eager(task_dict)
             if sum(1 for k in self.graphs if k[0] != "generic") >= self.max_graphs:

@@ -250,11 +250,14 @@ def test_data_parallel_world2_equals_world1(dev, tmp_path):
     assert not torch.equal(r0["backbone.resnet.1.running_mean"], r1["backbone.resnet.1.running_mean"])
 
 
-def test_graphed_episode_bit_identical_to_eager(dev):
+@pytest.mark.parametrize("fresh_tensors", [False, True])
+def test_graphed_episode_bit_identical_to_eager(dev, fresh_tensors):
     """trainloop.GraphedEpisode: the episode captured into a hipGraph (forward + loss + backward on three streams, dropout seeds and
     class plan in device memory, packed weights refreshed in place) replays the SAME kernels on the same data: losses, accuracies,
     accumulated gradients, BatchNorm running statistics and the weights after an optimizer step are bit-identical to the eager loop
-    over the same episodes with the same RNG state (dropout 0.1 active)."""
+    over the same episodes with the same RNG state (dropout 0.1 active).
+    fresh_tensors False: a resident pool of episodes - one graph per episode, captured on the episode's own tensors (bench.py);
+    True: every episode arrives in new tensors (a data loader) - ONE graph on static copies, inputs and class plan copied in."""
     from litemkd_amd import ops, trainloop as TL
     from litemkd_amd.model.model_select import Student, Teacher
     from litemkd_amd.distillers import Distiller
@@ -270,7 +273,7 @@ def test_graphed_episode_bit_identical_to_eager(dev):
         student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
         opt = TL.FusedOptimizer(student, "sgd", cfg.learning_rate)
         distiller = Distiller(cfg.distill_name, cfg.cfg, dev)
-        runner = TL.GraphedEpisode(student, teacher, distiller, aggregate_accuracy, cfg) if graph else None
+        runner = TL.GraphedEpisode(student, teacher, distiller, aggregate_accuracy, cfg, max_graphs=2) if graph else None
         prev = (ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD)
         ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD = True, False, True
         out = []
@@ -278,7 +281,8 @@ def test_graphed_episode_bit_identical_to_eager(dev):
             torch.manual_seed(5)                      # the dropout seeds are drawn from the CPU generator, one per head and episode
             for i, e in enumerate(order):
                 if graph:
-                    loss, acc, _ = runner(pool[e])
+                    ep = {k: v.clone() for k, v in pool[e].items()} if fresh_tensors else pool[e]
+                    loss, acc, _ = runner(ep)
                 else:
                     loss, acc, _ = TL.train_task(pool[e], student, teacher, distiller, aggregate_accuracy, cfg)
                 out.append((float(loss), float(acc)))
@@ -294,7 +298,10 @@ def test_graphed_episode_bit_identical_to_eager(dev):
         return out, opt.bucket.grad.clone(), opt.bucket.flat.clone(), stats, runner
     o_e, g_e, w_e, s_e, _ = run(False)
     o_g, g_g, w_g, s_g, runner = run(True)
-    assert runner.replays == len(order) - 2 and runner.eager == 2 and len(runner.graphs) == 2, (runner.replays, runner.eager)
+    if fresh_tensors:      # two new keys eager (max_graphs), then the generic graph: its first episode eager, captured on the next
+        assert runner.replays == len(order) - 3 and runner.eager == 3 and len(runner.graphs) == 1, (runner.replays, runner.eager)
+    else:                  # first sight of each of the two episodes eager, then their own graphs
+        assert runner.replays == len(order) - 2 and runner.eager == 2 and len(runner.graphs) == 2, (runner.replays, runner.eager)
     assert o_e == o_g, (o_e, o_g)
     assert torch.equal(w_e, w_g)
     assert torch.equal(g_e, g_g), float((g_e - g_g).abs().max())
