@@ -87,6 +87,10 @@ def main():
                     help="replay each resident episode as a captured hipGraph (trainloop.GraphedEpisode; default, LMKD_GRAPH=0 or --no-graph: "
                          "eager launches).  Same kernels, same results; the ~600 launches of an episode leave the host path")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
+    ap.add_argument("--stream-inputs", action="store_true", help="extra measurement after the headline line: every episode's inputs arrive "
+                    "from HOST memory - decoded uint8 frames (320x240, pinned) + teacher features go H2D on a copy stream, the GPU frame "
+                    "transform (Resize 256 / crop 224 / flip / ToTensor, video_transform.py) runs there too, overlapped with the previous "
+                    "episode's compute (trainwandb.py:419-443, video_reader.py:474-485); reported under `stream_inputs`, never as `value`")
     ap.add_argument("--emulate-world", type=int, default=0, help="single-GPU rehearsal of the per-rank cadence of a W-rank run: the optimizer "
                     "step (+ weight re-pack) every tasks_per_batch / W episodes; no collective runs, `value` stays the 1-GPU figure of that cadence")
     a = ap.parse_args()
@@ -365,6 +369,8 @@ def main():
         out["emulated_world"] = {"world": a.emulate_world, "episodes_per_optimizer_step": every,
                                  "note": "per-rank cadence of a %d-rank run rehearsed on ONE GPU (optimizer step + weight re-pack every %d episodes, "
                                          "no collective): value x %d would be the job's rate at perfect scaling" % (a.emulate_world, every, a.emulate_world)}
+    if a.stream_inputs:
+        out["stream_inputs"] = stream_inputs_pass(a, cfg, dev, student, teacher, distiller, aggregate_accuracy, opt, sch, every, fence, TL, ops)
     if world == 1 and a.dtype == "f32" and not a.no_other_modes:
         # the same job in the two other arithmetic modes of the convolutions, for the record (never part of `value`):
         # short timed regions right here, same process, same resident episodes, each with its own per-kernel roofline pass
@@ -404,6 +410,81 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stream_inputs_pass(a, cfg, dev, student, teacher, distiller, accuracy_fn, opt, sch, every, fence, TL, ops, episodes=None):
+    """The input side inside the loop (trainwandb.py:419-443 prepare_task + video_reader.py:474-485 the loader's output): per episode
+    92 MB of decoded uint8 frames (50 videos x 8 frames of 320x240x3, HMDB's resolution) and 3.3 MB of teacher features leave
+    PINNED host memory on a copy stream; Resize(256) -> crop 224 / flip -> ToTensor run on that stream as HIP kernels
+    (GpuFrameTransform.batch) into one of two static NHWC4 input sets; the compute stream waits for the set's event and the copy
+    stream, before overwriting a set, for the episode that last read it.  Episode i + 1 is staged while episode i computes."""
+    import random
+    from litemkd_amd.video_transform import GpuFrameTransform
+    n = episodes or a.steps
+    way, L = cfg.way, cfg.seq_len
+    ns, nq = way * cfg.shot, way * cfg.query_per_class
+    nv = ns + nq
+    g = torch.Generator().manual_seed(4321)
+    host = []
+    for e in range(2):      # two decoded episodes in pinned memory, cycled (what a loader's worker processes would hand over)
+        host.append({"frames": torch.randint(0, 256, (nv * L, 240, 320, 3), dtype=torch.uint8, generator=g).pin_memory(),
+                     "feat": torch.randn(nv, L, 2048, generator=g).pin_memory(),
+                     "sl": torch.arange(way).repeat_interleave(cfg.shot)[torch.randperm(ns, generator=g)].float(),
+                     "tl": torch.arange(way).repeat_interleave(cfg.query_per_class)[torch.randperm(nq, generator=g)].float()})
+    tf = GpuFrameTransform(cfg.img_size, dev)
+    copy = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    sets = [{"u8": torch.empty((nv * L, 240, 320, 3), dtype=torch.uint8, device=dev),
+             "x": torch.empty((nv * L, cfg.img_size, cfg.img_size, 4), dtype=torch.float32, device=dev),
+             "feat": torch.empty((nv, L, 2048), dtype=torch.float32, device=dev),
+             "ready": torch.cuda.Event(), "free": torch.cuda.Event(), "h2d": (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))}
+            for _ in range(2)]
+    for s_ in sets:
+        s_["free"].record(main)
+    random.seed(99)
+
+    def stage(i):
+        h, s_ = host[i % 2], sets[i % 2]
+        params = [tf.draw(240, 320, True) for _ in range(nv)]
+        with torch.cuda.stream(copy):
+            copy.wait_event(s_["free"])                    # the episode that last read this set has finished
+            s_["h2d"][0].record(copy)
+            s_["u8"].copy_(h["frames"], non_blocking=True)
+            s_["feat"].copy_(h["feat"], non_blocking=True)
+            s_["h2d"][1].record(copy)
+            tf.batch(s_["u8"], params, L, out=s_["x"])
+            s_["ready"].record(copy)
+        return {"support_set": s_["x"][:ns * L].unsqueeze(0), "target_set": s_["x"][ns * L:].unsqueeze(0),
+                "support_set_feature_teacher": s_["feat"][:ns].unsqueeze(0), "target_set_feature_teacher": s_["feat"][ns:].unsqueeze(0),
+                "support_labels": h["sl"].unsqueeze(0), "target_labels": h["tl"].unsqueeze(0)}
+
+    def loop(k, it):
+        nxt = stage(0)
+        for i in range(k):
+            it += 1
+            ep, s_ = nxt, sets[i % 2]
+            if i + 1 < k:
+                nxt = stage(i + 1)                         # staged while episode i computes
+            main.wait_event(s_["ready"])
+            TL.train_task(ep, student, teacher, distiller, accuracy_fn, cfg)
+            s_["free"].record(main)
+            if (it + 1) % every == 0:
+                opt.step()
+                opt.zero_grad()
+            sch.step()
+        return it
+    it = loop(3, 0)
+    fence()
+    t0 = time.perf_counter()
+    loop(n, it)
+    fence()
+    dt = time.perf_counter() - t0
+    nbytes = sets[0]["u8"].numel() + 4 * sets[0]["feat"].numel()
+    h2d_ms = sum(s_["h2d"][0].elapsed_time(s_["h2d"][1]) for s_ in sets) / len(sets)
+    return {"value": n / dt, "unit": "episodes/s", "steps": n, "h2d_bytes_per_episode": nbytes, "h2d_ms_per_episode": h2d_ms,
+            "pcie_GBps": nbytes / (h2d_ms * 1e-3) / 1e9,
+            "what": "eager episodes with every episode's inputs streamed from pinned host memory (uint8 frames 320x240 + teacher features), "
+                    "GPU frame transform on the copy stream, double-buffered; compare with `value` (inputs resident in HBM)"}
 
 
 def usable_cores():

@@ -61,7 +61,10 @@ class TemporalCrossTransformer(nn.Module):
         p = self.pe.p
         if not self.training or p <= 0.0:
             return None
-        return ops.dropout_mask((n_rows, 2048), p, self.draw_dropout_seed(), device)
+        # while a hipGraph is being captured the kernel reads its seed from a device slot (ops.SEED_SLOTS) that the replay loop fills:
+        # the capture itself must not consume a draw, or the replays' seed sequence would lag the eager loop's by one episode
+        seed = 0 if ops.SEED_SLOTS is not None else self.draw_dropout_seed()
+        return ops.dropout_mask((n_rows, 2048), p, seed, device)
 
     def forward(self, support_set, support_labels, queries, with_sim=False):
         L = self.args.seq_len

@@ -152,6 +152,56 @@ def _grad_target(param):
     return param.grad
 
 
+# Inference Linear on the bf16-plane convolution kernels: y = relu?(x W^T + b) is a 1x1 convolution over M one-pixel "frames" whose
+# BatchNorm-affine epilogue (lmkd_conv2d_fwd_bn: acc * scale + shift, ReLU) carries scale = 1, shift = b.  In the library's default
+# arithmetic (fp32 as 3 x bf16) this runs the MFM teacher's 0.57 TFLOP of encoder GEMMs on the bf16 matrix pipe instead of the
+# fp32 MFMA of gemm_kernel; the packed / split weights of the frozen modules are cached like the trunk's.
+_AFFINE_CACHE = {}
+
+
+def linear_infer(x, w, b=None, relu=False):
+    M, K = x.shape
+    N = w.shape[0]
+    cd = lib().value("lmkd_conv_get_compute_dtype")
+    if cd == 0 or K % 32 != 0 or N % 32 != 0 or _ACT_DTYPE[0] is not torch.float32 or torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        y = _empty((M, N), x)
+        return gemm("K", "K", M, N, K, x, K, w, K, y, N, bias=b, relu=relu)
+    _chk(x, w, b)
+    mark_cacheable(w)
+    wp = _pack_linear(w, w.view(N, K, 1, 1), K)
+    key = (b.data_ptr() if b is not None else 0, N, b._version if b is not None else 0)
+    st = _AFFINE_CACHE.get(key)
+    if st is None:
+        st = torch.zeros((5, N), dtype=torch.float32, device=x.device)
+        st[2].fill_(1.0)
+        if b is not None:
+            st[3].copy_(b)
+        if len(_AFFINE_CACHE) > 256:
+            _AFFINE_CACHE.clear()
+        _AFFINE_CACHE[key] = st
+    y = _empty((M, N), x)
+    lib().call("lmkd_conv2d_fwd_bn", _p(x), _p(wp), _p(y), _p(st), None, int(relu), M, 1, 1, K, N, 1, 1, 1, 0, _stream())
+    return y
+
+
+def _pack_linear(w, w4, K):
+    """pack cache entry of a 2-D Linear weight, packed as the [N, K, 1, 1] convolution weight it is"""
+    e = _pack_cache[w.data_ptr()]
+    tag = (w._version, WEIGHT_EPOCH[0])
+    key = (K, 0, lib().value("lmkd_conv_get_compute_dtype"))
+    cur = torch.cuda.current_stream()
+    hit = e["packs"].get(key)
+    if hit is not None and hit[0] == tag:
+        if hit[3] is not None and hit[3] != cur.cuda_stream:
+            cur.wait_event(hit[2])
+        return hit[1]
+    wp = _pack_weights(w4, K, 0, out=hit[1] if hit is not None else None)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    e["packs"][key] = (tag, wp, ev, cur.cuda_stream)
+    return wp
+
+
 class LinearFn(torch.autograd.Function):
     """nn.Linear (resnet18_2fc.py:56-64 fc1/fc2).  fwd/dgrad/wgrad on the MFMA GEMM, bias grad = column sum."""
 
@@ -698,7 +748,7 @@ class StemFn(torch.autograd.Function):
         return None, dw, dgamma, dbeta, None, None, None
 
 
-def frames_u8_to_nhwc4(frames_u8, crop_y, crop_x, flip, size, frames_per_video=8):
+def frames_u8_to_nhwc4(frames_u8, crop_y, crop_x, flip, size, frames_per_video=8, out=None):
     """uint8 frames [F,Hs,Ws,3] (after the host Resize) -> float NHWC4 [F,size,size,4] in [0,1]: per-video crop offsets and
     horizontal-flip flags (int32 device tensors, one entry per video), ToTensor scaling.  The result can be passed to the
     backbones in place of the float NCHW frames (the stem recognises the layout)."""
@@ -709,7 +759,10 @@ def frames_u8_to_nhwc4(frames_u8, crop_y, crop_x, flip, size, frames_per_video=8
     nv = F_ // frames_per_video
     if nv * frames_per_video != F_ or crop_y.numel() != nv or crop_x.numel() != nv or flip.numel() != nv:
         raise RuntimeError("one crop/flip entry per video of %d frames expected" % frames_per_video)
-    out = torch.empty((F_, size, size, 4), dtype=torch.float32, device=frames_u8.device)
+    if out is None:
+        out = torch.empty((F_, size, size, 4), dtype=torch.float32, device=frames_u8.device)
+    elif tuple(out.shape) != (F_, size, size, 4) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("frames_u8_to_nhwc4: `out` must be a contiguous float32 [%d, %d, %d, 4] tensor" % (F_, size, size))
     lib().call("lmkd_frames_u8_to_nhwc4", _p(frames_u8), _p(out), _p(crop_y), _p(crop_x), _p(flip), F_, Hs, Ws, size, size,
                frames_per_video, _stream())
     return out

@@ -54,15 +54,15 @@ def _encoder_layer(x, layer, L, nhead):
     """nn.TransformerEncoderLayer defaults: post-norm, ReLU, eps 1e-5, batch_first.  x [B*L, D]"""
     M, D = x.shape
     at = layer.self_attn
-    qkv = ops.linear_fwd(x, at.in_proj_weight, at.in_proj_bias)
+    # the four Linear layers: ops.linear_infer - the bf16-plane convolution kernels (1x1 convolution + bias / ReLU epilogue) in the
+    # library's default arithmetic, the fp32 MFMA GEMM in the native mode
+    qkv = ops.linear_infer(x, at.in_proj_weight, at.in_proj_bias)
     ctx = torch.empty_like(x)
     lib().call("lmkd_mha_small", _p(qkv), _p(ctx), M // L, L, D, nhead, _s())
-    o = ops.linear_fwd(ctx, at.out_proj.weight, at.out_proj.bias)
+    o = ops.linear_infer(ctx, at.out_proj.weight, at.out_proj.bias)
     x = layernorm(x, layer.norm1.weight, layer.norm1.bias, o, M)
-    dff = layer.linear1.weight.shape[0]
-    h = torch.empty((M, dff), dtype=torch.float32, device=x.device)
-    ops.gemm("K", "K", M, dff, D, x, D, layer.linear1.weight, D, h, dff, bias=layer.linear1.bias, relu=True)
-    f = ops.linear_fwd(h, layer.linear2.weight, layer.linear2.bias)
+    h = ops.linear_infer(x, layer.linear1.weight, layer.linear1.bias, relu=True)
+    f = ops.linear_infer(h, layer.linear2.weight, layer.linear2.bias)
     return layernorm(x, layer.norm2.weight, layer.norm2.bias, f, M)
 
 
@@ -89,7 +89,7 @@ class _Fusion(nn.Module):
         h = cat
         for layer in self.transformer_encoder.layers:
             h = _encoder_layer(h, layer, L, self.n_mod)
-        return ops.linear_fwd(h, self.f1.weight, self.f1.bias).reshape(N, L, d)
+        return ops.linear_infer(h, self.f1.weight, self.f1.bias).reshape(N, L, d)
 
 
 class ThreeTransforTemproal(_Fusion):

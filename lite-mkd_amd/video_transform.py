@@ -76,6 +76,18 @@ class GpuFrameTransform:
                 out[i * L:(i + 1) * L] = x[j * L:(j + 1) * L]
         return out
 
+    def batch(self, frames_u8, params, frames_per_video=8, out=None):
+        """the same transform for an episode whose decoded frames share one resolution and already sit in ONE uint8 device tensor
+        [F, H, W, 3] (one H2D copy of the whole episode): resize + crop / flip / ToTensor, two launches + the crop parameters.
+        params: [(flip, x1, y1)] per video (draw()).  out: optional preallocated [F, S, S, 4] fp32 tensor (static input buffers)."""
+        S = self.img_size
+        r = ops.resize_frames_u8(frames_u8, self.resize)
+        ow = r.shape[2]
+        i32 = lambda vals: torch.tensor(vals, dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)      # noqa: E731
+        cx = [(ow - S - p[1]) if p[0] else p[1] for p in params]
+        return ops.frames_u8_to_nhwc4(r, i32([p[2] for p in params]), i32(cx), i32([int(p[0]) for p in params]), S,
+                                      frames_per_video=frames_per_video, out=out)
+
 
 def load_teacher_feature(path):
     """video_reader.py:393-394: the fused teacher feature of one video, `feature.npy` [8, 2048] -> tensor"""
