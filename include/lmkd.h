@@ -65,6 +65,7 @@ int lmkd_conv_set_wgrad_planes(int on); /* tuning (modes 1-3): 1 = weight gradie
 int lmkd_conv_set_patch(int on); /* tuning (modes 1-3): 1 = same-size convolutions (3x3 / stride 1 forward and data gradient) read an LDS-resident input patch (default), 0 = im2col gather */
 int lmkd_conv_set_stem_patch(int on); /* tuning (modes 1-3): 1 = the 7x7 / stride-2 stem convolution reads an LDS-resident patch of input rows (default), 0 = im2col gather */
 int lmkd_conv_set_wgrad_window(int on); /* tuning (modes 1-3): 1 = 3x3 / stride-1 weight gradients read a rolling LDS window of x, all nine taps per workgroup (default), 0 = im2col-gather kernel */
+int lmkd_conv_set_patch_debug(int mask); /* measurement only: timing ablations of the patch kernel (results are garbage): 1 no weight-fragment loads, 2 no A-fragment LDS reads, 4 no patch split / store, 8 no output stores; 0 = off */
 int lmkd_conv_set_xcd_mode(int mode); /* tuning: -1 auto (XCD-aware tile order + XCD-grouped weight-gradient splits), 0 plain orders, 1 auto without the weight-gradient grouping */
 int lmkd_conv_set_tile(int id); /* tuning: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 64x128 */
 /* stat_partial (nullable): [row_tiles][Cout][2] per-tile (sum, sum of squares) for train-mode BatchNorm */

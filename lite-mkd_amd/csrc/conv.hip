@@ -674,6 +674,9 @@ static inline bool conv_same_size(int H, int W, int KH, int KW, int stride, int 
   return g_conv_patch && stride == 1 && conv_out(H, KH, stride, pad) == H && conv_out(W, KW, stride, pad) == W && (KH / 2) * W + KW / 2 <= PATCH_HALO_MAX;
 }
 
+static int g_patch_debug = 0;      // timing ablations of conv_patch_x3_kernel (DBG template argument; tools/patch_ablate.py); 0 = the product kernel
+extern "C" int lmkd_conv_set_patch_debug(int mask) { g_patch_debug = mask & 15; return LMKD_OK; }
+
 template <class Cfg>
 static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
   a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
@@ -696,6 +699,27 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
     }                                                                                                                          \
     hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>), grid, dim3(Cfg::THREADS), lds, s, a);                      \
   } while (0)
+  if constexpr (Cfg::BM == 128 && Cfg::BN == 64 && Cfg::THREADS == 256) {      // ablation instances exist for the benchmark's main tile only
+    if (g_patch_debug && g_conv_x3 == 6 && !g_lmkd_act_bf16 && !a.pre_stats && !a.ep_stats) {
+#define LMKD_PATCH_DBG(D)                                                                                                      \
+  do {                                                                                                                         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, 6, false, 0, D>),                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));   \
+    hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, 6, false, 0, D>), grid, dim3(Cfg::THREADS), lds, s, a);                      \
+  } while (0)
+      switch (g_patch_debug) {
+        case 1: LMKD_PATCH_DBG(1); return;
+        case 2: LMKD_PATCH_DBG(2); return;
+        case 3: LMKD_PATCH_DBG(3); return;
+        case 4: LMKD_PATCH_DBG(4); return;
+        case 7: LMKD_PATCH_DBG(7); return;
+        case 8: LMKD_PATCH_DBG(8); return;
+        case 15: LMKD_PATCH_DBG(15); return;
+        default: break;
+      }
+#undef LMKD_PATCH_DBG
+    }
+  }
   if (a.ep_stats) {      // inference: BatchNorm affine (+ residual, ReLU) in the epilogue, fp32 tensors
     if (g_conv_bf16) LMKD_PATCH(1, false, 4);
     else if (g_conv_x3 == 9) LMKD_PATCH(9, false, 4);

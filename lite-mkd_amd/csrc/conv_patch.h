@@ -23,7 +23,10 @@ template <int NPL> struct PatchRow { static constexpr int BYTES = NPL == 1 ? 80 
 // dynamic LDS bytes of a launch
 static inline size_t patch_lds_bytes(int bm, int halo, int npl) { return (size_t)(bm + 2 * halo + 1) * (npl == 1 ? 80 : 208); }
 
-template <class Cfg, int NPROD, bool PRE, int IO>
+// DBG (tools/patch_ablate.py, never in the product path): timing ablations that leave a part of the work out - results are garbage -
+// to see what the kernel waits for: 1 = no weight-fragment loads after the first two steps, 2 = no A-fragment LDS reads after the
+// first step, 4 = no patch split / LDS store (the loads are still issued), 8 = no output stores
+template <class Cfg, int NPROD, bool PRE, int IO, int DBG = 0>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(ConvGemmArgs a) {
   constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0, EP = (IO & 4) != 0;      // IO bits: conv_gemm_x3_kernel
   constexpr int NPL = NPROD == 1 ? 1 : 3;
@@ -160,17 +163,20 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
   const int nk = ntap * a.cps;
   u32x4 rb0[LB::NR], rb1[LB::NR];
   int b_tp = 0, b_cc = 0;      // (tap, chunk) of the next B fragments to fetch
+  int dbg_b = 0;
   auto issue_b = [&](u32x4 (&rb)[LB::NR]) {
+    if ((DBG & 1) && ++dbg_b > 2) return;
     lb.load(s_tap_kofs[b_tp] + b_cc * LMKD_BK, rb);
     if (++b_tp == ntap) { b_tp = 0; ++b_cc; }
   };
+  bf16x8 dbg_av[(DBG & 2) ? 2 : 1][NPL][Cfg::TM];
   int k_tp = 0, k_cc = 0;      // (tap, chunk) of the current K-step
   // K-step t: MFMAs with the B set `rb`; afterwards the set fetched before them (`rbn`, step t+1) is landed - every load in flight
   // is then one MFMA phase old - and `rb` is refilled with step t+2.  At a chunk boundary the patch is replaced first.
   auto step = [&](int t, u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR]) {
     if (k_tp == 0) {
       __syncthreads();                       // every wave has finished reading the previous chunk
-      store_patch();
+      if (!(DBG & 4) || t == 0) store_patch();
       __syncthreads();
       if (k_cc + 1 < a.cps) issue_patch(k_cc + 1);
     }
@@ -182,10 +188,20 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     constexpr bool AHEAD = NPL * Cfg::TM < 12 && (Cfg::THREADS == 512 || NPL == 1);
     bf16x8 av[2][NPL][Cfg::TM];
     auto read_a = [&](int g) {
+      if ((DBG & 2) && t > 0) {      // ablation: the fragments of the first step, kept in registers
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+          for (int i = 0; i < Cfg::TM; ++i) av[AHEAD ? g : 0][p][i] = dbg_av[g][p][i];
+        return;
+      }
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
 #pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i) av[AHEAD ? g : 0][p][i] = *reinterpret_cast<const bf16x8*>(psm + ad[i] + p * 64 + g * 32);
+        for (int i = 0; i < Cfg::TM; ++i) {
+          av[AHEAD ? g : 0][p][i] = *reinterpret_cast<const bf16x8*>(psm + ad[i] + p * 64 + g * 32);
+          if (DBG & 2) dbg_av[g][p][i] = av[AHEAD ? g : 0][p][i];
+        }
     };
     read_a(0);
     if (AHEAD) read_a(1);
@@ -253,6 +269,17 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
       step(t + 1, rb1, rb0);
     }
     if (t < nk) step(t, rb0, rb1);
+  }
+  if (DBG & 8) {      // ablation: keep the accumulators alive without storing them
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
+    if (sacc == 1.2345e-30f) a.out[0] = sacc;
+    return;
   }
   x3_epilogue<Cfg, true, OUT16, EP>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid, neg);
 }
