@@ -87,6 +87,10 @@ def main():
                     help="replay each resident episode as a captured hipGraph (trainloop.GraphedEpisode; default, LMKD_GRAPH=0 or --no-graph: "
                          "eager launches).  Same kernels, same results; the ~600 launches of an episode leave the host path")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=os.environ.get("LMKD_PIPELINE", "1") != "0",
+                    help="software pipelining across episodes (trainloop.PipelinedEpisodes, default): the forward of episode i + 1 runs beside "
+                         "the backward of episode i on a second stream set; same kernels, same results, same optimizer cadence")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false")
     ap.add_argument("--stream-inputs", action="store_true", help="extra measurement after the headline line: every episode's inputs arrive "
                     "from HOST memory - decoded uint8 frames (320x240, pinned) + teacher features go H2D on a copy stream, the GPU frame "
                     "transform (Resize 256 / crop 224 / flip / ToTensor, video_transform.py) runs there too, overlapped with the previous "
@@ -148,7 +152,9 @@ def main():
         mods = [{k: torch.randn(nv, cfg.seq_len, 2048, generator=g, device=dev).abs() for k in ("rgb", "depth", "flow")}
                 for _ in range(a.pool)]
     every = max(1, cfg.tasks_per_batch // (a.emulate_world if a.emulate_world > 0 else world))
-    use_graph = a.graph and not a.serial and mfm is None
+    use_pipe = a.pipeline and not a.serial and mfm is None
+    use_graph = a.graph and not a.serial and mfm is None and not use_pipe
+    pipe = TL.PipelinedEpisodes(student, teacher, distiller, aggregate_accuracy, cfg) if use_pipe else None
     runners = {}      # one GraphedEpisode per arithmetic mode: a captured graph holds that mode's kernels and packed-weight buffers
     state = {"mode": a.dtype}
 
@@ -169,14 +175,20 @@ def main():
                 ns = cfg.way * cfg.shot
                 ep = dict(ep, support_set_feature_teacher=fused[:ns].unsqueeze(0), target_set_feature_teacher=fused[ns:].unsqueeze(0))
             graphed = graph_runner()
-            if graphed is not None:
+            if pipe is not None and state.get("pipe", True):
+                pipe.push(ep)
+            elif graphed is not None:
                 graphed(ep)
             else:
                 TL.train_task(ep, student, teacher, distiller, aggregate_accuracy, cfg)
             if (it + 1) % every == 0:
+                if pipe is not None:
+                    pipe.flush()                       # the step needs the gradients of every episode up to this one
                 opt.step()
                 opt.zero_grad()
             sch.step()
+        if pipe is not None:
+            pipe.flush()
         return it
 
     def fence():
@@ -362,6 +374,7 @@ def main():
         # queue whenever the GPU is the bottleneck
         "host_enqueue_ms_per_episode": host_idle * 1e3,
         "host_loop_ms_per_episode_in_timed_region": t_enq / a.steps * 1e3,
+        "episode_pipelining": bool(use_pipe),
         "hipgraph": {"enabled": bool(use_graph), "replays": runners[a.dtype].replays if use_graph else 0,
                      "eager_episodes": runners[a.dtype].eager if use_graph else None, "graphs": len(runners[a.dtype].graphs) if use_graph else 0},
     }

@@ -144,6 +144,7 @@ class ResNet50Trunk(ResNet18Trunk):
 # its OWN batch statistics; the running-statistics updates are deferred and applied in the reference's order
 # (support, then query).  autograd runs each call's backward on the stream of its forward, so the backward overlaps too.
 OVERLAP_TRUNK_CALLS = True
+_BN_UPDATE_EVENT = {}
 
 
 def two_trunk_calls(trunk, head, context_frames, target_frames):
@@ -179,8 +180,17 @@ def two_trunk_calls(trunk, head, context_frames, target_frames):
     main.wait_stream(side)
     tf.record_stream(main)
     if defer:
+        # the running-statistics updates of successive episodes stay in program order also when the episodes' forwards run on
+        # different stream sets (trainloop.PipelinedEpisodes)
+        key = context_frames.device.index
+        prev = _BN_UPDATE_EVENT.get(key)
+        if prev is not None:
+            main.wait_event(prev)
         ops.apply_deferred(s_upd + q_upd)
         trunk.bump_counters(2)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        _BN_UPDATE_EVENT[key] = ev
     return cf, tf
 
 

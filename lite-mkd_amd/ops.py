@@ -145,10 +145,10 @@ def _grad_target(param):
     # kernels of the side stream (query-frame trunk call: BatchNorm parameters) and of the auxiliary stream (second TRX head: TRX
     # parameters) add to the shadow buffer, everything on the caller's stream to .grad: no address is ever added to from two streams
     cur = torch.cuda.current_stream(param.device).cuda_stream
-    key = (param.device.type, param.device.index)
-    for other in (_side_streams.get(key), _aux_streams.get(key)):
-        if other is not None and cur == other.cuda_stream:
-            return e[1]
+    for table in (_side_streams, _aux_streams):
+        for key, other in table.items():
+            if key[1] == param.device.index and cur == other.cuda_stream:
+                return e[1]
     return param.grad
 
 
@@ -598,14 +598,31 @@ def apply_deferred(entries):
         lib().call("lmkd_bn_running_update", _p(rm), _p(rv), _p(stats), rm.shape[0], _f32(BN_MOMENTUM), _stream())
 
 
+# Stream sets ("lanes").  An episode uses up to three forward streams: the caller's (support-frame trunk call, heads, loss), a side
+# stream (query-frame trunk call) and an auxiliary one (frozen teacher head, second TRX head).  trainloop.PipelinedEpisodes runs
+# the forward of episode i + 1 beside the backward of episode i: the two episodes in flight use different lanes (LANE 0 / 1), each
+# with a main stream of its own (lane_main) in place of the caller's.
+LANE = [0]
 _side_streams = {}
+_lane_mains = {}
+
+
+def set_lane(k):
+    LANE[0] = int(k)
 
 
 def side_stream(device):
-    key = (device.type, device.index)
+    key = (device.type, device.index, LANE[0])
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]
+
+
+def lane_main(device):
+    key = (device.type, device.index, LANE[0])
+    if key not in _lane_mains:
+        _lane_mains[key] = torch.cuda.Stream(device=device)
+    return _lane_mains[key]
 
 
 HEADS_ON_TWO_STREAMS = True      # TRX_2fcsup: the 'ce' head on the auxiliary stream beside the 'kl' head
@@ -614,7 +631,7 @@ _aux_streams = {}
 
 def aux_stream(device):
     """a third forward stream: the frozen teacher head of an episode runs there beside the student's trunk (trainloop.train_task)"""
-    key = (device.type, device.index)
+    key = (device.type, device.index, LANE[0])
     if key not in _aux_streams:
         _aux_streams[key] = torch.cuda.Stream(device=device)
     return _aux_streams[key]

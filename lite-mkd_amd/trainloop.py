@@ -125,6 +125,13 @@ def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
 
 
 def _train_task_prepared(prepared, student, teacher, distiller, accuracy_fn, config):
+    task_loss, task_accuracy = _episode_forward(prepared, student, teacher, distiller, accuracy_fn, config)
+    task_loss.backward(retain_graph=False)
+    return task_loss.detach(), task_accuracy, {"accuracy": task_accuracy}
+
+
+def _episode_forward(prepared, student, teacher, distiller, accuracy_fn, config):
+    """forward + loss + accuracy of one episode (trainwandb.py:190-283) -> (task_loss with its autograd graph, accuracy)"""
     (context_images, target_images, context_teacher_feature, target_teacher_feature, context_labels,
      target_labels, _, _) = prepared
     teacher_model_dict, joined = _teacher_forward(teacher, context_teacher_feature, context_labels, target_teacher_feature, config.way)
@@ -148,8 +155,74 @@ def _train_task_prepared(prepared, student, teacher, distiller, accuracy_fn, con
         task_accuracy = accuracy_fn(target_logits["kl"], target_labels)
     else:
         task_accuracy = accuracy_fn(target_logits, target_labels)
-    task_loss.backward(retain_graph=False)
-    return task_loss.detach(), task_accuracy, {"accuracy": task_accuracy}
+    return task_loss, task_accuracy
+
+
+class PipelinedEpisodes:
+    """Software pipelining ACROSS episodes: the forward of episode i + 1 is queued (on the other stream set, ops.set_lane) before the
+    backward of episode i, so the two run side by side on the GPU.  Within one episode the launch sequence has stretches the chip
+    cannot fill - the matcher / loss section between the trunk's forward and backward (~2 ms of 126-workgroup GEMMs and
+    wavefront-reduction kernels on an otherwise idle chip), the stem / pooling passes, every convolution launch's last partial round
+    of workgroups (10-20 % of a launch at 200 frames) - and the only other work available is the second trunk call's.  Two
+    episodes in flight double that supply.  Nothing else changes: each episode runs the same kernels on the same data; forwards stay
+    in program order among themselves (BatchNorm running statistics), backwards too (every gradient accumulates in the order of the
+    sequential loop, so the flat gradient buffer is bit-identical to it), weights only change in the optimizer step, before which
+    flush() drains the pipeline.
+
+        pipe = PipelinedEpisodes(student, teacher, distiller, accuracy_fn, config)
+        for task_dict in loader:
+            done = pipe.push(task_dict)          # -> (loss, accuracy) of the PREVIOUS episode, or None for the first
+            if optimizer step due: pipe.flush(); optimizer.step(); optimizer.zero_grad()
+        pipe.flush()                             # -> (loss, accuracy) of the last episode; the caller's stream waits for everything"""
+
+    def __init__(self, student, teacher, distiller, accuracy_fn, config):
+        self.student, self.teacher, self.distiller, self.accuracy_fn, self.config = student, teacher, distiller, accuracy_fn, config
+        self.pending = None
+        self.bwd_done = None
+        self.count = 0
+
+    def push(self, task_dict):
+        dev = self.config.device
+        caller = torch.cuda.current_stream(dev)
+        lane = self.count & 1
+        self.count += 1
+        ops.set_lane(lane)
+        try:
+            main = ops.lane_main(dev)
+            main.wait_stream(caller)                 # the optimizer's weight update / zeroed gradients, the caller's input tensors
+            with torch.cuda.stream(main):
+                prepared = prepare_task(task_dict, dev)
+                loss, acc = _episode_forward(prepared, self.student, self.teacher, self.distiller, self.accuracy_fn, self.config)
+            prev, self.pending = self.pending, (loss, acc, lane)
+            return self._backward(prev) if prev is not None else None
+        finally:
+            ops.set_lane(0)
+
+    def _backward(self, item):
+        loss, acc, lane = item
+        dev = self.config.device
+        ops.set_lane(lane)
+        try:
+            main = ops.lane_main(dev)
+            with torch.cuda.stream(main):
+                if self.bwd_done is not None:
+                    main.wait_event(self.bwd_done)       # gradients accumulate in episode order
+                loss.backward(retain_graph=False)
+                ev = torch.cuda.Event()
+                ev.record(main)                          # (the autograd engine has joined the lane's other streams into `main`)
+                self.bwd_done = ev
+        finally:
+            ops.set_lane(0)
+        return loss.detach(), acc
+
+    def flush(self):
+        """run the pending backward; afterwards the caller's current stream waits for every episode pushed so far"""
+        out = None
+        if self.pending is not None:
+            out, self.pending = self._backward(self.pending), None
+        if self.bwd_done is not None:
+            torch.cuda.current_stream(self.config.device).wait_event(self.bwd_done)
+        return out
 
 
 def init_model(config):

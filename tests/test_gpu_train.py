@@ -308,3 +308,54 @@ def test_graphed_episode_bit_identical_to_eager(dev, fresh_tensors):
     for k in s_e:
         assert torch.equal(s_e[k], s_g[k]), k
     assert len({l for l, _ in o_e}) > 4                 # the episodes really differ (dropout masks, optimizer step)
+
+
+def test_pipelined_episodes_bit_identical_to_sequential(dev):
+    """trainloop.PipelinedEpisodes: the forward of episode i + 1 queued beside the backward of episode i on a second stream set.
+    Same kernels on the same data, forwards and backwards each in program order: losses, accuracies, the accumulated flat gradient
+    (incl. the side-stream shadow), BatchNorm running statistics and the weights after the optimizer steps are BIT-identical to the
+    sequential loop (dropout 0.1 active, same RNG state, an optimizer step in the middle and one at the end)."""
+    from litemkd_amd import ops, trainloop as TL
+    from litemkd_amd.options import default_args
+    cfg = default_args(shot=1, query_per_class=1, img_size=64, trans_dropout=0.1, device=dev, learning_rate=1e-2)
+    src = TL.SyntheticEpisodes(cfg, base_seed=177, device=dev)
+    eps = [src.episode(e) for e in range(7)]
+
+    def run(pipelined):
+        torch.manual_seed(91)
+        student, teacher, _, distiller, accuracy_fn, _, opt, _ = TL.make(cfg)
+        prev = (ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD)
+        ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD = True, False, True
+        out = []
+        try:
+            torch.manual_seed(5)
+            pipe = TL.PipelinedEpisodes(student, teacher, distiller, accuracy_fn, cfg) if pipelined else None
+            for i, ep in enumerate(eps):
+                if pipelined:
+                    r = pipe.push(ep)
+                    if r is not None:
+                        out.append(r)
+                else:
+                    loss, acc, _ = TL.train_task(ep, student, teacher, distiller, accuracy_fn, cfg)
+                    out.append((loss, acc))
+                if i == 3:
+                    if pipelined:
+                        out.append(pipe.flush())
+                    opt.step()
+                    opt.zero_grad()
+            if pipelined:
+                out.append(pipe.flush())
+            ops.wait_weight_grads()
+            opt.bucket.fold_shadow()
+            torch.cuda.synchronize()
+        finally:
+            ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD = prev
+        stats = {k: v.clone() for k, v in student.state_dict().items() if "running" in k or "num_batches" in k}
+        return [(float(l), float(a)) for l, a in out], opt.bucket.grad.clone(), opt.bucket.flat.clone(), stats
+    o_s, g_s, w_s, s_s = run(False)
+    o_p, g_p, w_p, s_p = run(True)
+    assert len(o_p) == len(eps) and o_s == o_p, (o_s, o_p)
+    assert torch.equal(w_s, w_p)
+    assert torch.equal(g_s, g_p), float((g_s - g_p).abs().max())
+    for k in s_s:
+        assert torch.equal(s_s[k], s_p[k]), k
