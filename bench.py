@@ -83,13 +83,16 @@ def main():
     ap.add_argument("--live-mfm", action="store_true", help="fuse rgb/depth/flow teacher features with the MFM transformer "
                     "inside every episode (BASELINE configs[4]) instead of using precomputed fused features")
     ap.add_argument("--cpu-episodes", type=int, default=3, help="episodes of the bounded cpu_baseline sample")
-    ap.add_argument("--graph", dest="graph", action="store_true", default=os.environ.get("LMKD_GRAPH", "1") != "0",
-                    help="replay each resident episode as a captured hipGraph (trainloop.GraphedEpisode; default, LMKD_GRAPH=0 or --no-graph: "
-                         "eager launches).  Same kernels, same results; the ~600 launches of an episode leave the host path")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=os.environ.get("LMKD_GRAPH", "0") == "1",
+                    help="replay each resident episode as a captured hipGraph (trainloop.GraphedEpisode).  Same kernels, bit-identical results; "
+                         "the ~560 launches of an episode leave the host path (1.3-2.0 ms of host time per episode instead of 8-11).  OFF by "
+                         "default: on one MI355X with a free host the replay is 5 %% slower on the GPU side than the eager three-stream "
+                         "launches (31.4 vs 33.0 episodes/s; bf16 66.5 vs 72.3) - for hosts with less than ~1 core per rank")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
-    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=os.environ.get("LMKD_PIPELINE", "1") != "0",
-                    help="software pipelining across episodes (trainloop.PipelinedEpisodes, default): the forward of episode i + 1 runs beside "
-                         "the backward of episode i on a second stream set; same kernels, same results, same optimizer cadence")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=os.environ.get("LMKD_PIPELINE", "0") == "1",
+                    help="software pipelining across episodes (trainloop.PipelinedEpisodes): the forward of episode i + 1 runs beside the "
+                         "backward of episode i on a second stream set; same kernels, bit-identical results, same optimizer cadence.  OFF by "
+                         "default: measured 6 %% SLOWER on one MI355X (31.0 vs 32.9 episodes/s) - more kernels side by side disturb each other's L2 working sets")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false")
     ap.add_argument("--stream-inputs", action="store_true", help="extra measurement after the headline line: every episode's inputs arrive "
                     "from HOST memory - decoded uint8 frames (320x240, pinned) + teacher features go H2D on a copy stream, the GPU frame "
@@ -110,7 +113,7 @@ def main():
     from litemkd_amd.options import default_args
     from litemkd_amd.utils import aggregate_accuracy
     from litemkd_amd.model.backbone import resnet as R
-    R.OVERLAP_TRUNK_CALLS = not a.serial
+    R.OVERLAP_TRUNK_CALLS = (not a.serial) and os.environ.get("LMKD_OVERLAP", "1") != "0"
     ops.SIDE_WGRAD = (not a.serial) and os.environ.get("LMKD_SIDE_WGRAD", "1") != "0"   # weight gradients on a third stream
     ops.SYNC_WGRAD_AT_BACKWARD_END = os.environ.get("LMKD_SYNC_WG", "0") == "1"           # FusedOptimizer waits for them itself
     TL.TEACHER_STREAM = os.environ.get("LMKD_TEACHER_STREAM", "1") != "0"                  # tuning switches of the round-3 schedule changes

@@ -675,7 +675,7 @@ static inline bool conv_same_size(int H, int W, int KH, int KW, int stride, int 
 }
 
 static int g_patch_debug = 0;      // timing ablations of conv_patch_x3_kernel (DBG template argument; tools/patch_ablate.py); 0 = the product kernel
-extern "C" int lmkd_conv_set_patch_debug(int mask) { g_patch_debug = mask & 15; return LMKD_OK; }
+extern "C" int lmkd_conv_set_patch_debug(int mask) { g_patch_debug = mask & 31; return LMKD_OK; }
 
 template <class Cfg>
 static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
@@ -715,6 +715,7 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
         case 7: LMKD_PATCH_DBG(7); return;
         case 8: LMKD_PATCH_DBG(8); return;
         case 15: LMKD_PATCH_DBG(15); return;
+        case 16: LMKD_PATCH_DBG(16); return;
         default: break;
       }
 #undef LMKD_PATCH_DBG

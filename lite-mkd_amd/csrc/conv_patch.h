@@ -169,7 +169,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     lb.load(s_tap_kofs[b_tp] + b_cc * LMKD_BK, rb);
     if (++b_tp == ntap) { b_tp = 0; ++b_cc; }
   };
-  bf16x8 dbg_av[(DBG & 2) ? 2 : 1][NPL][Cfg::TM];
+  bf16x8 dbg_av[2][NPL][Cfg::TM];      // (dead unless DBG & 2)
   int k_tp = 0, k_cc = 0;      // (tap, chunk) of the current K-step
   // K-step t: MFMAs with the B set `rb`; afterwards the set fetched before them (`rbn`, step t+1) is landed - every load in flight
   // is then one MFMA phase old - and `rb` is refilled with step t+2.  At a chunk boundary the patch is replaced first.
@@ -186,22 +186,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     for (int i = 0; i < Cfg::TM; ++i) ad[i] = ((a_mask[i] >> k_tp) & 1u) ? a_base[i] + sh : zero_addr;
     // both k-groups' A fragments are read up front (group 1 lands under group 0's MFMAs) unless that would be 96 registers
     constexpr bool AHEAD = NPL * Cfg::TM < 12 && (Cfg::THREADS == 512 || NPL == 1);
-    bf16x8 av[2][NPL][Cfg::TM];
+    bf16x8 av_local[2][NPL][Cfg::TM];
+    bf16x8 (&av)[2][NPL][Cfg::TM] = (DBG & 2) ? dbg_av : av_local;      // ablation 2: the fragments of the first step stay in registers
     auto read_a = [&](int g) {
-      if ((DBG & 2) && t > 0) {      // ablation: the fragments of the first step, kept in registers
-#pragma unroll
-        for (int p = 0; p < NPL; ++p)
-#pragma unroll
-          for (int i = 0; i < Cfg::TM; ++i) av[AHEAD ? g : 0][p][i] = dbg_av[g][p][i];
-        return;
-      }
+      if ((DBG & 2) && (t > 0 || (!AHEAD && g == 1))) return;
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
 #pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i) {
-          av[AHEAD ? g : 0][p][i] = *reinterpret_cast<const bf16x8*>(psm + ad[i] + p * 64 + g * 32);
-          if (DBG & 2) dbg_av[g][p][i] = av[AHEAD ? g : 0][p][i];
-        }
+        for (int i = 0; i < Cfg::TM; ++i) av[AHEAD ? g : 0][p][i] = *reinterpret_cast<const bf16x8*>(psm + ad[i] + p * 64 + g * 32);
     };
     read_a(0);
     if (AHEAD) read_a(1);
@@ -269,6 +261,20 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
       step(t + 1, rb1, rb0);
     }
     if (t < nk) step(t, rb0, rb1);
+  }
+  if (DBG & 16) {      // ablation: the same bytes written with 16-byte stores (wrong element mapping): what would a transposed epilogue buy?
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ob = s_out[wm * (Cfg::TM * 32) + i * 32 + (lane & 31)];
+          const int col = n0 + wn * (Cfg::TN * 32) + j * 32 + (lane >> 5) * 16 + q * 4;
+          if (ob >= 0 && col < a.Co)
+            *reinterpret_cast<float4*>(a.out + (long)ob + col) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        }
+    return;
   }
   if (DBG & 8) {      // ablation: keep the accumulators alive without storing them
     float sacc = 0.f;

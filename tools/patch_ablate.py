@@ -22,7 +22,7 @@ def tm(f, reps=8):
 N = 200
 ops.set_conv_compute_dtype("fp32x3")
 lib().call("lmkd_conv_set_tile", 11)
-NAMES = {0: "full", 1: "-B loads", 2: "-A LDS reads", 3: "-B -A", 4: "-split/store", 7: "-B -A -store", 8: "-out stores", 15: "MFMA only"}
+NAMES = {0: "full", 1: "-B loads", 2: "-A LDS reads", 4: "-split/store", 8: "-out stores", 16: "16B out stores", 15: "MFMA only"}
 print("%-4s" % "", " ".join("%14s" % NAMES[d] for d in NAMES))
 for (name, C, H) in (("l1", 64, 56), ("l2", 128, 28), ("l3", 256, 14), ("l4", 512, 7)):
     x = torch.relu(torch.randn(N, H, H, C, device=dev))
