@@ -123,6 +123,10 @@ long lmkd_ticket_words(void);
 int lmkd_bn_finalize(const float* partial, int T, int C, long count, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float momentum, float eps, float* stats, double* scratch, unsigned* tickets, void* stream);
 int lmkd_bn_running_update(float* running_mean, float* running_var, const float* stats, int C, float momentum, void* stream);
+/* n BatchNorm layers in one launch: HOST arrays of n device pointers / channel counts; layer i applies stats_first[i], then (if not
+   null) stats_second[i] - the two trunk calls of an episode in the reference's order */
+int lmkd_bn_running_update_multi(float* const* running_mean, float* const* running_var, const float* const* stats_first,
+                                 const float* const* stats_second, const int* C, int n, float momentum, void* stream);
 int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                        float* stats, void* stream);
 /* y = act(x*scale+shift [+res | +res*rscale+rshift]); res_mode 0 none, 1 plain, 2 affine.  mask_bits (nullable; needs

@@ -287,6 +287,52 @@ extern "C" int lmkd_bn_running_update(float* running_mean, float* running_var, c
   return LMKD_OK;
 }
 
+// All deferred running-statistics updates of an episode in ONE launch (round 3; before: one launch per BatchNorm and trunk call, 40 per
+// episode).  Block b owns BatchNorm layer b and applies its (up to) two updates in order - support-frame call first, then the
+// query-frame call, the order of the reference's two sequential trunk calls (resnet18_2fc.py:41-42).
+#define BN_MULTI_MAX 64
+struct BnMultiArgs {
+  float* rm[BN_MULTI_MAX];
+  float* rv[BN_MULTI_MAX];
+  const float* st0[BN_MULTI_MAX];
+  const float* st1[BN_MULTI_MAX];
+  int C[BN_MULTI_MAX];
+};
+__global__ void bn_running_update_multi_kernel(BnMultiArgs a, float momentum) {
+  const int b = blockIdx.x;
+  const int C = a.C[b];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float m = a.rm[b][c], v = a.rv[b][c];
+    m = (1.f - momentum) * m + momentum * a.st0[b][c];
+    v = (1.f - momentum) * v + momentum * a.st0[b][4 * C + c];
+    if (a.st1[b]) {
+      m = (1.f - momentum) * m + momentum * a.st1[b][c];
+      v = (1.f - momentum) * v + momentum * a.st1[b][4 * C + c];
+    }
+    a.rm[b][c] = m;
+    a.rv[b][c] = v;
+  }
+}
+// rm / rv / stats_first / stats_second / C: HOST arrays of n entries (device pointers inside); stats_second[i] may be null
+extern "C" int lmkd_bn_running_update_multi(float* const* running_mean, float* const* running_var, const float* const* stats_first,
+                                            const float* const* stats_second, const int* C, int n, float momentum, void* stream) {
+  LMKD_REQUIRE(running_mean && running_var && stats_first && stats_second && C && n > 0, "lmkd_bn_running_update_multi: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += BN_MULTI_MAX) {
+    BnMultiArgs a;
+    memset(&a, 0, sizeof(a));
+    const int m = std::min(BN_MULTI_MAX, n - i0);
+    for (int i = 0; i < m; ++i) {
+      LMKD_REQUIRE(running_mean[i0 + i] && running_var[i0 + i] && stats_first[i0 + i] && C[i0 + i] > 0, "lmkd_bn_running_update_multi: null entry %d", i0 + i);
+      a.rm[i] = running_mean[i0 + i]; a.rv[i] = running_var[i0 + i];
+      a.st0[i] = stats_first[i0 + i]; a.st1[i] = stats_second[i0 + i];
+      a.C[i] = C[i0 + i];
+    }
+    hipLaunchKernelGGL(bn_running_update_multi_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, a, momentum);
+    LMKD_CHECK_LAUNCH("bn_running_update_multi_kernel");
+  }
+  return LMKD_OK;
+}
+
 // eval mode: stats from running estimates
 __global__ void bn_eval_stats_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps,
