@@ -169,16 +169,20 @@ def linear_infer(x, w, b=None, relu=False):
     _chk(x, w, b)
     mark_cacheable(w)
     wp = _pack_linear(w, w.view(N, K, 1, 1), K)
-    key = (b.data_ptr() if b is not None else 0, N, b._version if b is not None else 0)
-    st = _AFFINE_CACHE.get(key)
-    if st is None:
+    # [5][N] epilogue table (scale = 1, shift = bias), cached per bias TENSOR (identity checked through a weak reference: a recycled
+    # device address must never return another module's bias) and in-place version
+    key = (b.data_ptr() if b is not None else 0, N, str(x.device))
+    hit = _AFFINE_CACHE.get(key)
+    if hit is not None and (hit[0] is None) == (b is None) and (b is None or (hit[0]() is b and hit[1] == b._version)):
+        st = hit[2]
+    else:
         st = torch.zeros((5, N), dtype=torch.float32, device=x.device)
         st[2].fill_(1.0)
         if b is not None:
             st[3].copy_(b)
         if len(_AFFINE_CACHE) > 256:
             _AFFINE_CACHE.clear()
-        _AFFINE_CACHE[key] = st
+        _AFFINE_CACHE[key] = (weakref.ref(b) if b is not None else None, b._version if b is not None else 0, st)
     y = _empty((M, N), x)
     lib().call("lmkd_conv2d_fwd_bn", _p(x), _p(wp), _p(y), _p(st), None, int(relu), M, 1, 1, K, N, 1, 1, 1, 0, _stream())
     return y
@@ -1043,12 +1047,22 @@ class PoolHeadFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------
 # matchers
 # ------------------------------------------------------------------------------------------
-class ClassPlan:
-    """Host-side description of the support set's class structure (one small D2H copy of the
-    labels per episode, done before any kernel is queued).  Mirrors torch.unique +
-    _extract_class_indices of the reference (TRX_2fcsup.py:108,118-119)."""
+def h2d_async(t, device, dtype=None):
+    """host tensor -> device without stalling the stream: through pinned memory, non-blocking.  (A `.to(device)` of a PAGEABLE host
+    tensor makes the host wait until the stream has drained: five such copies per episode - labels, class plan - left the GPU idle for
+    0.2 - 0.5 ms at every episode start, 1.6 ms per episode in the kernel trace of round 3.)"""
+    if t.is_cuda:
+        return t.to(dtype) if dtype is not None and t.dtype != dtype else t
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
 
-    def __init__(self, support_labels, way, cpu_copy=None):
+
+class ClassPlan:
+    """Host-side description of the support set's class structure (built from the CPU copy of the labels; ONE small pinned,
+    non-blocking upload per episode).  Mirrors torch.unique + _extract_class_indices of the reference (TRX_2fcsup.py:108,118-119)."""
+
+    def __init__(self, support_labels, way, cpu_copy=None, nq_hint=None):
         lab = cpu_copy if cpu_copy is not None else support_labels.detach().to("cpu")
         vals = [int(v) for v in lab.long().tolist()]
         self.way = way
@@ -1065,17 +1079,27 @@ class ClassPlan:
         pos = [0] * self.ns                       # pos[n] = class-sorted position of support video n
         for p_, n in enumerate(order):
             pos[n] = p_
-        dev = support_labels.device
-        self.rowmap = torch.tensor(pos, dtype=torch.int32, device=dev)
-        self.cls = torch.tensor(vals, dtype=torch.int32, device=dev)
+        dev = support_labels.device if support_labels.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        # one upload: [cls | rowmap | identity tail]: rowmap followed by the tail IS full_rowmap() for any query count up to `tail`
+        tail = max(64, 2 * self.ns) if nq_hint is None else int(nq_hint)
+        packed = torch.tensor(vals + pos + list(range(self.ns, self.ns + tail)), dtype=torch.int32)
+        self._packed = h2d_async(packed, dev)
+        self.cls = self._packed[:self.ns]
+        self.rowmap = self._packed[self.ns:2 * self.ns]
+        self._tail = tail
         self.uniform = len(set(self.counts)) == 1
         self._full = {}
 
     def full_rowmap(self, nv):
-        """support rows class-sorted, query rows in place: [Ns + Nq] int32 (cached per query count: the student heads and the
-        teacher head of an episode share it)"""
+        """support rows class-sorted, query rows in place: [Ns + Nq] int32 - a view of the plan's single upload (no launch) while
+        the query count fits its identity tail"""
         if nv not in self._full:
-            self._full[nv] = torch.cat([self.rowmap, torch.arange(self.ns, nv, dtype=torch.int32, device=self.rowmap.device)])
+            nq = nv - self.ns
+            if 0 <= nq <= self._tail:
+                self._full[nv] = self._packed[self.ns:self.ns + nv]
+            else:
+                self._full[nv] = torch.cat([self.rowmap, torch.arange(self.ns, nv, dtype=torch.int32, device=self.rowmap.device)])
         return self._full[nv]
 
 
@@ -1426,6 +1450,7 @@ def accuracy(l1, l2, labels):
 
 _plan_cache = [None, None, None]
 _cpu_labels = [None, None]
+_PLANS_BY_CPU = {}      # (id of the CPU label tensor, its _version, way) -> (weakref, plan): a resident episode pool re-uses its plans
 
 
 def note_cpu_labels(device_labels, cpu_labels):
@@ -1436,10 +1461,22 @@ def note_cpu_labels(device_labels, cpu_labels):
 
 def get_plan(support_labels, way):
     """ClassPlan for this label tensor; cached on tensor identity so Student.forward can build it BEFORE the backbone
-    kernels are queued and the classifier reuses it."""
+    kernels are queued and the classifier reuses it.  Plans are also remembered per CPU label tensor (identity + in-place version):
+    an episode that comes round again (a resident pool) costs no upload at all."""
     if _plan_cache[0] is support_labels and _plan_cache[1] == way:
         return _plan_cache[2]
-    src = _cpu_labels[1] if _cpu_labels[0] is support_labels else None
-    plan = ClassPlan(support_labels, way, src)
+    src = _cpu_labels[1] if _cpu_labels[0] is support_labels else (support_labels if not support_labels.is_cuda else None)
+    plan = None
+    if src is not None:
+        key = (id(src), src._version, way)
+        hit = _PLANS_BY_CPU.get(key)
+        if hit is not None and hit[0]() is src:
+            plan = hit[1]
+    if plan is None:
+        plan = ClassPlan(support_labels, way, src)
+        if src is not None:
+            if len(_PLANS_BY_CPU) > 64:
+                _PLANS_BY_CPU.clear()
+            _PLANS_BY_CPU[(id(src), src._version, way)] = (weakref.ref(src), plan)
     _plan_cache[0], _plan_cache[1], _plan_cache[2] = support_labels, way, plan
     return plan

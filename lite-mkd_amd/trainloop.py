@@ -71,16 +71,25 @@ def prepare_task(task_dict, device, images_to_device=True):
     target_teacher_feature = task_dict["target_set_feature_teacher"][0]
     real_target_labels = task_dict.get("real_target_labels", [None])[0]
     batch_class_list = task_dict.get("batch_class_list", [None])[0]
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        if images_to_device:
+            context_images, target_images = context_images.to(dev), target_images.to(dev)
+            context_teacher_feature, target_teacher_feature = context_teacher_feature.to(dev), target_teacher_feature.to(dev)
+        return (context_images, target_images, context_teacher_feature, target_teacher_feature, context_labels.to(dev),
+                target_labels.long().to(dev), real_target_labels, batch_class_list)
+    # host tensors go up through pinned memory, non-blocking (ops.h2d_async): a pageable .to(device) stalls the host until the
+    # stream has drained, i.e. once per episode
     if images_to_device:
-        context_images = context_images.to(device)
-        target_images = target_images.to(device)
-        context_teacher_feature = context_teacher_feature.to(device)
-        target_teacher_feature = target_teacher_feature.to(device)
+        context_images = ops.h2d_async(context_images, dev)
+        target_images = ops.h2d_async(target_images, dev)
+        context_teacher_feature = ops.h2d_async(context_teacher_feature, dev)
+        target_teacher_feature = ops.h2d_async(target_teacher_feature, dev)
     cpu_labels = context_labels if context_labels.device.type == "cpu" else None
-    context_labels = context_labels.to(device)
+    context_labels = _labels_to_device(context_labels, dev, None)
     if cpu_labels is not None and context_labels is not cpu_labels:
         ops.note_cpu_labels(context_labels, cpu_labels)
-    target_labels = target_labels.long().to(device)
+    target_labels = _labels_to_device(target_labels, dev, torch.int64)
     return (context_images, target_images, context_teacher_feature, target_teacher_feature, context_labels,
             target_labels, real_target_labels, batch_class_list)
 
@@ -117,6 +126,24 @@ def _teacher_forward(teacher, ctf, labels, ttf, way):
     for t in _tensors(out):
         t.record_stream(main)
     return out, aux
+
+
+_LABEL_CACHE = {}      # (id of the CPU tensor, _version, dtype) -> (weakref, device copy): labels of a resident episode pool go up once
+
+
+def _labels_to_device(t, dev, dtype):
+    if t.is_cuda:
+        return t.to(dtype) if dtype is not None and t.dtype != dtype else t
+    import weakref
+    key = (id(t), t._version, dtype)
+    hit = _LABEL_CACHE.get(key)
+    if hit is not None and hit[0]() is t:
+        return hit[1]
+    d = ops.h2d_async(t, dev, dtype)
+    if len(_LABEL_CACHE) > 256:
+        _LABEL_CACHE.clear()
+    _LABEL_CACHE[key] = (weakref.ref(t), d)
+    return d
 
 
 def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
@@ -362,11 +389,7 @@ class GraphedEpisode:
             return self._eager(task_dict)
         for k in self.KEYS:
             ent["task"][k].copy_(task_dict[k], non_blocking=True)
-        sp = ent["plan"]
-        sp.rowmap.copy_(plan.rowmap)
-        sp.cls.copy_(plan.cls)
-        for nv, full in sp._full.items():
-            full[:sp.ns].copy_(plan.rowmap)
+        ent["plan"]._packed.copy_(plan._packed)      # class ids, row map and its full-row-map views in one device copy
         # prepare_task's derived tensor (target labels as int64) lives in the static `prepared` tuple
         ent["prepared"][5].copy_(ent["task"]["target_labels"][0].long())
         return self._replay(ent)
