@@ -44,8 +44,9 @@ for ev in prof.events():
     if not ev.name.startswith("aten::") or not ev.kernels:
         continue
     if any(k for k in ev.kernels):
-        fr = [f for f in (ev.stack or []) if ROOT in f or "lite-mkd_amd" in f or "litemkd" in f]
-        ops_c[(ev.name, fr[0].strip()[-110:] if fr else "(autograd engine / no repo frame)")] += len(ev.kernels)
+        st = [f.strip() for f in (ev.stack or [])]
+        fr = [f for f in st if "lite-mkd_amd" in f or "litemkd" in f or "bench.py" in f or "tools/" in f]
+        ops_c[(ev.name, (fr[0] if fr else " <- ".join(st[:3]) or "(no python stack: autograd engine)")[-150:])] += len(ev.kernels)
 print("device launches per episode by kernel name (top 60):")
 for k, v in kern_c.most_common(60):
     print("  %6.1f  %s" % (v / n, k))
