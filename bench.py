@@ -67,9 +67,9 @@ def main():
                     "mode under rocprofv3 so per-kernel durations are not inflated by concurrent kernels")
     ap.add_argument("--roofline-episodes", type=int, default=2)
     ap.add_argument("--dtype", choices=["f32", "f32native", "bf16", "bf16conv", "f32x3"], default="f32", help="f32 (headline, BASELINE "
-                    "configs[1]): fp32 tensors, fp32 accumulation, the convolution products on the bf16 matrix pipe from an EXACT "
-                    "3-way bf16 split of both operands, 6 products per fp32 product (csrc/conv_x3.h, wgrad_x3.h; error vs fp64 of "
-                    "the class of the native fp32 MFMA: tests/test_gpu_fullsize.py); f32x3: alias of f32; f32native: the same "
+                    "configs[1]; the library's default arithmetic): fp32 tensors, fp32 accumulation, the convolution products on the bf16 "
+                    "matrix pipe from an EXACT 3-way bf16 split of both operands, 6 products per fp32 product (csrc/conv_x3.h, wgrad_x3.h; "
+                    "error vs fp64 of the class of the native fp32 MFMA: tests/test_gpu_fullsize.py); f32x3: alias of f32; f32native: the same "
                     "job on v_mfma_f32_32x32x2_f32 (round 1's headline arithmetic, reported under other_modes by default); "
                     "bf16 (configs[2]): bf16 tensors in HBM for every activation / activation gradient of the trunk, bf16 MFMA with "
                     "fp32 accumulation, fp32 statistics, weights and heads; bf16conv: round 1's variant (fp32 tensors, only the "
@@ -347,10 +347,13 @@ def main():
         "config": {"workload": "HMDB-shape 5-way %d-shot %s + TRX_2fcsup + D2M fc_2_sup_dist training episode%s, %s"
                                % (a.shot, a.backbone, " + live MFM fusion" if a.live_mfm else "",
                                   {"f32": "fp32", "f32native": "fp32", "bf16": "bf16 tensors / fp32 accumulate", "bf16conv": "bf16 conv operands / fp32 tensors"}[a.dtype]),
-                   "conv_arithmetic": {"f32": "fp32 tensors and accumulation; products on the bf16 matrix pipe from an exact 3-way bf16 "
-                                              "split of both operands, 6 of 9 cross products (stem weight gradient on the fp32 MFMA); "
-                                              "error vs fp64 within 3x of torch-CPU fp32 per layer and per parameter gradient "
-                                              "(tests/test_gpu_fullsize.py, test_gpu_episode.py)",
+                   "conv_arithmetic": {"f32": "the library default: fp32 tensors and accumulation; every convolution (forward, data and weight "
+                                              "gradient, stem included) forms its products on the bf16 matrix pipe from an exact 3-way bf16 split of "
+                                              "both operands, 6 of 9 cross products; half the row tiles of a launch accumulate -y so that the MFMA's "
+                                              "directional truncation cancels in sums over pixels (DESIGN 8.5).  Relative-L2 error vs fp64 at the "
+                                              "benchmark's 200 frames: forward / data gradient <= 3 x torch-CPU-fp32's + 1e-6 (measured 1.2e-7 ... "
+                                              "1.0e-6, torch-CPU 1.4e-7 ... 5e-7), weight gradient <= 3 x + 2e-6; measured pairs of every anchored test: "
+                                              "profiles/r03_parity_errors.txt (tests/test_gpu_fullsize.py, test_gpu_ops.py, test_gpu_episode.py)",
                                        "f32native": "v_mfma_f32_32x32x2_f32 (exact fp32 products)",
                                        "bf16": "trunk activations and their gradients stored as bf16 in HBM, bf16 MFMA, fp32 accumulation; BatchNorm "
                                                "statistics, weights, weight gradients, heads and loss fp32",
