@@ -57,14 +57,16 @@ int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound 
    lmkd_conv2d_split_weights (in that mode). */
 int lmkd_conv_set_compute_dtype(int mode);
 /* wp: fp32 K-major packed weights [ncols][Kp] (lmkd_conv2d_pack_weights; ncols = Cout forward, Cin data gradient)
-   -> wf: bf16 in MFMA fragment order: mode 1: ncols * Kp (one round-to-nearest plane); modes 2/3: 6 * ncols * Kp (the three planes
-   of W followed by the three planes of -W: odd row tiles accumulate -y, csrc/conv_x3.h X3FragB) */
+   -> wf: bf16 in MFMA fragment order: mode 1: ncols * Kp (one round-to-nearest plane); modes 2/3: 12 * ncols * Kp = the three planes
+   of W and the three planes of -W (half the row tiles accumulate -y, csrc/conv_x3.h X3FragB) in the v_mfma 32x32x16 fragment order,
+   then the same six planes in the 16x16x32 order (csrc/conv_patch16.h) */
 int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, int Kp, void* stream);
 int lmkd_conv_get_compute_dtype(void);
 int lmkd_conv_set_wgrad_planes(int on); /* tuning (modes 1-3): 1 = weight gradient on the bf16-plane kernel with transposed LDS reads (default), 0 = fp32-tile kernel */
 int lmkd_conv_set_patch(int on); /* tuning (modes 1-3): 1 = same-size convolutions (3x3 / stride 1 forward and data gradient) read an LDS-resident input patch (default), 0 = im2col gather */
 int lmkd_conv_set_stem_patch(int on); /* tuning (modes 1-3): 1 = the 7x7 / stride-2 stem convolution reads an LDS-resident patch of input rows (default), 0 = im2col gather */
 int lmkd_conv_set_wgrad_window(int on); /* tuning (modes 1-3): 1 = 3x3 / stride-1 weight gradients read a rolling LDS window of x, all nine taps per workgroup (default), 0 = im2col-gather kernel */
+int lmkd_conv_set_patch16(int on); /* tuning (modes 2/3, fp32 tensors): 1 = the 4-wave patch tiles run on v_mfma_f32_16x16x32_bf16 (conv_patch16_x3_kernel, default), 0 = on 32x32x16 (conv_patch_x3_kernel) */
 int lmkd_conv_set_patch_debug(int mask); /* measurement only: timing ablations of the patch kernel (results are garbage): 1 no weight-fragment loads, 2 no A-fragment LDS reads, 4 no patch split / store, 8 no output stores; 0 = off */
 int lmkd_conv_set_xcd_mode(int mode); /* tuning: -1 auto (XCD-aware tile order + XCD-grouped weight-gradient splits), 0 plain orders, 1 auto without the weight-gradient grouping */
 int lmkd_conv_set_tile(int id); /* tuning: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 64x128 */

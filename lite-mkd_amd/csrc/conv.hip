@@ -324,6 +324,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
 
 #include "conv_x3.h"
 #include "conv_patch.h"
+#include "conv_patch16.h"
 #include "conv_stem.h"
 
 // ---------------------------------------------------------------------------------
@@ -563,12 +564,16 @@ extern "C" int lmkd_conv_get_compute_dtype(void) { return g_conv_bf16 ? 1 : (g_c
 extern "C" int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, int Kp, void* stream) {
   LMKD_REQUIRE(wp && wf, "lmkd_conv2d_split_weights: null pointer");
   LMKD_REQUIRE(ncols > 0 && ncols % 32 == 0 && Kp > 0 && Kp % 32 == 0, "lmkd_conv2d_split_weights: ncols=%d and Kp=%d must be multiples of 32", ncols, Kp);
-  LMKD_REQUIRE((long)ncols * Kp * 12 < 0xffffffe0L, "lmkd_conv2d_split_weights: weights exceed the 4 GiB buffer range");
+  LMKD_REQUIRE((long)ncols * Kp * 24 < 0xffffffe0L, "lmkd_conv2d_split_weights: weights exceed the 4 GiB buffer range");
   int grid = cdiv((long)ncols * Kp, 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(split_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wp, (unsigned short*)wf, ncols, Kp,
                      g_conv_bf16 ? 1 : 3);
   LMKD_CHECK_LAUNCH("split_weights_kernel");
+  if (!g_conv_bf16) {      // three-plane modes: the 16x16x32 fragment order behind the two 32x32x16 copies (conv_patch16.h)
+    hipLaunchKernelGGL(split_weights16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wp, (unsigned short*)wf + (long)ncols * Kp * 6, ncols, Kp);
+    LMKD_CHECK_LAUNCH("split_weights16_kernel");
+  }
   return LMKD_OK;
 }
 
@@ -674,8 +679,10 @@ static inline bool conv_same_size(int H, int W, int KH, int KW, int stride, int 
   return g_conv_patch && stride == 1 && conv_out(H, KH, stride, pad) == H && conv_out(W, KW, stride, pad) == W && (KH / 2) * W + KW / 2 <= PATCH_HALO_MAX;
 }
 
+static int g_patch16 = 1;      // three-plane modes, fp32 tensors, the 4-wave tiles: conv_patch16_x3_kernel (v_mfma_f32_16x16x32_bf16); 0 = conv_patch_x3_kernel (32x32x16)
+extern "C" int lmkd_conv_set_patch16(int on) { g_patch16 = on ? 1 : 0; return LMKD_OK; }
 static int g_patch_debug = 0;      // timing ablations of conv_patch_x3_kernel (DBG template argument; tools/patch_ablate.py); 0 = the product kernel
-extern "C" int lmkd_conv_set_patch_debug(int mask) { g_patch_debug = mask & 31; return LMKD_OK; }
+extern "C" int lmkd_conv_set_patch_debug(int mask) { g_patch_debug = mask & 63; return LMKD_OK; }
 
 template <class Cfg>
 static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
@@ -716,9 +723,30 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
         case 8: LMKD_PATCH_DBG(8); return;
         case 15: LMKD_PATCH_DBG(15); return;
         case 16: LMKD_PATCH_DBG(16); return;
+        case 32: LMKD_PATCH_DBG(32); return;
+        case 47: LMKD_PATCH_DBG(47); return;
         default: break;
       }
 #undef LMKD_PATCH_DBG
+    }
+  }
+  if constexpr (Cfg::THREADS == 256 && Cfg::BM == 128) {      // the benchmark's tiles (ids 11 / 12) on the 16x16x32 MFMA (conv_patch16.h)
+    if (g_patch16 && g_conv_x3 && !g_lmkd_act_bf16) {
+#define LMKD_PATCH16(NPROD, PRE, EP)                                                                                           \
+  do {                                                                                                                         \
+    static bool attr16_set = false;                                                                                            \
+    if (!attr16_set) {                                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch16_x3_kernel<Cfg, NPROD, PRE, EP>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3)); \
+      attr16_set = true;                                                                                                       \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((conv_patch16_x3_kernel<Cfg, NPROD, PRE, EP>), grid, dim3(Cfg::THREADS), lds, s, a);                    \
+  } while (0)
+      if (a.ep_stats) { if (g_conv_x3 == 9) LMKD_PATCH16(9, false, true); else LMKD_PATCH16(6, false, true); }
+      else if (a.pre_stats) { if (g_conv_x3 == 9) LMKD_PATCH16(9, true, false); else LMKD_PATCH16(6, true, false); }
+      else { if (g_conv_x3 == 9) LMKD_PATCH16(9, false, false); else LMKD_PATCH16(6, false, false); }
+#undef LMKD_PATCH16
+      return;
     }
   }
   if (a.ep_stats) {      // inference: BatchNorm affine (+ residual, ReLU) in the epilogue, fp32 tensors

@@ -214,6 +214,28 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
           for (int i = 0; i < Cfg::TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][0][i], b0, acc[i][j], 0, 0, 0);
         } else {
           const bf16x8 b0 = x3_as_bf16(rb[j * 6 + g * 3 + 0]), b1 = x3_as_bf16(rb[j * 6 + g * 3 + 1]), b2 = x3_as_bf16(rb[j * 6 + g * 3 + 2]);
+          if constexpr ((DBG & 32) != 0) {      // power / clock probe: the same FLOPs as v_mfma_f32_16x16x32_bf16 (two per 32x32x16), garbage results
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) {
+              f32x4 c4[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) c4[q] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+              c4[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][1][i], b1, c4[0], 0, 0, 0);
+              c4[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][1][i], b1, c4[1], 0, 0, 0);
+              c4[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][0][i], b2, c4[2], 0, 0, 0);
+              c4[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][0][i], b2, c4[3], 0, 0, 0);
+              c4[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][2][i], b0, c4[0], 0, 0, 0);
+              c4[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][2][i], b0, c4[1], 0, 0, 0);
+              c4[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][0][i], b1, c4[2], 0, 0, 0);
+              c4[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][0][i], b1, c4[3], 0, 0, 0);
+              c4[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][1][i], b0, c4[0], 0, 0, 0);
+              c4[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][1][i], b0, c4[1], 0, 0, 0);
+              c4[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][0][i], b0, c4[2], 0, 0, 0);
+              c4[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ga][0][i], b0, c4[3], 0, 0, 0);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { acc[i][j][4 * q] = c4[q][0]; acc[i][j][4 * q + 1] = c4[q][1]; acc[i][j][4 * q + 2] = c4[q][2]; acc[i][j][4 * q + 3] = c4[q][3]; }
+            }
+          } else
 #pragma unroll
           for (int i = 0; i < Cfg::TM; ++i) {
             f32x16 c = acc[i][j];

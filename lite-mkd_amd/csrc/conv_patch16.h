@@ -1,0 +1,349 @@
+// conv_patch_x3_kernel (conv_patch.h) on v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16 (round 3).
+//
+// Same algorithm, same LDS patch, same loader: only the matrix instruction, the fragment geometry and the epilogue differ.  Why: with
+// every other instruction of the kernel left in place, issuing the same FLOPs as 16x16x32 MFMAs ran the four 3x3 layers at 200 frames
+// in 227 / 196 / 195 / 220 us against 255 / 224 / 215 / 235 (tools/patch_ablate.py, ablation 32) - the chip holds a higher clock under
+// this shape (MI355X_MICROARCH.md: 1.12-1.15x at equal cycles per FLOP on random data).
+//
+// Operand roles are swapped with respect to conv_patch.h: A (rows of the 16x16 result) = 16 OUTPUT CHANNELS of the weight operand,
+// B (columns) = 16 PIXELS of the patch.  A lane then holds, for pixel lane % 16, the four consecutive channels 4 * (lane / 16) + e of a
+// 16-channel block: the epilogue stores 16 bytes per lane (64 contiguous bytes per pixel and instruction) instead of 4, and the
+// BatchNorm sums of a channel are a 16-lane row reduction.  Fragments: a lane's 8 bf16 of either operand are k = 8 * (lane / 16) .. + 7
+// of its row / column, i.e. ONE ds_read_b128 per (16-pixel block, plane) covers the whole 32-channel K-step (conv_patch.h: two reads of a
+// 32-pixel block, one per 16-k group - the same number of reads per FLOP), and the weights come in a fragment order of their own
+// (lmkd_conv2d_split_weights writes it behind the 32x32x16 order: Wf16[n / 16][k / 32][plane][lane][8]).
+// Three-plane modes with fp32 tensors only (NPROD 6 / 9); bf16 tensors and the one-plane mode stay on conv_patch_x3_kernel.
+#pragma once
+
+template <int TN>
+struct X3FragB16 {
+  static constexpr int NT = 2 * TN;      // 16-channel blocks of this wave
+  static constexpr int NR = NT * 3;
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned off[NT];
+  __device__ __forceinline__ void init(const void* wf, int ncols, int Kp, int col0 /* of this wave */, int lane, bool neg) {
+    const long copy_bytes = (long)ncols * Kp * 2 * 3;
+    // buffer: [32x32x16 order: W planes | -W planes][16x16x32 order: W planes | -W planes]
+    rs = x3_rsrc(reinterpret_cast<const unsigned char*>(wf) + (neg ? 3 : 2) * copy_bytes, copy_bytes);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int nt = (col0 >> 4) + j;
+      off[j] = (nt * 16 < ncols) ? (unsigned)(((long)nt * (Kp >> 5) * 3 * 64 + lane) * 16) : X3_OOB;
+    }
+  }
+  __device__ __forceinline__ void load(int koff /* multiple of 32 */, u32x4 (&reg)[NR]) const {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        reg[j * 3 + p] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j] == X3_OOB ? X3_OOB : off[j] + (unsigned)(((koff >> 5) * 3 + p) * 1024), 0, 0);
+  }
+};
+
+// fp32 K-major packed weights Wp[col][Kp] -> the 16x16x32 fragment order, W planes followed by -W planes (3 x ncols x Kp bf16 each)
+__global__ void split_weights16_kernel(const float* __restrict__ wp, unsigned short* __restrict__ wf, int ncols, int Kp) {
+  const long total = (long)ncols * Kp;
+  const int G = Kp >> 5;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx / Kp), k = (int)(idx - (long)col * Kp);
+    const float x = wp[idx];
+    const int lane = (col & 15) + 16 * ((k >> 3) & 3);
+    const long o = ((((long)(col >> 4) * G + (k >> 5)) * 3) * 64 + lane) * 8 + (k & 7);
+    const unsigned b0 = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(b0 & 0xffff0000u);
+    const unsigned b1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
+    const unsigned short p0 = (unsigned short)(b0 >> 16), p1 = (unsigned short)(b1 >> 16), p2 = (unsigned short)(__float_as_uint(r2) >> 16);
+    wf[o] = p0;
+    wf[o + 512] = p1;
+    wf[o + 1024] = p2;
+    const long o2 = o + total * 3;
+    wf[o2] = p0 ^ 0x8000u;
+    wf[o2 + 512] = p1 ^ 0x8000u;
+    wf[o2 + 1024] = p2 ^ 0x8000u;
+  }
+}
+
+template <class Cfg, int NPROD, bool PRE, bool EP>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kernel(ConvGemmArgs a) {
+  static_assert(NPROD == 6 || NPROD == 9, "three-plane modes");
+  constexpr int NPL = 3;
+  constexpr int ROWB = PatchRow<NPL>::BYTES;
+  constexpr int LPR = 8;                                  // lanes per patch row (16 bytes each)
+  constexpr int RPP = Cfg::THREADS / LPR;                 // patch rows per pass
+  constexpr int NI = (Cfg::BM + 2 * PATCH_HALO_MAX + RPP - 1) / RPP;
+  constexpr int NB = 2 * Cfg::TM, NC = 2 * Cfg::TN;       // 16-pixel blocks / 16-channel blocks of a wave
+  using LB = X3FragB16<Cfg::TN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+  __shared__ int s_out[Cfg::BM];
+  __shared__ int s_tap_shift[LMKD_MAX_TAPS], s_tap_kofs[LMKD_MAX_TAPS];
+  __shared__ float s_red[Cfg::WM * Cfg::BN * 2];
+  const int tid = threadIdx.x;
+  int rt, ct;
+  if (!xcd_decode(blockIdx.x, a.n_rt, a.n_ct, a.xcd_mode, rt, ct)) return;
+  const int tile = rt / a.nclass;
+  const int cls = rt - tile * a.nclass;
+  const int ph = cls >> 1, pw = cls & 1;
+  const int ntap = a.ntap[cls];
+  if (a.accum && ntap == 0) return;      // out += 0
+  const Tap* taps = a.taps[cls];
+  const int halo = a.halo, P = Cfg::BM + 2 * halo;
+  const int M = a.rows_per_class;
+  const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
+  if (tid < ntap) {
+    const Tap tp = taps[tid];
+    s_tap_shift[tid] = (tp.dh * a.Ws + tp.dw) * ROWB;
+    s_tap_kofs[tid] = tp.kofs;
+  }
+  for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
+    const int m = row0 + r;
+    int ob = -1;
+    if (m < M) {
+      if (a.nclass == 1) {
+        ob = m * a.Co;
+      } else {
+        const int n = fdiv(m, a.div_hw);
+        const int rem = m - n * a.Hs * a.Ws;
+        const int aa = fdiv(rem, a.div_w), bb = rem - aa * a.Ws;
+        const int oh = aa * a.omul + ph, ow = bb * a.omul + pw;
+        if (oh < a.Ho && ow < a.Wo) ob = ((n * a.Ho + oh) * a.Wo + ow) * a.Co;
+      }
+    }
+    s_out[r] = ob;
+  }
+  for (int j = tid; j < ROWB / 4; j += Cfg::THREADS) reinterpret_cast<unsigned*>(psm + (long)P * ROWB)[j] = 0u;   // the zero row
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int kq = lane >> 4;                               // this lane's 8 k of a 32-k step: 8 kq .. 8 kq + 7
+  // per 16-pixel block of this lane: LDS byte address of its own pixel's row (tap shift 0) and one validity bit per tap
+  unsigned a_base[NB], a_mask[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int r = wm * (Cfg::TM * 32) + 16 * b + (lane & 15), m = row0 + r;
+    a_base[b] = (unsigned)((r + halo) * ROWB + 16 * kq);
+    unsigned mk = 0;
+    if (m < M) {
+      const int n = fdiv(m, a.div_hw);
+      const int rem = m - n * a.Hs * a.Ws;
+      const int hh = fdiv(rem, a.div_w), ww = rem - hh * a.Ws;
+      for (int tp = 0; tp < ntap; ++tp) {
+        const int y = hh + taps[tp].dh, x = ww + taps[tp].dw;
+        if ((unsigned)y < (unsigned)a.Hs && (unsigned)x < (unsigned)a.Ws) mk |= 1u << tp;
+      }
+    }
+    a_mask[b] = mk;
+  }
+  const unsigned zero_addr = (unsigned)(P * ROWB + 16 * kq);
+  // patch loader (conv_patch.h): LPR lanes x 16 B per pixel row
+  const __amdgpu_buffer_rsrc_t prs = x3_rsrc(a.src, (long)a.N * a.Hs * a.Ws * a.Cs * 4);
+  const int pk = (tid & (LPR - 1)) * 4;
+  const long pix0 = (long)row0 - halo + tid / LPR;
+  const unsigned p_off0 = (unsigned)((pix0 * a.Cs + pk) * 4), p_step = (unsigned)(RPP * a.Cs * 4);
+  unsigned p_ok = 0;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const long pix = pix0 + RPP * i;
+    if (tid / LPR + RPP * i < P && pix >= 0 && pix < (long)a.N * a.Hs * a.Ws) p_ok |= 1u << i;
+  }
+  u32x4 rp[NI];
+  float4 psc = float4(), psh = float4();
+  auto issue_patch = [&](int cc) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (i * RPP < P) rp[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, ((p_ok >> i) & 1u) ? p_off0 + i * p_step + (unsigned)(cc * 32 * 4) : X3_OOB, 0, 0);
+    if (PRE) {
+      psc = *reinterpret_cast<const float4*>(a.pre_stats + 2 * a.Cs + cc * 32 + pk);
+      psh = *reinterpret_cast<const float4*>(a.pre_stats + 3 * a.Cs + cc * 32 + pk);
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int j = tid / LPR + RPP * i;
+      if (j >= P) continue;
+      unsigned char* d = psm + j * ROWB + pk * 2;
+      float4 v = make_float4(__uint_as_float(rp[i].x), __uint_as_float(rp[i].y), __uint_as_float(rp[i].z), __uint_as_float(rp[i].w));
+      if (PRE && ((p_ok >> i) & 1u)) {      // relu(BatchNorm(raw)), bit-identical to bn_apply_kernel; padding never reaches here
+        v.x = fmaxf(fmaf(v.x, psc.x, psh.x), 0.f); v.y = fmaxf(fmaf(v.y, psc.y, psh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, psc.z, psh.z), 0.f); v.w = fmaxf(fmaf(v.w, psc.w, psh.w), 0.f);
+      }
+      uint2 q0, q1, q2;
+      x3_split4(v, q0, q1, q2);
+      *reinterpret_cast<uint2*>(d) = q0;
+      *reinterpret_cast<uint2*>(d + 64) = q1;
+      *reinterpret_cast<uint2*>(d + 128) = q2;
+    }
+  };
+  const bool neg = x3_neg_tile(tile, a.tiles_per_class);      // half the row tiles accumulate -y: X3FragB::init
+  LB lb;
+  lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, neg);
+  f32x4 acc[NB][NC];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = ntap * a.cps;
+  u32x4 rb0[LB::NR], rb1[LB::NR];
+  int b_tp = 0, b_cc = 0;      // (tap, chunk) of the next weight fragments to fetch
+  auto issue_b = [&](u32x4 (&rb)[LB::NR]) {
+    lb.load(s_tap_kofs[b_tp] + b_cc * LMKD_BK, rb);
+    if (++b_tp == ntap) { b_tp = 0; ++b_cc; }
+  };
+  int k_tp = 0, k_cc = 0;      // (tap, chunk) of the current K-step
+  // K-step t (one tap of one 32-channel chunk = ONE 16x16x32 MFMA deep): see conv_patch.h for the prefetch / landing discipline
+  auto step = [&](int t, u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR]) {
+    if (k_tp == 0) {
+      __syncthreads();                       // every wave has finished reading the previous chunk
+      store_patch();
+      __syncthreads();
+      if (k_cc + 1 < a.cps) issue_patch(k_cc + 1);
+    }
+    const unsigned sh = (unsigned)s_tap_shift[k_tp];
+    unsigned ad[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) ad[b] = ((a_mask[b] >> k_tp) & 1u) ? a_base[b] + sh : zero_addr;
+    // the pixel blocks in two halves (conv_patch.h's two k-groups): one register set, the second half's fragments are read after the
+    // first half's MFMAs (the set that would hold both halves costs the third workgroup per CU)
+    constexpr int HB = NB / 2;
+    bf16x8 av[NPL][HB];
+    auto read_a = [&](int hf) {
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+#pragma unroll
+        for (int b = 0; b < HB; ++b) av[p][b] = *reinterpret_cast<const bf16x8*>(psm + ad[hf * HB + b] + p * 64);
+    };
+    read_a(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      if (hf == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const bf16x8 w0 = x3_as_bf16(rb[c * 3 + 0]), w1 = x3_as_bf16(rb[c * 3 + 1]), w2 = x3_as_bf16(rb[c * 3 + 2]);
+#pragma unroll
+        for (int b = 0; b < HB; ++b) {
+          f32x4 d = acc[hf * HB + b][c];
+          // rows = channels (weights), columns = pixels (patch); smallest terms first, as in conv_patch.h
+          if (NPROD == 9) {
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, av[2][b], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, av[1][b], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, av[2][b], d, 0, 0, 0);
+          }
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, av[1][b], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, av[0][b], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, av[2][b], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, av[0][b], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, av[1][b], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, av[0][b], d, 0, 0, 0);
+          acc[hf * HB + b][c] = d;
+        }
+      }
+    }
+    if (++k_tp == ntap) { k_tp = 0; ++k_cc; }
+    __builtin_amdgcn_sched_barrier(0);
+    x3_landed(rbn);
+    x3_landed(rp);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nk) issue_b(rb);
+  };
+  __syncthreads();      // tap tables, s_out, zero row
+  if (nk > 0) {
+    issue_patch(0);
+    issue_b(rb0);
+    if (nk > 1) issue_b(rb1);
+    x3_landed(rp);
+    x3_landed(rb0);
+    x3_landed(rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      step(t, rb0, rb1);
+      step(t + 1, rb1, rb0);
+    }
+    if (t < nk) step(t, rb0, rb1);
+  }
+
+  // ---- epilogue: lane = (pixel lane % 16 of each 16-pixel block, channels 4 kq .. 4 kq + 3 of each 16-channel block)
+  const int ch0 = n0 + wn * (Cfg::TN * 32) + 4 * kq;      // + 16 c
+  float4 s1[NC], s2[NC];
+  float4 esc[NC], esh[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    s1[c] = s2[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EP) {
+      const int col = ch0 + 16 * c;
+      esc[c] = col < a.Co ? *reinterpret_cast<const float4*>(a.ep_stats + 2 * a.Co + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      esh[c] = col < a.Co ? *reinterpret_cast<const float4*>(a.ep_stats + 3 * a.Co + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int ob = s_out[wm * (Cfg::TM * 32) + 16 * b + (lane & 15)];
+    float4 prev[NC];
+    if (a.accum) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = ch0 + 16 * c;
+        prev[c] = (ob >= 0 && col < a.Co) ? *reinterpret_cast<const float4*>(a.out + (long)ob + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = ch0 + 16 * c;
+      float4 v = make_float4(acc[b][c][0], acc[b][c][1], acc[b][c][2], acc[b][c][3]);
+      if (neg) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
+      const bool ok = ob >= 0 && col < a.Co;
+      if (EP) {      // inference: the operations of bn_apply_kernel in its order (x3_epilogue<EP>)
+        v.x = fmaf(v.x, esc[c].x, esh[c].x); v.y = fmaf(v.y, esc[c].y, esh[c].y); v.z = fmaf(v.z, esc[c].z, esh[c].z); v.w = fmaf(v.w, esc[c].w, esh[c].w);
+        if (a.ep_res && ok) {
+          const float4 r = *reinterpret_cast<const float4*>(a.ep_res + (long)ob + col);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (a.ep_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      } else if (a.accum) {
+        v.x += prev[c].x; v.y += prev[c].y; v.z += prev[c].z; v.w += prev[c].w;
+      }
+      if (ok) *reinterpret_cast<float4*>(a.out + (long)ob + col) = v;
+      if (!EP) {      // BatchNorm partial sums (rows outside the tensor hold exact zeros: their patch rows were zero)
+        s1[c].x += v.x; s1[c].y += v.y; s1[c].z += v.z; s1[c].w += v.w;
+        s2[c].x = fmaf(v.x, v.x, s2[c].x); s2[c].y = fmaf(v.y, v.y, s2[c].y); s2[c].z = fmaf(v.z, v.z, s2[c].z); s2[c].w = fmaf(v.w, v.w, s2[c].w);
+      }
+    }
+  }
+  if (!EP && a.stat_partial) {
+    // sum over the 16 pixel lanes of each 16-lane row, then over the WM row groups of the workgroup through LDS
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float v1[4] = {s1[c].x, s1[c].y, s1[c].z, s1[c].w}, v2[4] = {s2[c].x, s2[c].y, s2[c].z, s2[c].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          v1[e] += __shfl_xor(v1[e], o, 64);
+          v2[e] += __shfl_xor(v2[e], o, 64);
+        }
+        if ((lane & 15) == 0) {
+          const int cl = wn * (Cfg::TN * 32) + 16 * c + 4 * kq + e;
+          s_red[(wm * Cfg::BN + cl) * 2 + 0] = v1[e];
+          s_red[(wm * Cfg::BN + cl) * 2 + 1] = v2[e];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < Cfg::BN && n0 + tid < a.Co) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < Cfg::WM; ++w) {
+        t1 += s_red[(w * Cfg::BN + tid) * 2 + 0];
+        t2 += s_red[(w * Cfg::BN + tid) * 2 + 1];
+      }
+      float* p = a.stat_partial + ((long)rt * a.Co + n0 + tid) * 2;
+      p[0] = t1;
+      p[1] = t2;
+    }
+  }
+}

@@ -325,8 +325,8 @@ def _pack_weights(w, Cs, mode, out=None):
     wp = _empty((n,), w)
     lib().call("lmkd_conv2d_pack_weights", _p(w), _p(wp), Cout, Cin, Cs, KH, KW, mode, _stream())
     ncols = Cout if mode == 0 else Cin
-    # one RNE plane, or the three planes of W followed by the three planes of -W (lmkd_conv2d_split_weights)
-    planes = out if out is not None else torch.empty(((1 if cd == 1 else 6) * n,), dtype=torch.int16, device=w.device)
+    # one RNE plane, or the planes of W and of -W in both fragment orders (lmkd_conv2d_split_weights: 2 orders x 2 signs x 3 planes)
+    planes = out if out is not None else torch.empty(((1 if cd == 1 else 12) * n,), dtype=torch.int16, device=w.device)
     lib().call("lmkd_conv2d_split_weights", _p(wp), planes.data_ptr(), ncols, n // ncols, _stream())
     return planes
 

@@ -40,3 +40,5 @@ def _library_default_modes(request):
     if gpu:
         ops.reset_compute_dtypes()
         litemkd_amd.lib().call("lmkd_conv_set_tile", 0)
+        litemkd_amd.lib().call("lmkd_conv_set_patch", 1)
+        litemkd_amd.lib().call("lmkd_conv_set_patch16", 1)

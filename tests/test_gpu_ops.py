@@ -1290,12 +1290,15 @@ def test_conv_patch_kernel_bit_identical_to_gather_kernel(dev, mode, tile):
             st[2], st[3] = (1 + 0.3 * rnd(C, seed=74)).to(dev), (0.2 * rnd(C, seed=75)).to(dev)
             wp, wd = ops._pack_weights(w, C, 0), ops._pack_weights(w, C, 1)
             out = {}
-            for patch in (0, 1):
-                L.call("lmkd_conv_set_patch", patch)
+            # 0 = gather kernel, 1 = patch kernel on the 32x32x16 MFMA (bit-identical to the gather kernel), 2 = patch kernel on the
+            # 16x16x32 MFMA (round 3: three-plane modes, tiles 11 / 12; 32 k per accumulation instead of 16: equal to fp32 rounding)
+            for patch in (0, 1, 2):
+                L.call("lmkd_conv_set_patch", min(patch, 1))
+                L.call("lmkd_conv_set_patch16", 1 if patch == 2 else 0)
                 L.call("lmkd_conv_set_tile", tile)
                 info = (ctypes.c_int * 5)()
                 L.call("lmkd_conv2d_plan", 0, N, H, W, C, C, Cout, K, K, 1, p, info)
-                assert info[4] == patch and (tile == 0 or not patch or info[0] == (tile if Cout > 64 or tile in (7, 9, 11) else {8: 9, 10: 7, 12: 11}[tile])), list(info)
+                assert info[4] == min(patch, 1) and (tile == 0 or not patch or info[0] == (tile if Cout > 64 or tile in (7, 9, 11) else {8: 9, 10: 7, 12: 11}[tile])), list(info)
                 y, part = ops.conv_fwd(x, wp, Cout, K, K, 1, p, True)
                 dx = ops.conv_bwd_data(dy, wd, (N, H, W, C), Cout, K, K, 1, p)
                 acc = r0.clone()
@@ -1304,6 +1307,9 @@ def test_conv_patch_kernel_bit_identical_to_gather_kernel(dev, mode, tile):
                 if not act16:
                     o.append(ops.conv_fwd(x, wp, Cout, K, K, 1, p, True, pre_stats=st)[0])
                 out[patch] = o
+            for i, (g_, p_) in enumerate(zip(out[0], out[2])):      # the 16x16x32 kernel (where it exists; otherwise identical to out[1])
+                tol = (1e-5 if i == 1 else 4e-6) * float(g_.float().abs().max()) + 1e-12
+                assert float((g_.float() - p_.float()).abs().max()) <= tol, (mode, tile, (N, C, H, W, Cout, K), i, "16x16x32 kernel")
             for i, (g_, p_) in enumerate(zip(out[0], out[1])):
                 if i == 1:      # per-row-tile partial sums (tile heights differ between instances): compare the column totals
                     assert torch.allclose(g_, p_, rtol=1e-6, atol=1e-6 * float(g_.abs().max()) + 1e-12), (mode, tile, (N, C, H, W, Cout, K), "BN sums")
@@ -1317,6 +1323,7 @@ def test_conv_patch_kernel_bit_identical_to_gather_kernel(dev, mode, tile):
                     assert torch.equal(g_, p_), (mode, tile, (N, C, H, W, Cout, K), i, float((g_.float() - p_.float()).abs().max()))
     finally:
         L.call("lmkd_conv_set_patch", 1)
+        L.call("lmkd_conv_set_patch16", 1)
         L.call("lmkd_conv_set_tile", 0)
         ops.set_activation_dtype("fp32")
         ops.reset_compute_dtypes()
@@ -1440,19 +1447,23 @@ def test_stride2_data_gradient_on_patch_kernel_bit_identical(dev, mode):
             r0 = rnd(N, H, W, Cin, seed=97).to(dev).to(dt)
             wd = ops._pack_weights(w, Cin, 1)
             out = {}
-            for patch in (0, 1):
-                L.call("lmkd_conv_set_patch", patch)
+            for patch in (0, 1, 2):      # gather kernel, patch kernel on the 32x32x16 MFMA (bit-identical), on the 16x16x32 MFMA (fp32 rounding)
+                L.call("lmkd_conv_set_patch", min(patch, 1))
+                L.call("lmkd_conv_set_patch16", 1 if patch == 2 else 0)
                 info = (ctypes.c_int * 5)()
                 L.call("lmkd_conv2d_plan", 1, N, H, W, Cin, Cin, Cout, K, K, 2, p, info)
-                assert info[4] == patch and info[2] == 4, list(info)
+                assert info[4] == min(patch, 1) and info[2] == 4, list(info)
                 dx = ops.conv_bwd_data(dy, wd, (N, H, W, Cin), Cout, K, K, 2, p)
                 acc = r0.clone()
                 ops.conv_bwd_data(dy, wd, (N, H, W, Cin), Cout, K, K, 2, p, out=acc, accumulate=True)
                 out[patch] = (dx, acc)
             for i in range(2):
                 assert torch.equal(out[0][i], out[1][i]), (mode, (N, Cin, H, W, Cout, K), i, float((out[0][i].float() - out[1][i].float()).abs().max()))
+                d = float((out[0][i].float() - out[2][i].float()).abs().max())
+                assert d <= 4e-6 * float(out[0][i].float().abs().max()), (mode, (N, Cin, H, W, Cout, K), i, d, "16x16x32 kernel")
     finally:
         L.call("lmkd_conv_set_patch", 1)
+        L.call("lmkd_conv_set_patch16", 1)
         ops.set_activation_dtype("fp32")
         ops.reset_compute_dtypes()
 

@@ -22,7 +22,8 @@ def tm(f, reps=8):
 N = 200
 ops.set_conv_compute_dtype("fp32x3")
 lib().call("lmkd_conv_set_tile", 11)
-NAMES = {0: "full", 1: "-B loads", 2: "-A LDS reads", 4: "-split/store", 8: "-out stores", 16: "16B out stores", 15: "MFMA only"}
+lib().call("lmkd_conv_set_patch16", 0)      # the ablation instances are variants of the 32x32x16 kernel
+NAMES = {0: "full", 1: "-B loads", 2: "-A LDS reads", 4: "-split/store", 8: "-out stores", 16: "16B out stores", 15: "MFMA only", 32: "16x16x32 MFMAs", 47: "16x16x32 only"}
 print("%-4s" % "", " ".join("%14s" % NAMES[d] for d in NAMES))
 for (name, C, H) in (("l1", 64, 56), ("l2", 128, 28), ("l3", 256, 14), ("l4", 512, 7)):
     x = torch.relu(torch.randn(N, H, H, C, device=dev))
@@ -35,5 +36,9 @@ for (name, C, H) in (("l1", 64, 56), ("l2", 128, 28), ("l3", 256, 14), ("l4", 51
             lib().call("lmkd_conv_set_patch_debug", d)
             best[d] = min(best[d], tm(lambda: ops.conv_fwd(x, wp, C, 3, 3, 1, 1, True)))
     lib().call("lmkd_conv_set_patch_debug", 0)
+    lib().call("lmkd_conv_set_patch16", 1)
+    real16 = min(tm(lambda: ops.conv_fwd(x, wp, C, 3, 3, 1, 1, True)) for _ in range(3))
+    lib().call("lmkd_conv_set_patch16", 0)
+    print("%-4s conv_patch16_x3_kernel (the product kernel): %6.1f us %4.0fTF" % (name, real16 * 1e3, fl / real16 / 1e9))
     print("%-4s" % name, " ".join("%6.1f us %4.0fTF" % (best[d] * 1e3, fl / best[d] / 1e9) for d in NAMES), flush=True)
 lib().call("lmkd_conv_set_tile", 0)
