@@ -755,7 +755,7 @@ class StemFn(torch.autograd.Function):
         cmax = torch.empty_like(y) if (training and STEM_POOLED_BWD) else None
         lib().call("lmkd_bn_relu_maxpool_fwd", _p(c), _p(stats), _p(y), _p(idx), _p(cmax), N, Hc, Wc, C, _stream())
         if BLOCK_TAPS is not None:
-            BLOCK_TAPS.append({"stem_c": c, "stem_st": stats})
+            BLOCK_TAPS.append({"stem_c": c, "stem_st": stats, "stem_idx": idx})
         if training:
             ctx.save_for_backward(x4, c, stats, idx, gamma, w, cmax)
             ctx.beta = beta

@@ -5,6 +5,7 @@ import math
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 from _anchor import anchored, anchored_dict
 
@@ -79,6 +80,31 @@ def _hip_relu_masks(taps):
     return masks
 
 
+def _hip_pool_choices(taps):
+    """the arg-max selections of the HIP trunk calls in the oracle's order: per call ("stem": flat index into the H x W plane of the
+    pooling input for every [n, c, oh, ow], from the kernel's own arg-max bytes; "head": the same for AdaptiveMaxPool2d((4, 4)) on
+    the call's last block output - torch's kernel on the HIP tensor picks, like lmkd_adaptive_maxpool_mean, the first maximum in scan
+    order)"""
+    import torch.nn.functional as F
+    calls, cur = [], None
+    for t in taps:
+        if "stem_c" in t:
+            cur = {}
+            calls.append(cur)
+            N, Hc, Wc, C = t["stem_c"].shape
+            k = t["stem_idx"].permute(0, 3, 1, 2).long()                       # [N, C, OH, OW], window position kh * 3 + kw
+            OH, OW = k.shape[2], k.shape[3]
+            oh = torch.arange(OH, device=k.device).view(1, 1, OH, 1)
+            ow = torch.arange(OW, device=k.device).view(1, 1, 1, OW)
+            cur["stem"] = ((2 * oh - 1 + k // 3) * Wc + (2 * ow - 1 + k % 3)).cpu()
+        else:
+            cur["last_y"] = t["y"]
+    for c in calls:
+        y = c.pop("last_y").float().permute(0, 3, 1, 2).contiguous()
+        c["head"] = F.adaptive_max_pool2d(y, (4, 4), return_indices=True)[1].cpu()
+    return calls
+
+
 def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
     from litemkd_amd.model.model_select import Student, Teacher
     from litemkd_amd.distillers import Distiller
@@ -109,7 +135,9 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
     loss.backward()
     acc, pred = ops.accuracy(out["logits"]["kl"], out["logits"]["ce"], labels.to(dev))
     masks = _hip_relu_masks(taps) if impose else None
+    pools = _hip_pool_choices(taps) if impose else None
     flips = [0, 0]
+    pflips = [0, 0]
 
     def oracle(dt, imposed):
         p = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sp.items()}
@@ -131,12 +159,30 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
                 lim = ((3e-2 if O.ACT_BF16 else 1e-2) if bf16 else 1e-5) * float(t.detach().abs().max())
                 assert not bool(diff.any()) or float(t.detach()[diff].abs().max()) < lim, site[0]
             return _MaskedReLU.apply(t, m.to(dt))
+        psite = {"stem": 0, "head": 0}
+
+        def pool_hook(kind, t):
+            """the pooling with the HIP path's selection imposed (a gather: differentiable); in fp64 the selection may differ from
+            the natural arg-max only where the two candidates are within rounding of each other"""
+            idx = pools[psite[kind]][kind]
+            psite[kind] += 1
+            v = t.flatten(2).gather(2, idx.flatten(2)).reshape(idx.shape)
+            if dt == torch.float64:
+                nat = (F.max_pool2d(t.detach(), 3, 2, 1) if kind == "stem" else F.adaptive_max_pool2d(t.detach(), (4, 4)))
+                d = (nat - v.detach())
+                pflips[0] += int((d > 0).sum())
+                pflips[1] += d.numel()
+                lim = ((3e-2 if O.ACT_BF16 else 1e-2) if bf16 else 1e-5) * float(t.detach().abs().max())
+                assert float(d.max()) <= lim, (kind, float(d.max()), lim)
+            return v
         O.RELU_HOOK = hook if imposed else None
+        O.POOL_HOOK = pool_hook if imposed else None
         O.CONV_BF16 = bf16
         try:
             o = O.student_forward(e, p, 5, shot, classifier=clf, backbone=bb)
         finally:
             O.RELU_HOOK = None
+            O.POOL_HOOK = None
             O.CONV_BF16 = False
         ot = O.clf_TRX_2fcsup_fixed(e["support_set_feature_teacher"], e["support_labels"], e["target_set_feature_teacher"],
                                     {k: v.to(dt) for k, v in tp.items()}, 5, shot)
@@ -198,9 +244,12 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
             # (round 3: 1e-4 - with another arithmetic mode or another summation order in the stem's BatchNorm backward the near-ties
             # fall differently; measured up to 7.6e-5 on layer-1 / stem BatchNorm parameters in the 64-px episodes, while the block
             # tests, where every mask is imposed, hold the 2e-6 floor at 200 frames in the same arithmetic)
-            e_hip, e_cpu = anchored(k, pg[k].grad, sp32[k].grad, sp64[k].grad, factor, 1e-4, 1e-7 * gmax)
+            # (round 3, later: the pooling selections ARE imposed now for the BasicBlock trunks - _hip_pool_choices / oracle.POOL_HOOK -
+            # so what remains there is a linear map; the ResNet-50 cases, whose masks and selections are not imposed, keep 1e-4)
+            e_hip, e_cpu = anchored(k, pg[k].grad, sp32[k].grad, sp64[k].grad, factor, 5e-5 if impose else 1e-4, 1e-7 * gmax)
             worst = max(worst, (e_hip / (e_cpu + 1e-6), k, e_hip, e_cpu))
-    print("worst HIP/CPU gradient error ratio vs fp64:", worst, "loss", loss.item(), ol.item(), ol64.item(), "mask flips vs fp64:", flips)
+    print("worst HIP/CPU gradient error ratio vs fp64:", worst, "loss", loss.item(), ol.item(), ol64.item(), "mask flips vs fp64:", flips,
+          "pooling selections that differ from fp64's:", pflips)
     from _anchor import record
     record("episode %d-shot %d-query %dpx %s %s [%s%s]" % (shot, query, img, clf, bb, ops.get_conv_compute_dtype(),
                                                           ", bf16 tensors" if ops.get_activation_dtype() == "bf16" else ""),
