@@ -86,6 +86,14 @@ int lmkd_conv2d_fwd_bn(const float* x, const float* wp_fwd, float* y, const floa
 /* accumulate != 0: dx += ... (the block's residual-branch gradient is already in dx) */
 int lmkd_conv2d_bwd_data(const float* dy, const float* wp_dgrad, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int accumulate, void* stream);
+/* the data gradient that feeds relu + train-mode BatchNorm backward (torchvision BasicBlock: d relu(bn1(c1)) = dgrad(conv2);
+   resnet18_2fc.py:41-42 runs that block): besides dx the kernel's epilogue leaves the per-row-tile sums (sum g, sum g * xhat) of
+   lmkd_bn_backward(mask_mode 2) over (dx, bn_x) in part[tiles][Cin][2], so lmkd_bn_backward_part needs no reduction pass.
+   bn_x: the BatchNorm's input, shaped like dx; bn_stats: its [5][Cin] table.  lmkd_conv2d_bwd_data_bn_tiles: rows of `part`, or 0 when
+   the launch has no such form in the current arithmetic (then run lmkd_conv2d_bwd_data + lmkd_bn_backward). */
+int lmkd_conv2d_bwd_data_bn_tiles(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int lmkd_conv2d_bwd_data_bn(const float* dy, const float* wp_dgrad, float* dx, const float* bn_x, const float* bn_stats, float* part,
+                            int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
 long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad);
 int lmkd_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, float* workspace, long ws_bytes, int N, int H, int W,
                            int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
@@ -142,6 +150,10 @@ long lmkd_bn_bwd_workspace(int C);
 int lmkd_bn_backward(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dx,
                      float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, int C,
                      int mask_mode, int accumulate_param_grads, void* stream);
+/* lmkd_bn_backward(mask_mode 2, no g_out) from the partial sums of lmkd_conv2d_bwd_data_bn: part [T][C][2]; dx may alias dy */
+int lmkd_bn_backward_part(const float* part, int T, const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
+                          float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, int C,
+                          int accumulate_param_grads, void* stream);
 int lmkd_relu_backward(const float* dy, const float* y, float* g, long n, void* stream);
 /* stem: y = maxpool3x3/2/1(relu(x * scale + shift)), idx = arg-max byte (0..8) per output element, cmax (nullable) = x at the arg-max
    (torchvision resnet children 1-3, resnet18_2fc.py:33) */

@@ -37,6 +37,11 @@ struct ConvGemmArgs {
   // and ReLU, relu(fmaf(v, scale[c], shift[c])) with scale/shift = rows 2/3 of its [5][C] table, while it fills LDS - the
   // normalised activation never exists in HBM.  Zero padding stays zero (it pads the activation, not the raw tensor).
   const float* pre_stats;
+  // data gradient whose result feeds relu + train-mode BatchNorm backward (lmkd_conv2d_bwd_data_bn): bnb_x = that BatchNorm's input (the
+  // raw convolution output, shaped like `out`), bnb_stats = its [5][Co] table; stat_partial then receives per row tile
+  // (sum g, sum g * xhat), g = out * [fma(x, scale, shift) > 0], xhat = (x - mean) * invstd - what bn_bwd_reduce_kernel sums
+  const float* bnb_x;
+  const float* bnb_stats;
   FastDiv div_hw, div_w;
   int ntap[LMKD_MAX_CLASSES];
   Tap taps[LMKD_MAX_CLASSES][LMKD_MAX_TAPS];
@@ -960,10 +965,8 @@ extern "C" int lmkd_conv2d_fwd_bn(const float* x, const float* wp, float* y, con
 }
 
 // dx[N,H,W,Cin] (+= when accumulate) from dy[N,Ho,Wo,Cout]; wd = weights packed with mode 1
-extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx, int N, int H, int W, int Cin, int Cout,
-                                    int KH, int KW, int stride, int pad, int accumulate, void* stream) {
-  LMKD_REQUIRE(dy && wd && dx, "lmkd_conv2d_bwd_data: null pointer");
-  LMKD_REQUIRE(aligned16(dy) && aligned16(wd), "lmkd_conv2d_bwd_data: operands must be 16-byte aligned");
+static int bwd_data_args(ConvGemmArgs& a, const float* dy, const float* wd, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                         int stride, int pad, int accumulate) {
   LMKD_REQUIRE(Cout % 32 == 0, "lmkd_conv2d_bwd_data: Cout=%d must be a multiple of 32", Cout);
   LMKD_REQUIRE(stride == 1 || stride == 2, "lmkd_conv2d_bwd_data: stride %d unsupported", stride);
   LMKD_REQUIRE(KH * KW <= LMKD_MAX_TAPS, "lmkd_conv2d_bwd_data: kernel too large");
@@ -973,7 +976,6 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
                "lmkd_conv2d_bwd_data: tensor exceeds 2^31 elements");
   LMKD_REQUIRE(!(g_conv_x3 || g_conv_bf16) || (long)N * Ho * Wo * Cout * (g_lmkd_act_bf16 ? 2 : 4) < 0xffffffe0L,
                "lmkd_conv2d_bwd_data: dy exceeds the 4 GiB buffer range of the bf16-plane kernels");
-  ConvGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.src = dy; a.wpk = wd; a.out = dx; a.stat_partial = nullptr; a.accum = accumulate;
   a.N = N; a.Hs = Ho; a.Ws = Wo; a.Cs = Cout;
@@ -1008,6 +1010,43 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
   a.tiles_per_class = cdiv(a.rows_per_class, 128);
   a.div_hw = make_fastdiv(a.Hr * a.Wr); a.div_w = make_fastdiv(a.Wr);
   a.same = patch_halo(a) >= 0 ? 1 : 0;
+  return LMKD_OK;
+}
+
+extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx, int N, int H, int W, int Cin, int Cout,
+                                    int KH, int KW, int stride, int pad, int accumulate, void* stream) {
+  LMKD_REQUIRE(dy && wd && dx, "lmkd_conv2d_bwd_data: null pointer");
+  LMKD_REQUIRE(aligned16(dy) && aligned16(wd), "lmkd_conv2d_bwd_data: operands must be 16-byte aligned");
+  ConvGemmArgs a;
+  if (const int rc = bwd_data_args(a, dy, wd, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, accumulate)) return rc;
+  return launch_conv_gemm<false, 0>(a, Cin, (hipStream_t)stream);
+}
+
+// The data gradient that feeds relu + train-mode BatchNorm backward (BasicBlock: d a1 = dgrad(conv2), a1 = relu(bn1(c1));
+// resnet18_2fc.py:41-42 runs torchvision's block): the epilogue of the patch kernel also reads the BatchNorm's input at the pixels it
+// has just produced and leaves the per-row-tile sums (sum g, sum g * xhat) in `part`, so lmkd_bn_backward_part needs no reduction pass
+// over (dx, bn_x).  Exists for the launches conv_patch16_x3_kernel serves (stride 1, three-plane arithmetic, fp32 tensors, 128-row
+// tiles); lmkd_conv2d_bwd_data_bn_tiles returns the row count of `part` ([tiles][Cin][2] floats) or 0 when the launch has no such form.
+static bool bwd_data_bn_ok(const ConvGemmArgs& a, int Cin) {
+  if (!(g_patch16 && g_conv_x3 && !g_lmkd_act_bf16 && !g_patch_debug) || a.nclass != 1 || Cin % 4 != 0) return false;
+  if (patch_halo(a) < 0) return false;
+  const int id = pick_conv_cfg(a.rows_per_class, a.nclass, Cin, a.same != 0);
+  return id == 11 || id == 12;
+}
+extern "C" int lmkd_conv2d_bwd_data_bn_tiles(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  if (stride != 1 || Cout % 32 != 0 || KH * KW > LMKD_MAX_TAPS) return 0;
+  ConvGemmArgs a;
+  if (bwd_data_args(a, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, 0)) return 0;
+  return bwd_data_bn_ok(a, Cin) ? cdiv(a.rows_per_class, 128) : 0;
+}
+extern "C" int lmkd_conv2d_bwd_data_bn(const float* dy, const float* wd, float* dx, const float* bn_x, const float* bn_stats, float* part,
+                                       int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  LMKD_REQUIRE(dy && wd && dx && bn_x && bn_stats && part, "lmkd_conv2d_bwd_data_bn: null pointer");
+  LMKD_REQUIRE(aligned16(dy) && aligned16(wd) && aligned16(bn_x) && aligned16(bn_stats), "lmkd_conv2d_bwd_data_bn: operands must be 16-byte aligned");
+  ConvGemmArgs a;
+  if (const int rc = bwd_data_args(a, dy, wd, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, 0)) return rc;
+  LMKD_REQUIRE(bwd_data_bn_ok(a, Cin), "lmkd_conv2d_bwd_data_bn: this launch has no fused form (lmkd_conv2d_bwd_data_bn_tiles returned 0)");
+  a.bnb_x = bn_x; a.bnb_stats = bn_stats; a.stat_partial = part;
   return launch_conv_gemm<false, 0>(a, Cin, (hipStream_t)stream);
 }
 

@@ -624,6 +624,26 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
   return LMKD_OK;
 }
 
+// lmkd_bn_backward whose reduction pass already happened in the epilogue of the data gradient that produced dy
+// (lmkd_conv2d_bwd_data_bn): part = [T][C][2] per-row-tile sums (sum g, sum g * xhat) of mask mode 2.  Coefficient kernel + apply pass.
+extern "C" int lmkd_bn_backward_part(const float* part, int T, const float* dy, const float* x, const float* stats, const float* gamma,
+                                     float* dx, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, int C,
+                                     int accumulate_param_grads, void* stream) {
+  LMKD_REQUIRE(part && T > 0 && dy && x && stats && dx && coef && workspace && tickets, "lmkd_bn_backward_part: null pointer");
+  LMKD_REQUIRE(!g_lmkd_act_bf16 && C % 4 == 0, "lmkd_bn_backward_part: fp32 tensors, C %% 4 == 0");
+  LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS, "lmkd_bn_backward_part: C=%d exceeds the ticket buffer", C);
+  hipStream_t s = (hipStream_t)stream;
+  double* dscr = (double*)((char*)workspace + (((long)2048 * 2 * C * sizeof(float) + 63) / 64) * 64);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(2 * C, CS_COLS), cs_slices(T)), dim3(CS_COLS, CS_LANES), 0, s, part, T, C, (double)rows, gamma,
+                     stats, coef, dgamma, dbeta, accumulate_param_grads, dscr, tickets);
+  LMKD_CHECK_LAUNCH("bn_bwd_coef_kernel");
+  const long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, dy, x, (const float*)nullptr, stats, (const float*)coef,
+                     dx, (float*)nullptr, n4, C, 2);
+  LMKD_CHECK_LAUNCH("bn_bwd_apply_kernel");
+  return LMKD_OK;
+}
+
 // The stem's BatchNorm backward statistics from the POOLED side (round 3).  The gradient that reaches the stem's BatchNorm is the
 // max-pool backward of dy: non-zero only at the arg-max position of each pooling window, so
 //   sum g = sum over windows of dy * [bn(c_max) > 0],   sum g * xhat = sum over windows of dy * [..] * xhat(c_max)

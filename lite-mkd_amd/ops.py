@@ -432,16 +432,36 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None):
     return y, part
 
 
-def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumulate=False):
+# The data gradient that feeds relu + BatchNorm backward can leave that backward's reduction in its epilogue (lmkd_conv2d_bwd_data_bn)
+# where the launch has the form: one pass over (dx, bn input) and one launch per such BatchNorm less (16 launches, 0.44 ms of
+# bn_bwd_reduce_kernel per episode).  OFF by default: same-box A/B 33.73 / 33.74 / 33.85 episodes/s with it against 33.91 / 33.87 / 33.90
+# without - the reduction kernels it removes ran beside the weight-gradient stream's MFMA kernels for free, the extra epilogue reads
+# lengthen the MFMA kernels themselves.
+DGRAD_BN_STATS = False
+
+
+def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumulate=False, bn=None):
+    """bn = (x_bn, stats): the gradient feeds relu(BatchNorm(x_bn)) backward -> (dx, part | None), part = the [T, Cin, 2] partial sums
+    bn_backward(part=...) takes in place of its reduction pass (None: this launch has no fused form)"""
     N, H, W, Cin = x_shape
     _chk(dy, wd, out)
     if accumulate and out is None:
         raise ValueError("accumulate needs an output buffer")
     dx = out if out is not None else _empty_act((N, H, W, Cin), dy)
+    part = None
+    if bn is not None and DGRAD_BN_STATS and not accumulate:
+        T = lib().value("lmkd_conv2d_bwd_data_bn_tiles", N, H, W, Cin, Cout, KH, KW, stride, pad)
+        if T > 0:
+            _chk(bn[0], bn[1])
+            part = _empty((T, Cin, 2), dy)
     with _timed(_conv_family(1, N, H, W, Cin, Cin, Cout, KH, KW, stride, pad), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
                 dy.element_size() * dy.numel() + dx.element_size() * dx.numel() * (2 if accumulate else 1) + 4 * wd.numel()):
-        lib().call("lmkd_conv2d_bwd_data", _p(dy), _p(wd), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, int(accumulate), _stream())
-    return dx
+        if part is not None:
+            lib().call("lmkd_conv2d_bwd_data_bn", _p(dy), _p(wd), _p(dx), _p(bn[0]), _p(bn[1]), _p(part), N, H, W, Cin, Cout, KH, KW, stride,
+                       pad, _stream())
+        else:
+            lib().call("lmkd_conv2d_bwd_data", _p(dy), _p(wd), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, int(accumulate), _stream())
+    return (dx, part) if bn is not None else dx
 
 
 def conv_bwd_weight(x, dy, w_shape, stride, pad, pre_stats=None, acc_into=None):
@@ -562,10 +582,11 @@ def bn_apply(x, stats, relu, res=None, rstats=None, want_bits=False):
     return (y, bits) if want_bits else y
 
 
-def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None, beta=None):
+def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None, beta=None, part=None):
     """-> dx, g (masked dy) | None, dgamma, dbeta.  mask_mode 1: yact = the activation output; 3: yact = its packed bit mask.
     beta (the BatchNorm bias parameter) given and DIRECT_PARAM_GRAD on: dgamma / dbeta are added into gamma.grad / beta.grad (or
-    their side-stream shadows) by the coefficient kernel and None is returned for both."""
+    their side-stream shadows) by the coefficient kernel and None is returned for both.
+    part: the reduction already happened in the data gradient that produced dy (conv_bwd_data(bn=...); mask_mode 2, no g)"""
     C = x.shape[-1]
     rows = x.numel() // C
     _chk(dy, x, yact, stats, gamma)
@@ -577,8 +598,15 @@ def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None,
     dgamma, dbeta = (tg, tb) if direct else (_empty((C,), x), _empty((C,), x))
     coef = _empty((3, C), x)
     ws = torch.empty(lib().value("lmkd_bn_bwd_workspace", C), dtype=torch.uint8, device=x.device)
-    lib().call("lmkd_bn_backward", _p(dy), _p(x), _p(yact), _p(stats), _p(gamma), _p(dx), _p(g), _p(dgamma), _p(dbeta),
-               _p(coef), _p(ws), _p(_tickets(x)), rows, C, mask_mode, int(direct), _stream())
+    if part is not None:
+        if mask_mode != 2 or want_g:
+            raise ValueError("partial sums of the data gradient: mask_mode 2 without g")
+        _chk(part)
+        lib().call("lmkd_bn_backward_part", _p(part), part.shape[0], _p(dy), _p(x), _p(stats), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
+                   _p(coef), _p(ws), _p(_tickets(x)), rows, C, int(direct), _stream())
+    else:
+        lib().call("lmkd_bn_backward", _p(dy), _p(x), _p(yact), _p(stats), _p(gamma), _p(dx), _p(g), _p(dgamma), _p(dbeta),
+                   _p(coef), _p(ws), _p(_tickets(x)), rows, C, mask_mode, int(direct), _stream())
     return (dx, g, None, None) if direct else (dx, g, dgamma, dbeta)
 
 
@@ -920,9 +948,9 @@ class BasicBlockFn(torch.autograd.Function):
         wd2 = pack_weights(w2, Cmid, 1)
         # first: its stream then waits for the BatchNorm backward only, not for the data gradient
         dw2 = weight_grad(w2, c1, dc2, 1, 1, st1) if a1 is None else weight_grad(w2, a1, dc2, 1, 1)
-        da1 = conv_bwd_data(dc2, wd2, c1.shape, Cmid, 3, 3, 1, 1)
+        da1, part1 = conv_bwd_data(dc2, wd2, c1.shape, Cmid, 3, 3, 1, 1, bn=(c1, st1))      # + bn1's backward sums where the launch has the form
         del dc2
-        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1, beta=ctx.betas[0])    # mask from c1*scale+shift > 0
+        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1, beta=ctx.betas[0], part=part1)    # mask from c1*scale+shift > 0
         dw1 = weight_grad(w1, x, dc1, stride, 1)
         dwd = dgd = dbd = None
         need_dx = ctx.needs_input_grad[0]
@@ -998,13 +1026,13 @@ class BottleneckFn(torch.autograd.Function):
         Cm, Co = w1.shape[0], w3.shape[0]
         dc3, g, dg3, db3 = bn_backward(dy, c3, y, st3, g3, 3 if fused else 1, want_g=True, beta=ctx.betas[2])
         dw3 = weight_grad(w3, c2, dc3, 1, 0, st2) if a2 is None else weight_grad(w3, a2, dc3, 1, 0)       # weight gradients first (BasicBlockFn)
-        da2 = conv_bwd_data(dc3, pack_weights(w3, Cm, 1), c2.shape, Co, 1, 1, 1, 0)
+        da2, part2 = conv_bwd_data(dc3, pack_weights(w3, Cm, 1), c2.shape, Co, 1, 1, 1, 0, bn=(c2, st2))
         del dc3
-        dc2, _, dg2, db2 = bn_backward(da2, c2, None, st2, g2, 2, dx_out=da2, beta=ctx.betas[1])
+        dc2, _, dg2, db2 = bn_backward(da2, c2, None, st2, g2, 2, dx_out=da2, beta=ctx.betas[1], part=part2)
         dw2 = weight_grad(w2, c1, dc2, stride, 1, st1) if a1 is None else weight_grad(w2, a1, dc2, stride, 1)
-        da1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), c1.shape, Cm, 3, 3, stride, 1)
+        da1, part1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), c1.shape, Cm, 3, 3, stride, 1, bn=(c1, st1))
         del dc2, da2
-        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1, beta=ctx.betas[0])
+        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1, beta=ctx.betas[0], part=part1)
         dw1 = weight_grad(w1, x, dc1, 1, 0)
         dwd = dgd = dbd = None
         need_dx = ctx.needs_input_grad[0]

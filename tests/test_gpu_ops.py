@@ -188,6 +188,54 @@ def test_conv_fused_bn_relu_loader_bit_identical(dev, cfg, mode):
     assert float((a1 == 0).float().mean()) > 0.2          # the ReLU did clip: the test would not see a missing max otherwise
 
 
+@pytest.mark.parametrize("mode", ["fp32x3", "fp32x3_9", "fp32", "bf16"])
+@pytest.mark.parametrize("cfg", [(5, 64, 14, 14, 64, 3), (3, 128, 9, 11, 64, 3), (4, 256, 7, 7, 128, 1), (40, 128, 28, 28, 128, 3), (60, 64, 56, 56, 64, 3)])
+def test_dgrad_epilogue_bn_backward_sums(dev, cfg, mode):
+    """lmkd_conv2d_bwd_data_bn + lmkd_bn_backward_part (the BatchNorm backward's reduction in the data gradient's epilogue) against
+    lmkd_conv2d_bwd_data + lmkd_bn_backward: the data gradient bit-identical, the BatchNorm backward equal up to the order of the
+    fp32 partial sums (fp64 from the row tiles on), and both against an fp64 reference of the sums.  Modes without the fused form
+    (native fp32, one-plane bf16) must report 0 tiles and take the plain path."""
+    from litemkd_amd import ops
+    N, Cout, H, W, Cin, K = cfg
+    pad = K // 2
+    c1 = (rnd(N, H, W, Cin, seed=50) * 1.5 + 0.2).to(dev)
+    gamma, beta = (1 + 0.2 * rnd(Cin, seed=51)).to(dev), (0.3 * rnd(Cin, seed=52)).to(dev)
+    flat = c1.reshape(-1, Cin)
+    part = torch.stack([flat.sum(0, keepdim=True), (flat ** 2).sum(0, keepdim=True)], -1).contiguous()
+    st = ops.bn_stats_train(part, flat.shape[0], gamma, beta, None, None)
+    w = (rnd(Cout, Cin, K, K, seed=53) * math.sqrt(2.0 / (Cout * K * K))).to(dev)
+    dy = rnd(N, H, W, Cout, seed=54).to(dev)
+    ops.set_conv_compute_dtype(mode)
+    was = ops.DGRAD_BN_STATS
+    ops.DGRAD_BN_STATS = True
+    try:
+        wd = ops.pack_weights(w, Cin, 1)
+        T = ops.lib().value("lmkd_conv2d_bwd_data_bn_tiles", N, H, W, Cin, Cout, K, K, 1, pad)
+        assert (T > 0) == (mode in ("fp32x3", "fp32x3_9")), T
+        da0 = ops.conv_bwd_data(dy, wd, c1.shape, Cout, K, K, 1, pad)
+        da1, p1 = ops.conv_bwd_data(dy, wd, c1.shape, Cout, K, K, 1, pad, bn=(c1, st))
+        assert torch.equal(da0, da1)
+        assert (p1 is not None) == (T > 0)
+        dc0, _, dg0, db0 = ops.bn_backward(da0.clone(), c1, None, st, gamma, 2)
+        dc1, _, dg1, db1 = ops.bn_backward(da1.clone(), c1, None, st, gamma, 2, part=p1)
+    finally:
+        ops.DGRAD_BN_STATS = was
+        ops.reset_compute_dtypes()
+    if p1 is None:
+        assert torch.equal(dc0, dc1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+        return
+    assert p1.shape == (T, Cin, 2)
+    g = (da0 * (torch.addcmul(st[3], c1, st[2]) > 0)).double().reshape(-1, Cin)
+    xh = ((c1 - st[0]) * st[1]).double().reshape(-1, Cin)
+    sg, sgx = g.sum(0), (g * xh).sum(0)
+    scale = float(g.abs().sum(0).max())
+    for name, got in (("fused", (db1, dg1)), ("plain", (db0, dg0))):
+        assert float((got[0].double() - sg).abs().max()) <= 2e-6 * scale, name
+        assert float((got[1].double() - sgx).abs().max()) <= 2e-6 * scale * float(xh.abs().max()), name
+    assert float((dc1 - dc0).abs().max()) <= 1e-5 * float(dc0.abs().max())
+    assert float((g != 0).double().mean()) < 0.9          # the mask did clip
+
+
 def test_bn_apply_relu_bit_mask(dev):
     """lmkd_bn_apply's packed ReLU mask (bit e = y[e] > 0) and lmkd_bn_backward(mask_mode 3) reading it: bit-identical to the
     backward that reads y itself (mask_mode 1)"""
