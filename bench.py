@@ -119,6 +119,7 @@ def main():
     TL.TEACHER_STREAM = os.environ.get("LMKD_TEACHER_STREAM", "1") != "0"                  # tuning switches of the round-3 schedule changes
     ops.HEADS_ON_TWO_STREAMS = os.environ.get("LMKD_HEADS2", "1") != "0"
     ops.STEM_POOLED_BWD = os.environ.get("LMKD_STEM_POOLED", "1") != "0"
+    ops.GEMM_SPLIT_K = os.environ.get("LMKD_GEMM_SPLIT", "0") == "1"                         # split-K for the head's small GEMMs
     ops.DGRAD_BN_STATS = os.environ.get("LMKD_DGRAD_BN", "0") == "1"                       # BatchNorm-backward sums in the data gradient's epilogue
     ops.FUSE_PRE_ALL_MODES = os.environ.get("LMKD_FUSE_PRE", "0") == "1"                   # inner BatchNorm + ReLU in the consumers' loaders also in the plane modes
     ops.DIRECT_PARAM_GRAD = os.environ.get("LMKD_DIRECT_GRAD", "1") != "0"               # BatchNorm / Linear / TRX parameter gradients added into .grad by the kernels

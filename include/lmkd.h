@@ -36,6 +36,13 @@ int lmkd_get_activation_dtype(void);
 int lmkd_gemm_f32(char layA, char layB, int M, int N, int K, float alpha, const float* A, long lda, long sA,
                   const float* B, long ldb, long sB, float beta, float* C, long ldc, long sC, const float* bias,
                   int relu, int batch, void* stream);
+/* the same with split-K for launches of at most 64 output tiles (the fc layers' 200-row calls): given a workspace the K range is split
+   over more workgroups and the last-arriving block of each output tile adds the partial tiles in split order (deterministic).  workspace: any size (the split count adapts), tickets: lmkd_gemm_ticket_words() zeroed words (left zeroed); both
+   private to the stream while its launches may be in flight. */
+long lmkd_gemm_ticket_words(void);
+int lmkd_gemm_f32_splitk(char layA, char layB, int M, int N, int K, float alpha, const float* A, long lda, long sA,
+                         const float* B, long ldb, long sB, float beta, float* C, long ldc, long sC, const float* bias,
+                         int relu, int batch, void* workspace, long ws_bytes, unsigned* tickets, void* stream);
 
 /* ---- convolution (torchvision ResNet conv layers called at resnet18_2fc.py:41-42) ----
  * x,y NHWC.  Cs = channels of the NHWC tensor (4 for the channel-padded stem, else multiple of 32). */

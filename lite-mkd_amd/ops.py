@@ -79,11 +79,35 @@ def gemm(layA, layB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, beta=0.0, bias=
     """C = alpha*op(A)*op(B) + beta*C + bias.  *_off are element offsets into the tensors' storage."""
     _chk(A, B, C, bias)
     es = 4
+    if GEMM_SPLIT_K:
+        ws, tk = _gemm_workspace(C)
+        lib().call("lmkd_gemm_f32_splitk", layA.encode(), layB.encode(), M, N, K, _f32(alpha),
+                   ctypes.c_void_p(A.data_ptr() + A_off * es), lda, sA,
+                   ctypes.c_void_p(B.data_ptr() + B_off * es), ldb, sB, _f32(beta),
+                   ctypes.c_void_p(C.data_ptr() + C_off * es), ldc, sC, _p(bias), int(relu), batch, _p(ws), ws.numel(), _p(tk), _stream())
+        return C
     lib().call("lmkd_gemm_f32", layA.encode(), layB.encode(), M, N, K, _f32(alpha),
                ctypes.c_void_p(A.data_ptr() + A_off * es), lda, sA,
                ctypes.c_void_p(B.data_ptr() + B_off * es), ldb, sB, _f32(beta),
                ctypes.c_void_p(C.data_ptr() + C_off * es), ldc, sC, _p(bias), int(relu), batch, _stream())
     return C
+
+
+# split-K workspace (32 MB) + ticket words of lmkd_gemm_f32_splitk, one pair per (device, stream): GEMMs of two streams may run together.
+# OFF by default: alone, the 32-tile fc GEMMs run twice as fast split (tools/gemm_splitk_bench.py), inside the episode the same-box A/B
+# reads 34.24 / 34.21 / 34.18 episodes/s with it against 34.43 / 34.33 / 34.34 without (they overlap the other trunk call's kernels).
+GEMM_SPLIT_K = False
+_GEMM_WS = {}
+
+
+def _gemm_workspace(like):
+    cur = torch.cuda.current_stream(like.device)
+    key = (like.device.index, cur.cuda_stream)
+    e = _GEMM_WS.get(key)
+    if e is None:
+        e = _GEMM_WS[key] = (torch.empty(32 << 20, dtype=torch.uint8, device=like.device),
+                             torch.zeros(lib().value("lmkd_gemm_ticket_words"), dtype=torch.int32, device=like.device))
+    return e
 
 
 def linear_fwd(x, w, b):

@@ -78,6 +78,39 @@ def test_gemm_batched_beta_relu(dev):
     close(C, ref, 1e-4, 1e-3, "batched gemm")
 
 
+@pytest.mark.parametrize("layA,layB", [("K", "K"), ("K", "N"), ("M", "N")])
+@pytest.mark.parametrize("M,N,K,batch", [(200, 512, 2048, 1), (200, 512, 8192, 1), (100, 700, 1152, 1), (96, 64, 4096, 3)])
+def test_gemm_split_k(dev, layA, layB, M, N, K, batch):
+    """lmkd_gemm_f32_splitk (the K range over several workgroups, partial tiles added in split order by the last-arriving block):
+    against fp64, against the unsplit kernel, bit-identical from run to run, and the ticket words are zero again afterwards"""
+    from litemkd_amd import ops
+    A = rnd(batch, M, K, seed=7)
+    B = rnd(batch, K, N, seed=8)
+    C0 = rnd(batch, M, N, seed=9)
+    bias = rnd(N, seed=10)
+    ref = torch.relu(0.25 * torch.einsum("bmk,bkn->bmn", A.double(), B.double()) + 0.5 * C0.double() + bias.double()).float()
+    Ad = (A if layA == "K" else A.transpose(1, 2)).contiguous().to(dev)
+    Bd = (B.transpose(1, 2) if layB == "K" else B).contiguous().to(dev)
+
+    def run(split):
+        was = ops.GEMM_SPLIT_K
+        ops.GEMM_SPLIT_K = split
+        try:
+            C = C0.clone().to(dev)
+            ops.gemm(layA, layB, M, N, K, Ad, Ad.shape[2], Bd, Bd.shape[2], C, N, alpha=0.25, beta=0.5, bias=bias.to(dev), relu=True,
+                     batch=batch, sA=M * K, sB=K * N, sC=M * N)
+            return C
+        finally:
+            ops.GEMM_SPLIT_K = was
+    c1, c2, c0 = run(True), run(True), run(False)
+    assert torch.equal(c1, c2)
+    assert not torch.equal(c1, c0)          # the split did happen (another summation order)
+    close(c1, ref, 1e-4, 1e-4 * math.sqrt(K), "split-K gemm %s%s" % (layA, layB))
+    close(c1, c0, 1e-5, 1e-5 * math.sqrt(K), "split-K vs unsplit")
+    ws, tk = ops._gemm_workspace(c1)
+    assert int(tk.abs().sum()) == 0
+
+
 def test_gemm_rejects_bad_alignment(dev):
     from litemkd_amd import ops
     A = torch.zeros(8, 6, device=dev)
