@@ -119,6 +119,11 @@ def main():
     TL.TEACHER_STREAM = os.environ.get("LMKD_TEACHER_STREAM", "1") != "0"                  # tuning switches of the round-3 schedule changes
     ops.HEADS_ON_TWO_STREAMS = os.environ.get("LMKD_HEADS2", "1") != "0"
     ops.STEM_POOLED_BWD = os.environ.get("LMKD_STEM_POOLED", "1") != "0"
+    if os.environ.get("LMKD_PRIO"):                                                         # stream priorities "lane0,lane1,wgrad" (-1 high, 0 default)
+        pr = [int(v) for v in os.environ["LMKD_PRIO"].split(",")]
+        ops.STREAM_PRIORITY.update({0: pr[0], 1: pr[1], "wgrad": pr[2]})
+    if os.environ.get("LMKD_WGRAD_STEM", "1") == "0":                                     # the stem's weight gradient back on the im2col-gather kernel
+        ops.lib().call("lmkd_conv_set_wgrad_stem", 0)
     ops.GEMM_SPLIT_K = os.environ.get("LMKD_GEMM_SPLIT", "0") == "1"                         # split-K for the head's small GEMMs
     ops.DGRAD_BN_STATS = os.environ.get("LMKD_DGRAD_BN", "0") == "1"                       # BatchNorm-backward sums in the data gradient's epilogue
     ops.FUSE_PRE_ALL_MODES = os.environ.get("LMKD_FUSE_PRE", "0") == "1"                   # inner BatchNorm + ReLU in the consumers' loaders also in the plane modes
@@ -170,7 +175,19 @@ def main():
             runners[state["mode"]] = TL.GraphedEpisode(student, teacher, distiller, aggregate_accuracy, cfg, max_graphs=max(4, a.pool))
         return runners[state["mode"]]
 
+    main_lane = os.environ.get("LMKD_MAIN_LANE", "0") == "1" and pipe is None      # the episode loop on lane 0's main stream (its priority)
+
     def run(n, it0):
+        if not main_lane:
+            return run_on_current(n, it0)
+        ml = ops.lane_main(dev)
+        ml.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(ml):
+            it = run_on_current(n, it0)
+        torch.cuda.current_stream(dev).wait_stream(ml)
+        return it
+
+    def run_on_current(n, it0):
         it = it0
         for i in range(n):
             it += 1

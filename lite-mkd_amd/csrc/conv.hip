@@ -498,6 +498,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 
 #include "wgrad_x3.h"
 #include "wgrad_win.h"
+#include "wgrad_stem.h"
 
 // K-major packed weights (the GEMM's B operand: one row of K per output column):
 // mode 0 (forward): Wp[co][(kh*KWp+kw)*Cs + ci] = W[co][ci][kh][kw]   (zero for padded kw / ci)
@@ -1119,9 +1120,28 @@ static void wgrad_plan(int Mpix, int Cout, int Kp, int* splits, int* steps_per_s
   *splits = cdiv(steps, *steps_per_split);
 }
 
+// the stem's weight gradient on stem_wgrad_kernel (wgrad_stem.h): three-plane modes, fp32 tensors, 64 output channels, rows of 17 - 128
+// output pixels.  -> slabs (0: not that kind of launch), units per slab
+static int g_wgrad_stem = 1;
+extern "C" int lmkd_conv_set_wgrad_stem(int on) { g_wgrad_stem = on ? 1 : 0; return LMKD_OK; }
+static int stem_wgrad_plan(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, int* G) {
+  if (!g_wgrad_stem || !g_wgrad_planes || !g_conv_x3 || g_lmkd_act_bf16 || Cs != 4 || Cout != 64 || KH != 7 || KW != 7 || stride != 2 || pad != 3) return 0;
+  const int Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
+  if (Wo < 17 || Wo > 128 || W > 2 * Wo || Ho < 1) return 0;      // >= 2 steps of 32 pixels per unit; LDS: 60 * (16 Wo + 64) + 30720 bytes
+  const int units = N * cdiv(Ho, 2);
+  int g = std::max(1, 2048 / (2 * Wo));                 // about 2048 pixels per slab (wgrad_plan: the accumulation error of a long partial sum)
+  g = std::min(g, std::max(1, units / 256));            // but at least one slab per CU where the problem has that many units
+  *G = g;
+  return cdiv(units, g);
+}
+
 extern "C" long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
   const int Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
   const int Kp = KH * kw_padded(Cs, KW) * Cs;
+  {
+    int G;
+    if (const int slabs = stem_wgrad_plan(N, H, W, Cs, Cout, KH, KW, stride, pad, &G)) return (long)slabs * Cout * Kp * sizeof(float);
+  }
   int splits, sps, bm, bn;
   wgrad_plan(N * Ho * Wo, Cout, Kp, &splits, &sps, &bm, &bn, wgrad_uses_planes(Cs));
   if (wgrad_win_eligible(W, Cs, Cout, KH, KW, stride, pad)) {
@@ -1153,6 +1173,52 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   a.Mpix = N * a.Ho * a.Wo;
   LMKD_REQUIRE((long)N * H * W * Cs < 2147483647L && (long)a.Mpix * Cout < 2147483647L, "lmkd_conv2d_bwd_weight: tensor too large");
   hipStream_t s = (hipStream_t)stream;
+  {
+    int G;
+    if (const int slabs = stem_wgrad_plan(N, H, W, Cs, Cout, KH, KW, stride, pad, &G)) {
+      LMKD_REQUIRE(ws_bytes >= (long)slabs * Cout * a.Kp * (long)sizeof(float), "lmkd_conv2d_bwd_weight: workspace too small");
+      LMKD_REQUIRE((long)a.Mpix * 64 * 4 < 0xffffffe0L && (long)N * H * W * 16 < 0xffffffe0L, "lmkd_conv2d_bwd_weight: tensor too large for 32-bit byte offsets");
+      StemWgradArgs w;
+      memset(&w, 0, sizeof(w));
+      w.dy = dy; w.x = x; w.slab = workspace;
+      w.N = N; w.H = H; w.W = W; w.Ho = a.Ho; w.Wo = a.Wo;
+      w.upi = cdiv(a.Ho, 2); w.units = N * w.upi; w.G = G; w.slabs = slabs;
+      w.RL = 16 * a.Wo + 64;
+      const size_t lds = (size_t)2 * 10 * 3 * w.RL + 2 * 3 * STEM_WG_APLANE;
+      // one workgroup per slab (the kernel can also walk several): a grid of exactly one resident workgroup per CU ran in TWO rounds
+      // whenever a CU was not free (583 us alone, erratic beside other streams)
+      const dim3 grid(slabs);
+      const bool deep = cdiv(2 * a.Wo, 32) >= 6;      // dy tiles fetched six steps ahead (224-pixel images: seven steps per unit), else two
+#define LMKD_STEM_WG(NPROD, D, RLC)                                                                                                      \
+  do {                                                                                                                                   \
+    static bool attr_set = false;                                                                                                        \
+    if (!attr_set) {                                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel<NPROD, D, RLC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                160 * 1024);                                                                                             \
+      attr_set = true;                                                                                                                   \
+    }                                                                                                                                    \
+    hipLaunchKernelGGL((stem_wgrad_kernel<NPROD, D, RLC>), grid, dim3(512), lds, s, w);                                                   \
+  } while (0)
+      if (g_conv_x3 == 9) {
+        if (deep && w.RL == 1856) LMKD_STEM_WG(9, 6, 1856);      // 224-pixel images
+        else if (deep) LMKD_STEM_WG(9, 6, 0);
+        else LMKD_STEM_WG(9, 2, 0);
+      } else {
+        if (deep && w.RL == 1856) LMKD_STEM_WG(6, 6, 1856);
+        else if (deep) LMKD_STEM_WG(6, 6, 0);
+        else LMKD_STEM_WG(6, 2, 0);
+      }
+#undef LMKD_STEM_WG
+      LMKD_CHECK_LAUNCH("stem_wgrad_kernel");
+      const long total = (long)Cout * KH * KW * Cin;
+      int rg = cdiv(total, 256);
+      if (rg > 4096) rg = 4096;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, s, (const float*)workspace, dw_oihw, slabs, Cout, Cin, Cs, KH, KW, a.KWp, a.Kp,
+                         accumulate);
+      LMKD_CHECK_LAUNCH("wgrad_reduce_kernel");
+      return LMKD_OK;
+    }
+  }
   if (wgrad_win_eligible(W, Cs, Cout, KH, KW, stride, pad)) {
     WgradWinArgs w;
     memset(&w, 0, sizeof(w));

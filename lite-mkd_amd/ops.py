@@ -550,7 +550,7 @@ def weight_grad(w, x, dy, stride, pad, pre_stats=None):
         return conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats)
     dev = x.device.index
     if dev not in _WG_STREAM:
-        _WG_STREAM[dev] = torch.cuda.Stream(device=x.device)
+        _WG_STREAM[dev] = _new_stream(x.device, "wgrad")
     sw = _WG_STREAM[dev]
     sw.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(sw):
@@ -681,6 +681,13 @@ def apply_deferred(entries):
 LANE = [0]
 _side_streams = {}
 _lane_mains = {}
+# HIP stream priorities (torch: -1 = high, 0 = default) of the streams this module creates, by lane and for the weight-gradient stream;
+# set before the first stream is created (bench.py LMKD_PRIO)
+STREAM_PRIORITY = {0: 0, 1: 0, "wgrad": 0}
+
+
+def _new_stream(device, key):
+    return torch.cuda.Stream(device=device, priority=int(STREAM_PRIORITY.get(key, 0)))
 
 
 def set_lane(k):
@@ -690,14 +697,14 @@ def set_lane(k):
 def side_stream(device):
     key = (device.type, device.index, LANE[0])
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
+        _side_streams[key] = _new_stream(device, LANE[0])
     return _side_streams[key]
 
 
 def lane_main(device):
     key = (device.type, device.index, LANE[0])
     if key not in _lane_mains:
-        _lane_mains[key] = torch.cuda.Stream(device=device)
+        _lane_mains[key] = _new_stream(device, LANE[0])
     return _lane_mains[key]
 
 
@@ -709,7 +716,7 @@ def aux_stream(device):
     """a third forward stream: the frozen teacher head of an episode runs there beside the student's trunk (trainloop.train_task)"""
     key = (device.type, device.index, LANE[0])
     if key not in _aux_streams:
-        _aux_streams[key] = torch.cuda.Stream(device=device)
+        _aux_streams[key] = _new_stream(device, LANE[0])
     return _aux_streams[key]
 
 

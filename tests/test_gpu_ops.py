@@ -128,6 +128,9 @@ CONVS = [  # N, Cin, H, W, Cout, K, stride, pad
     (5, 256, 7, 7, 512, 3, 1, 1),      # ragged row tile (M = 245)
     (3, 64, 7, 7, 128, 3, 2, 1),       # stride 2 on an odd map (7 -> 4): parity classes of unequal size
     (3, 64, 9, 5, 64, 1, 2, 0),        # 1x1 stride 2, odd H and W
+    (3, 3, 100, 84, 64, 7, 2, 3),      # stem sizes of stem_wgrad_kernel: 3 steps per unit (dy fetched 2 steps ahead)
+    (2, 3, 97, 150, 64, 7, 2, 3),      # odd output height (the last unit of an image has one row), 5 steps
+    (5, 3, 224, 224, 64, 7, 2, 3),     # 7 steps per unit (6 ahead), several units per slab
 ]
 
 

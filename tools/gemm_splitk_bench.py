@@ -1,7 +1,8 @@
 """lmkd_gemm_f32 vs lmkd_gemm_f32_splitk on the head's GEMM shapes (400 frames / 700 tuples), microseconds per launch."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import litemkd_amd  # noqa: F401
 from litemkd_amd import ops
 
