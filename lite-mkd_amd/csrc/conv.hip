@@ -1057,6 +1057,8 @@ extern "C" int lmkd_conv2d_bwd_data_bn(const float* dy, const float* wd, float* 
 static int g_wgrad_planes = 1;   // bf16 / 3xbf16 modes: weight gradient on the bf16-plane kernel (wgrad_x3.h); 0 = fp32-tile kernel
 extern "C" int lmkd_conv_set_wgrad_planes(int on) { g_wgrad_planes = on ? 1 : 0; return LMKD_OK; }
 // 3x3 / stride-1 weight gradients of the bf16-plane modes from a rolling LDS window of x (wgrad_win.h); 0 = im2col-gather kernel
+static int g_wgrad_win16 = 1;      // three-plane modes, fp32 tensors: conv_wgrad_win16_kernel (v_mfma_f32_16x16x32_bf16); 0 = the 32x32x16 form
+extern "C" int lmkd_conv_set_wgrad_win16(int on) { g_wgrad_win16 = on ? 1 : 0; return LMKD_OK; }
 static int g_wgrad_window = 1;
 extern "C" int lmkd_conv_set_wgrad_window(int on) { g_wgrad_window = on < 0 ? 0 : on; return LMKD_OK; }      // > 1: workgroup target of the split plan
 static inline bool wgrad_win_eligible(int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
@@ -1242,8 +1244,20 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
     if (big) hipLaunchKernelGGL((conv_wgrad_win_kernel<COB, NPROD, A16, 256, PRE, TPW>), wgrid, dim3(NT), 0, s, w);     \
     else hipLaunchKernelGGL((conv_wgrad_win_kernel<COB, NPROD, A16, 128, PRE, TPW>), wgrid, dim3(NT), 0, s, w);         \
   } while (0)
+#define LMKD_WIN16(COB, NPROD, PRE)                                                                                     \
+  do {                                                                                                                  \
+    constexpr int TPW = COB == 2 ? 5 : 9;                                                                               \
+    constexpr int NT = 64 * COB * ((9 + TPW - 1) / TPW);                                                                \
+    if (big) hipLaunchKernelGGL((conv_wgrad_win16_kernel<COB, NPROD, 256, PRE, TPW>), wgrid, dim3(NT), 0, s, w);        \
+    else hipLaunchKernelGGL((conv_wgrad_win16_kernel<COB, NPROD, 128, PRE, TPW>), wgrid, dim3(NT), 0, s, w);            \
+  } while (0)
 #define LMKD_WIN_MODE(COB)                                                                                              \
   do {                                                                                                                  \
+    if (g_wgrad_win16 && g_conv_x3 && !g_lmkd_act_bf16) {      /* three-plane modes, fp32 tensors: the 16x16x32 MFMA form */ \
+      if (g_conv_x3 == 9) { if (pre_stats) LMKD_WIN16(COB, 9, true); else LMKD_WIN16(COB, 9, false); }                  \
+      else { if (pre_stats) LMKD_WIN16(COB, 6, true); else LMKD_WIN16(COB, 6, false); }                                 \
+      break;                                                                                                            \
+    }                                                                                                                   \
     if (g_lmkd_act_bf16) LMKD_WIN(COB, 1, true, false);                                                                 \
     else if (g_conv_bf16) { if (pre_stats) LMKD_WIN(COB, 1, false, true); else LMKD_WIN(COB, 1, false, false); }        \
     else if (g_conv_x3 == 9) { if (pre_stats) LMKD_WIN(COB, 9, false, true); else LMKD_WIN(COB, 9, false, false); }     \
@@ -1252,6 +1266,7 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
     if (cob == 4) LMKD_WIN_MODE(4);
     else LMKD_WIN_MODE(2);
 #undef LMKD_WIN_MODE
+#undef LMKD_WIN16
 #undef LMKD_WIN
     LMKD_CHECK_LAUNCH("conv_wgrad_win_kernel");
     const long total = (long)Cout * KH * KW * Cin;

@@ -228,3 +228,214 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
     }
   }
 }
+
+// ---- the same kernel on v_mfma_f32_16x16x32_bf16 (round 3; three-plane modes, fp32 tensors).  Same window, same loaders, same
+// slabs; what changes is the fragment geometry (conv_patch16.h has the reason: the chip holds a higher clock under this shape):
+//   * one MFMA takes the whole 32-pixel step; the 32 x 32 (co x ci) tile of a (wave, tap) is four 16 x 16 accumulators.
+//   * k order inside a step: lane group q4 = lane / 16, element j <-> pixel 16 (j / 4) + 4 q4 + (j % 4) (wgrad_stem.h): the lower /
+//     upper transposed read of a lane group covers rows 4 q4 .. 4 q4 + 3 / 16 + 4 q4 .. + 3, so a 32-lane half reads EIGHT consecutive
+//     rows of one 16-column block at once.
+//   * banks: dy rows are BM * 2 + 32 bytes (an odd multiple of 32: eight consecutive rows' 32-byte segments tile the 256-byte bank
+//     row).  The x ring keeps its 64-byte rows; rows s and s + 4 would collide, so the two 32-byte halves (ci 0-15 | 16-31) of the
+//     slots with bit 2 set are SWAPPED when a row is stored: eight consecutive slots then tile the bank row for either half.  The
+//     address table carries the swap bit in bit 5 of an entry, and the reader's block select is an XOR with 32.
+//   * address table of a step: entry (tap, row slot 4 q4 + q) = {lower row, upper row}: one ds_read_b64 per lane and tap.
+template <int COB, int NPROD, int R, bool PRE = false, int TPW = 9>
+__global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_win16_kernel(WgradWinArgs a) {
+  static_assert(NPROD == 6 || NPROD == 9, "three-plane modes");
+  constexpr int NPL = 3;
+  constexpr int THREADS = 64 * COB * ((9 + TPW - 1) / TPW), BM = 32 * COB;
+  constexpr int LDA = BM * 2 + 32, A_PLANE = LMKD_BK * LDA;      // dy image [k][co], bytes
+  constexpr int LDX = 64, X_PLANE = (R + 1) * LDX;               // x ring [slot][32 ci]; slot R = the zero row
+  constexpr int A_LPR = BM / 4, A_RPP = THREADS / A_LPR, A_NI = (LMKD_BK + A_RPP - 1) / A_RPP;      // dy loader: lanes per row, rows per pass
+  constexpr int X_LPR = 8, X_RPP = THREADS / X_LPR, X_NI = (LMKD_BK + X_RPP - 1) / X_RPP;
+  static_assert(THREADS % A_LPR == 0 && THREADS % X_LPR == 0 && (LDA / 32) % 2 == 1, "tile layout");
+  __shared__ __attribute__((aligned(16))) unsigned char s_dy[NPL * A_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char s_x[NPL * X_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned s_adr[2][9 * LMKD_BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles = a.n_ct * a.n_it;
+  const int xj = blockIdx.x >> 3;
+  const int z = (blockIdx.x & 7) + 8 * (xj / tiles);
+  if (z >= a.splits) return;
+  const int tz = xj - (xj / tiles) * tiles;
+  const int co0 = (tz % a.n_ct) * BM, ci0 = (tz / a.n_ct) * 32;
+  const int s0 = z * a.steps_per_split;
+  int nk = a.steps_total - s0;
+  if (nk > a.steps_per_split) nk = a.steps_per_split;
+  const int halo = a.W + 1;
+
+  const __amdgpu_buffer_rsrc_t rs_dy = x3_rsrc(a.dy, (long)a.Mpix * a.Co * 4);
+  const __amdgpu_buffer_rsrc_t rs_x = x3_rsrc(a.x, (long)a.Mpix * a.Cs * 4);
+  const int a_c = (tid % A_LPR) * 4, a_r = tid / A_LPR;
+  const bool a_cin = co0 + a_c < a.Co;
+  const int x_c = (tid % X_LPR) * 4, x_r = tid / X_LPR;
+  u32x4 ra[A_NI], rx[X_NI];
+  unsigned x_ok = 0;
+  float4 psc = float4(), psh = float4();
+  if (PRE) {
+    psc = *reinterpret_cast<const float4*>(a.pre_stats + 2 * a.Cs + ci0 + x_c);
+    psh = *reinterpret_cast<const float4*>(a.pre_stats + 3 * a.Cs + ci0 + x_c);
+  }
+  auto load_dy = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_NI; ++i) {
+      const int p = k0 + a_r + A_RPP * i;
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (a_cin && a_r + A_RPP * i < LMKD_BK && p < a.Mpix) ? (unsigned)((p * a.Co + co0 + a_c) * 4) : X3_OOB, 0, 0);
+    }
+  };
+  auto load_x = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < X_NI; ++i) {
+      const int q = q0 + x_r + X_RPP * i;
+      const bool ok = x_r + X_RPP * i < LMKD_BK && q >= 0 && q < a.Mpix;
+      rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)((q * a.Cs + ci0 + x_c) * 4) : X3_OOB, 0, 0);
+      if (PRE) x_ok = ok ? (x_ok | (1u << i)) : (x_ok & ~(1u << i));
+    }
+  };
+  auto as_f4 = [](const u32x4& r) { return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)); };
+  auto store_dy = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_NI; ++i) {
+      if (a_r + A_RPP * i >= LMKD_BK) continue;
+      tr_store4<NPL, LDA, A_PLANE>(s_dy, a_r + A_RPP * i, a_c, as_f4(ra[i]));
+    }
+  };
+  auto store_x = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < X_NI; ++i) {
+      if (x_r + X_RPP * i >= LMKD_BK) continue;
+      const int slot = (q0 + x_r + X_RPP * i) & (R - 1);
+      float4 v = as_f4(rx[i]);
+      if (PRE && ((x_ok >> i) & 1u)) {      // bit-identical to bn_apply_kernel
+        v.x = fmaxf(fmaf(v.x, psc.x, psh.x), 0.f); v.y = fmaxf(fmaf(v.y, psc.y, psh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, psc.z, psh.z), 0.f); v.w = fmaxf(fmaf(v.w, psc.w, psh.w), 0.f);
+      }
+      uint2 p0, p1, p2;
+      x3_split4(v, p0, p1, p2);
+      unsigned char* d = s_x + slot * LDX + ((x_c * 2) ^ (((slot >> 2) & 1) << 5));      // halves swapped in the slots with bit 2 set
+      *reinterpret_cast<uint2*>(d) = p0;
+      *reinterpret_cast<uint2*>(d + X_PLANE) = p1;
+      *reinterpret_cast<uint2*>(d + 2 * X_PLANE) = p2;
+    }
+  };
+  auto fill_adr = [&](unsigned* tab, int k0) {
+    for (int e = tid; e < 9 * LMKD_BK; e += THREADS) {
+      const int tp = e >> 5, r = e & 31;
+      const int p = k0 + r;
+      unsigned adr = (unsigned)(R * LDX);
+      if (p < a.Mpix) {
+        const int n = fdiv(p, a.div_hw);
+        const int rem = p - n * a.H * a.W;
+        const int h = fdiv(rem, a.div_w), w = rem - h * a.W;
+        const int dh = tp / 3 - 1, dw = tp - (tp / 3) * 3 - 1;
+        if ((unsigned)(h + dh) < (unsigned)a.H && (unsigned)(w + dw) < (unsigned)a.W) {
+          const int slot = (p + dh * a.W + dw) & (R - 1);
+          adr = (unsigned)(slot * LDX + (((slot >> 2) & 1) << 5));
+        }
+      }
+      tab[tp * LMKD_BK + (r & 15) * 2 + (r >> 4)] = adr;
+    }
+  };
+
+  const int q4 = lane >> 4, idx = lane & 15;
+  const int cw = wave % COB, tap0 = (wave / COB) * TPW;
+  const int offA = (4 * q4 + (idx >> 2)) * LDA + (cw * 32 + 4 * (idx & 3)) * 2;      // + 32 bytes: second 16-channel block; + 16 LDA: upper rows
+  const unsigned cbx = (unsigned)(8 * (idx & 3));
+  f32x4 acc[TPW][2][2];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    const int kfirst = s0 * LMKD_BK;
+    for (int j = tid; j < NPL * LDX / 4; j += THREADS)      // the zero row of every plane
+      reinterpret_cast<unsigned*>(s_x + (j / (LDX / 4)) * X_PLANE + R * LDX)[j % (LDX / 4)] = 0u;
+    for (int q0 = kfirst - halo; q0 < kfirst + halo; q0 += LMKD_BK) {
+      load_x(q0);
+      store_x(q0);
+    }
+    fill_adr(s_adr[0], kfirst);
+    load_dy(kfirst);
+    load_x(kfirst + halo);
+    for (int t = 0; t < nk; ++t) {
+      const int k0 = kfirst + t * LMKD_BK;
+      store_dy();
+      store_x(k0 + halo);
+      __syncthreads();
+      if (t + 1 < nk) {
+        load_dy(k0 + LMKD_BK);
+        load_x(k0 + LMKD_BK + halo);
+        fill_adr(s_adr[(t + 1) & 1], k0 + LMKD_BK);
+      }
+      bf16x8 fa[2][NPL];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+          const unsigned char* ap = s_dy + p * A_PLANE + offA + i * 32;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)ap);
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(ap + 16 * LDA));
+          union { s16x4_t s[2]; bf16x8 b; } u;
+          u.s[0] = lo; u.s[1] = hi;
+          fa[i][p] = u.b;
+        }
+#pragma unroll
+      for (int ti = 0; ti < TPW; ++ti) {
+        const int tp = tap0 + ti;
+        if (9 % TPW != 0 && ti >= 9 - TPW * (9 / TPW) && tp >= 9) break;      // only the last wave group's trailing taps can be missing
+        const uint2 a2 = *reinterpret_cast<const uint2*>(&s_adr[t & 1][tp * LMKD_BK + (4 * q4 + (idx >> 2)) * 2]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {      // the two 16-channel blocks of x
+          bf16x8 fb[NPL];
+          const unsigned lo_a = (a2.x ^ (unsigned)(j << 5)) + cbx, hi_a = (a2.y ^ (unsigned)(j << 5)) + cbx;
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) {
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(s_x + p * X_PLANE + lo_a));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(s_x + p * X_PLANE + hi_a));
+            union { s16x4_t s[2]; bf16x8 b; } u;
+            u.s[0] = lo; u.s[1] = hi;
+            fb[p] = u.b;
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            f32x4 c = acc[ti][i][j];
+            if (NPROD == 9) {
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][2], fb[2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][2], fb[1], c, 0, 0, 0);
+            }
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[1], c, 0, 0, 0);     // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][2], fb[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[0], c, 0, 0, 0);
+            acc[ti][i][j] = c;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  float* C = a.slab + (long)z * a.Co * a.Kp;
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) {
+    if (9 % TPW != 0 && tap0 + ti >= 9) break;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (tap0 + ti) * a.Cs + ci0 + 16 * j + idx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = co0 + cw * 32 + 16 * i + 4 * q4 + e;
+          if (row < a.Co) C[(long)row * a.Kp + col] = acc[ti][i][j][e];
+        }
+      }
+  }
+}
