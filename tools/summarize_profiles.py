@@ -1,5 +1,5 @@
 """Turns the rocprofv3 outputs of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the summaries committed under profiles/:
-  <tag>_kernel_stats_serial_<mode>.csv   per-kernel statistics of `bench.py --serial` (5 episodes) in each arithmetic mode
+  <tag>_kernel_stats_serial_<mode>.csv   per-kernel statistics of `bench.py --serial` in each arithmetic mode (+ _kernel_time_per_episode_<mode>.txt)
   <tag>_conv_by_shape.txt                conv launches by kernel instance and grid (headline mode)
   <tag>_hbm_traffic.json                 FETCH_SIZE x2 + WRITE_SIZE per launch and kernel family, with the hash of the kernel
                                          sources it was measured on (bench.py reports `roofline.traffic` only when it matches)
@@ -55,9 +55,15 @@ for mode in ("f32", "f32native", "bf16"):
     fam = collections.defaultdict(float)
     for r in rows:
         fam[family(r["Name"])] += float(r["TotalDurationNs"])
-    print("%s: sum of kernel time per episode (5 serialized episodes): %.2f ms" % (mode, tot / 1e6 / 5))
-    for k, v in sorted(fam.items(), key=lambda kv: -kv[1])[:12]:
-        print("    %-40s %7.3f ms/episode  %5.1f %%" % (k, v / 1e6 / 5, 100 * v / tot))
+    neps = max([int(r["Calls"]) for r in rows if "d2m_loss_kernel" in r["Name"]] + [1])      # one loss kernel per episode (warm-up + timed + roofline pass)
+    nl = sum(int(r["Calls"]) for r in rows)
+    lines = ["%s: %d serialized episodes in the trace; sum of kernel time per episode %.2f ms, %.0f launches per episode" % (mode, neps, tot / 1e6 / neps, nl / neps)]
+    for k, v in sorted(fam.items(), key=lambda kv: -kv[1])[:24]:
+        lines.append("    %-40s %7.3f ms/episode  %5.1f %%" % (k, v / 1e6 / neps, 100 * v / tot))
+    print("\n".join(lines[:14]))
+    with open("profiles/%s_kernel_time_per_episode_%s.txt" % (tag, mode), "w") as fo:
+        fo.write("# tools/summarize_profiles.py from profiles/%s_kernel_stats_serial_%s.csv (rocprofv3 --kernel-trace --stats of bench.py --serial)\n" % (tag, mode))
+        fo.write("\n".join(lines) + "\n")
 
 tr = find("trace_f32", "kernel_trace.csv")
 if tr:
@@ -68,8 +74,8 @@ if tr:
             key = (n.replace("void ", "").split("(")[0], int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["LDS_Block_Size"], r["VGPR_Count"])
             g[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open("profiles/%s_conv_by_shape.txt" % tag, "w") as fo:
-        fo.write("# rocprofv3 --kernel-trace --stats of `python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-modes --serial` (5 episodes,\n"
-                 "# headline arithmetic), conv kernels by instance and grid\n# kernel | workgroups | LDS bytes | VGPRs | launches | avg us | total ms\n")
+        fo.write("# rocprofv3 --kernel-trace --stats of `python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-modes --serial` (9 episodes with\n"
+                 "# the roofline pass, headline arithmetic), conv kernels by instance and grid\n# kernel | workgroups | LDS bytes | VGPRs | launches | avg us | total ms\n")
         for k, v in sorted(g.items(), key=lambda kv: -sum(kv[1])):
             fo.write("%s | %s | %s | %s | %d | %.1f | %.2f\n" % (k[0], k[1], k[2], k[3], len(v), sum(v) / len(v) / 1e3, sum(v) / 1e6))
 
