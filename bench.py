@@ -124,6 +124,8 @@ def main():
         ops.STREAM_PRIORITY.update({0: pr[0], 1: pr[1], "wgrad": pr[2]})
     if os.environ.get("LMKD_WGRAD_STEM", "1") == "0":                                     # the stem's weight gradient back on the im2col-gather kernel
         ops.lib().call("lmkd_conv_set_wgrad_stem", 0)
+    if os.environ.get("LMKD_S2_PATCH", "1") == "0":                                       # stride-2 3x3 forward back on the im2col-gather kernel
+        ops.lib().call("lmkd_conv_set_s2_patch", 0)
     if os.environ.get("LMKD_WIN16", "1") == "0":                                          # rolling-window weight gradient back on the 32x32x16 MFMA
         ops.lib().call("lmkd_conv_set_wgrad_win16", 0)
     ops.SIDE_LINEAR_WGRAD = os.environ.get("LMKD_SIDE_LINEAR", "1") != "0"                   # Linear / TRX weight-gradient GEMMs on the weight-gradient stream

@@ -72,6 +72,7 @@ int lmkd_conv_get_compute_dtype(void);
 int lmkd_conv_set_wgrad_planes(int on); /* tuning (modes 1-3): 1 = weight gradient on the bf16-plane kernel with transposed LDS reads (default), 0 = fp32-tile kernel */
 int lmkd_conv_set_patch(int on); /* tuning (modes 1-3): 1 = same-size convolutions (3x3 / stride 1 forward and data gradient) read an LDS-resident input patch (default), 0 = im2col gather */
 int lmkd_conv_set_stem_patch(int on); /* tuning (modes 1-3): 1 = the 7x7 / stride-2 stem convolution reads an LDS-resident patch of input rows (default), 0 = im2col gather */
+int lmkd_conv_set_s2_patch(int on); /* tuning (modes 2-3, fp32 tensors): 1 = stride-2 3x3 forward convolutions on the LDS-patch kernel, as four same-size convolutions over the input's parity classes (default), 0 = im2col gather */
 int lmkd_conv_set_wgrad_win16(int on); /* tuning (modes 2-3, fp32 tensors): 1 = the rolling-window weight gradient on v_mfma_f32_16x16x32_bf16 (default), 0 = 32x32x16 */
 int lmkd_conv_set_wgrad_stem(int on); /* tuning (modes 2-3, fp32 tensors): 1 = the stem's weight gradient on stem_wgrad_kernel (input rows resident in LDS, no im2col copy; default), 0 = im2col-gather kernel */
 int lmkd_conv_set_wgrad_window(int on); /* tuning (modes 1-3): 1 = 3x3 / stride-1 weight gradients read a rolling LDS window of x, all nine taps per workgroup (default), 0 = im2col-gather kernel */

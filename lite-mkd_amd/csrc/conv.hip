@@ -42,6 +42,11 @@ struct ConvGemmArgs {
   // (sum g, sum g * xhat), g = out * [fma(x, scale, shift) > 0], xhat = (x - mean) * invstd - what bn_bwd_reduce_kernel sums
   const float* bnb_x;
   const float* bnb_stats;
+  // SRC2 (conv_patch16.h): stride-2 forward convolution as four same-size convolutions over the input's parity classes.  Hs / Ws then
+  // hold the CLASS grid (= the output grid), s2_wfull the input's width, s2_off[c] the element offset of class c's origin
+  // ((sph * W + spw) * Cs) and taps[0][s2_t0[c] .. s2_t0[c + 1] - 1] the taps of class c (dh / dw in the class grid)
+  int src2, s2_ncls, s2_wfull;
+  int s2_t0[5], s2_off[4];
   FastDiv div_hw, div_w;
   int ntap[LMKD_MAX_CLASSES];
   Tap taps[LMKD_MAX_CLASSES][LMKD_MAX_TAPS];
@@ -685,6 +690,8 @@ static inline bool conv_same_size(int H, int W, int KH, int KW, int stride, int 
   return g_conv_patch && stride == 1 && conv_out(H, KH, stride, pad) == H && conv_out(W, KW, stride, pad) == W && (KH / 2) * W + KW / 2 <= PATCH_HALO_MAX;
 }
 
+static int g_conv_s2_patch = 1;      // stride-2 3x3 forward on conv_patch16_x3_kernel's SRC2 form; 0 = im2col-gather kernel
+extern "C" int lmkd_conv_set_s2_patch(int on) { g_conv_s2_patch = on ? 1 : 0; return LMKD_OK; }
 static int g_patch16 = 1;      // three-plane modes, fp32 tensors, the 4-wave tiles: conv_patch16_x3_kernel (v_mfma_f32_16x16x32_bf16); 0 = conv_patch_x3_kernel (32x32x16)
 extern "C" int lmkd_conv_set_patch16(int on) { g_patch16 = on ? 1 : 0; return LMKD_OK; }
 static int g_patch_debug = 0;      // timing ablations of conv_patch_x3_kernel (DBG template argument; tools/patch_ablate.py); 0 = the product kernel
@@ -748,6 +755,22 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
     }                                                                                                                          \
     hipLaunchKernelGGL((conv_patch16_x3_kernel<Cfg, NPROD, PRE, EP>), grid, dim3(Cfg::THREADS), lds, s, a);                    \
   } while (0)
+      if (a.src2) {
+#define LMKD_PATCH16S(NPROD, EP)                                                                                               \
+  do {                                                                                                                         \
+    static bool attr16s_set = false;                                                                                           \
+    if (!attr16s_set) {                                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch16_x3_kernel<Cfg, NPROD, false, EP, true>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3)); \
+      attr16s_set = true;                                                                                                      \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((conv_patch16_x3_kernel<Cfg, NPROD, false, EP, true>), grid, dim3(Cfg::THREADS), lds, s, a);            \
+  } while (0)
+        if (a.ep_stats) { if (g_conv_x3 == 9) LMKD_PATCH16S(9, true); else LMKD_PATCH16S(6, true); }
+        else { if (g_conv_x3 == 9) LMKD_PATCH16S(9, false); else LMKD_PATCH16S(6, false); }
+#undef LMKD_PATCH16S
+        return;
+      }
       if (a.ep_stats) { if (g_conv_x3 == 9) LMKD_PATCH16(9, false, true); else LMKD_PATCH16(6, false, true); }
       else if (a.pre_stats) { if (g_conv_x3 == 9) LMKD_PATCH16(9, true, false); else LMKD_PATCH16(6, true, false); }
       else { if (g_conv_x3 == 9) LMKD_PATCH16(9, false, false); else LMKD_PATCH16(6, false, false); }
@@ -918,6 +941,32 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
       for (int kw = 0; kw < KW; ++kw) a.taps[0][kh * KW + kw] = Tap{kh - pad, kw - pad, (kh * KWp + kw) * Cs};
   }
   hipStream_t s = (hipStream_t)stream;
+  // stride-2 3x3 forward on the patch kernel (SRC2): even input, the 16x16x32 instances (tile ids 11 / 12), no BatchNorm loader
+  if (g_conv_s2_patch && g_patch16 && g_conv_patch && g_conv_x3 && !g_lmkd_act_bf16 && !g_patch_debug && !smallc && !pre_stats && stride == 2 &&
+      KH == 3 && KW == 3 && pad == 1 && H % 2 == 0 && W % 2 == 0 && a.Wo + 1 <= PATCH_HALO_MAX) {
+    const int id = pick_conv_cfg(a.rows_per_class, 1, Cout, true);
+    if (id == 11 || id == 12) {
+      a.src2 = 1; a.s2_ncls = 4; a.s2_wfull = W;
+      a.Hs = a.Ho; a.Ws = a.Wo; a.sh = 1; a.same = 1;
+      LMKD_REQUIRE((long)N * H * W * Cs * 4 < 2147483647L, "lmkd_conv2d_fwd: input tensor exceeds the 2 GiB offset range of the stride-2 patch form");
+      static const int order[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}};      // classes by tap count 4, 2, 2, 1
+      int nt = 0;
+      for (int c = 0; c < 4; ++c) {
+        const int sph = order[c][0], spw = order[c][1];
+        a.s2_t0[c] = nt;
+        a.s2_off[c] = (sph * W + spw) * Cs;
+        for (int kh = 0; kh < 3; ++kh) {
+          if (((kh - 1) & 1) != sph) continue;
+          for (int kw = 0; kw < 3; ++kw) {
+            if (((kw - 1) & 1) != spw) continue;
+            a.taps[0][nt++] = Tap{(kh - 1 - sph) / 2, (kw - 1 - spw) / 2, (kh * KWp + kw) * Cs};
+          }
+        }
+      }
+      a.s2_t0[4] = nt;
+      a.ntap[0] = nt;
+    }
+  }
   if (const int wp = ep_stats ? 0 : stem_patch_pitch(W, Cs, Cout, KH, KW, stride, pad)) {
     a.halo = wp;      // row pitch of the input-row patch
     a.n_rt = N * cdiv(a.Ho, 2); a.n_ct = 1;

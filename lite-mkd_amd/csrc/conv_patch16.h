@@ -75,9 +75,16 @@ __global__ void split_weights16_kernel(const float* __restrict__ wp, unsigned sh
   }
 }
 
-template <class Cfg, int NPROD, bool PRE, bool EP>
+// SRC2: a stride-2 FORWARD convolution (3x3 / pad 1 on an even-sized input).  The input's four parity classes x[:, sph::2, spw::2] are
+// images of the OUTPUT's size, and a tap (kh, kw) reads one of them at a shift of -1 or 0 pixels: the convolution is the sum of four
+// same-size convolutions with 4 + 2 + 2 + 1 taps.  The K loop runs (chunk, class, tap of the class); the patch of a (chunk, class) is the
+// class image's pixel range of the tile - gathered from every second pixel of every second row (a pixel's 32-channel chunk is 128
+// contiguous bytes) through a per-tile table of source offsets, s_src - and everything behind the patch store is the same-size kernel.
+// (before: conv_gemm_x3_kernel's im2col gather, 125-135 TFLOP/s on the three stride-2 3x3 layers.)
+template <class Cfg, int NPROD, bool PRE, bool EP, bool SRC2 = false>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kernel(ConvGemmArgs a) {
   static_assert(NPROD == 6 || NPROD == 9, "three-plane modes");
+  static_assert(!SRC2 || !PRE, "the stride-2 source form has no BatchNorm loader");
   constexpr int NPL = 3;
   constexpr int ROWB = PatchRow<NPL>::BYTES;
   constexpr int LPR = 8;                                  // lanes per patch row (16 bytes each)
@@ -89,6 +96,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   __shared__ int s_out[Cfg::BM];
   __shared__ int s_tap_shift[LMKD_MAX_TAPS], s_tap_kofs[LMKD_MAX_TAPS];
   __shared__ float s_red[Cfg::WM * Cfg::BN * 2];
+  __shared__ int s_src[SRC2 ? Cfg::BM + 2 * PATCH_HALO_MAX : 1];      // SRC2: byte offset of patch row j's pixel in class (0, 0), -1 outside
   const int tid = threadIdx.x;
   int rt, ct;
   if (!xcd_decode(blockIdx.x, a.n_rt, a.n_ct, a.xcd_mode, rt, ct)) return;
@@ -123,6 +131,19 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     s_out[r] = ob;
   }
   for (int j = tid; j < ROWB / 4; j += Cfg::THREADS) reinterpret_cast<unsigned*>(psm + (long)P * ROWB)[j] = 0u;   // the zero row
+  if constexpr (SRC2) {
+    for (int j = tid; j < P; j += Cfg::THREADS) {
+      const int m = row0 - halo + j;
+      int off = -1;
+      if (m >= 0 && m < M) {
+        const int n = fdiv(m, a.div_hw);
+        const int rem = m - n * a.Hs * a.Ws;
+        const int aa = fdiv(rem, a.div_w), bb = rem - aa * a.Ws;
+        off = (((n * 2 * a.Hs + 2 * aa) * a.s2_wfull + 2 * bb) * a.Cs) * 4;
+      }
+      s_src[j] = off;
+    }
+  }
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int kq = lane >> 4;                               // lane group: result rows 4 kq .. 4 kq + 3; k-slot patch16_kslot(kq) of a 32-k step
@@ -148,7 +169,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   }
   const unsigned zero_addr = (unsigned)(P * ROWB + 16 * ksl);
   // patch loader (conv_patch.h): LPR lanes x 16 B per pixel row
-  const __amdgpu_buffer_rsrc_t prs = x3_rsrc(a.src, (long)a.N * a.Hs * a.Ws * a.Cs * 4);
+  const __amdgpu_buffer_rsrc_t prs = x3_rsrc(a.src, (long)a.N * a.Hs * a.Ws * a.Cs * 4 * (SRC2 ? 4 : 1));
   const int pk = (tid & (LPR - 1)) * 4;
   const long pix0 = (long)row0 - halo + tid / LPR;
   const unsigned p_off0 = (unsigned)((pix0 * a.Cs + pk) * 4), p_step = (unsigned)(RPP * a.Cs * 4);
@@ -160,7 +181,18 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   }
   u32x4 rp[NI];
   float4 psc = float4(), psh = float4();
-  auto issue_patch = [&](int cc) {
+  auto issue_patch = [&](int cc, int sc = 0) {
+    if constexpr (SRC2) {      // patch row j = pixel s_src[j] of class (0, 0), moved to class sc's origin
+      const unsigned rel = (unsigned)((a.s2_off[sc] + cc * 32 + pk) * 4);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (i * RPP >= P) continue;
+        const int j = tid / LPR + RPP * i;
+        const int so = j < P ? s_src[j] : -1;
+        rp[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, so >= 0 ? (unsigned)so + rel : X3_OOB, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i)
       if (i * RPP < P) rp[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, ((p_ok >> i) & 1u) ? p_off0 + i * p_step + (unsigned)(cc * 32 * 4) : X3_OOB, 0, 0);
@@ -203,13 +235,19 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     if (++b_tp == ntap) { b_tp = 0; ++b_cc; }
   };
   int k_tp = 0, k_cc = 0;      // (tap, chunk) of the current K-step
+  int k_sc = 0;                // SRC2: source class of the current K-step (taps are ordered by class: class c = taps s2_t0[c] .. s2_t0[c + 1] - 1)
   // K-step t (one tap of one 32-channel chunk = ONE 16x16x32 MFMA deep): see conv_patch.h for the prefetch / landing discipline
   auto step = [&](int t, u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR]) {
-    if (k_tp == 0) {
+    if (SRC2 ? k_tp == a.s2_t0[k_sc] : k_tp == 0) {
       __syncthreads();                       // every wave has finished reading the previous chunk
       store_patch();
       __syncthreads();
-      if (k_cc + 1 < a.cps) issue_patch(k_cc + 1);
+      if constexpr (SRC2) {
+        if (k_sc + 1 < a.s2_ncls) issue_patch(k_cc, k_sc + 1);
+        else if (k_cc + 1 < a.cps) issue_patch(k_cc + 1, 0);
+      } else {
+        if (k_cc + 1 < a.cps) issue_patch(k_cc + 1);
+      }
     }
     const unsigned sh = (unsigned)s_tap_shift[k_tp];
     unsigned ad[NB];
@@ -256,7 +294,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
         }
       }
     }
-    if (++k_tp == ntap) { k_tp = 0; ++k_cc; }
+    ++k_tp;
+    if (SRC2 && k_sc + 1 < a.s2_ncls && k_tp == a.s2_t0[k_sc + 1]) ++k_sc;
+    if (k_tp == ntap) { k_tp = 0; ++k_cc; k_sc = 0; }
     __builtin_amdgcn_sched_barrier(0);
     x3_landed(rbn);
     x3_landed(rp);

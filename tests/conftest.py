@@ -42,3 +42,6 @@ def _library_default_modes(request):
         litemkd_amd.lib().call("lmkd_conv_set_tile", 0)
         litemkd_amd.lib().call("lmkd_conv_set_patch", 1)
         litemkd_amd.lib().call("lmkd_conv_set_patch16", 1)
+        litemkd_amd.lib().call("lmkd_conv_set_s2_patch", 1)
+        litemkd_amd.lib().call("lmkd_conv_set_wgrad_win16", 1)
+        litemkd_amd.lib().call("lmkd_conv_set_wgrad_stem", 1)

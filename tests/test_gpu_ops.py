@@ -313,6 +313,9 @@ def test_block_fused_training_path_bit_identical(dev, kind, cin, cout, stride, m
     outs = []
     ops.set_conv_compute_dtype(mode)
     ops.FUSE_PRE_ALL_MODES = True          # the loaders of the bf16-plane kernels too (policy: native fp32 only, ops._train_pre)
+    # the Bottleneck's stride-2 3x3 convolution: with the loader fusion it runs the gather kernel (the patch kernel's stride-2 form has
+    # no BatchNorm loader), without it the patch form, whose taps are summed class by class - same kernel for both arms here
+    ops.lib().call("lmkd_conv_set_s2_patch", 0)
     for fuse in (False, True):
         ops.FUSE_TRAIN_BN = fuse
         try:
@@ -1550,6 +1553,36 @@ def test_stride2_data_gradient_on_patch_kernel_bit_identical(dev, mode):
         L.call("lmkd_conv_set_patch16", 1)
         ops.set_activation_dtype("fp32")
         ops.reset_compute_dtypes()
+
+
+@pytest.mark.parametrize("mode", ["fp32x3", "fp32x3_9"])
+@pytest.mark.parametrize("cfg", [(40, 64, 56, 56, 128), (7, 128, 28, 28, 256), (3, 256, 14, 14, 512), (2, 64, 10, 6, 64), (5, 64, 112, 112, 64)])
+def test_stride2_forward_on_patch_kernel(dev, cfg, mode):
+    """conv_patch16_x3_kernel SRC2 (a stride-2 3x3 forward convolution as four same-size convolutions over the input's parity classes)
+    against the im2col-gather kernel: same products, another summation order (taps class by class) - equal to fp32 rounding of the
+    sums, BatchNorm partial sums likewise, and both within the anchored criterion of an fp64 convolution"""
+    from litemkd_amd import ops
+    from _anchor import anchored
+    N, Cin, H, W, Cout = cfg
+    x = torch.relu(rnd(N, H, W, Cin, seed=60)).to(dev)
+    w = (rnd(Cout, Cin, 3, 3, seed=61) * math.sqrt(2.0 / (Cin * 9))).to(dev)
+    ops.set_conv_compute_dtype(mode)
+    try:
+        wp = ops.pack_weights(w, Cin, 0)
+        y1, p1 = ops.conv_fwd(x, wp, Cout, 3, 3, 2, 1, True)
+        ops.lib().call("lmkd_conv_set_s2_patch", 0)
+        y0, p0 = ops.conv_fwd(x, wp, Cout, 3, 3, 2, 1, True)
+    finally:
+        ops.lib().call("lmkd_conv_set_s2_patch", 1)
+        ops.reset_compute_dtypes()
+    assert y1.shape == y0.shape and p1.shape == p0.shape
+    assert not torch.equal(y0, y1)          # the patch form did run
+    scale = float(y0.abs().max())
+    assert float((y1 - y0).abs().max()) <= 4e-6 * scale
+    assert float((p1.sum(0) - p0.sum(0)).abs().max()) <= 1e-5 * float(p0.sum(0).abs().max())
+    ref = F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), w.cpu().double(), None, 2, 1).permute(0, 2, 3, 1)
+    cpu = F.conv2d(x.cpu().permute(0, 3, 1, 2), w.cpu(), None, 2, 1).permute(0, 2, 3, 1)
+    anchored("stride-2 forward, patch form", y1, cpu, ref, 3.0, 2e-6)
 
 
 @pytest.mark.parametrize("mode", ["fp32x3", "bf16act"])
