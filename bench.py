@@ -332,17 +332,18 @@ def main():
     achieved = cg[0] / cg[1] / 1e12
     # dense MFMA peaks (MI355X_MICROARCH.md); the 3xbf16 arithmetic issues 6 bf16 MFMA flops per algorithmic fp32 flop
     PEAK = {"f32": 2500.0 / 6, "f32native": PEAK_FP32_MFMA_TFLOPS, "bf16": 2500.0, "bf16conv": 2500.0}
-    ARITH = {"f32": "v_mfma_f32_32x32x16_bf16 x6 per fp32 product, exact 3-way bf16 operand split, fp32 accumulate; peak = dense bf16 MFMA peak / 6",
+    ARITH = {"f32": "v_mfma_f32_16x16x32_bf16 x6 per fp32 product, exact 3-way bf16 operand split, fp32 accumulate; peak = dense bf16 MFMA peak / 6",
              "f32native": "v_mfma_f32_32x32x2_f32",
              "bf16": "one bf16 plane, bf16 tensors, v_mfma_f32_32x32x16_bf16",
              "bf16conv": "one bf16 plane, fp32 tensors, v_mfma_f32_32x32x16_bf16"}
 
     def kernel_name(mode, patch):
         if patch:
-            return "conv_patch_x3_kernel (3x3 stride-1 conv fwd + dgrad from an LDS-resident input patch): " + ARITH[mode]
+            return ("conv_patch16_x3_kernel" if mode == "f32" else "conv_patch_x3_kernel") + \
+                " (3x3 conv fwd + dgrad from an LDS-resident input patch; stride-2 launches as parity classes): " + ARITH[mode]
         return ("conv_gemm_kernel" if mode == "f32native" else "conv_gemm_x3_kernel") + " (implicit-GEMM conv fwd + dgrad): " + ARITH[mode]
     KERNEL = {a.dtype: kernel_name(a.dtype, patch_dom)}
-    PMC_KEY = "conv_patch_x3_kernel" if patch_dom else ("conv_gemm_kernel" if a.dtype == "f32native" else "conv_gemm_x3_kernel")
+    PMC_KEY = ("conv_patch16_x3_kernel" if a.dtype == "f32" else "conv_patch_x3_kernel") if patch_dom else ("conv_gemm_kernel" if a.dtype == "f32native" else "conv_gemm_x3_kernel")
     peak = PEAK[a.dtype]
     # HBM-side traffic of the same kernel family: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950) of `bench.py --serial`,

@@ -877,6 +877,15 @@ static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
 
 // The stem (7x7 / stride 2 / pad 3 on the NHWC4 input, Cout <= 64) of the bf16-plane modes runs conv_stem_patch_kernel (conv_stem.h):
 // one workgroup per pair of output rows.  Returns the patch row pitch in pixels, or 0 when the launch is not of that kind.
+// stride-2 3x3 forward convolution as four same-size convolutions over the input's parity classes (conv_patch16.h, SRC2)?
+static bool fwd_s2_patch_ok(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
+  if (!(g_conv_s2_patch && g_patch16 && g_conv_patch && g_conv_x3 && !g_lmkd_act_bf16 && !g_patch_debug) || Cs % 32 != 0 || stride != 2 || KH != 3 ||
+      KW != 3 || pad != 1 || H % 2 != 0 || W % 2 != 0 || W / 2 + 1 > PATCH_HALO_MAX)
+    return false;
+  const int id = pick_conv_cfg((long)N * (H / 2) * (W / 2), 1, Cout, true);
+  return id == 11 || id == 12;
+}
+
 static int g_conv_stem_patch = 1;
 extern "C" int lmkd_conv_set_stem_patch(int on) { g_conv_stem_patch = on ? 1 : 0; return LMKD_OK; }
 static int stem_patch_pitch(int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
@@ -942,10 +951,8 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
   }
   hipStream_t s = (hipStream_t)stream;
   // stride-2 3x3 forward on the patch kernel (SRC2): even input, the 16x16x32 instances (tile ids 11 / 12), no BatchNorm loader
-  if (g_conv_s2_patch && g_patch16 && g_conv_patch && g_conv_x3 && !g_lmkd_act_bf16 && !g_patch_debug && !smallc && !pre_stats && stride == 2 &&
-      KH == 3 && KW == 3 && pad == 1 && H % 2 == 0 && W % 2 == 0 && a.Wo + 1 <= PATCH_HALO_MAX) {
-    const int id = pick_conv_cfg(a.rows_per_class, 1, Cout, true);
-    if (id == 11 || id == 12) {
+  if (!pre_stats && fwd_s2_patch_ok(N, H, W, Cs, Cout, KH, KW, stride, pad)) {
+    {
       a.src2 = 1; a.s2_ncls = 4; a.s2_wfull = W;
       a.Hs = a.Ho; a.Ws = a.Wo; a.sh = 1; a.same = 1;
       LMKD_REQUIRE((long)N * H * W * Cs * 4 < 2147483647L, "lmkd_conv2d_fwd: input tensor exceeds the 2 GiB offset range of the stride-2 patch form");
@@ -1488,7 +1495,7 @@ extern "C" int lmkd_conv2d_plan(int kind, int N, int H, int W, int Cs, int Cin, 
     else { nclass = 4; rows = (long)N * ((H + 1) / 2) * ((W + 1) / 2); }
   }
   const bool s2patch = kind == 1 && stride == 2 && dgrad_s2_patch_ok(H, W, Cout, KH, KW, pad);
-  const bool same = conv_same_size(H, W, KH, KW, stride, pad) || s2patch;
+  const bool same = conv_same_size(H, W, KH, KW, stride, pad) || s2patch || (kind == 0 && fwd_s2_patch_ok(N, H, W, Cs, Cout, KH, KW, stride, pad));
   int id = pick_conv_cfg(rows, nclass, ncols, same);
   const bool patch = same && (g_conv_x3 || g_conv_bf16) && (kind == 0 ? Cs : Cout) % 32 == 0;      // patch_halo() >= 0 for these launches
   if (!patch) id = id == 10 ? 7 : (id == 11 ? 9 : (id == 12 ? 8 : id));

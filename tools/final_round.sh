@@ -20,3 +20,8 @@ python tools/x3_bias_probe.py 40 2>/dev/null > $out/x3_bias_probe.txt; echo "bia
 python tools/patch_ablate.py 2>/dev/null > $out/patch_ablate.txt; echo "ablate $?"
 python tools/host_ahead.py 10 2>/dev/null > $out/host_ahead.txt; echo "host $?"
 python tools/aten_ops.py f32 2 2>/dev/null > $out/launches_f32.txt; echo "launches $?"
+python tools/phase_times.py 14 2>/dev/null | tail -1 > $out/phase_times.txt; echo "phases $?"
+python tools/stem_wgrad_bench.py 2>/dev/null | tail -2 > $out/stem_wgrad_bench.txt; echo "stem wgrad $?"
+python tools/gemm_splitk_bench.py 2>/dev/null | tail -7 > $out/gemm_splitk_bench.txt; echo "splitk $?"
+LMKD_DGRAD_BN=1 $B --steps 32 --warmup 5 --no-cpu-baseline --no-other-modes > $out/bench_dgrad_bn_sums.json 2>/dev/null; echo "dgrad bn $?"
+$B --steps 32 --warmup 5 --no-cpu-baseline --no-other-modes > $out/bench_repeat.json 2>/dev/null; echo "repeat $?"
