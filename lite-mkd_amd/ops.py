@@ -333,6 +333,14 @@ def refresh_packs(streams=()):
                 n += 1
             if hit[0] != tag or hit[3] is not None:
                 e["packs"][key] = (tag, hit[1], hit[2], None)
+    for key, e in _WCAT.items():      # concatenated TRX projection weights (_trx_wcat_packs)
+        wk, wv = e["rk"](), e["rv"]()
+        if wk is None or wv is None or key[2] != cd:
+            continue
+        if e["tag"] != (wk._version, wv._version, WEIGHT_EPOCH[0]):
+            _wcat_build(e, wk, wv)
+            n += 1
+        e["stream"] = None
     for s in streams:
         s.wait_stream(cur)
     return n
@@ -1196,6 +1204,49 @@ class ClassPlan:
         return self._full[nv]
 
 
+# The four projections of a TRX head, P = Xp @ [Wk[:, :Din] | Wk[:, Din:] | Wv[:, :Din] | Wv[:, Din:]]^T (400 x 4608 x 2048), and their
+# input gradient dXp = dP @ Wcat are 1x1 convolutions over 400 one-pixel frames: in the three-plane arithmetic (the library default)
+# they run the bf16-plane patch kernel - ONE launch of 288 (forward) / 128 (input gradient) workgroups at the convolutions' rate
+# instead of 2 + 4 launches of the fp32-MFMA GEMM at 50 - 64 TFLOP/s.  Wcat's fragment-order planes are cached per (Wk, Wv) and rebuilt
+# in place when either changes (optimizer step).  The weight gradient stays on the GEMM (weight-gradient stream).
+TRX_PROJ_ON_CONV = True
+_WCAT = {}
+
+
+def _wcat_build(e, wk, wv):
+    D, Din = wk.shape[0], wk.shape[1] // 2
+    torch.cat([wk.detach()[:, :Din], wk.detach()[:, Din:], wv.detach()[:, :Din], wv.detach()[:, Din:]], 0, out=e["cat"])
+    w4 = e["cat"].view(4 * D, Din, 1, 1)
+    e["p0"] = _pack_weights(w4, Din, 0, out=e.get("p0"))
+    e["p1"] = _pack_weights(w4, Din, 1, out=e.get("p1"))
+    e["tag"] = (wk._version, wv._version, WEIGHT_EPOCH[0])
+    cur = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    e["event"], e["stream"] = ev, cur.cuda_stream
+
+
+def _trx_wcat_packs(wk, wv):
+    """-> (forward planes, data-gradient planes) of the concatenated projection weight as a [4D, Din, 1, 1] convolution weight, or None
+    when the projections stay on the GEMM (other arithmetic modes, bf16 tensors, odd sizes)"""
+    cd = lib().value("lmkd_conv_get_compute_dtype")
+    D, K2 = wk.shape
+    if not TRX_PROJ_ON_CONV or cd not in (2, 3) or _ACT_DTYPE[0] is not torch.float32 or K2 % 64 != 0 or D % 32 != 0 or wv.shape != wk.shape:
+        return None
+    key = (wk.data_ptr(), wv.data_ptr(), cd)
+    e = _WCAT.get(key)
+    if e is None or e["rk"]() is not wk or e["rv"]() is not wv:
+        if len(_WCAT) > 16:
+            _WCAT.clear()
+        e = _WCAT[key] = {"rk": weakref.ref(wk), "rv": weakref.ref(wv), "cat": torch.empty((4 * D, K2 // 2), dtype=torch.float32, device=wk.device)}
+        _wcat_build(e, wk, wv)
+    elif e["tag"] != (wk._version, wv._version, WEIGHT_EPOCH[0]):
+        _wcat_build(e, wk, wv)
+    elif e["stream"] is not None and e["stream"] != torch.cuda.current_stream().cuda_stream:
+        torch.cuda.current_stream().wait_event(e["event"])
+    return e["p0"], e["p1"]
+
+
 def _trx_forward(sup, qry, plan, wk, bk, wv, bv, gamma, beta, pe, mask, want_grad):
     """Shared by the student heads (with grad) and the frozen teacher head.
     sup [Ns,L,2048], qry [Nq,L,2048] -> logits [Nq,way] (+ saved tensors)"""
@@ -1209,8 +1260,12 @@ def _trx_forward(sup, qry, plan, wk, bk, wv, bv, gamma, beta, pe, mask, want_gra
     lib().call("lmkd_add_pe", _p(X), _p(pe), _p(mask), _p(Xp), NV * L, Din, L, _stream())
     # per-frame projections: P = Xp @ [Wk[:, :Din] | Wk[:, Din:] | Wv[:, :Din] | Wv[:, Din:]]^T
     P = _empty((NV * L, 4 * D), X)
-    gemm("K", "K", NV * L, D, Din, Xp, Din, wk, 2 * Din, P, 4 * D, batch=2, sB=Din, sC=D)
-    gemm("K", "K", NV * L, D, Din, Xp, Din, wv, 2 * Din, P, 4 * D, batch=2, sB=Din, sC=D, C_off=2 * D)
+    packs = _trx_wcat_packs(wk, wv)
+    if packs is not None:
+        lib().call("lmkd_conv2d_fwd", _p(Xp), _p(packs[0]), _p(P), None, NV * L, 1, 1, Din, 4 * D, 1, 1, 1, 0, _stream())
+    else:
+        gemm("K", "K", NV * L, D, Din, Xp, Din, wk, 2 * Din, P, 4 * D, batch=2, sB=Din, sC=D)
+        gemm("K", "K", NV * L, D, Din, Xp, Din, wv, 2 * Din, P, 4 * D, batch=2, sB=Din, sC=D, C_off=2 * D)
     rowmap = plan.full_rowmap(NV)
     Kn = _empty((NV * T, D), X)
     V = _empty((NV * T, D), X)
@@ -1251,6 +1306,7 @@ class TRXLogitsFn(torch.autograd.Function):
         ctx.plan, ctx.seg_off, ctx.seg_cnt = plan, seg_off, seg_cnt
         ctx.shapes = (sup.shape, qry.shape)
         ctx.biases = (bk, bv, beta)
+        ctx.wkv = (wk, wv)      # the parameter OBJECTS (saved tensors come back as other Python objects): identity keys of the caches
         return logits
 
     @staticmethod
@@ -1326,10 +1382,14 @@ def _trx_backward(ctx, g, gsim=None, gram=None):
                  beta=0.0 if tv is None else 1.0)
         # input grads: dXp = sum_blk dP[:, blk] @ W[:, half]
         dX = _empty((NV * L, Din), Xp)
-        gemm("K", "N", NV * L, Din, D, dP, 4 * D, wk, 2 * Din, dX, Din)
-        gemm("K", "N", NV * L, Din, D, dP, 4 * D, wk, 2 * Din, dX, Din, beta=1.0, A_off=D, B_off=Din)
-        gemm("K", "N", NV * L, Din, D, dP, 4 * D, wv, 2 * Din, dX, Din, beta=1.0, A_off=2 * D)
-        gemm("K", "N", NV * L, Din, D, dP, 4 * D, wv, 2 * Din, dX, Din, beta=1.0, A_off=3 * D, B_off=Din)
+        packs = _trx_wcat_packs(*getattr(ctx, "wkv", (wk, wv)))
+        if packs is not None:      # dXp = dP @ Wcat: the data gradient of the 1x1 convolution of _trx_forward
+            lib().call("lmkd_conv2d_bwd_data", _p(dP), _p(packs[1]), _p(dX), NV * L, 1, 1, Din, 4 * D, 1, 1, 1, 0, 0, _stream())
+        else:
+            gemm("K", "N", NV * L, Din, D, dP, 4 * D, wk, 2 * Din, dX, Din)
+            gemm("K", "N", NV * L, Din, D, dP, 4 * D, wk, 2 * Din, dX, Din, beta=1.0, A_off=D, B_off=Din)
+            gemm("K", "N", NV * L, Din, D, dP, 4 * D, wv, 2 * Din, dX, Din, beta=1.0, A_off=2 * D)
+            gemm("K", "N", NV * L, Din, D, dP, 4 * D, wv, 2 * Din, dX, Din, beta=1.0, A_off=3 * D, B_off=Din)
         if mask is not None:
             lib().call("lmkd_mul", _p(dX), _p(mask), _p(dX), dX.numel(), _stream())
         dsup = dX[:Ns * L].reshape(Ns, L, Din)
@@ -1360,6 +1420,7 @@ class TRXSupFn(torch.autograd.Function):
         ctx.plan, ctx.seg_off, ctx.seg_cnt = plan, seg_off, seg_cnt
         ctx.shapes = (sup.shape, qry.shape)
         ctx.biases = (bk, bv, beta)
+        ctx.wkv = (wk, wv)
         return logits, sim
 
     @staticmethod
