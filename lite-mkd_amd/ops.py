@@ -333,14 +333,16 @@ def refresh_packs(streams=()):
                 n += 1
             if hit[0] != tag or hit[3] is not None:
                 e["packs"][key] = (tag, hit[1], hit[2], None)
-    for key, e in _WCAT.items():      # concatenated TRX projection weights (_trx_wcat_packs)
-        wk, wv = e["rk"](), e["rv"]()
-        if wk is None or wv is None or key[2] != cd:
-            continue
-        if e["tag"] != (wk._version, wv._version, WEIGHT_EPOCH[0]):
-            _wcat_build(e, wk, wv)
-            n += 1
-        e["stream"] = None
+    with _x3_scope():      # concatenated TRX projection weights (_trx_wcat_packs): three-plane packs also in the one-plane mode
+        cdx = lib().value("lmkd_conv_get_compute_dtype")
+        for key, e in _WCAT.items():
+            wk, wv = e["rk"](), e["rv"]()
+            if wk is None or wv is None or key[2] != cdx:
+                continue
+            if e["tag"] != (wk._version, wv._version, WEIGHT_EPOCH[0]):
+                _wcat_build(e, wk, wv)
+                n += 1
+            e["stream"] = None
     for s in streams:
         s.wait_stream(cur)
     return n
@@ -1226,9 +1228,28 @@ def _wcat_build(e, wk, wv):
     e["event"], e["stream"] = ev, cur.cuda_stream
 
 
+@contextlib.contextmanager
+def _x3_scope():
+    """the head's fp32 GEMMs on the convolution kernels: in the one-plane bf16 mode (BASELINE configs[2]: bf16 trunk, heads fp32) the
+    process-wide arithmetic is switched to fp32-as-3xbf16 / fp32 tensors for the enclosed launches and restored afterwards (one host
+    thread launches at a time: the forward's, then the autograd engine's)"""
+    cd = lib().value("lmkd_conv_get_compute_dtype")
+    if cd != 1:
+        yield
+        return
+    act = get_activation_dtype()
+    lib().call("lmkd_conv_set_compute_dtype", 2)
+    set_activation_dtype("fp32")
+    try:
+        yield
+    finally:
+        lib().call("lmkd_conv_set_compute_dtype", 1)
+        set_activation_dtype(act)
+
+
 def _trx_wcat_packs(wk, wv):
     """-> (forward planes, data-gradient planes) of the concatenated projection weight as a [4D, Din, 1, 1] convolution weight, or None
-    when the projections stay on the GEMM (other arithmetic modes, bf16 tensors, odd sizes)"""
+    when the projections stay on the GEMM (native fp32 mode, odd sizes).  Call inside _x3_scope()."""
     cd = lib().value("lmkd_conv_get_compute_dtype")
     D, K2 = wk.shape
     if not TRX_PROJ_ON_CONV or cd not in (2, 3) or _ACT_DTYPE[0] is not torch.float32 or K2 % 64 != 0 or D % 32 != 0 or wv.shape != wk.shape:
@@ -1260,10 +1281,13 @@ def _trx_forward(sup, qry, plan, wk, bk, wv, bv, gamma, beta, pe, mask, want_gra
     lib().call("lmkd_add_pe", _p(X), _p(pe), _p(mask), _p(Xp), NV * L, Din, L, _stream())
     # per-frame projections: P = Xp @ [Wk[:, :Din] | Wk[:, Din:] | Wv[:, :Din] | Wv[:, Din:]]^T
     P = _empty((NV * L, 4 * D), X)
-    packs = _trx_wcat_packs(wk, wv)
-    if packs is not None:
-        lib().call("lmkd_conv2d_fwd", _p(Xp), _p(packs[0]), _p(P), None, NV * L, 1, 1, Din, 4 * D, 1, 1, 1, 0, _stream())
-    else:
+    packs = None
+    if TRX_PROJ_ON_CONV:
+        with _x3_scope():
+            packs = _trx_wcat_packs(wk, wv)
+            if packs is not None:
+                lib().call("lmkd_conv2d_fwd", _p(Xp), _p(packs[0]), _p(P), None, NV * L, 1, 1, Din, 4 * D, 1, 1, 1, 0, _stream())
+    if packs is None:
         gemm("K", "K", NV * L, D, Din, Xp, Din, wk, 2 * Din, P, 4 * D, batch=2, sB=Din, sC=D)
         gemm("K", "K", NV * L, D, Din, Xp, Din, wv, 2 * Din, P, 4 * D, batch=2, sB=Din, sC=D, C_off=2 * D)
     rowmap = plan.full_rowmap(NV)
@@ -1382,10 +1406,13 @@ def _trx_backward(ctx, g, gsim=None, gram=None):
                  beta=0.0 if tv is None else 1.0)
         # input grads: dXp = sum_blk dP[:, blk] @ W[:, half]
         dX = _empty((NV * L, Din), Xp)
-        packs = _trx_wcat_packs(*getattr(ctx, "wkv", (wk, wv)))
-        if packs is not None:      # dXp = dP @ Wcat: the data gradient of the 1x1 convolution of _trx_forward
-            lib().call("lmkd_conv2d_bwd_data", _p(dP), _p(packs[1]), _p(dX), NV * L, 1, 1, Din, 4 * D, 1, 1, 1, 0, 0, _stream())
-        else:
+        packs = None
+        if TRX_PROJ_ON_CONV:
+            with _x3_scope():
+                packs = _trx_wcat_packs(*getattr(ctx, "wkv", (wk, wv)))
+                if packs is not None:      # dXp = dP @ Wcat: the data gradient of the 1x1 convolution of _trx_forward
+                    lib().call("lmkd_conv2d_bwd_data", _p(dP), _p(packs[1]), _p(dX), NV * L, 1, 1, Din, 4 * D, 1, 1, 1, 0, 0, _stream())
+        if packs is None:
             gemm("K", "N", NV * L, Din, D, dP, 4 * D, wk, 2 * Din, dX, Din)
             gemm("K", "N", NV * L, Din, D, dP, 4 * D, wk, 2 * Din, dX, Din, beta=1.0, A_off=D, B_off=Din)
             gemm("K", "N", NV * L, Din, D, dP, 4 * D, wv, 2 * Din, dX, Din, beta=1.0, A_off=2 * D)
