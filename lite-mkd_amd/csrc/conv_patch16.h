@@ -26,6 +26,20 @@
 __device__ __host__ __forceinline__ constexpr int patch16_kslot(int q) { return ((q & 1) << 1) | (q >> 1); }      // self-inverse
 __device__ __forceinline__ int patch16_pixel(int j) { return (j >= 4 && j < 12) ? 2 * (j - 4) : (j < 4 ? 2 * j + 1 : 2 * (j - 8) + 1); }
 
+// v + (v of the lane a DPP row permutation pairs this lane with): quad_perm [1,0,3,2] (0xB1), [2,3,0,1] (0x4E), row_half_mirror (0x141),
+// row_mirror (0x140) in turn leave the sum of a 16-lane row in every lane of it - on the VALU, no ds_bpermute (64 of them per wave and
+// tile in the BatchNorm-sum epilogue before)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  return dpp_add<0x140>(v);
+}
+
 template <int TN>
 struct X3FragB16 {
   static constexpr int NT = 2 * TN;      // 16-channel blocks of this wave
@@ -387,11 +401,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       float v1[4] = {s1[c].x, s1[c].y, s1[c].z, s1[c].w}, v2[4] = {s2[c].x, s2[c].y, s2[c].z, s2[c].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-          v1[e] += __shfl_xor(v1[e], o, 64);
-          v2[e] += __shfl_xor(v2[e], o, 64);
-        }
+        v1[e] = row16_sum(v1[e]);
+        v2[e] = row16_sum(v2[e]);
         if ((lane & 15) == 0) {
           const int cl = wn * (Cfg::TN * 32) + 16 * c + 4 * kq + e;
           s_red[(wm * Cfg::BN + cl) * 2 + 0] = v1[e];
