@@ -128,10 +128,11 @@ def main():
         ops.lib().call("lmkd_conv_set_s2_patch", 0)
     if os.environ.get("LMKD_WIN16", "1") == "0":                                          # rolling-window weight gradient back on the 32x32x16 MFMA
         ops.lib().call("lmkd_conv_set_wgrad_win16", 0)
-    ops.TRX_PROJ_ON_CONV = os.environ.get("LMKD_TRX_CONV", "1") != "0"                        # TRX projections + their input gradient as 1x1 convolutions
+    ops.TRX_PROJ_ON_CONV = os.environ.get("LMKD_TRX_CONV", "0") == "1"                        # TRX projections + their input gradient as 1x1 convolutions
     ops.SIDE_LINEAR_WGRAD = os.environ.get("LMKD_SIDE_LINEAR", "1") != "0"                   # Linear / TRX weight-gradient GEMMs on the weight-gradient stream
     ops.GEMM_SPLIT_K = os.environ.get("LMKD_GEMM_SPLIT", "0") == "1"                         # split-K for the head's small GEMMs
     ops.DGRAD_BN_STATS = os.environ.get("LMKD_DGRAD_BN", "0") == "1"                       # BatchNorm-backward sums in the data gradient's epilogue
+    ops.PRE_IN_PLANE_MODES = os.environ.get("LMKD_PRE_X3", "1") != "0"
     ops.FUSE_PRE_ALL_MODES = os.environ.get("LMKD_FUSE_PRE", "0") == "1"                   # inner BatchNorm + ReLU in the consumers' loaders also in the plane modes
     ops.DIRECT_PARAM_GRAD = os.environ.get("LMKD_DIRECT_GRAD", "1") != "0"               # BatchNorm / Linear / TRX parameter gradients added into .grad by the kernels
 

@@ -798,6 +798,7 @@ def conv_bn_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, relu, res=None):
 # gradient up to 30 us, against 12-56 us for the bn_apply launch they save (tools/pre_bench.py).  FUSE_PRE_ALL_MODES forces them on.
 FUSE_TRAIN_BN = True
 FUSE_PRE_ALL_MODES = False
+PRE_IN_PLANE_MODES = True      # the three-plane modes' share of that policy (bench.py LMKD_PRE_X3=0 switches it off for an A/B)
 
 
 def _train_fused():
@@ -810,8 +811,9 @@ def _train_pre():
     since round 3, the three-plane modes - with the patch / window kernels the loader arithmetic runs once per patch / window row
     and the headline benchmark is indifferent (31.8 vs 31.6 episodes/s, same box) while 16 launches per episode and a quarter of
     the activation memory go away; the one-plane bf16 mode keeps the materialised activation (56.0 vs 59.7)."""
+    cd = lib().value("lmkd_conv_get_compute_dtype")
     return (FUSE_TRAIN_BN and _ACT_DTYPE[0] is torch.float32
-            and (FUSE_PRE_ALL_MODES or lib().value("lmkd_conv_get_compute_dtype") != 1))
+            and (FUSE_PRE_ALL_MODES or cd == 0 or (cd in (2, 3) and PRE_IN_PLANE_MODES)))
 
 
 def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training, pre_stats=None):
@@ -1211,7 +1213,10 @@ class ClassPlan:
 # they run the bf16-plane patch kernel - ONE launch of 288 (forward) / 128 (input gradient) workgroups at the convolutions' rate
 # instead of 2 + 4 launches of the fp32-MFMA GEMM at 50 - 64 TFLOP/s.  Wcat's fragment-order planes are cached per (Wk, Wv) and rebuilt
 # in place when either changes (optimizer step).  The weight gradient stays on the GEMM (weight-gradient stream).
-TRX_PROJ_ON_CONV = True
+# OFF by default: measured (rocprofv3, in the episode) the forward launch takes 116 us against 2 x 55 for the GEMMs and the input
+# gradient (128 workgroups, K = 4608) 226 - 263 us against 4 x 35; same-box episodes/s 35.74 / 35.73 vs 35.60 / 35.58 (f32) and 72.9 vs
+# 72.3 (bf16 tensors) - inside the noise.  The heads keep their native fp32 MFMA products.
+TRX_PROJ_ON_CONV = False
 _WCAT = {}
 
 

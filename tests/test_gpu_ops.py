@@ -609,9 +609,24 @@ def test_head_golden(dev, golden_dir, case):
         close(fc.bias.grad, rb, 2e-3, 2e-3 * float(rb.abs().max()), "fc%d.bias" % h)
 
 
+@pytest.mark.parametrize("proj", ["gemm", "conv"])
 @pytest.mark.parametrize("case", [0, 1, 2])
-def test_trx_golden(dev, golden_dir, case):
-    """TRX_2fcsup / TRX_2fcsup_fixed vs the fixtures produced by the reference's own module."""
+def test_trx_golden(dev, golden_dir, case, proj):
+    """TRX_2fcsup / TRX_2fcsup_fixed vs the fixtures produced by the reference's own module.  proj = conv: the four projections and
+    their input gradient as 1x1 convolutions on the bf16-plane patch kernel (ops.TRX_PROJ_ON_CONV, opt-in) - same fixtures"""
+    import os
+    from litemkd_amd import ops
+    from litemkd_amd.model import classifiers as C
+    from oracle.gen_golden import trx_case_inputs
+    was = ops.TRX_PROJ_ON_CONV
+    ops.TRX_PROJ_ON_CONV = proj == "conv"
+    try:
+        _trx_golden(dev, golden_dir, case)
+    finally:
+        ops.TRX_PROJ_ON_CONV = was
+
+
+def _trx_golden(dev, golden_dir, case):
     import os
     from litemkd_amd.model import classifiers as C
     from oracle.gen_golden import trx_case_inputs
