@@ -19,13 +19,14 @@ class resnet18_2fc(nn.Module):
         # two separate trunk calls = two separate BatchNorm batches (resnet18_2fc.py:41-42)
         cf, tf = two_trunk_calls(self.resnet, ops.PoolHeadFn.apply, context_feature, target_feature)     # :41-54
         L, D = self.args.seq_len, self.args.trans_linear_in_dim
+        c1, t1, c2, t2 = ops.two_head_linear(cf, tf, self.fc1, self.fc2)      # :56-64, one autograd node for the four calls
         context_feature_dict = {
-            "context_features_1": self.fc1(cf).reshape(-1, L, D),
-            "context_features_2": self.fc2(cf).reshape(-1, L, D),
+            "context_features_1": c1.reshape(-1, L, D),
+            "context_features_2": c2.reshape(-1, L, D),
         }
         target_features_dict = {
-            "target_features_1": self.fc1(tf).reshape(-1, L, D),
-            "target_features_2": self.fc2(tf).reshape(-1, L, D),
+            "target_features_1": t1.reshape(-1, L, D),
+            "target_features_2": t2.reshape(-1, L, D),
         }
         return context_feature_dict, target_features_dict
 

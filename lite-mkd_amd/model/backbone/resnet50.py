@@ -18,8 +18,9 @@ class resnet50_2fc(nn.Module):
     def forward(self, context_feature, context_labels, target_feature):
         cf, tf = two_trunk_calls(self.resnet, ops.PoolHeadFn.apply, context_feature, target_feature)     # :40-57
         L, D = self.args.seq_len, self.args.trans_linear_in_dim
-        return ({"context_features_1": self.fc1(cf).reshape(-1, L, D), "context_features_2": self.fc2(cf).reshape(-1, L, D)},
-                {"target_features_1": self.fc1(tf).reshape(-1, L, D), "target_features_2": self.fc2(tf).reshape(-1, L, D)})
+        c1, t1, c2, t2 = ops.two_head_linear(cf, tf, self.fc1, self.fc2)
+        return ({"context_features_1": c1.reshape(-1, L, D), "context_features_2": c2.reshape(-1, L, D)},
+                {"target_features_1": t1.reshape(-1, L, D), "target_features_2": t2.reshape(-1, L, D)})
 
     def distribute_model(self):
         return None

@@ -75,11 +75,12 @@ def _empty_act(shape, like):
 # GEMM
 # ------------------------------------------------------------------------------------------
 def gemm(layA, layB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, beta=0.0, bias=None, relu=False,
-         batch=1, sA=0, sB=0, sC=0, A_off=0, B_off=0, C_off=0):
-    """C = alpha*op(A)*op(B) + beta*C + bias.  *_off are element offsets into the tensors' storage."""
+         batch=1, sA=0, sB=0, sC=0, A_off=0, B_off=0, C_off=0, split_k=None):
+    """C = alpha*op(A)*op(B) + beta*C + bias.  *_off are element offsets into the tensors' storage.
+    split_k: True / False forces lmkd_gemm_f32_splitk / lmkd_gemm_f32 for this call (None: the module default GEMM_SPLIT_K)"""
     _chk(A, B, C, bias)
     es = 4
-    if GEMM_SPLIT_K:
+    if GEMM_SPLIT_K if split_k is None else split_k:
         ws, tk = _gemm_workspace(C)
         lib().call("lmkd_gemm_f32_splitk", layA.encode(), layB.encode(), M, N, K, _f32(alpha),
                    ctypes.c_void_p(A.data_ptr() + A_off * es), lda, sA,
@@ -267,6 +268,86 @@ class LinearFn(torch.autograd.Function):
             else:
                 db = colsum(dy)
         return dx, dw, db
+
+
+# fc1 / fc2 over the support-frame and the query-frame features (resnet18_2fc.py:56-64: four nn.Linear calls on 200-row inputs) as ONE
+# autograd node: the rows of the two trunk calls are stacked, so each weight sees one 400-row GEMM forward and one for the weight
+# gradient, and the input gradient of BOTH heads is one GEMM over the concatenated K = 2 x 2048 (split-K: 56 output tiles) instead of
+# four 32-workgroup launches of 56 us each in the idle stretch between the heads' and the trunk's backward.
+FUSE_TWO_HEAD_LINEAR = True
+
+
+class TwoHeadLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cf, tf, w1, b1, w2, b2):
+        Nc = cf.shape[0]
+        X = torch.cat([cf, tf], 0).contiguous()
+        M, K = X.shape
+        N = w1.shape[0]
+        Y1, Y2 = _empty((M, N), X), _empty((M, N), X)
+        gemm("K", "K", M, N, K, X, K, w1, K, Y1, N, bias=b1)
+        gemm("K", "K", M, N, K, X, K, w2, K, Y2, N, bias=b2)
+        ctx.save_for_backward(X, w1, w2)
+        ctx.Nc = Nc
+        ctx.params = (w1, b1, w2, b2)
+        return Y1[:Nc], Y1[Nc:], Y2[:Nc], Y2[Nc:]
+
+    @staticmethod
+    def backward(ctx, g1c, g1t, g2c, g2t):
+        X, w1, w2 = ctx.saved_tensors
+        pw1, pb1, pw2, pb2 = ctx.params
+        M, K = X.shape
+        N = w1.shape[0]
+        Nc = ctx.Nc
+
+        def full(gc, gt):
+            if gc is None and gt is None:
+                return None
+            gc = gc if gc is not None else torch.zeros((Nc, N), dtype=X.dtype, device=X.device)
+            gt = gt if gt is not None else torch.zeros((M - Nc, N), dtype=X.dtype, device=X.device)
+            return torch.cat([gc, gt], 0).contiguous()
+        G = [full(g1c, g1t), full(g2c, g2t)]
+        dX = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            live = [(g, w) for g, w in zip(G, (w1, w2)) if g is not None]
+            dX = _empty((M, K), X)
+            if len(live) == 2:      # dX = [G1 | G2] @ [W1; W2]: one GEMM over K = 2 N
+                Gc = torch.cat(G, 1).contiguous()
+                Wc = torch.cat([w1, w2], 0).contiguous()
+                gemm("K", "N", M, K, 2 * N, Gc, 2 * N, Wc, K, dX, K, split_k=True)
+            elif live:
+                gemm("K", "N", M, K, N, live[0][0], N, live[0][1], K, dX, K)
+            else:
+                dX.zero_()
+        outs = [None, None]
+        for g, pw, pb in zip(G, (pw1, pw2), (pb1, pb2)):
+            dw = db = None
+            if g is not None:
+                if pw.requires_grad:
+                    if not side_accumulate(pw, lambda t, g=g: gemm("M", "N", N, K, M, g, N, X, K, t, K, beta=1.0), g, X):
+                        tw = _grad_target(pw)
+                        if tw is not None:
+                            gemm("M", "N", N, K, M, g, N, X, K, tw, K, beta=1.0)
+                        else:
+                            dw = _empty((N, K), X)
+                            gemm("M", "N", N, K, M, g, N, X, K, dw, K)
+                if pb is not None and pb.requires_grad:
+                    tb = _grad_target(pb)
+                    if tb is not None:
+                        colsum(g, out=tb, accumulate=True)
+                    else:
+                        db = colsum(g)
+            outs += [dw, db]
+        outs[0] = dX[:Nc] if dX is not None and ctx.needs_input_grad[0] else None
+        outs[1] = dX[Nc:] if dX is not None and ctx.needs_input_grad[1] else None
+        return tuple(outs)
+
+
+def two_head_linear(cf, tf, fc1, fc2):
+    """-> fc1(cf), fc1(tf), fc2(cf), fc2(tf)"""
+    if FUSE_TWO_HEAD_LINEAR and cf.is_cuda and cf.dim() == 2 and fc1.weight.shape == fc2.weight.shape and fc1.bias is not None and fc2.bias is not None:
+        return TwoHeadLinearFn.apply(cf.contiguous(), tf.contiguous(), fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+    return fc1(cf), fc1(tf), fc2(cf), fc2(tf)
 
 
 # ------------------------------------------------------------------------------------------

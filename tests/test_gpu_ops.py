@@ -1641,3 +1641,31 @@ def test_stem_pooled_backward_matches_materialised_path(dev, N, H, W, mode):
         err = float((u - v).norm() / (v.norm() + 1e-30))
         assert err < tol, (name, err)
     assert float(a[3][:8].abs().max()) >= 0.0
+
+
+def test_two_head_linear_matches_four_linear_calls(dev):
+    """ops.TwoHeadLinearFn (fc1 / fc2 over both trunk calls' features as one autograd node, resnet18_2fc.py:56-64) against four
+    LinearFn calls: outputs bit-identical (the same GEMM rows), gradients equal to fp32 rounding of the re-ordered sums"""
+    from litemkd_amd import ops
+    from litemkd_amd.model.backbone.resnet import Linear
+    torch.manual_seed(5)
+    fc1, fc2 = Linear(512, 2048).to(dev), Linear(512, 2048).to(dev)
+    cf0, tf0 = rnd(200, 512, seed=80).to(dev), rnd(120, 512, seed=81).to(dev)
+    ws = [rnd(200, 2048, seed=82).to(dev), rnd(120, 2048, seed=83).to(dev), rnd(200, 2048, seed=84).to(dev), rnd(120, 2048, seed=85).to(dev)]
+    res = {}
+    for fused in (False, True):
+        ops.FUSE_TWO_HEAD_LINEAR = fused
+        try:
+            for m in (fc1, fc2):
+                m.zero_grad(set_to_none=True)
+            cf, tf = cf0.clone().requires_grad_(), tf0.clone().requires_grad_()
+            outs = ops.two_head_linear(cf, tf, fc1, fc2)
+            sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+            res[fused] = [o.detach() for o in outs] + [cf.grad, tf.grad, fc1.weight.grad, fc1.bias.grad, fc2.weight.grad, fc2.bias.grad]
+        finally:
+            ops.FUSE_TWO_HEAD_LINEAR = True
+    for i, (a, b) in enumerate(zip(res[False], res[True])):
+        if i < 4:
+            assert torch.equal(a, b), i
+        else:
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (i, float((a - b).abs().max()), float(a.abs().max()))
