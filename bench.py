@@ -132,7 +132,7 @@ def main():
     ops.FUSE_TWO_HEAD_LINEAR = os.environ.get("LMKD_FC_FUSED", "1") != "0"                    # fc1 / fc2 of both trunk calls as one autograd node
     ops.SIDE_LINEAR_WGRAD = os.environ.get("LMKD_SIDE_LINEAR", "1") != "0"                   # Linear / TRX weight-gradient GEMMs on the weight-gradient stream
     ops.GEMM_SPLIT_K = os.environ.get("LMKD_GEMM_SPLIT", "0") == "1"                         # split-K for the head's small GEMMs
-    ops.DGRAD_BN_STATS = os.environ.get("LMKD_DGRAD_BN", "0") == "1"                       # BatchNorm-backward sums in the data gradient's epilogue
+    ops.DGRAD_BN_STATS = os.environ.get("LMKD_DGRAD_BN", "1") != "0"                       # BatchNorm-backward sums in the data gradient's epilogue
     ops.PRE_IN_PLANE_MODES = os.environ.get("LMKD_PRE_X3", "1") != "0"
     ops.FUSE_PRE_ALL_MODES = os.environ.get("LMKD_FUSE_PRE", "0") == "1"                   # inner BatchNorm + ReLU in the consumers' loaders also in the plane modes
     ops.DIRECT_PARAM_GRAD = os.environ.get("LMKD_DIRECT_GRAD", "1") != "0"               # BatchNorm / Linear / TRX parameter gradients added into .grad by the kernels

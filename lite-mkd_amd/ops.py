@@ -549,12 +549,12 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None):
     return y, part
 
 
-# The data gradient that feeds relu + BatchNorm backward can leave that backward's reduction in its epilogue (lmkd_conv2d_bwd_data_bn)
-# where the launch has the form: one pass over (dx, bn input) and one launch per such BatchNorm less (16 launches, 0.44 ms of
-# bn_bwd_reduce_kernel per episode).  OFF by default: same-box A/B 33.73 / 33.74 / 33.85 episodes/s with it against 33.91 / 33.87 / 33.90
-# without - the reduction kernels it removes ran beside the weight-gradient stream's MFMA kernels for free, the extra epilogue reads
-# lengthen the MFMA kernels themselves.
-DGRAD_BN_STATS = False
+# The data gradient that feeds relu + BatchNorm backward leaves that backward's reduction in its epilogue (lmkd_conv2d_bwd_data_bn) where
+# the launch has the form: one pass over (dx, bn input) and one launch per such BatchNorm less (16 launches, 0.44 ms of
+# bn_bwd_reduce_kernel per episode; BatchNorm family 3.8 -> 3.4 ms, 453 -> 437 launches).  Neutral in episodes/s (same-box: first 33.73 /
+# 33.74 / 33.85 with against 33.91 / 33.87 / 33.90 without, on the final kernels 36.11 / 36.06 / 36.01 / 36.06 against 36.11 / 36.04 /
+# 36.03 / 36.00): the reduction kernels it removes ran beside the weight-gradient stream's MFMA kernels.  On: fewer passes over HBM.
+DGRAD_BN_STATS = True
 
 
 def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumulate=False, bn=None):

@@ -243,7 +243,7 @@ def test_dgrad_epilogue_bn_backward_sums(dev, cfg, mode):
     dy = rnd(N, H, W, Cout, seed=54).to(dev)
     ops.set_conv_compute_dtype(mode)
     was = ops.DGRAD_BN_STATS
-    ops.DGRAD_BN_STATS = True
+    ops.DGRAD_BN_STATS = True      # (the default)
     try:
         wd = ops.pack_weights(w, Cin, 1)
         T = ops.lib().value("lmkd_conv2d_bwd_data_bn_tiles", N, H, W, Cin, Cout, K, K, 1, pad)

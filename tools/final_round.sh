@@ -23,5 +23,5 @@ python tools/aten_ops.py f32 2 2>/dev/null > $out/launches_f32.txt; echo "launch
 python tools/phase_times.py 14 2>/dev/null | tail -1 > $out/phase_times.txt; echo "phases $?"
 python tools/stem_wgrad_bench.py 2>/dev/null | tail -2 > $out/stem_wgrad_bench.txt; echo "stem wgrad $?"
 python tools/gemm_splitk_bench.py 2>/dev/null | tail -7 > $out/gemm_splitk_bench.txt; echo "splitk $?"
-LMKD_DGRAD_BN=1 $B --steps 32 --warmup 5 --no-cpu-baseline --no-other-modes > $out/bench_dgrad_bn_sums.json 2>/dev/null; echo "dgrad bn $?"
+LMKD_DGRAD_BN=0 $B --steps 32 --warmup 5 --no-cpu-baseline --no-other-modes > $out/bench_no_dgrad_bn_sums.json 2>/dev/null; echo "no dgrad bn $?"
 $B --steps 32 --warmup 5 --no-cpu-baseline --no-other-modes > $out/bench_repeat.json 2>/dev/null; echo "repeat $?"
