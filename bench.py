@@ -129,6 +129,7 @@ def main():
     if os.environ.get("LMKD_WIN16", "1") == "0":                                          # rolling-window weight gradient back on the 32x32x16 MFMA
         ops.lib().call("lmkd_conv_set_wgrad_win16", 0)
     ops.TRX_PROJ_ON_CONV = os.environ.get("LMKD_TRX_CONV", "0") == "1"                        # TRX projections + their input gradient as 1x1 convolutions
+    TL.REPACK_AT_STEP = os.environ.get("LMKD_REPACK", "1") != "0"                             # all weight packs re-packed by one launch at the optimizer step
     ops.FUSE_TWO_HEAD_LINEAR = os.environ.get("LMKD_FC_FUSED", "1") != "0"                    # fc1 / fc2 of both trunk calls as one autograd node
     ops.SIDE_LINEAR_WGRAD = os.environ.get("LMKD_SIDE_LINEAR", "1") != "0"                   # Linear / TRX weight-gradient GEMMs on the weight-gradient stream
     ops.GEMM_SPLIT_K = os.environ.get("LMKD_GEMM_SPLIT", "0") == "1"                         # split-K for the head's small GEMMs

@@ -63,6 +63,10 @@ int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound 
    In modes 1/2/3 the packed-weight arguments of lmkd_conv2d_fwd / lmkd_conv2d_bwd_data point at the buffer written by
    lmkd_conv2d_split_weights (in that mode). */
 int lmkd_conv_set_compute_dtype(int mode);
+/* re-pack n convolution weights in ONE launch (after an optimizer step; trainwandb.py:142): entry i = OIHW weight ws[i] -> wfs[i], the
+   buffer lmkd_conv2d_pack_weights + lmkd_conv2d_split_weights would fill for dims[6 i ..] = (Cout, Cin, Cs, KH, KW, mode), bit for bit.
+   Modes 1-3 of lmkd_conv_set_compute_dtype.  The pointer / dims arrays are host memory. */
+int lmkd_conv2d_repack_multi(const float* const* ws, void* const* wfs, const int* dims, int n, void* stream);
 /* wp: fp32 K-major packed weights [ncols][Kp] (lmkd_conv2d_pack_weights; ncols = Cout forward, Cin data gradient)
    -> wf: bf16 in MFMA fragment order: mode 1: ncols * Kp (one round-to-nearest plane); modes 2/3: 12 * ncols * Kp = the three planes
    of W and the three planes of -W (half the row tiles accumulate -y, csrc/conv_x3.h X3FragB) in the v_mfma 32x32x16 fragment order,

@@ -588,6 +588,94 @@ extern "C" int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, i
   return LMKD_OK;
 }
 
+// Re-pack MANY convolution weights in one launch (after an optimizer step: 40 cached packs = 120 pack / split launches before).
+// Entry e: OIHW weight -> the fragment-order planes lmkd_conv2d_pack_weights + lmkd_conv2d_split_weights would write for (Cs, mode) in
+// the current arithmetic (modes 1-3), bit for bit; blockIdx.y = entry.
+struct RepackEntry {
+  const float* w;
+  unsigned short* wf;
+  int Co, Cin, Cs, KH, KW, KWp, mode, ncols, Kp;
+};
+#define LMKD_REPACK_MAX 40
+struct RepackArgs {
+  RepackEntry e[LMKD_REPACK_MAX];
+  int npl;
+};
+__global__ void repack_multi_kernel(RepackArgs a) {
+  const RepackEntry& e = a.e[blockIdx.y];
+  const long total = (long)e.ncols * e.Kp;
+  const int G = e.Kp >> 4, G16 = e.Kp >> 5;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx / e.Kp), k = (int)(idx - (long)col * e.Kp);
+    float x;
+    if (e.mode == 0) {      // pack_weights_kernel mode 0: col = co, k = (kh * KWp + kw) * Cs + ci
+      const int ci = k % e.Cs;
+      const int r = k / e.Cs;
+      const int kw = r % e.KWp, kh = r / e.KWp;
+      x = (ci < e.Cin && kw < e.KW) ? e.w[(((long)col * e.Cin + ci) * e.KH + kh) * e.KW + kw] : 0.f;
+    } else {                // mode 1: col = ci, k = (kh * KW + kw) * Co + co
+      const int co = k % e.Co;
+      const int r = k / e.Co;
+      const int kw = r % e.KW, kh = r / e.KW;
+      x = e.w[(((long)co * e.Cin + col) * e.KH + kh) * e.KW + kw];
+    }
+    const int lane = (col & 31) + 32 * ((k >> 3) & 1);
+    const long o = ((((long)(col >> 5) * G + (k >> 4)) * a.npl) * 64 + lane) * 8 + (k & 7);
+    if (a.npl == 1) {
+      union { __bf16 h; unsigned short u; } c;
+      c.h = (__bf16)x;
+      e.wf[o] = c.u;
+      continue;
+    }
+    const unsigned b0 = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(b0 & 0xffff0000u);
+    const unsigned b1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
+    const unsigned short p0 = (unsigned short)(b0 >> 16), p1 = (unsigned short)(b1 >> 16), p2 = (unsigned short)(__float_as_uint(r2) >> 16);
+    const unsigned short n0 = p0 ^ 0x8000u, n1 = p1 ^ 0x8000u, n2 = p2 ^ 0x8000u;
+    e.wf[o] = p0; e.wf[o + 512] = p1; e.wf[o + 1024] = p2;                        // split_weights_kernel: W, then -W
+    const long o2 = o + total * 3;
+    e.wf[o2] = n0; e.wf[o2 + 512] = n1; e.wf[o2 + 1024] = n2;
+    unsigned short* w16 = e.wf + total * 6;                                         // split_weights16_kernel behind them
+    const int lane16 = (col & 15) + 16 * patch16_kslot((k >> 3) & 3);
+    const long q = ((((long)(col >> 4) * G16 + (k >> 5)) * 3) * 64 + lane16) * 8 + (k & 7);
+    w16[q] = p0; w16[q + 512] = p1; w16[q + 1024] = p2;
+    const long q2 = q + total * 3;
+    w16[q2] = n0; w16[q2 + 512] = n1; w16[q2 + 1024] = n2;
+  }
+}
+
+// ws[i], wfs[i]: OIHW weight and destination planes of entry i; dims[i * 6 ..] = Cout, Cin, Cs, KH, KW, mode.  Modes 1-3 only.
+extern "C" int lmkd_conv2d_repack_multi(const float* const* ws, void* const* wfs, const int* dims, int n, void* stream) {
+  LMKD_REQUIRE(ws && wfs && dims && n > 0, "lmkd_conv2d_repack_multi: null pointer");
+  LMKD_REQUIRE(g_conv_x3 || g_conv_bf16, "lmkd_conv2d_repack_multi: fragment-order planes exist in the bf16-plane modes only");
+  for (int i0 = 0; i0 < n; i0 += LMKD_REPACK_MAX) {
+    RepackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.npl = g_conv_bf16 ? 1 : 3;
+    const int m = std::min(LMKD_REPACK_MAX, n - i0);
+    long most = 0;
+    for (int j = 0; j < m; ++j) {
+      const int* d = dims + (long)(i0 + j) * 6;
+      RepackEntry& e = a.e[j];
+      e.w = ws[i0 + j]; e.wf = (unsigned short*)wfs[i0 + j];
+      e.Co = d[0]; e.Cin = d[1]; e.Cs = d[2]; e.KH = d[3]; e.KW = d[4]; e.mode = d[5];
+      LMKD_REQUIRE(e.w && e.wf && (e.mode == 0 || e.mode == 1), "lmkd_conv2d_repack_multi: bad entry %d", i0 + j);
+      LMKD_REQUIRE(e.Cs >= e.Cin && (e.Cs % 32 == 0 || e.Cs == 4), "lmkd_conv2d_repack_multi: Cs=%d must be 4 or a multiple of 32", e.Cs);
+      e.KWp = kw_padded(e.Cs, e.KW);
+      e.ncols = e.mode == 0 ? e.Co : e.Cin;
+      e.Kp = e.mode == 0 ? e.KH * e.KWp * e.Cs : e.KH * e.KW * e.Co;
+      LMKD_REQUIRE(e.ncols % 32 == 0 && e.Kp % 32 == 0, "lmkd_conv2d_repack_multi: entry %d: ncols=%d and Kp=%d must be multiples of 32", i0 + j, e.ncols, e.Kp);
+      most = std::max(most, (long)e.ncols * e.Kp);
+    }
+    int gx = cdiv(most, 256 * 4);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(repack_multi_kernel, dim3(gx, m), dim3(256), 0, (hipStream_t)stream, a);
+    LMKD_CHECK_LAUNCH("repack_multi_kernel");
+  }
+  return LMKD_OK;
+}
+
 // ---- tile configuration -------------------------------------------------------------------------
 // id: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 (rows x cols, 4 waves), 5 = 128x128 and 6 = 128x64 with 8 waves (2 per SIMD).
 // Workgroups per CU by LDS: 2 / 2 / 4 / 2 / 2.

@@ -393,6 +393,9 @@ def pack_weights(w, Cs, mode):
     return wp
 
 
+_REPACK_KEEP = [None]
+
+
 def refresh_packs(streams=()):
     """Re-pack, on the current stream and IN PLACE, every cached pack of the current arithmetic mode whose weights have changed since
     (optimizer step, in-place update), make `streams` wait for it and mark the packs as visible everywhere.  A captured episode
@@ -401,6 +404,7 @@ def refresh_packs(streams=()):
     cur = torch.cuda.current_stream()
     cd = lib().value("lmkd_conv_get_compute_dtype")
     n = 0
+    stale = []      # (weight, planes, (Cout, Cin, Cs, KH, KW, mode)): re-packed by ONE launch in the bf16-plane modes
     for e in _pack_cache.values():
         owner = e["ref"]()
         if owner is None:
@@ -410,10 +414,20 @@ def refresh_packs(streams=()):
             if key[2] != cd:
                 continue
             if hit[0] != tag:
-                _pack_weights(owner, key[0], key[1], out=hit[1])
+                if cd == 0 or owner.dim() != 4 or not owner.is_contiguous() or owner.dtype != torch.float32:
+                    _pack_weights(owner.view(owner.shape[0], -1, 1, 1) if owner.dim() == 2 else owner, key[0], key[1], out=hit[1])
+                else:
+                    stale.append((owner, hit[1], tuple(owner.shape[:2]) + (key[0],) + tuple(owner.shape[2:]) + (key[1],)))
                 n += 1
             if hit[0] != tag or hit[3] is not None:
                 e["packs"][key] = (tag, hit[1], hit[2], None)
+    if stale:
+        m = len(stale)
+        ws = (ctypes.c_void_p * m)(*[t[0].data_ptr() for t in stale])
+        wfs = (ctypes.c_void_p * m)(*[t[1].data_ptr() for t in stale])
+        dims = (ctypes.c_int * (6 * m))(*[v for t in stale for v in t[2]])
+        lib().call("lmkd_conv2d_repack_multi", ws, wfs, dims, m, _stream())
+        _REPACK_KEEP[0] = stale      # the weights / planes stay referenced until the next refresh (the launch reads them asynchronously)
     with _x3_scope():      # concatenated TRX projection weights (_trx_wcat_packs): three-plane packs also in the one-plane mode
         cdx = lib().value("lmkd_conv_get_compute_dtype")
         for key, e in _WCAT.items():

@@ -14,6 +14,9 @@ from ._lib import lib
 import ctypes
 
 
+REPACK_AT_STEP = True
+
+
 class FusedOptimizer:
     """SGD (no momentum; trainwandb.py:103-104, options.py:72-73) or Adam over the flat buffers."""
 
@@ -45,6 +48,10 @@ class FusedOptimizer:
         else:
             lib().call("lmkd_adam_step", P(b.flat), P(b.grad), P(self.m), P(self.v), ctypes.c_float(self.lr),
                        ctypes.c_float(0.9), ctypes.c_float(0.999), ctypes.c_float(1e-8), self.steps, b.numel, 0, s)
+        if REPACK_AT_STEP:
+            # every cached fragment-order pack of the convolution weights in ONE launch behind the update (otherwise each is re-packed
+            # by three launches at its first use in the next forward: ~120 launches per step, one step per 2 episodes at world 8)
+            ops.refresh_packs()
 
 
 class MultiStepLR:

@@ -1669,3 +1669,28 @@ def test_two_head_linear_matches_four_linear_calls(dev):
             assert torch.equal(a, b), i
         else:
             assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (i, float((a - b).abs().max()), float(a.abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["fp32x3", "fp32x3_9", "bf16"])
+def test_repack_multi_bit_identical_to_pack_and_split(dev, mode):
+    """lmkd_conv2d_repack_multi (every cached pack of the convolution weights in one launch after an optimizer step) writes exactly
+    the bytes lmkd_conv2d_pack_weights + lmkd_conv2d_split_weights write, for forward and data-gradient packs of every weight shape of
+    the trunk (3x3, 1x1, the channel-padded stem)"""
+    import ctypes
+    from litemkd_amd import ops
+    shapes = [(64, 3, 7, 7, 4, 0), (64, 64, 3, 3, 64, 0), (64, 64, 3, 3, 64, 1), (128, 64, 3, 3, 64, 0), (128, 64, 3, 3, 64, 1),
+              (128, 64, 1, 1, 64, 0), (128, 64, 1, 1, 64, 1), (512, 512, 3, 3, 512, 0), (512, 512, 3, 3, 512, 1), (96, 32, 3, 3, 32, 0)]
+    ops.set_conv_compute_dtype(mode)
+    try:
+        ws = [(rnd(co, ci, kh, kw, seed=90 + i) * 0.1).to(dev) for i, (co, ci, kh, kw, cs, md) in enumerate(shapes)]
+        ref = [ops._pack_weights(w, s[4], s[5]) for w, s in zip(ws, shapes)]
+        out = [torch.full_like(r, -1) for r in ref]
+        m = len(shapes)
+        a = (ctypes.c_void_p * m)(*[w.data_ptr() for w in ws])
+        b = (ctypes.c_void_p * m)(*[o.data_ptr() for o in out])
+        d = (ctypes.c_int * (6 * m))(*[v for s in shapes for v in (s[0], s[1], s[4], s[2], s[3], s[5])])
+        ops.lib().call("lmkd_conv2d_repack_multi", a, b, d, m, ops._stream())
+        for i, (r, o) in enumerate(zip(ref, out)):
+            assert torch.equal(r, o), (mode, shapes[i], int((r != o).sum()))
+    finally:
+        ops.reset_compute_dtypes()
