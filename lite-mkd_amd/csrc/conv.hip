@@ -758,6 +758,22 @@ static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
   hipLaunchKernelGGL((conv_gemm_kernel<Cfg, SMALLC, STATS, BF16>), grid, dim3(Cfg::THREADS), 0, s, a);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel instance, once per (instance, device), from whichever host thread launches
+// first (the forward's thread and the autograd engine's both launch): `mask` is the instance's static bit set of devices done.
+#include <atomic>
+static inline void lmkd_lds_attr_once(std::atomic<unsigned long long>& mask, const void* fn, int bytes) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) d = 0;
+  const unsigned long long bit = 1ull << (d & 63);
+  if (mask.load(std::memory_order_acquire) & bit) return;
+  const hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (err != hipSuccess) {      // the launch that follows fails with its own message; leave the bit clear so that the next launch retries
+    lmkd_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d): %s", bytes, hipGetErrorString(err));
+    return;
+  }
+  mask.fetch_or(bit, std::memory_order_release);
+}
+
 // Same-size convolutions (3x3 / stride 1 forward and data gradient, 1x1 / stride 1) of the bf16-plane modes read an LDS-resident
 // input patch (conv_patch.h).  Returns the halo (largest |dh * Ws + dw| over the taps), or -1 when the launch is not of that kind.
 static int patch_halo(const ConvGemmArgs& a) {
@@ -798,21 +814,18 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
   const size_t lds = patch_lds_bytes(Cfg::BM, halo, npl);
 #define LMKD_PATCH(NPROD, PRE, IO)                                                                                             \
   do {                                                                                                                         \
-    static bool attr_set = false;                                                                                              \
-    if (!attr_set) {                                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>),                     \
-                                hipFuncAttributeMaxDynamicSharedMemorySize,                                                   \
-                                (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, NPROD == 1 ? 1 : 3));                            \
-      attr_set = true;                                                                                                         \
-    }                                                                                                                          \
+    static std::atomic<unsigned long long> attr_done{0};                                                                       \
+    lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>),                   \
+                       (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, NPROD == 1 ? 1 : 3));                                     \
     hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>), grid, dim3(Cfg::THREADS), lds, s, a);                      \
   } while (0)
   if constexpr (Cfg::BM == 128 && Cfg::BN == 64 && Cfg::THREADS == 256) {      // ablation instances exist for the benchmark's main tile only
     if (g_patch_debug && g_conv_x3 == 6 && !g_lmkd_act_bf16 && !a.pre_stats && !a.ep_stats) {
 #define LMKD_PATCH_DBG(D)                                                                                                      \
   do {                                                                                                                         \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, 6, false, 0, D>),                       \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));   \
+    static std::atomic<unsigned long long> attr_done{0};                                                                       \
+    lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, 6, false, 0, D>),                   \
+                       (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));                                                      \
     hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, 6, false, 0, D>), grid, dim3(Cfg::THREADS), lds, s, a);                      \
   } while (0)
       switch (g_patch_debug) {
@@ -835,23 +848,17 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
     if (g_patch16 && g_conv_x3 && !g_lmkd_act_bf16) {
 #define LMKD_PATCH16(NPROD, PRE, EP)                                                                                           \
   do {                                                                                                                         \
-    static bool attr16_set = false;                                                                                            \
-    if (!attr16_set) {                                                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch16_x3_kernel<Cfg, NPROD, PRE, EP>),                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3)); \
-      attr16_set = true;                                                                                                       \
-    }                                                                                                                          \
+    static std::atomic<unsigned long long> attr_done{0};                                                                       \
+    lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch16_x3_kernel<Cfg, NPROD, PRE, EP>),                 \
+                       (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));                                                      \
     hipLaunchKernelGGL((conv_patch16_x3_kernel<Cfg, NPROD, PRE, EP>), grid, dim3(Cfg::THREADS), lds, s, a);                    \
   } while (0)
       if (a.src2) {
 #define LMKD_PATCH16S(NPROD, EP)                                                                                               \
   do {                                                                                                                         \
-    static bool attr16s_set = false;                                                                                           \
-    if (!attr16s_set) {                                                                                                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch16_x3_kernel<Cfg, NPROD, false, EP, true>),           \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3)); \
-      attr16s_set = true;                                                                                                      \
-    }                                                                                                                          \
+    static std::atomic<unsigned long long> attr_done{0};                                                                       \
+    lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch16_x3_kernel<Cfg, NPROD, false, EP, true>),         \
+                       (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));                                                      \
     hipLaunchKernelGGL((conv_patch16_x3_kernel<Cfg, NPROD, false, EP, true>), grid, dim3(Cfg::THREADS), lds, s, a);            \
   } while (0)
         if (a.ep_stats) { if (g_conv_x3 == 9) LMKD_PATCH16S(9, true); else LMKD_PATCH16S(6, true); }
@@ -1337,12 +1344,8 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
       const bool deep = cdiv(2 * a.Wo, 32) >= 6;      // dy tiles fetched six steps ahead (224-pixel images: seven steps per unit), else two
 #define LMKD_STEM_WG(NPROD, D, RLC)                                                                                                      \
   do {                                                                                                                                   \
-    static bool attr_set = false;                                                                                                        \
-    if (!attr_set) {                                                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel<NPROD, D, RLC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                160 * 1024);                                                                                             \
-      attr_set = true;                                                                                                                   \
-    }                                                                                                                                    \
+    static std::atomic<unsigned long long> attr_done{0};                                                                                 \
+    lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&stem_wgrad_kernel<NPROD, D, RLC>), 160 * 1024);                         \
     hipLaunchKernelGGL((stem_wgrad_kernel<NPROD, D, RLC>), grid, dim3(512), lds, s, w);                                                   \
   } while (0)
       if (g_conv_x3 == 9) {
