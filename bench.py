@@ -231,7 +231,7 @@ def main():
     # warm-up: with graphs every resident episode has to be seen twice before it replays (first eager, then captured)
     it = run(max(a.warmup, 2 * len(pool) + 1) if use_graph else a.warmup, 0)
     fence()
-    ops.CONV_TIMING = None if use_graph else []      # per-launch HIP events cannot be recorded into a captured graph (roofline_pass below times them)
+    ops.CONV_TIMING = None if (use_graph or os.environ.get("LMKD_TIMED_EVENTS", "1") == "0") else []      # per-launch HIP events cannot be recorded into a captured graph (roofline_pass below times them)
     PAR.ALLREDUCE_TIMING = []
     steps0 = opt.steps
     t0 = time.perf_counter()
