@@ -338,13 +338,21 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   const int ch0 = n0 + wn * (Cfg::TN * 32) + 4 * kq;      // + 16 c
   float4 s1[NC], s2[NC];
   float4 esc[NC], esh[NC];
+  float4 bmean[NC], bistd[NC];      // bnb_x: the BatchNorm table of this lane's channels, once per tile (esc / esh hold scale / shift)
+  const bool bnb = !EP && a.bnb_x != nullptr;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     s1[c] = s2[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EP) {
-      const int col = ch0 + 16 * c;
-      esc[c] = col < a.Co ? *reinterpret_cast<const float4*>(a.ep_stats + 2 * a.Co + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-      esh[c] = col < a.Co ? *reinterpret_cast<const float4*>(a.ep_stats + 3 * a.Co + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int col = ch0 + 16 * c;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EP || bnb) {
+      const float* st = EP ? a.ep_stats : a.bnb_stats;
+      esc[c] = col < a.Co ? *reinterpret_cast<const float4*>(st + 2 * a.Co + col) : z4;
+      esh[c] = col < a.Co ? *reinterpret_cast<const float4*>(st + 3 * a.Co + col) : z4;
+    }
+    if (bnb) {
+      bmean[c] = col < a.Co ? *reinterpret_cast<const float4*>(a.bnb_stats + col) : z4;
+      bistd[c] = col < a.Co ? *reinterpret_cast<const float4*>(a.bnb_stats + a.Co + col) : z4;
     }
   }
 #pragma unroll
@@ -376,11 +384,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       }
       if (ok) *reinterpret_cast<float4*>(a.out + (long)ob + col) = v;
       if (!EP) {
-        if (a.bnb_x) {      // sums of the BatchNorm backward this gradient feeds (ConvGemmArgs::bnb_x): bn_bwd_reduce_kernel's terms, mask mode 2
+        if (bnb) {      // sums of the BatchNorm backward this gradient feeds (ConvGemmArgs::bnb_x): bn_bwd_reduce_kernel's terms, mask mode 2
           if (ok) {
             const float4 xv = *reinterpret_cast<const float4*>(a.bnb_x + (long)ob + col);
-            const float4 mean = *reinterpret_cast<const float4*>(a.bnb_stats + col), istd = *reinterpret_cast<const float4*>(a.bnb_stats + a.Co + col);
-            const float4 sc = *reinterpret_cast<const float4*>(a.bnb_stats + 2 * a.Co + col), sh = *reinterpret_cast<const float4*>(a.bnb_stats + 3 * a.Co + col);
+            const float4 mean = bmean[c], istd = bistd[c], sc = esc[c], sh = esh[c];
             const float gx = fmaf(xv.x, sc.x, sh.x) > 0.f ? v.x : 0.f, gy = fmaf(xv.y, sc.y, sh.y) > 0.f ? v.y : 0.f;
             const float gz = fmaf(xv.z, sc.z, sh.z) > 0.f ? v.z : 0.f, gw = fmaf(xv.w, sc.w, sh.w) > 0.f ? v.w : 0.f;
             s1[c].x += gx; s1[c].y += gy; s1[c].z += gz; s1[c].w += gw;

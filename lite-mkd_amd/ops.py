@@ -586,7 +586,8 @@ def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumula
             _chk(bn[0], bn[1])
             part = _empty((T, Cin, 2), dy)
     with _timed(_conv_family(1, N, H, W, Cin, Cin, Cout, KH, KW, stride, pad), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
-                dy.element_size() * dy.numel() + dx.element_size() * dx.numel() * (2 if accumulate else 1) + 4 * wd.numel()):
+                dy.element_size() * dy.numel() + dx.element_size() * dx.numel() * (2 if accumulate else 1) + 4 * wd.numel()
+                + (bn[0].element_size() * bn[0].numel() if part is not None else 0)):      # the fused form also reads the BatchNorm input
         if part is not None:
             lib().call("lmkd_conv2d_bwd_data_bn", _p(dy), _p(wd), _p(dx), _p(bn[0]), _p(bn[1]), _p(part), N, H, W, Cin, Cout, KH, KW, stride,
                        pad, _stream())
