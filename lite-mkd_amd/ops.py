@@ -14,8 +14,15 @@ from ._lib import lib
 # ------------------------------------------------------------------------------------------
 # helpers
 # ------------------------------------------------------------------------------------------
+def _raw_stream(device_index=None):
+    """the current HIP stream of the (current) device as an integer handle: torch.cuda.current_stream() builds a Stream object and
+    resolves the device through four Python layers (7.6 us, 230 times per episode: 1.75 ms of the forward's host time); the raw
+    binding costs 0.3 us"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice() if device_index is None else device_index)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream())
 
 
 def _p(t):
@@ -102,8 +109,7 @@ _GEMM_WS = {}
 
 
 def _gemm_workspace(like):
-    cur = torch.cuda.current_stream(like.device)
-    key = (like.device.index, cur.cuda_stream)
+    key = (like.device.index, _raw_stream(like.device.index))
     e = _GEMM_WS.get(key)
     if e is None:
         e = _GEMM_WS[key] = (torch.empty(32 << 20, dtype=torch.uint8, device=like.device),
@@ -125,8 +131,7 @@ _TICKETS = {}
 
 
 def _tickets(like):
-    cur = torch.cuda.current_stream(like.device)
-    key = (like.device.index, cur.cuda_stream)
+    key = (like.device.index, _raw_stream(like.device.index))
     t = _TICKETS.get(key)
     if t is None:
         t = _TICKETS[key] = torch.zeros(lib().value("lmkd_ticket_words"), dtype=torch.int32, device=like.device)
@@ -169,7 +174,7 @@ def _grad_target(param):
         return None
     # kernels of the side stream (query-frame trunk call: BatchNorm parameters) and of the auxiliary stream (second TRX head: TRX
     # parameters) add to the shadow buffer, everything on the caller's stream to .grad: no address is ever added to from two streams
-    cur = torch.cuda.current_stream(param.device).cuda_stream
+    cur = _raw_stream(param.device.index)
     for table in (_side_streams, _aux_streams):
         for key, other in table.items():
             if key[1] == param.device.index and cur == other.cuda_stream:
@@ -378,12 +383,12 @@ def pack_weights(w, Cs, mode):
         return _pack_weights(w, Cs, mode)
     tag = (owner._version, WEIGHT_EPOCH[0])
     key = (Cs, mode, lib().value("lmkd_conv_get_compute_dtype"))      # one persistent buffer per arithmetic mode
-    cur = torch.cuda.current_stream()
     hit = e["packs"].get(key)
     if hit is not None and hit[0] == tag:
-        if hit[3] is not None and hit[3] != cur.cuda_stream:
-            cur.wait_event(hit[2])            # packed on the other stream: order this stream behind the pack kernel
+        if hit[3] is not None and hit[3] != _raw_stream():
+            torch.cuda.current_stream().wait_event(hit[2])            # packed on the other stream: order this stream behind the pack kernel
         return hit[1]
+    cur = torch.cuda.current_stream()
     # stale or missing: (re)pack - into the SAME buffer when there is one, so that its address stays valid for a captured hipGraph
     # (trainloop.GraphedEpisode) and the allocator is left alone
     wp = _pack_weights(w, Cs, mode, out=hit[1] if hit is not None else None)
