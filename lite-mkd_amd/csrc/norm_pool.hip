@@ -585,7 +585,11 @@ static int bn_bwd_stats_impl(const float* dy, const float* x, const float* yact,
   LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS, "%s: C=%d exceeds the ticket buffer", who, C);
   const int RL1 = NP_THREADS / (CC / 4), RL = RL1 * U;
   int nb = cdiv(rows, (long)RL1 * 8);      // virtual blocks of RL1 row lanes (U of them per workgroup)
-  if (nb > 256 * g_ew_wg_per_cu) nb = 256 * g_ew_wg_per_cu;
+  // cap: twice the elementwise kernels' workgroup count, for BOTH element types (the partial sums stay bit-identical between them).  A
+  // bf16 workgroup carries two virtual blocks: capped at the workgroup count itself, the bf16 launch had half the workgroups and ran
+  // as long as the fp32 one on half the bytes (27.0 vs 28.9 us)
+  if (nb > 256 * g_ew_wg_per_cu * 2) nb = 256 * g_ew_wg_per_cu * 2;
+  if (nb > 2048) nb = 2048;      // rows of the partial buffer (lmkd_bn_bwd_workspace)
   if (nb < 1) nb = 1;
   float* partial = (float*)workspace;
   double* dscr = (double*)((char*)workspace + (((long)2048 * 2 * C * sizeof(float) + 63) / 64) * 64);
@@ -683,19 +687,27 @@ extern "C" int lmkd_relu_backward(const float* dy, const float* y, float* g, lon
 template <typename T>
 __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ stats, T* __restrict__ y,
                                        uchar4* __restrict__ idx, T* __restrict__ cmax, int N, int H, int W, int C, int OH, int OW) {
-  const int C4 = C >> 2;
-  const long total = (long)N * OH * OW * C4;
+  // a thread owns U groups of 4 consecutive channels of one output pixel (U = 2 with bf16 tensors: every access 16 bytes; with 8-byte
+  // accesses the bf16 instance took as long as the fp32 one on half the bytes - 260 vs 280 us at 200 frames)
+  constexpr int U = ActU<T>::U;
+  const int CU = C / (4 * U);
+  const long total = (long)N * OH * OW * CU;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % C4);
-    long r = i / C4;
+    const int cq = (int)(i % CU);
+    long r = i / CU;
     const int ow = (int)(r % OW); r /= OW;
     const int oh = (int)(r % OH);
     const int n = (int)(r / OH);
-    const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + cq * 4);
-    const float4 sh = *reinterpret_cast<const float4*>(stats + 3 * C + cq * 4);
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    float4 cm = make_float4(0.f, 0.f, 0.f, 0.f);      // the raw convolution output at the arg-max (backward: lmkd_bn_backward_stats)
-    uchar4 am = make_uchar4(255, 255, 255, 255);
+    float4 sc[U], sh[U], m[U], cm[U];      // cm: the raw convolution output at the arg-max (backward: lmkd_bn_backward_stats)
+    uchar4 am[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      sc[u] = *reinterpret_cast<const float4*>(stats + 2 * C + (cq * U + u) * 4);
+      sh[u] = *reinterpret_cast<const float4*>(stats + 3 * C + (cq * U + u) * 4);
+      m[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      cm[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      am[u] = make_uchar4(255, 255, 255, 255);
+    }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int h = oh * 2 - 1 + kh;
@@ -704,28 +716,34 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __r
       for (int kw = 0; kw < 3; ++kw) {
         const int w = ow * 2 - 1 + kw;
         if ((unsigned)w >= (unsigned)W) continue;
-        const float4 r = ld4<T>(x, ((long)(n * H + h) * W + w) * C4 + cq);
-        float4 v;
-        v.x = fmaxf(fmaf(r.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(r.y, sc.y, sh.y), 0.f);
-        v.z = fmaxf(fmaf(r.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(r.w, sc.w, sh.w), 0.f);
+        float4 rr[U];
+        ldv<T, U>(x, ((long)(n * H + h) * W + w) * CU + cq, rr);
         const unsigned char t = (unsigned char)(kh * 3 + kw);
-        if (v.x > m.x || am.x == 255) { m.x = v.x; am.x = t; cm.x = r.x; }
-        if (v.y > m.y || am.y == 255) { m.y = v.y; am.y = t; cm.y = r.y; }
-        if (v.z > m.z || am.z == 255) { m.z = v.z; am.z = t; cm.z = r.z; }
-        if (v.w > m.w || am.w == 255) { m.w = v.w; am.w = t; cm.w = r.w; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float4 r4 = rr[u];
+          float4 v;
+          v.x = fmaxf(fmaf(r4.x, sc[u].x, sh[u].x), 0.f); v.y = fmaxf(fmaf(r4.y, sc[u].y, sh[u].y), 0.f);
+          v.z = fmaxf(fmaf(r4.z, sc[u].z, sh[u].z), 0.f); v.w = fmaxf(fmaf(r4.w, sc[u].w, sh[u].w), 0.f);
+          if (v.x > m[u].x || am[u].x == 255) { m[u].x = v.x; am[u].x = t; cm[u].x = r4.x; }
+          if (v.y > m[u].y || am[u].y == 255) { m[u].y = v.y; am[u].y = t; cm[u].y = r4.y; }
+          if (v.z > m[u].z || am[u].z == 255) { m[u].z = v.z; am[u].z = t; cm[u].z = r4.z; }
+          if (v.w > m[u].w || am[u].w == 255) { m[u].w = v.w; am[u].w = t; cm[u].w = r4.w; }
+        }
       }
     }
-    st4<T>(y, i, m);
-    idx[i] = am;
-    if (cmax) st4<T>(cmax, i, cm);
+    stv<T, U>(y, i, m);
+#pragma unroll
+    for (int u = 0; u < U; ++u) idx[i * U + u] = am[u];
+    if (cmax) stv<T, U>(cmax, i, cm);
   }
 }
 
 extern "C" int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int H, int W,
                                         int C, void* stream) {
-  LMKD_REQUIRE(x && stats && y && idx && C % 4 == 0, "lmkd_bn_relu_maxpool_fwd: bad arguments");
+  LMKD_REQUIRE(x && stats && y && idx && C % (g_lmkd_act_bf16 ? 8 : 4) == 0, "lmkd_bn_relu_maxpool_fwd: bad arguments");
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  const long total = (long)N * OH * OW * C / 4;
+  const long total = (long)N * OH * OW * C / (g_lmkd_act_bf16 ? 8 : 4);
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<lmkd_bf16_t>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)x,
                        stats, (lmkd_bf16_t*)y, (uchar4*)idx, (lmkd_bf16_t*)cmax, N, H, W, C, OH, OW);
