@@ -94,6 +94,8 @@ def main():
                          "backward of episode i on a second stream set; same kernels, bit-identical results, same optimizer cadence.  OFF by "
                          "default: measured 6 %% SLOWER on one MI355X (31.0 vs 32.9 episodes/s) - more kernels side by side disturb each other's L2 working sets")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false")
+    ap.add_argument("--graph-interval", action="store_true", help="with --graph: capture the episodes between two optimizer steps as ONE graph "
+                    "(the weight-gradient stream keeps running under the next episode's forward, as in the eager loop)")
     ap.add_argument("--stream-inputs", action="store_true", help="extra measurement after the headline line: every episode's inputs arrive "
                     "from HOST memory - decoded uint8 frames (320x240, pinned) + teacher features go H2D on a copy stream, the GPU frame "
                     "transform (Resize 256 / crop 224 / flip / ToTensor, video_transform.py) runs there too, overlapped with the previous "
@@ -196,7 +198,26 @@ def main():
         torch.cuda.current_stream(dev).wait_stream(ml)
         return it
 
+    def run_intervals(n, it0):
+        """--graph-interval: the episodes between two optimizer steps as ONE graph replay (GraphedEpisode.run_interval)"""
+        it, i = it0, 0
+        g = graph_runner()
+        while i < n:
+            k = min(every - ((it + 1) % every), n - i) or every      # up to the next optimizer step
+            k = min(k, n - i)
+            g.run_interval([pool[(it + j) % len(pool)] for j in range(k)])      # by the global episode count: the same interval comes round
+            i += k
+            it += k
+            if (it + 1) % every == 0:
+                opt.step()
+                opt.zero_grad()
+            for _ in range(k):
+                sch.step()
+        return it
+
     def run_on_current(n, it0):
+        if use_graph and a.graph_interval and mfm is None:
+            return run_intervals(n, it0)
         it = it0
         for i in range(n):
             it += 1
@@ -229,7 +250,12 @@ def main():
         torch.cuda.synchronize()
 
     # warm-up: with graphs every resident episode has to be seen twice before it replays (first eager, then captured)
-    it = run(max(a.warmup, 2 * len(pool) + 1) if use_graph else a.warmup, 0)
+    interval_mode = use_graph and a.graph_interval and mfm is None
+    if interval_mode:      # whole optimizer intervals only: the interval that repeats is seen (eager), captured and replayed before the timed region
+        a.steps = max(every, a.steps // every * every)
+        it = run(every - 1 + 3 * every, 0)
+    else:
+        it = run(max(a.warmup, 2 * len(pool) + 1) if use_graph else a.warmup, 0)
     fence()
     ops.CONV_TIMING = None if (use_graph or os.environ.get("LMKD_TIMED_EVENTS", "1") == "0") else []      # per-launch HIP events cannot be recorded into a captured graph (roofline_pass below times them)
     PAR.ALLREDUCE_TIMING = []
@@ -246,8 +272,8 @@ def main():
     for _ in range(4):
         fence()
         th = time.perf_counter()
-        it = run(1, it)
-        host_idle += time.perf_counter() - th
+        it = run(every if interval_mode else 1, it)
+        host_idle += (time.perf_counter() - th) / (every if interval_mode else 1)
     fence()
     host_idle /= 4
     ar_events, PAR.ALLREDUCE_TIMING = PAR.ALLREDUCE_TIMING, None

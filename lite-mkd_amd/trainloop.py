@@ -401,6 +401,62 @@ class GraphedEpisode:
         ent["prepared"][5].copy_(ent["task"]["target_labels"][0].long())
         return self._replay(ent)
 
+    # ---- several episodes per graph.  A one-episode graph must join the weight-gradient stream before it ends, so its ~4 ms tail no
+    # longer runs under the next episode's forward (the replay loop is ~5 % slower than the eager loop on the GPU side).  The episodes
+    # between two optimizer steps depend on each other only through the gradient buffers, which the eager loop orders on the
+    # weight-gradient stream anyway: captured as ONE graph they keep that overlap and join once, where the optimizer would wait too.
+    def run_interval(self, task_dicts):
+        """the episodes of one optimizer interval, resident in device tensors (keyed like __call__): first sight eager, then captured
+        as one graph, then one replay per call.  -> [(loss, accuracy, info)] per episode, bit-identical to the eager loop"""
+        keys = tuple(self._key(t) for t in task_dicts)
+        if any(k is None for k in keys):
+            return [self(t) for t in task_dicts]
+        ikey = ("interval",) + keys
+        ent = self.graphs.get(ikey)
+        if ent is None:
+            if ikey not in self.seen:
+                self.seen.add(ikey)
+                return [self._eager(t) for t in task_dicts]
+            ent = self._capture_interval(task_dicts, ikey)
+        ops.wait_weight_grads()
+        ops.refresh_packs()
+        ent["slots"].stage(self._seeds(ent["slots"].used))
+        ent["graph"].replay()
+        self.replays += len(task_dicts)
+        return [(l, a, {"accuracy": a}) for l, a in ent["out"]]
+
+    def _capture_interval(self, task_dicts, ikey):
+        cfg = self.config
+        prepared = [prepare_task(t, cfg.device) for t in task_dicts]
+        plans = []
+        for pr in prepared:
+            plan = ops.get_plan(pr[4], cfg.way)
+            plan.full_rowmap(pr[2].shape[0] + pr[3].shape[0])
+            plan.full_rowmap(pr[0].shape[0] // cfg.seq_len + pr[1].shape[0] // cfg.seq_len)
+            plans.append(plan)
+        streams = [ops.side_stream(cfg.device), ops.aux_stream(cfg.device)] + list(ops._WG_STREAM.values())
+        ops.refresh_packs(streams)
+        slots = ops.SeedSlots(cfg.device, n=16 * len(prepared))
+        g = torch.cuda.CUDAGraph()
+        prev_sync = ops.SYNC_WGRAD_AT_BACKWARD_END
+        torch.cuda.synchronize()
+        ops.SEED_SLOTS = slots
+        ops.SYNC_WGRAD_AT_BACKWARD_END = False                     # the weight-gradient stream runs on under the next episode's forward ...
+        out = []
+        try:
+            with torch.cuda.graph(g):
+                for pr, plan in zip(prepared, plans):
+                    ops._plan_cache[0], ops._plan_cache[1], ops._plan_cache[2] = pr[4], cfg.way, plan      # (get_plan's one-entry identity cache)
+                    loss, acc, _ = _train_task_prepared(pr, self.student, self.teacher, self.distiller, self.accuracy_fn, cfg)
+                    out.append((loss, acc))
+                ops.wait_weight_grads()                            # ... and joins the capture stream once, at the end
+        finally:
+            ops.SEED_SLOTS = None
+            ops.SYNC_WGRAD_AT_BACKWARD_END = prev_sync
+        ent = {"graph": g, "slots": slots, "out": out, "prepared": prepared, "plans": plans, "tasks": list(task_dicts)}
+        self.graphs[ikey] = ent
+        return ent
+
     def __call__(self, task_dict):
         key = self._key(task_dict)
         if key is None:

@@ -310,6 +310,56 @@ def test_graphed_episode_bit_identical_to_eager(dev, fresh_tensors):
     assert len({l for l, _ in o_e}) > 4                 # the episodes really differ (dropout masks, optimizer step)
 
 
+def test_graphed_interval_bit_identical_to_eager(dev):
+    """GraphedEpisode.run_interval: the episodes between two optimizer steps captured as ONE hipGraph (the weight-gradient stream joins
+    once, at the end of the interval): losses, accumulated gradients, weights after the steps and BatchNorm running statistics
+    bit-identical to the eager loop; the interval is seen once eagerly, captured at its second occurrence, replayed afterwards"""
+    from litemkd_amd import ops, trainloop as TL
+    from litemkd_amd.model.model_select import Student, Teacher
+    from litemkd_amd.distillers import Distiller
+    from litemkd_amd.options import default_args
+    from litemkd_amd.utils import aggregate_accuracy
+    cfg = default_args(shot=1, query_per_class=1, img_size=64, trans_dropout=0.1, device=dev, learning_rate=1e-2)
+    src = TL.SyntheticEpisodes(cfg, base_seed=78, device=dev)
+    pool = [src.episode(e) for e in range(2)]
+    interval = [0, 1, 0]
+    n_int = 4
+
+    def run(graph):
+        torch.manual_seed(92)
+        student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)
+        opt = TL.FusedOptimizer(student, "sgd", cfg.learning_rate)
+        distiller = Distiller(cfg.distill_name, cfg.cfg, dev)
+        runner = TL.GraphedEpisode(student, teacher, distiller, aggregate_accuracy, cfg) if graph else None
+        prev = (ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD)
+        ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD = True, False, True
+        out = []
+        try:
+            torch.manual_seed(6)
+            for it in range(n_int):
+                eps = [pool[e] for e in interval]
+                res = runner.run_interval(eps) if graph else [TL.train_task(e, student, teacher, distiller, aggregate_accuracy, cfg) for e in eps]
+                out += [(float(l), float(a)) for l, a, _ in res]
+                if it < n_int - 1:
+                    opt.step()
+                    opt.zero_grad()
+            ops.wait_weight_grads()
+            opt.bucket.fold_shadow()
+            torch.cuda.synchronize()
+        finally:
+            ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD = prev
+        stats = {k: v.clone() for k, v in student.state_dict().items() if "running" in k or "num_batches" in k}
+        return out, opt.bucket.grad.clone(), opt.bucket.flat.clone(), stats, runner
+    o_e, g_e, w_e, s_e, _ = run(False)
+    o_g, g_g, w_g, s_g, runner = run(True)
+    assert runner.eager == len(interval) and runner.replays == (n_int - 1) * len(interval) and len(runner.graphs) == 1, (runner.eager, runner.replays)
+    assert o_e == o_g, (o_e, o_g)
+    assert torch.equal(w_e, w_g)
+    assert torch.equal(g_e, g_g), float((g_e - g_g).abs().max())
+    for k in s_e:
+        assert torch.equal(s_e[k], s_g[k]), k
+
+
 def test_pipelined_episodes_bit_identical_to_sequential(dev):
     """trainloop.PipelinedEpisodes: the forward of episode i + 1 queued beside the backward of episode i on a second stream set.
     Same kernels on the same data, forwards and backwards each in program order: losses, accuracies, the accumulated flat gradient
