@@ -1393,10 +1393,11 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   } while (0)
 #define LMKD_WIN16(COB, NPROD, PRE)                                                                                     \
   do {                                                                                                                  \
-    constexpr int TPW = COB == 2 ? 5 : 9;                                                                               \
-    constexpr int NT = 64 * COB * ((9 + TPW - 1) / TPW);                                                                \
-    if (big) hipLaunchKernelGGL((conv_wgrad_win16_kernel<COB, NPROD, 256, PRE, TPW>), wgrid, dim3(NT), 0, s, w);        \
-    else hipLaunchKernelGGL((conv_wgrad_win16_kernel<COB, NPROD, 128, PRE, TPW>), wgrid, dim3(NT), 0, s, w);            \
+    /* Cout = 64 (two channel blocks): the second pair of waves takes the other 16 input channels of all nine taps */   \
+    constexpr int JW = COB == 2 ? 1 : 2;                                                                                \
+    constexpr int NT = 64 * COB * (2 / JW);                                                                             \
+    if (big) hipLaunchKernelGGL((conv_wgrad_win16_kernel<COB, NPROD, 256, PRE, 9, JW>), wgrid, dim3(NT), 0, s, w);      \
+    else hipLaunchKernelGGL((conv_wgrad_win16_kernel<COB, NPROD, 128, PRE, 9, JW>), wgrid, dim3(NT), 0, s, w);          \
   } while (0)
 #define LMKD_WIN_MODE(COB)                                                                                              \
   do {                                                                                                                  \

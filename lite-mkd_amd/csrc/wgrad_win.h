@@ -240,11 +240,15 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
 //     slots with bit 2 set are SWAPPED when a row is stored: eight consecutive slots then tile the bank row for either half.  The
 //     address table carries the swap bit in bit 5 of an entry, and the reader's block select is an XOR with 32.
 //   * address table of a step: entry (tap, row slot 4 q4 + q) = {lower row, upper row}: one ds_read_b64 per lane and tap.
-template <int COB, int NPROD, int R, bool PRE = false, int TPW = 9>
-__global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_win16_kernel(WgradWinArgs a) {
+// JW: 16-channel blocks of x per wave (2 = the whole 32-channel tile).  Where Cout = 64 leaves two channel blocks, the second pair of
+// waves takes the OTHER 16 input channels of all nine taps (TPW = 9, JW = 1: 108 MFMAs per wave and step for every wave) instead of
+// four of the nine taps (TPW = 5: 120 / 96 - the 4-tap waves idle a fifth of the time): 244 -> measured in DESIGN 8.8.
+template <int COB, int NPROD, int R, bool PRE = false, int TPW = 9, int JW = 2>
+__global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void conv_wgrad_win16_kernel(WgradWinArgs a) {
+  static_assert(JW == 2 || (JW == 1 && TPW == 9), "the channel-block split exists for nine taps per wave");
   static_assert(NPROD == 6 || NPROD == 9, "three-plane modes");
   constexpr int NPL = 3;
-  constexpr int THREADS = 64 * COB * ((9 + TPW - 1) / TPW), BM = 32 * COB;
+  constexpr int THREADS = 64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW), BM = 32 * COB;
   constexpr int LDA = BM * 2 + 32, A_PLANE = LMKD_BK * LDA;      // dy image [k][co], bytes
   constexpr int LDX = 64, X_PLANE = (R + 1) * LDX;               // x ring [slot][32 ci]; slot R = the zero row
   constexpr int A_LPR = BM / 4, A_RPP = THREADS / A_LPR, A_NI = (LMKD_BK + A_RPP - 1) / A_RPP;      // dy loader: lanes per row, rows per pass
@@ -339,16 +343,16 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
   };
 
   const int q4 = lane >> 4, idx = lane & 15;
-  const int cw = wave % COB, tap0 = (wave / COB) * TPW;
+  const int cw = wave % COB, tap0 = JW == 2 ? (wave / COB) * TPW : 0, j0 = JW == 2 ? 0 : wave / COB;
   const int offA = (4 * q4 + (idx >> 2)) * LDA + (cw * 32 + 4 * (idx & 3)) * 2;      // + 32 bytes: second 16-channel block; + 16 LDA: upper rows
   const unsigned cbx = (unsigned)(8 * (idx & 3));
-  f32x4 acc[TPW][2][2];
+  f32x4 acc[TPW][2][JW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < JW; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) {
     const int kfirst = s0 * LMKD_BK;
@@ -389,9 +393,9 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
         if (9 % TPW != 0 && ti >= 9 - TPW * (9 / TPW) && tp >= 9) break;      // only the last wave group's trailing taps can be missing
         const uint2 a2 = *reinterpret_cast<const uint2*>(&s_adr[t & 1][tp * LMKD_BK + (4 * q4 + (idx >> 2)) * 2]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {      // the two 16-channel blocks of x
+        for (int j = 0; j < JW; ++j) {      // the 16-channel blocks of x this wave owns
           bf16x8 fb[NPL];
-          const unsigned lo_a = (a2.x ^ (unsigned)(j << 5)) + cbx, hi_a = (a2.y ^ (unsigned)(j << 5)) + cbx;
+          const unsigned lo_a = (a2.x ^ (unsigned)((j0 + j) << 5)) + cbx, hi_a = (a2.y ^ (unsigned)((j0 + j) << 5)) + cbx;
 #pragma unroll
           for (int p = 0; p < NPL; ++p) {
             const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(s_x + p * X_PLANE + lo_a));
@@ -429,8 +433,8 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = (tap0 + ti) * a.Cs + ci0 + 16 * j + idx;
+      for (int j = 0; j < JW; ++j) {
+        const int col = (tap0 + ti) * a.Cs + ci0 + 16 * (j0 + j) + idx;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = co0 + cw * 32 + 16 * i + 4 * q4 + e;
