@@ -433,7 +433,7 @@ def refresh_packs(streams=()):
         dims = (ctypes.c_int * (6 * m))(*[v for t in stale for v in t[2]])
         lib().call("lmkd_conv2d_repack_multi", ws, wfs, dims, m, _stream())
         _REPACK_KEEP[0] = stale      # the weights / planes stay referenced until the next refresh (the launch reads them asynchronously)
-    with _x3_scope():      # concatenated TRX projection weights (_trx_wcat_packs): three-plane packs also in the one-plane mode
+    with (_x3_scope() if _WCAT else contextlib.nullcontext()):      # concatenated TRX projection weights (_trx_wcat_packs; opt-in): three-plane packs also in the one-plane mode
         cdx = lib().value("lmkd_conv_get_compute_dtype")
         for key, e in _WCAT.items():
             wk, wv = e["rk"](), e["rv"]()

@@ -1694,3 +1694,36 @@ def test_repack_multi_bit_identical_to_pack_and_split(dev, mode):
             assert torch.equal(r, o), (mode, shapes[i], int((r != o).sum()))
     finally:
         ops.reset_compute_dtypes()
+
+
+@pytest.mark.parametrize("mode", ["fp32x3", "bf16"])
+def test_trx_projections_on_conv_kernels_match_gemm(dev, mode):
+    """ops.TRX_PROJ_ON_CONV (opt-in): the TRX projections and their input gradient as 1x1 convolutions in the three-plane arithmetic -
+    also inside the one-plane bf16 mode, where the process-wide arithmetic is switched for those launches and restored (ops._x3_scope):
+    logits and gradients equal to the GEMM path's to fp32-class rounding, and the mode is what it was afterwards"""
+    from litemkd_amd import ops
+    from litemkd_amd.model import classifiers as C
+    args = _args(dev, shot=2)
+    torch.manual_seed(11)
+    clf = C.TRX_2fcsup(args).to(dev)
+    sup = [rnd(10, 8, 2048, seed=100 + i).to(dev) for i in range(2)]
+    qry = [rnd(5, 8, 2048, seed=110 + i).to(dev) for i in range(2)]
+    lab = torch.arange(5).repeat_interleave(2).to(dev)
+    ops.set_conv_compute_dtype(mode)
+    if mode == "bf16":
+        ops.set_activation_dtype("bf16")
+    res = {}
+    try:
+        for on in (False, True):
+            ops.TRX_PROJ_ON_CONV = on
+            clf.zero_grad(set_to_none=True)
+            t = [x.clone().requires_grad_() for x in sup + qry]
+            r = clf({"context_features_1": t[0], "context_features_2": t[1]}, lab, {"target_features_1": t[2], "target_features_2": t[3]})["logits"]
+            (r["kl"].square().sum() + r["ce"].square().sum()).backward()
+            assert ops.get_conv_compute_dtype() == mode and ops.get_activation_dtype() == ("bf16" if mode == "bf16" else "fp32")
+            res[on] = [r["kl"].detach(), r["ce"].detach()] + [x.grad for x in t] + [clf.transformers.k_linear.weight.grad.clone()]
+    finally:
+        ops.TRX_PROJ_ON_CONV = False
+        ops.reset_compute_dtypes()
+    for i, (a, b) in enumerate(zip(res[False], res[True])):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12, (i, float((a - b).abs().max()), float(a.abs().max()))
