@@ -244,6 +244,47 @@ int lmkd_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                    long step, long n, int zero_grad, void* stream);
 int lmkd_fill(float* p, float v, long n, void* stream);
 
+/* ---- both trunk calls of an episode in ONE launch per layer (round 4) ----
+ * The reference calls the trunk twice per episode with the same weights and shapes - self.resnet(context_images) and
+ * self.resnet(target_images), model/backbone/resnet18_2fc.py:41-42 - and train-mode BatchNorm gives each call its own batch statistics.
+ * The *_seg entry points take the two calls as ONE tensor [F0 + F1, H, W, C] with a frame split seg_n0 = F0 (rows0 = F0 * H * W for the
+ * per-row kernels): "two frame segments".  BatchNorm tables become [2][5][C] (segment-major), partial-sum buffers hold segment 0's row
+ * tiles first (no tile straddles the split), and every tensor element is computed by exactly the arithmetic, in the order, that a launch on
+ * its own segment would use: outputs and activation gradients are bit-identical to the two-call form; weight / BatchNorm-parameter
+ * gradients are summed over both segments in one pass (another summation order than two accumulating launches).
+ * seg_n0 = 0 or N (rows0 = rows, T0 = T) = one segment = the plain entry point.  Modes 1-3 of lmkd_conv_set_compute_dtype. */
+int lmkd_conv2d_fwd_row_tiles_seg(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0, int* tiles0 /*host, nullable*/);
+int lmkd_conv2d_fwd_seg(const float* x, const float* pre_stats /*nullable: [2][5][Cs], lmkd_conv2d_fwd_pre*/, const float* wp, float* y,
+                        float* stat_partial, int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0, void* stream);
+int lmkd_conv2d_bwd_data_bn_tiles_seg(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int seg_n0, int* tiles0 /*host, nullable*/);
+int lmkd_conv2d_bwd_data_seg(const float* dy, const float* wd, float* dx, const float* bn_x /*nullable with bn_stats, part: lmkd_conv2d_bwd_data_bn*/,
+                             const float* bn_stats, float* part, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                             int accumulate, int seg_n0, void* stream);
+long lmkd_conv2d_bwd_weight_workspace_seg(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0);
+int lmkd_conv2d_bwd_weight_seg(const float* x, const float* pre_stats /*nullable: [2][5][Cs]*/, const float* dy, float* dw_oihw, float* workspace,
+                               long ws_bytes, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,
+                               int seg_n0, void* stream);
+/* BatchNorm family.  lmkd_bn_finalize_seg does not touch the running statistics (lmkd_bn_running_update_multi applies both segments'
+   updates in the reference's order); scratch: 2 * 64 * 2 * C doubles.  The backward forms take coef = [2][5][C] floats of scratch and a
+   workspace of 2 * lmkd_bn_bwd_workspace(C) bytes; dgamma / dbeta (+)= (segment 0's sums + segment 1's), written by the apply pass. */
+int lmkd_bn_finalize_seg(const float* partial, int T, int T0, int C, long count0, long count1, const float* gamma, const float* beta, float eps,
+                         float* stats /*[2][5][C]*/, double* scratch, unsigned* tickets, void* stream);
+int lmkd_bn_apply_seg(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows, long rows0, int C, int relu,
+                      int res_mode, unsigned* mask_bits, void* stream);
+int lmkd_bn_backward_seg(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dx, float* g_out,
+                         float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, long rows0, int C, int mask_mode,
+                         int accumulate_param_grads, void* stream);
+int lmkd_bn_backward_part_seg(const float* part, int T, int T0, const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
+                              float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, long rows0, int C,
+                              int accumulate_param_grads, void* stream);
+/* the stem (resnet children 0-3): BatchNorm + ReLU + max-pool forward, and its backward from the pooled side */
+int lmkd_bn_relu_maxpool_fwd_seg(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int N0, int H, int W, int C,
+                                 void* stream);
+int lmkd_bn_backward_stats_seg(const float* dy, const float* cmax, const float* stats, const float* gamma, float* coef, void* workspace,
+                               unsigned* tickets, long pooled_rows, long pooled_rows0, long count, long count0, int C, void* stream);
+int lmkd_stem_unpool_bn_bwd_seg(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef, float* dc,
+                                float* dgamma, float* dbeta, int accumulate_param_grads, int N, int N0, int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

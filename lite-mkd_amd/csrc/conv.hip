@@ -47,10 +47,33 @@ struct ConvGemmArgs {
   // ((sph * W + spw) * Cs) and taps[0][s2_t0[c] .. s2_t0[c + 1] - 1] the taps of class c (dh / dw in the class grid)
   int src2, s2_ncls, s2_wfull;
   int s2_t0[5], s2_off[4];
+  // Two frame segments in one launch (round 4: the support-frame and the query-frame trunk call of an episode, resnet18_2fc.py:41-42, as
+  // ONE tensor [F0 + F1, H, W, C]): rows [0, seg_m0) of a class belong to segment 0, the rest to segment 1.  The row tiles are dealt per
+  // segment - tiles [0, seg_t0) cover segment 0, tile seg_t0 starts at row seg_m0 - so no tile straddles the boundary: every tile's
+  // BatchNorm partial sums belong to one segment, the [2][5][C] tables (pre_stats, bnb_stats) are indexed by the tile's segment, and the
+  // tiles (with their -W halves, x3_neg_tile) are exactly those of two separate launches: bit-identical results.
+  // Unsegmented launch: seg_m0 = rows_per_class, seg_t0 = tiles_per_class (conv_set_tiles).
+  int seg_m0, seg_t0;
   FastDiv div_hw, div_w;
   int ntap[LMKD_MAX_CLASSES];
   Tap taps[LMKD_MAX_CLASSES][LMKD_MAX_TAPS];
 };
+
+// tile -> first row, row limit, segment, index / count of the tile inside its segment (ConvGemmArgs::seg_m0)
+struct SegTile { int row0, mend, seg, ltile, ltiles; };
+__device__ __forceinline__ SegTile seg_tile(const ConvGemmArgs& a, int tile, int BM) {
+  SegTile s;
+  if (tile < a.seg_t0) { s.row0 = tile * BM; s.mend = a.seg_m0; s.seg = 0; s.ltile = tile; s.ltiles = a.seg_t0; }
+  else { s.row0 = a.seg_m0 + (tile - a.seg_t0) * BM; s.mend = a.rows_per_class; s.seg = 1; s.ltile = tile - a.seg_t0; s.ltiles = a.tiles_per_class - a.seg_t0; }
+  return s;
+}
+// host: row tiles of a launch with BM rows per tile (per class), segment-aware
+static inline void conv_set_tiles(ConvGemmArgs& a, int BM) {
+  if (a.seg_m0 <= 0 || a.seg_m0 >= a.rows_per_class) a.seg_m0 = a.rows_per_class;
+  a.seg_t0 = (a.seg_m0 + BM - 1) / BM;
+  a.tiles_per_class = a.seg_t0 + (a.rows_per_class - a.seg_m0 + BM - 1) / BM;
+  a.n_rt = a.nclass * a.tiles_per_class;
+}
 
 // K-major implicit-im2col loader (rows = output pixels of this tile).
 template <int ROWS, bool SMALLC, int THREADS = LMKD_THREADS, bool PRE = false>
@@ -349,8 +372,21 @@ struct WgradArgs {
   int Kp, Mpix, steps_total, steps_per_split;
   int n_mt, n_jt, splits, xcd_mode;   // 1-D grid decode (xcd_mode 1: all tiles of pixel split z run on XCD z % 8)
   const float* pre_stats;             // PRE: x is a raw conv output; the loader applies relu(BatchNorm(x)) (see ConvGemmArgs)
+  int seg_pix0, seg_splits0, sps1;    // two frame segments (wgrad_win.h WgradWinArgs): conv_wgrad_x3_kernel only; one segment: Mpix, splits, 0
   FastDiv div_hw, div_w;
 };
+
+// split z -> first pixel, pixel limit, number of 32-pixel steps, segment
+struct WinSlab { int kfirst, kend, nk, seg; };
+__device__ __forceinline__ WinSlab win_slab(int z, int Mpix, int sps0, int seg_pix0, int seg_splits0, int sps1) {
+  WinSlab w;
+  int sps;
+  if (z < seg_splits0) { w.kfirst = z * sps0 * LMKD_BK; w.kend = seg_pix0; w.seg = 0; sps = sps0; }
+  else { w.kfirst = seg_pix0 + (z - seg_splits0) * sps1 * LMKD_BK; w.kend = Mpix; w.seg = 1; sps = sps1; }
+  const int left = (w.kend - w.kfirst + LMKD_BK - 1) / LMKD_BK;
+  w.nk = left < sps ? (left < 0 ? 0 : left) : sps;
+  return w;
+}
 
 template <int ROWS, bool SMALLC, int THREADS = LMKD_THREADS, bool PRE = false>
 struct LoaderWgradGather {
@@ -743,8 +779,7 @@ static int pick_conv_cfg(long rows_per_class, int nclass, int ncols, bool same =
 
 template <class Cfg, bool SMALLC, int STATS, bool BF16 = false>
 static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
-  a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
-  a.n_rt = a.nclass * a.tiles_per_class;
+  conv_set_tiles(a, Cfg::BM);
   a.n_ct = cdiv(ncols, Cfg::BN);
   a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
   if (g_xcd_mode == 0) a.xcd_mode = 0;
@@ -803,8 +838,7 @@ extern "C" int lmkd_conv_set_patch_debug(int mask) { g_patch_debug = mask & 63; 
 
 template <class Cfg>
 static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
-  a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
-  a.n_rt = a.nclass * a.tiles_per_class;
+  conv_set_tiles(a, Cfg::BM);
   a.n_ct = cdiv(ncols, Cfg::BN);
   a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
   if (g_xcd_mode == 0) a.xcd_mode = 0;
@@ -892,8 +926,7 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
 
 template <class Cfg, bool SMALLC, bool STATS>
 static void launch_conv_x3(ConvGemmArgs a, int ncols, hipStream_t s) {
-  a.tiles_per_class = cdiv(a.rows_per_class, Cfg::BM);
-  a.n_rt = a.nclass * a.tiles_per_class;
+  conv_set_tiles(a, Cfg::BM);
   a.n_ct = cdiv(ncols, Cfg::BN);
   a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
   if (g_xcd_mode == 0) a.xcd_mode = 0;
@@ -992,10 +1025,23 @@ static int stem_patch_pitch(int W, int Cs, int Cout, int KH, int KW, int stride,
 }
 
 // number of row tiles (= rows of the BN partial-statistics buffer) of a forward conv
+extern "C" int lmkd_conv2d_fwd_row_tiles_seg(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0, int* tiles0);
 extern "C" int lmkd_conv2d_fwd_row_tiles_cs(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
-  if (stem_patch_pitch(W, Cs, Cout, KH, KW, stride, pad)) return N * cdiv(conv_out(H, KH, stride, pad), 2);
-  const long M = (long)N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad);
-  return cdiv(M, cfg_bm(pick_conv_cfg(M, 1, Cout, conv_same_size(H, W, KH, KW, stride, pad))));
+  return lmkd_conv2d_fwd_row_tiles_seg(N, H, W, Cs, Cout, KH, KW, stride, pad, 0, nullptr);
+}
+// two frame segments in one launch (ConvGemmArgs::seg_m0): frames [0, seg_n0) | [seg_n0, N).  Returns the rows of the partial-sum
+// buffer; *tiles0 (host pointer, nullable) receives how many of them - the leading ones - belong to segment 0.  seg_n0 = 0 or N: one segment.
+extern "C" int lmkd_conv2d_fwd_row_tiles_seg(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0, int* tiles0) {
+  if (seg_n0 <= 0 || seg_n0 >= N) seg_n0 = N;
+  const int Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
+  if (stem_patch_pitch(W, Cs, Cout, KH, KW, stride, pad)) {
+    if (tiles0) *tiles0 = seg_n0 * cdiv(Ho, 2);
+    return N * cdiv(Ho, 2);
+  }
+  const long M = (long)N * Ho * Wo, M0 = (long)seg_n0 * Ho * Wo;
+  const int bm = cfg_bm(pick_conv_cfg(M, 1, Cout, conv_same_size(H, W, KH, KW, stride, pad)));
+  if (tiles0) *tiles0 = cdiv(M0, bm);
+  return cdiv(M0, bm) + cdiv(M - M0, bm);
 }
 extern "C" int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   return lmkd_conv2d_fwd_row_tiles_cs(N, H, W, 32, Cout, KH, KW, stride, pad);
@@ -1003,8 +1049,10 @@ extern "C" int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, 
 
 static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* stat_partial, const float* ep_stats,
                            const float* ep_res, int ep_relu, int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride,
-                           int pad, void* stream, const float* pre_stats = nullptr) {
+                           int pad, void* stream, const float* pre_stats = nullptr, int seg_n0 = 0) {
   LMKD_REQUIRE(x && wp && y, "lmkd_conv2d_fwd: null pointer");
+  if (seg_n0 <= 0 || seg_n0 >= N) seg_n0 = 0;
+  LMKD_REQUIRE(!seg_n0 || ((g_conv_x3 || g_conv_bf16) && !ep_stats), "lmkd_conv2d_fwd_seg: two frame segments exist in the bf16-plane modes (training / plain forward)");
   LMKD_REQUIRE(aligned16(x) && aligned16(wp), "lmkd_conv2d_fwd: x / packed weights must be 16-byte aligned");
   LMKD_REQUIRE(Cs % 32 == 0 || Cs == 4, "lmkd_conv2d_fwd: channel count %d must be 4 (padded stem) or a multiple of 32", Cs);
   LMKD_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0, "lmkd_conv2d_fwd: empty tensor");
@@ -1030,6 +1078,7 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
   LMKD_REQUIRE(!(g_conv_x3 || g_conv_bf16) || (long)N * H * W * Cs * (g_lmkd_act_bf16 && Cs != 4 ? 2 : 4) < 0xffffffe0L,
                "lmkd_conv2d_fwd: input tensor exceeds the 4 GiB buffer range of the bf16-plane kernels");
   a.Hr = a.Ho; a.Wr = a.Wo; a.rows_per_class = N * a.Ho * a.Wo; a.tiles_per_class = cdiv(a.rows_per_class, 128);
+  a.seg_m0 = seg_n0 * a.Ho * a.Wo;      // 0: one segment (conv_set_tiles)
   a.sh = stride; a.omul = 1; a.nclass = 1;
   a.same = conv_same_size(H, W, KH, KW, stride, pad) ? 1 : 0;      // as in lmkd_conv2d_fwd_row_tiles
   a.Kp = KH * KWp * Cs;
@@ -1100,6 +1149,15 @@ extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float*
 // Training form for a convolution that consumes relu(BatchNorm(x_raw)): x_raw is the previous convolution's raw output and
 // pre_stats its [5][Cs] BatchNorm table (lmkd_bn_finalize); normalise + ReLU happen in the loader, bit-identical to running
 // lmkd_bn_apply first (torchvision BasicBlock: conv2(relu(bn1(conv1(x)))), resnet18_2fc.py:41-42).
+// lmkd_conv2d_fwd / lmkd_conv2d_fwd_pre (pre_stats nullable) over TWO frame segments [0, seg_n0) | [seg_n0, N) of one tensor - the support-
+// frame and the query-frame trunk call of an episode (resnet18_2fc.py:41-42) in one launch: pre_stats is a [2][5][Cs] table (one per
+// segment), stat_partial has lmkd_conv2d_fwd_row_tiles_seg rows of which the first *tiles0 belong to segment 0.  Results are bit-identical
+// to two launches on the two halves.  bf16-plane modes (lmkd_conv_set_compute_dtype 1-3).
+extern "C" int lmkd_conv2d_fwd_seg(const float* x, const float* pre_stats, const float* wp, float* y, float* stat_partial, int N, int H, int W,
+                                   int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0, void* stream) {
+  return conv2d_fwd_impl(x, wp, y, stat_partial, nullptr, nullptr, 0, N, H, W, Cs, Cout, KH, KW, stride, pad, stream, pre_stats, seg_n0);
+}
+
 extern "C" int lmkd_conv2d_fwd_pre(const float* x_raw, const float* pre_stats, const float* wp, float* y, float* stat_partial, int N,
                                    int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, void* stream) {
   LMKD_REQUIRE(pre_stats, "lmkd_conv2d_fwd_pre: BatchNorm table of the input missing");
@@ -1118,7 +1176,9 @@ extern "C" int lmkd_conv2d_fwd_bn(const float* x, const float* wp, float* y, con
 
 // dx[N,H,W,Cin] (+= when accumulate) from dy[N,Ho,Wo,Cout]; wd = weights packed with mode 1
 static int bwd_data_args(ConvGemmArgs& a, const float* dy, const float* wd, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                         int stride, int pad, int accumulate) {
+                         int stride, int pad, int accumulate, int seg_n0 = 0) {
+  if (seg_n0 <= 0 || seg_n0 >= N) seg_n0 = 0;
+  LMKD_REQUIRE(!seg_n0 || g_conv_x3 || g_conv_bf16, "lmkd_conv2d_bwd_data_seg: two frame segments exist in the bf16-plane modes");
   LMKD_REQUIRE(Cout % 32 == 0, "lmkd_conv2d_bwd_data: Cout=%d must be a multiple of 32", Cout);
   LMKD_REQUIRE(stride == 1 || stride == 2, "lmkd_conv2d_bwd_data: stride %d unsupported", stride);
   LMKD_REQUIRE(KH * KW <= LMKD_MAX_TAPS, "lmkd_conv2d_bwd_data: kernel too large");
@@ -1159,6 +1219,7 @@ static int bwd_data_args(ConvGemmArgs& a, const float* dy, const float* wd, floa
     }
   }
   a.rows_per_class = N * a.Hr * a.Wr;
+  a.seg_m0 = seg_n0 * a.Hr * a.Wr;
   a.tiles_per_class = cdiv(a.rows_per_class, 128);
   a.div_hw = make_fastdiv(a.Hr * a.Wr); a.div_w = make_fastdiv(a.Wr);
   a.same = patch_halo(a) >= 0 ? 1 : 0;
@@ -1185,11 +1246,33 @@ static bool bwd_data_bn_ok(const ConvGemmArgs& a, int Cin) {
   const int id = pick_conv_cfg(a.rows_per_class, a.nclass, Cin, a.same != 0);
   return id == 11 || id == 12;
 }
-extern "C" int lmkd_conv2d_bwd_data_bn_tiles(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+extern "C" int lmkd_conv2d_bwd_data_bn_tiles_seg(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int seg_n0, int* tiles0) {
   if (stride != 1 || Cout % 32 != 0 || KH * KW > LMKD_MAX_TAPS) return 0;
   ConvGemmArgs a;
-  if (bwd_data_args(a, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, 0)) return 0;
-  return bwd_data_bn_ok(a, Cin) ? cdiv(a.rows_per_class, 128) : 0;
+  if (bwd_data_args(a, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, 0, seg_n0)) return 0;
+  if (!bwd_data_bn_ok(a, Cin)) return 0;
+  conv_set_tiles(a, 128);
+  if (tiles0) *tiles0 = a.seg_t0;
+  return a.tiles_per_class;
+}
+extern "C" int lmkd_conv2d_bwd_data_bn_tiles(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  return lmkd_conv2d_bwd_data_bn_tiles_seg(N, H, W, Cin, Cout, KH, KW, stride, pad, 0, nullptr);
+}
+// lmkd_conv2d_bwd_data / lmkd_conv2d_bwd_data_bn (bn_x / bn_stats / part nullable together) over two frame segments (lmkd_conv2d_fwd_seg):
+// bn_stats is a [2][5][Cin] table, part has lmkd_conv2d_bwd_data_bn_tiles_seg rows.  Bit-identical to two launches on the halves.
+extern "C" int lmkd_conv2d_bwd_data_seg(const float* dy, const float* wd, float* dx, const float* bn_x, const float* bn_stats, float* part, int N,
+                                        int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate, int seg_n0, void* stream) {
+  LMKD_REQUIRE(dy && wd && dx, "lmkd_conv2d_bwd_data_seg: null pointer");
+  LMKD_REQUIRE(aligned16(dy) && aligned16(wd), "lmkd_conv2d_bwd_data_seg: operands must be 16-byte aligned");
+  LMKD_REQUIRE((bn_x != nullptr) == (bn_stats != nullptr) && (bn_x != nullptr) == (part != nullptr), "lmkd_conv2d_bwd_data_seg: bn_x, bn_stats and part go together");
+  ConvGemmArgs a;
+  if (const int rc = bwd_data_args(a, dy, wd, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, accumulate, seg_n0)) return rc;
+  if (bn_x) {
+    LMKD_REQUIRE(!accumulate && aligned16(bn_x) && aligned16(bn_stats), "lmkd_conv2d_bwd_data_seg: the fused BatchNorm sums need a plain (non-accumulating) launch and aligned operands");
+    LMKD_REQUIRE(bwd_data_bn_ok(a, Cin), "lmkd_conv2d_bwd_data_seg: this launch has no fused form (lmkd_conv2d_bwd_data_bn_tiles_seg returned 0)");
+    a.bnb_x = bn_x; a.bnb_stats = bn_stats; a.stat_partial = part;
+  }
+  return launch_conv_gemm<false, 0>(a, Cin, (hipStream_t)stream);
 }
 extern "C" int lmkd_conv2d_bwd_data_bn(const float* dy, const float* wd, float* dx, const float* bn_x, const float* bn_stats, float* part,
                                        int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
@@ -1288,6 +1371,18 @@ static int stem_wgrad_plan(int N, int H, int W, int Cs, int Cout, int KH, int KW
   return cdiv(units, g);
 }
 
+// workspace of the two-segment form (lmkd_conv2d_bwd_weight_seg).  Each segment is split into the slabs a launch of its own would
+// use - the same partial sums (a slab's length bounds the MFMA accumulation error, wgrad_plan), twice the workgroups - so the
+// workspace is the sum of the two plans (or the one-launch plan where the kernel has no segments: the stem's)
+extern "C" long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad);
+extern "C" long lmkd_conv2d_bwd_weight_workspace_seg(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0) {
+  const long whole = lmkd_conv2d_bwd_weight_workspace(N, H, W, Cs, Cout, KH, KW, stride, pad);
+  if (seg_n0 <= 0 || seg_n0 >= N) return whole;
+  const long parts = lmkd_conv2d_bwd_weight_workspace(seg_n0, H, W, Cs, Cout, KH, KW, stride, pad) +
+                     lmkd_conv2d_bwd_weight_workspace(N - seg_n0, H, W, Cs, Cout, KH, KW, stride, pad);
+  return std::max(whole, parts);
+}
+
 extern "C" long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
   const int Ho = conv_out(H, KH, stride, pad), Wo = conv_out(W, KW, stride, pad);
   const int Kp = KH * kw_padded(Cs, KW) * Cs;
@@ -1308,8 +1403,12 @@ extern "C" long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, in
 // dw_oihw[Cout,Cin,KH,KW] from x[N,H,W,Cs] (Cs >= Cin channel-padded) and dy[N,Ho,Wo,Cout]
 static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const float* dy, float* dw_oihw, float* workspace,
                                   long ws_bytes, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                  void* stream, int accumulate = 0) {
+                                  void* stream, int accumulate = 0, int seg_n0 = 0) {
   LMKD_REQUIRE(x && dy && dw_oihw && workspace, "lmkd_conv2d_bwd_weight: null pointer");
+  // two frame segments: each is split into the slabs a launch of its own would use (same partial sums, same accumulation error), the
+  // PRE loader takes the segment's BatchNorm table, ONE slab reduce sums everything
+  if (seg_n0 <= 0 || seg_n0 >= N) seg_n0 = 0;
+  LMKD_REQUIRE(!seg_n0 || ((g_conv_x3 || g_conv_bf16) && g_wgrad_planes), "lmkd_conv2d_bwd_weight_seg: two frame segments exist in the bf16-plane modes");
   LMKD_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(workspace), "lmkd_conv2d_bwd_weight: operands must be 16-byte aligned");
   LMKD_REQUIRE(Cs % 32 == 0 || Cs == 4, "lmkd_conv2d_bwd_weight: channel count %d must be 4 or a multiple of 32", Cs);
   LMKD_REQUIRE(Cout % 4 == 0, "lmkd_conv2d_bwd_weight: Cout %% 4 != 0");
@@ -1376,6 +1475,14 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
     w.steps_total = cdiv(a.Mpix, LMKD_BK);
     int cob;
     wgrad_win_plan(a.Mpix, W, Cs, Cout, &cob, &w.splits, &w.steps_per_split);
+    w.seg_pix0 = a.Mpix; w.seg_splits0 = w.splits; w.sps1 = 0;
+    if (seg_n0) {
+      int sp0, sp1, cob1;
+      w.seg_pix0 = seg_n0 * a.Ho * a.Wo;
+      wgrad_win_plan(w.seg_pix0, W, Cs, Cout, &cob, &sp0, &w.steps_per_split);
+      wgrad_win_plan(a.Mpix - w.seg_pix0, W, Cs, Cout, &cob1, &sp1, &w.sps1);
+      w.seg_splits0 = sp0; w.splits = sp0 + sp1;
+    }
     LMKD_REQUIRE(ws_bytes >= (long)w.splits * Cout * a.Kp * (long)sizeof(float), "lmkd_conv2d_bwd_weight: workspace too small");
     LMKD_REQUIRE((long)a.Mpix * std::max(Cs, Cout) * 4 < 2147483647L, "lmkd_conv2d_bwd_weight: tensor too large for 32-bit byte offsets");
     w.n_ct = cdiv(Cout, 32 * cob); w.n_it = Cs / 32;
@@ -1428,6 +1535,15 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   int splits, bm, bn;
   const bool planes = wgrad_uses_planes(Cs);
   wgrad_plan(a.Mpix, Cout, a.Kp, &splits, &a.steps_per_split, &bm, &bn, planes);
+  a.seg_pix0 = a.Mpix; a.seg_splits0 = splits; a.sps1 = 0;
+  if (seg_n0) {
+    LMKD_REQUIRE(planes, "lmkd_conv2d_bwd_weight_seg: the fp32-tile kernel has no two-segment form");
+    int sp0, sp1, bm1, bn1;
+    a.seg_pix0 = seg_n0 * a.Ho * a.Wo;
+    wgrad_plan(a.seg_pix0, Cout, a.Kp, &sp0, &a.steps_per_split, &bm, &bn, planes);
+    wgrad_plan(a.Mpix - a.seg_pix0, Cout, a.Kp, &sp1, &a.sps1, &bm1, &bn1, planes);      // (the tile shape depends on Cout and Kp only)
+    a.seg_splits0 = sp0; splits = sp0 + sp1;
+  }
   a.steps_total = cdiv(a.Mpix, LMKD_BK);
   LMKD_REQUIRE(ws_bytes >= (long)splits * Cout * a.Kp * (long)sizeof(float), "lmkd_conv2d_bwd_weight: workspace too small");
   a.div_hw = make_fastdiv(a.Ho * a.Wo); a.div_w = make_fastdiv(a.Wo);
@@ -1525,6 +1641,15 @@ extern "C" int lmkd_conv2d_bwd_weight_acc(const float* x, const float* pre_stats
   return conv2d_bwd_weight_impl(x, pre_stats, dy, dw_oihw, workspace, ws_bytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, stream, 1);
 }
 
+
+// weight gradient over two frame segments [0, seg_n0) | [seg_n0, N) of one tensor (lmkd_conv2d_fwd_seg): ONE launch + ONE slab reduce for
+// both trunk calls of an episode; pre_stats (nullable) = [2][5][Cs] table; accumulate: dw_oihw += ; workspace:
+// lmkd_conv2d_bwd_weight_workspace_seg bytes.  The split-K slabs are those of two separate launches; they are summed in one pass.
+extern "C" int lmkd_conv2d_bwd_weight_seg(const float* x, const float* pre_stats, const float* dy, float* dw_oihw, float* workspace, long ws_bytes,
+                                          int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,
+                                          int seg_n0, void* stream) {
+  return conv2d_bwd_weight_impl(x, pre_stats, dy, dw_oihw, workspace, ws_bytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, stream, accumulate, seg_n0);
+}
 
 // stride-2 data gradient: does the LDS-patch kernel run its four parity classes (patch_halo() of the launch's arguments >= 0)?
 static bool dgrad_s2_patch_ok(int H, int W, int Cout, int KH, int KW, int pad) {

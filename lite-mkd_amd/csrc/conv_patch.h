@@ -52,8 +52,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
   if (a.accum && ntap == 0) return;      // out += 0
   const Tap* taps = a.taps[cls];
   const int halo = a.halo, P = Cfg::BM + 2 * halo;
-  const int M = a.rows_per_class;
-  const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
+  const SegTile sg = seg_tile(a, tile, Cfg::BM);      // the tile's frame segment (ConvGemmArgs::seg_m0)
+  const int M = sg.mend;
+  const int row0 = sg.row0, n0 = ct * Cfg::BN;
   if (tid < ntap) {
     const Tap tp = taps[tid];
     s_tap_shift[tid] = (tp.dh * a.Ws + tp.dw) * ROWB;
@@ -115,13 +116,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
   }
   u32x4 rp[NI];
   float4 psc = float4(), psh = float4();
+  const float* pre_tab = PRE ? a.pre_stats + (long)sg.seg * 5 * a.Cs : nullptr;      // the [5][Cs] BatchNorm table of this tile's segment
   auto issue_patch = [&](int cc) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
       if (i * RPP < P) rp[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, ((p_ok >> i) & 1u) ? p_off0 + i * p_step + (unsigned)(cc * 32 * ESZ) : X3_OOB, 0, 0);
     if (PRE) {
-      psc = *reinterpret_cast<const float4*>(a.pre_stats + 2 * a.Cs + cc * 32 + pk);
-      psh = *reinterpret_cast<const float4*>(a.pre_stats + 3 * a.Cs + cc * 32 + pk);
+      psc = *reinterpret_cast<const float4*>(pre_tab + 2 * a.Cs + cc * 32 + pk);
+      psh = *reinterpret_cast<const float4*>(pre_tab + 3 * a.Cs + cc * 32 + pk);
     }
   };
   auto store_patch = [&]() {
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     }
   };
   LB lb;
-  const bool neg = NPL == 3 && x3_neg_tile(tile, a.tiles_per_class);      // half the row tiles accumulate -y: X3FragB::init
+  const bool neg = NPL == 3 && x3_neg_tile(sg.ltile, sg.ltiles);      // half the row tiles (of the segment) accumulate -y: X3FragB::init
   lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, neg);
   f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll

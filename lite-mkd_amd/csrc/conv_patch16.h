@@ -121,8 +121,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   if (a.accum && ntap == 0) return;      // out += 0
   const Tap* taps = a.taps[cls];
   const int halo = a.halo, P = Cfg::BM + 2 * halo;
-  const int M = a.rows_per_class;
-  const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
+  const SegTile sg = seg_tile(a, tile, Cfg::BM);      // the tile's frame segment (ConvGemmArgs::seg_m0): rows past its end are not this tile's
+  const int M = sg.mend;
+  const int row0 = sg.row0, n0 = ct * Cfg::BN;
   if (tid < ntap) {
     const Tap tp = taps[tid];
     s_tap_shift[tid] = (tp.dh * a.Ws + tp.dw) * ROWB;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     for (int j = tid; j < P; j += Cfg::THREADS) {
       const int m = row0 - halo + j;
       int off = -1;
-      if (m >= 0 && m < M) {
+      if (m >= 0 && m < a.rows_per_class) {
         const int n = fdiv(m, a.div_hw);
         const int rem = m - n * a.Hs * a.Ws;
         const int aa = fdiv(rem, a.div_w), bb = rem - aa * a.Ws;
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   }
   u32x4 rp[NI];
   float4 psc = float4(), psh = float4();
+  const float* pre_tab = PRE ? a.pre_stats + (long)sg.seg * 5 * a.Cs : nullptr;      // the [5][Cs] BatchNorm table of this tile's segment
   auto issue_patch = [&](int cc, int sc = 0) {
     if constexpr (SRC2) {      // patch row j = pixel s_src[j] of class (0, 0), moved to class sc's origin
       const unsigned rel = (unsigned)((a.s2_off[sc] + cc * 32 + pk) * 4);
@@ -211,8 +213,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     for (int i = 0; i < NI; ++i)
       if (i * RPP < P) rp[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, ((p_ok >> i) & 1u) ? p_off0 + i * p_step + (unsigned)(cc * 32 * 4) : X3_OOB, 0, 0);
     if (PRE) {
-      psc = *reinterpret_cast<const float4*>(a.pre_stats + 2 * a.Cs + cc * 32 + pk);
-      psh = *reinterpret_cast<const float4*>(a.pre_stats + 3 * a.Cs + cc * 32 + pk);
+      psc = *reinterpret_cast<const float4*>(pre_tab + 2 * a.Cs + cc * 32 + pk);
+      psh = *reinterpret_cast<const float4*>(pre_tab + 3 * a.Cs + cc * 32 + pk);
     }
   };
   auto store_patch = [&]() {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       *reinterpret_cast<uint2*>(d + 128) = q2;
     }
   };
-  const bool neg = x3_neg_tile(tile, a.tiles_per_class);      // half the row tiles accumulate -y: X3FragB::init
+  const bool neg = x3_neg_tile(sg.ltile, sg.ltiles);      // half the row tiles (of the segment) accumulate -y: X3FragB::init
   LB lb;
   lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, neg);
   f32x4 acc[NB][NC];
@@ -340,19 +342,20 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   float4 esc[NC], esh[NC];
   float4 bmean[NC], bistd[NC];      // bnb_x: the BatchNorm table of this lane's channels, once per tile (esc / esh hold scale / shift)
   const bool bnb = !EP && a.bnb_x != nullptr;
+  const float* bnb_tab = bnb ? a.bnb_stats + (long)sg.seg * 5 * a.Co : nullptr;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     s1[c] = s2[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int col = ch0 + 16 * c;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EP || bnb) {
-      const float* st = EP ? a.ep_stats : a.bnb_stats;
+      const float* st = EP ? a.ep_stats : bnb_tab;
       esc[c] = col < a.Co ? *reinterpret_cast<const float4*>(st + 2 * a.Co + col) : z4;
       esh[c] = col < a.Co ? *reinterpret_cast<const float4*>(st + 3 * a.Co + col) : z4;
     }
     if (bnb) {
-      bmean[c] = col < a.Co ? *reinterpret_cast<const float4*>(a.bnb_stats + col) : z4;
-      bistd[c] = col < a.Co ? *reinterpret_cast<const float4*>(a.bnb_stats + a.Co + col) : z4;
+      bmean[c] = col < a.Co ? *reinterpret_cast<const float4*>(bnb_tab + col) : z4;
+      bistd[c] = col < a.Co ? *reinterpret_cast<const float4*>(bnb_tab + a.Co + col) : z4;
     }
   }
 #pragma unroll

@@ -433,10 +433,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
     s_tap_rel[tid] = ((tp.dh * a.Ws + tp.dw) * a.Cs) * LA::ESZ;
     s_tap_kofs[tid] = tp.kofs;
   }
-  const int row0 = tile * Cfg::BM, n0 = ct * Cfg::BN;
+  const SegTile sg = seg_tile(a, tile, Cfg::BM);      // the tile's frame segment (ConvGemmArgs::seg_m0)
+  const int row0 = sg.row0, n0 = ct * Cfg::BN;
   for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
     const int m = row0 + r;
-    bool ok = m < a.rows_per_class;
+    bool ok = m < sg.mend;
     int n = 0, aa = 0, bb = 0;
     if (ok) {
       n = fdiv(m, a.div_hw);
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   LA la;
   LB lb;
   la.init(a.src, (long)a.N * a.Hs * a.Ws * a.Cs, a.Hs, a.Ws, s_src, s_hw, taps, a.ntap[cls]);
-  const bool neg = NPL == 3 && !SMALLC && x3_neg_tile(tile, a.tiles_per_class);      // the second half of the row tiles accumulates -y (X3FragB::init); the stem (K = 224) does not
+  const bool neg = NPL == 3 && !SMALLC && x3_neg_tile(sg.ltile, sg.ltiles);      // the second half of the row tiles accumulates -y (X3FragB::init); the stem (K = 224) does not
   lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, neg);
   f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll
@@ -496,8 +497,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_x3_kernel(ConvGemmArgs
   float4 psc_cur = float4(), psh_cur = float4(), psc_nxt = float4(), psh_nxt = float4();
   auto pre_fetch = [&](int cc, float4& sc, float4& sh) {
     const int c = (cc < a.cps ? cc : a.cps - 1) * LMKD_BK + la.kc4;
-    sc = *reinterpret_cast<const float4*>(a.pre_stats + 2 * a.Cs + c);
-    sh = *reinterpret_cast<const float4*>(a.pre_stats + 3 * a.Cs + c);
+    sc = *reinterpret_cast<const float4*>(a.pre_stats + (long)sg.seg * 5 * a.Cs + 2 * a.Cs + c);
+    sh = *reinterpret_cast<const float4*>(a.pre_stats + (long)sg.seg * 5 * a.Cs + 3 * a.Cs + c);
   };
   if (PRE) {
     pre_fetch(0, psc_cur, psh_cur);

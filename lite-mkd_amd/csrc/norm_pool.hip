@@ -158,7 +158,7 @@ extern "C" int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst,
 #define CS_COLS 32
 #define CS_LANES 8
 #define CS_MAX_SLICES 64
-#define LMKD_TICKET_WORDS 256      // >= cdiv(2 C, CS_COLS): C <= 4096
+#define LMKD_TICKET_WORDS 512      // two segments (blockIdx.z) x cdiv(2 C, CS_COLS) words: C <= 4096
 extern "C" long lmkd_ticket_words(void) { return LMKD_TICKET_WORDS; }
 static inline int cs_slices(int T) { return T <= 64 ? 1 : std::min(CS_MAX_SLICES, cdiv(T, 64)); }
 
@@ -166,11 +166,12 @@ static inline int cs_slices(int T) { return T <= 64 ? 1 : std::min(CS_MAX_SLICES
 template <bool PROD = false>      // PROD: sum in[r][c] * in2[r][c] (the float product, as a separate multiply)
 __device__ __forceinline__ bool colsum_ticket(const float* __restrict__ in, int T, int CV, double* __restrict__ scratch,
                                               unsigned* __restrict__ tickets, double (*sm)[CS_COLS], double* tot, int* s_last,
-                                              const float* __restrict__ in2 = nullptr) {
+                                              const float* __restrict__ in2 = nullptr, int S_ = 0) {
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int col = blockIdx.x * CS_COLS + tx;
   const bool act = col < CV;
-  const int S = gridDim.y;
+  const int S = S_ > 0 ? S_ : gridDim.y;      // S_: this segment's slice count (<= gridDim.y); blocks past it have nothing to do
+  if ((int)blockIdx.y >= S) return false;
   const int per = (T + S - 1) / S;
   const int t0 = blockIdx.y * per;
   const int t1 = t0 + per < T ? t0 + per : T;
@@ -241,14 +242,21 @@ __device__ __forceinline__ bool colsum_ticket(const float* __restrict__ in, int 
 // BatchNorm finalize: sums -> mean / invstd / fused scale+shift, running-stat update
 //   stats layout out: [5][C] = mean, invstd, scale (= gamma*invstd), shift (= beta - mean*scale), unbiased variance
 // ---------------------------------------------------------------------------------
+// Two frame segments (blockIdx.z = 1: the second trunk call of an episode, lmkd_bn_finalize_seg): rows [T0, T) of `part`, count1, the
+// second [5][C] table, scratch and ticket words of its own; the slices of a segment are those a launch of its own would use.
 __global__ void bn_finalize_kernel(const float* __restrict__ part, int T, int C, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, float* __restrict__ stats, double* __restrict__ scratch,
-                                   unsigned* __restrict__ tickets) {
+                                   unsigned* __restrict__ tickets, int T0 = 0, double count1 = 0.0, int S0 = 0, int S1 = 0) {
   __shared__ double sm[CS_LANES][CS_COLS];
   __shared__ double tot[CS_COLS];
   __shared__ int s_last;
-  if (!colsum_ticket(part, T, 2 * C, scratch, tickets, sm, tot, &s_last)) return;
+  int S = 0;
+  if (gridDim.z > 1) {
+    if (blockIdx.z) { part += (long)T0 * 2 * C; T -= T0; count = count1; stats += 5 * C; scratch += (long)CS_MAX_SLICES * 2 * C; tickets += LMKD_TICKET_WORDS / 2; S = S1; }
+    else { T = T0; S = S0; }
+  }
+  if (!colsum_ticket(part, T, 2 * C, scratch, tickets, sm, tot, &s_last, nullptr, S)) return;
   const int c = blockIdx.x * (CS_COLS / 2) + threadIdx.x;
   if (threadIdx.y != 0 || threadIdx.x >= CS_COLS / 2 || c >= C) return;
   const double s1 = tot[2 * threadIdx.x], s2 = tot[2 * threadIdx.x + 1];
@@ -360,6 +368,20 @@ extern "C" int lmkd_bn_finalize(const float* partial, int T, int C, long count, 
   return LMKD_OK;
 }
 
+// lmkd_bn_finalize for two frame segments in one launch: partial rows [0, T0) / [T0, T) -> stats[0] / stats[1] ([2][5][C]) with
+// count0 / count1 elements per channel; bit-identical to two lmkd_bn_finalize launches.  The running statistics are NOT updated here
+// (two segments = two sequential updates: lmkd_bn_running_update_multi applies them in order).  scratch: >= 2 * 64 * 2 * C doubles.
+extern "C" int lmkd_bn_finalize_seg(const float* partial, int T, int T0, int C, long count0, long count1, const float* gamma, const float* beta,
+                                    float eps, float* stats, double* scratch, unsigned* tickets, void* stream) {
+  LMKD_REQUIRE(partial && stats && scratch && tickets && T0 > 0 && T > T0 && C > 0 && count0 > 0 && count1 > 0, "lmkd_bn_finalize_seg: bad arguments");
+  LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS / 2, "lmkd_bn_finalize_seg: C=%d exceeds the ticket buffer", C);
+  const int S0 = cs_slices(T0), S1 = cs_slices(T - T0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(2 * C, CS_COLS), std::max(S0, S1), 2), dim3(CS_COLS, CS_LANES), 0, (hipStream_t)stream, partial, T,
+                     C, (double)count0, gamma, beta, (float*)nullptr, (float*)nullptr, 0.f, eps, stats, scratch, tickets, T0, (double)count1, S0, S1);
+  LMKD_CHECK_LAUNCH("bn_finalize_kernel");
+  return LMKD_OK;
+}
+
 extern "C" int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, const float* running_mean,
                                   const float* running_var, float eps, float* stats, void* stream) {
   LMKD_REQUIRE(running_mean && running_var && stats && C > 0, "lmkd_bn_eval_stats: bad arguments");
@@ -380,7 +402,8 @@ extern "C" int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, 
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const T* __restrict__ res,
                                 const float* __restrict__ rstats, T* __restrict__ y, long n4, int C, int relu, int res_mode,
-                                unsigned* __restrict__ mask_bits) {
+                                unsigned* __restrict__ mask_bits, long n4_0) {
+  // n4_0: groups of 4 elements in frame segment 0 (rows0 * C / 4; = n4 for one segment): elements past it use the second [5][C] table
   constexpr int U = ActU<T>::U;
   const int C4 = C >> 2;
   const long nu = n4 / U;
@@ -389,10 +412,11 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
     ldv<T, U>(x, iu, v);
     if (res_mode) ldv<T, U>(res, iu, r);
     unsigned nibs = 0;
+    const int so = iu * U >= n4_0 ? 5 * C : 0;      // (a thread's U groups lie in one row: C4 is a multiple of U)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long i = iu * U + u;
-      const int c = (int)(i % C4) * 4;
+      const int c = (int)(i % C4) * 4 + so;
       const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + c);
       const float4 sh = *reinterpret_cast<const float4*>(stats + 3 * C + c);
       float4& w = v[u];
@@ -419,9 +443,17 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
   }
 }
 
+extern "C" int lmkd_bn_apply_seg(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows, long rows0,
+                                 int C, int relu, int res_mode, unsigned* mask_bits, void* stream);
 extern "C" int lmkd_bn_apply(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows,
                              int C, int relu, int res_mode, unsigned* mask_bits, void* stream) {
+  return lmkd_bn_apply_seg(x, stats, res, rstats, y, rows, rows, C, relu, res_mode, mask_bits, stream);
+}
+// two frame segments: rows [0, rows0) use stats[0] (and rstats[0]), rows [rows0, rows) stats[1] / rstats[1] ([2][5][C] tables)
+extern "C" int lmkd_bn_apply_seg(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows, long rows0,
+                                 int C, int relu, int res_mode, unsigned* mask_bits, void* stream) {
   LMKD_REQUIRE(x && stats && y && rows > 0 && C > 0 && C % 4 == 0, "lmkd_bn_apply: bad arguments (C=%d)", C);
+  if (rows0 <= 0 || rows0 > rows) rows0 = rows;
   LMKD_REQUIRE(res_mode == 0 || res, "lmkd_bn_apply: residual pointer missing");
   LMKD_REQUIRE(res_mode != 2 || rstats, "lmkd_bn_apply: residual stats missing");
   LMKD_REQUIRE(!mask_bits || C % 32 == 0, "lmkd_bn_apply: the ReLU bit mask needs C %% 32 == 0 (C=%d)", C);
@@ -429,10 +461,10 @@ extern "C" int lmkd_bn_apply(const float* x, const float* stats, const float* re
   const long n4 = rows * C / 4;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_apply_kernel<lmkd_bf16_t>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)x, stats,
-                       (const lmkd_bf16_t*)res, rstats, (lmkd_bf16_t*)y, n4, C, relu, res_mode, mask_bits);
+                       (const lmkd_bf16_t*)res, rstats, (lmkd_bf16_t*)y, n4, C, relu, res_mode, mask_bits, rows0 * C / 4);
   else
     hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, stats, res, rstats, y, n4, C,
-                       relu, res_mode, mask_bits);
+                       relu, res_mode, mask_bits, rows0 * C / 4);
   LMKD_CHECK_LAUNCH("bn_apply_kernel");
   return LMKD_OK;
 }
@@ -466,12 +498,25 @@ __device__ __forceinline__ float4 bn_masked_grad(const float4 dy, const float4 x
 // a thread reads U groups of 4 consecutive channels (16 bytes) per row.  The rows are dealt to nbv "virtual blocks" of RL1 = 256 /
 // (CC / 4) row lanes whatever U is - a bf16 workgroup (U = 2) carries two of them - so that the partial sums, their order and with
 // them dgamma / dbeta are bit-identical between the fp32 and the bf16 tensor instances on the same values.
+// Two frame segments (BnSeg, blockIdx.z = 1): rows [rows0, rows) of every tensor with the second [5][C] table, nb1 virtual blocks and
+// the partial rows [2048, 2048 + nb1) - exactly the launch the segment would get on its own.
+struct BnSeg { long rows0; int nb1; };
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
                                      const float* __restrict__ stats, float* __restrict__ partial, long rows, int C, int CC,
-                                     int mask_mode, int nbv) {
+                                     int mask_mode, int nbv, BnSeg sg) {
   extern __shared__ float sm[];  // [RL][CC][2]
   constexpr int U = ActU<T>::U;
+  if (gridDim.z > 1) {
+    if (blockIdx.z) {
+      const long eo = sg.rows0 * C;      // element offset of segment 1
+      dy += eo; x += eo;
+      if (yact) yact = mask_mode == 3 ? reinterpret_cast<const T*>(reinterpret_cast<const unsigned*>(yact) + eo / 32) : yact + eo;
+      stats += 5 * C; partial += (long)2048 * 2 * C; rows -= sg.rows0; nbv = sg.nb1;
+    } else {
+      rows = sg.rows0;
+    }
+  }
   const int C4 = C >> 2, CCV = CC / (4 * U);
   const int RL = NP_THREADS / CCV, RL1 = RL / U;
   const int cq = threadIdx.x % CCV, rl = threadIdx.x / CCV;
@@ -517,13 +562,24 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
 
 // accumulate != 0: dgamma / dbeta point at the parameters' .grad (or at a per-stream shadow of it): += instead of = (gradient
 // accumulation over trunk calls / episodes without an ATen add per BatchNorm parameter)
+// Two frame segments (gridDim.z = 2): segment z sums ITS partial rows (part + z * pstride floats, Tz rows) into coef[z] ([2][5][C]: A,
+// mean g, mean g xhat, sum g xhat, sum g) with its own count, table, scratch and tickets.  The parameter gradients are NOT written here
+// (two blocks would add to the same address): the apply kernel that follows adds rows 3 / 4 of both segments (bn_param_grads_seg).
+struct CoefSeg { int T1; long pstride; double count1; int S0, S1; };
 __global__ void bn_bwd_coef_kernel(const float* __restrict__ part, int T, int C, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ stats, float* __restrict__ coef, float* __restrict__ dgamma,
-                                   float* __restrict__ dbeta, int accumulate, double* __restrict__ scratch, unsigned* __restrict__ tickets) {
+                                   float* __restrict__ dbeta, int accumulate, double* __restrict__ scratch, unsigned* __restrict__ tickets,
+                                   CoefSeg cs) {
   __shared__ double sm[CS_LANES][CS_COLS];
   __shared__ double tot[CS_COLS];
   __shared__ int s_last;
-  if (!colsum_ticket(part, T, 2 * C, scratch, tickets, sm, tot, &s_last)) return;
+  int S = 0;
+  const bool seg = gridDim.z > 1;
+  if (seg) {
+    if (blockIdx.z) { part += cs.pstride; T = cs.T1; count = cs.count1; stats += 5 * C; coef += 5 * C; scratch += (long)(CS_MAX_SLICES + 2) * 2 * C; tickets += LMKD_TICKET_WORDS / 2; S = cs.S1; }
+    else S = cs.S0;
+  }
+  if (!colsum_ticket(part, T, 2 * C, scratch, tickets, sm, tot, &s_last, nullptr, S)) return;
   const int c = blockIdx.x * (CS_COLS / 2) + threadIdx.x;
   if (threadIdx.y != 0 || threadIdx.x >= CS_COLS / 2 || c >= C) return;
   const double sg = tot[2 * threadIdx.x], sgx = tot[2 * threadIdx.x + 1];
@@ -532,31 +588,53 @@ __global__ void bn_bwd_coef_kernel(const float* __restrict__ part, int T, int C,
   coef[c] = g * invstd;                        // A
   coef[C + c] = (float)(sg / count);           // mean(g)
   coef[2 * C + c] = (float)(sgx / count);      // mean(g*xhat)
+  if (seg) {
+    coef[3 * C + c] = (float)sgx;
+    coef[4 * C + c] = (float)sg;
+    return;
+  }
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
+}
+
+// parameter gradients of a two-segment BatchNorm backward: dgamma (+)= sum g xhat of segment 0 + that of segment 1, dbeta likewise - by
+// block 0 of the apply pass that follows the coefficient kernel (one writer: deterministic, no launch of its own)
+struct ParamGradSeg { float* dgamma; float* dbeta; int accumulate; };
+__device__ __forceinline__ void bn_param_grads_seg(const float* __restrict__ coef, int C, const ParamGradSeg& pg) {
+  if (blockIdx.x != 0 || !pg.dgamma) return;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float gx = coef[3 * C + c] + coef[5 * C + 3 * C + c], g = coef[4 * C + c] + coef[5 * C + 4 * C + c];
+    pg.dgamma[c] = pg.accumulate ? pg.dgamma[c] + gx : gx;
+    if (pg.dbeta) pg.dbeta[c] = pg.accumulate ? pg.dbeta[c] + g : g;
+  }
 }
 
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
                                     const float* __restrict__ stats, const float* __restrict__ coef, T* __restrict__ dx,
-                                    T* __restrict__ g_out, long n4, int C, int mask_mode) {
+                                    T* __restrict__ g_out, long n4, int C, int mask_mode, long n4_0, ParamGradSeg pg) {
+  // n4_0 < n4: two frame segments - elements from n4_0 on use stats[1] / coef[1] ([2][5][C] tables), and pg carries the parameter gradients
   constexpr int U = ActU<T>::U;
   const int C4 = C >> 2;
   const long nu = n4 / U;
+  if (n4_0 < n4) bn_param_grads_seg(coef, C, pg);
   for (long iu = (long)blockIdx.x * blockDim.x + threadIdx.x; iu < nu; iu += (long)gridDim.x * blockDim.x) {
     float4 xv[U], dv[U], o[U], gq[U];
     ldv<T, U>(x, iu, xv);
     ldv<T, U>(dy, iu, dv);
+    const int so = iu * U >= n4_0 ? 5 * C : 0;
+    const float* st = stats + so;
+    const float* cf = coef + so;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long i = iu * U + u;
       const int c = (int)(i % C4) * 4;
-      const float4 g = bn_masked_grad<T>(dv[u], xv[u], yact, i, stats, C, c, mask_mode);
-      const float4 mean = *reinterpret_cast<const float4*>(stats + c);
-      const float4 istd = *reinterpret_cast<const float4*>(stats + C + c);
-      const float4 A = *reinterpret_cast<const float4*>(coef + c);
-      const float4 mg = *reinterpret_cast<const float4*>(coef + C + c);
-      const float4 mgx = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+      const float4 g = bn_masked_grad<T>(dv[u], xv[u], yact, i, st, C, c, mask_mode);
+      const float4 mean = *reinterpret_cast<const float4*>(st + c);
+      const float4 istd = *reinterpret_cast<const float4*>(st + C + c);
+      const float4 A = *reinterpret_cast<const float4*>(cf + c);
+      const float4 mg = *reinterpret_cast<const float4*>(cf + C + c);
+      const float4 mgx = *reinterpret_cast<const float4*>(cf + 2 * C + c);
       o[u].x = A.x * (g.x - mg.x - (xv[u].x - mean.x) * istd.x * mgx.x);
       o[u].y = A.y * (g.y - mg.y - (xv[u].y - mean.y) * istd.y * mgx.y);
       o[u].z = A.z * (g.z - mg.z - (xv[u].z - mean.z) * istd.z * mgx.z);
@@ -573,10 +651,14 @@ extern "C" long lmkd_bn_bwd_workspace(int C) { return (long)(2048 * 2 * C) * siz
 // reduce + coefficient launches of the BatchNorm backward: partial sums of (g, g * xhat) over `rows` rows of (dy, x), then
 // coef[3][C] = A, mean(g), mean(g * xhat) with the means taken over `count` elements per channel (count = rows except for the stem,
 // whose sums run over the POOLED tensor while the BatchNorm normalised the pre-pooling one: lmkd_bn_backward_stats)
+// rows0 in (0, rows): two frame segments [0, rows0) | [rows0, rows) with counts count0 | count - count0; stats / coef are then [2][5][C],
+// the workspace is 2 * lmkd_bn_bwd_workspace(C) bytes and dgamma / dbeta are left to the apply pass (bn_param_grads_seg)
 static int bn_bwd_stats_impl(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dgamma,
                              float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, long count, int C, int mask_mode,
-                             int accumulate_param_grads, hipStream_t s, const char* who) {
+                             int accumulate_param_grads, hipStream_t s, const char* who, long rows0 = 0, long count0 = 0) {
   LMKD_REQUIRE(dy && x && stats && coef && workspace && tickets, "%s: null pointer", who);
+  const bool seg = rows0 > 0 && rows0 < rows;
+  LMKD_REQUIRE(!seg || cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS / 2, "%s: C=%d exceeds the ticket buffer", who, C);
   const int CC = C > 1024 ? 1024 : C;   // channel chunk handled by one workgroup column
   const int U = g_lmkd_act_bf16 ? 2 : 1;      // groups of 4 channels per thread (16-byte accesses)
   LMKD_REQUIRE(C % (4 * U) == 0 && C % CC == 0 && 256 % (CC / 4) == 0, "%s: unsupported channel count %d", who, C);
@@ -584,24 +666,34 @@ static int bn_bwd_stats_impl(const float* dy, const float* x, const float* yact,
   LMKD_REQUIRE(mask_mode != 3 || C % 32 == 0, "%s: bit masks need C %% 32 == 0", who);
   LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS, "%s: C=%d exceeds the ticket buffer", who, C);
   const int RL1 = NP_THREADS / (CC / 4), RL = RL1 * U;
-  int nb = cdiv(rows, (long)RL1 * 8);      // virtual blocks of RL1 row lanes (U of them per workgroup)
-  // cap: twice the elementwise kernels' workgroup count, for BOTH element types (the partial sums stay bit-identical between them).  A
-  // bf16 workgroup carries two virtual blocks: capped at the workgroup count itself, the bf16 launch had half the workgroups and ran
-  // as long as the fp32 one on half the bytes (27.0 vs 28.9 us)
-  if (nb > 256 * g_ew_wg_per_cu * 2) nb = 256 * g_ew_wg_per_cu * 2;
-  if (nb > 2048) nb = 2048;      // rows of the partial buffer (lmkd_bn_bwd_workspace)
-  if (nb < 1) nb = 1;
+  auto blocks = [&](long r) {
+    int nb = cdiv(r, (long)RL1 * 8);      // virtual blocks of RL1 row lanes (U of them per workgroup)
+    // cap: twice the elementwise kernels' workgroup count, for BOTH element types (the partial sums stay bit-identical between them).  A
+    // bf16 workgroup carries two virtual blocks: capped at the workgroup count itself, the bf16 launch had half the workgroups and ran
+    // as long as the fp32 one on half the bytes (27.0 vs 28.9 us)
+    if (nb > 256 * g_ew_wg_per_cu * 2) nb = 256 * g_ew_wg_per_cu * 2;
+    if (nb > 2048) nb = 2048;      // rows of the partial buffer (lmkd_bn_bwd_workspace)
+    return nb < 1 ? 1 : nb;
+  };
+  const int nb = blocks(seg ? rows0 : rows), nb1 = seg ? blocks(rows - rows0) : 0;
+  const int nbx = std::max(nb, nb1);
   float* partial = (float*)workspace;
-  double* dscr = (double*)((char*)workspace + (((long)2048 * 2 * C * sizeof(float) + 63) / 64) * 64);
+  // (two segments: partial rows [0, 2048) | [2048, 4096), then the fp64 scratch of both)
+  double* dscr = (double*)((char*)workspace + (((long)(seg ? 2 : 1) * 2048 * 2 * C * sizeof(float) + 63) / 64) * 64);
+  BnSeg bs;
+  bs.rows0 = seg ? rows0 : rows; bs.nb1 = nb1;
+  const int gz = seg ? 2 : 1;
   if (g_lmkd_act_bf16)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<lmkd_bf16_t>, dim3(cdiv(nb, 2), C / CC), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s,
-                       (const lmkd_bf16_t*)dy, (const lmkd_bf16_t*)x, (const lmkd_bf16_t*)yact, stats, partial, rows, C, CC, mask_mode, nb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<lmkd_bf16_t>, dim3(cdiv(nbx, 2), C / CC, gz), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s,
+                       (const lmkd_bf16_t*)dy, (const lmkd_bf16_t*)x, (const lmkd_bf16_t*)yact, stats, partial, rows, C, CC, mask_mode, nb, bs);
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb, C / CC), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s, dy, x, yact,
-                       stats, partial, rows, C, CC, mask_mode, nb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nbx, C / CC, gz), dim3(NP_THREADS), (size_t)RL * CC * 2 * sizeof(float), s, dy, x, yact,
+                       stats, partial, rows, C, CC, mask_mode, nb, bs);
   LMKD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(2 * C, CS_COLS), cs_slices(nb)), dim3(CS_COLS, CS_LANES), 0, s, (const float*)partial, nb, C,
-                     (double)count, gamma, stats, coef, dgamma, dbeta, accumulate_param_grads, dscr, tickets);
+  CoefSeg cs;
+  cs.T1 = nb1; cs.pstride = (long)2048 * 2 * C; cs.count1 = (double)(count - count0); cs.S0 = cs_slices(nb); cs.S1 = seg ? cs_slices(nb1) : 0;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(2 * C, CS_COLS), std::max(cs.S0, cs.S1), gz), dim3(CS_COLS, CS_LANES), 0, s, (const float*)partial, nb, C,
+                     (double)(seg ? count0 : count), gamma, stats, coef, dgamma, dbeta, accumulate_param_grads, dscr, tickets, cs);
   LMKD_CHECK_LAUNCH("bn_bwd_coef_kernel");
   return LMKD_OK;
 }
@@ -609,41 +701,74 @@ static int bn_bwd_stats_impl(const float* dy, const float* x, const float* yact,
 // dy, x, (yact) : [rows, C];  stats from the forward;  outputs dx (may alias dy), g_out (optional), dgamma, dbeta
 // coef: [3][C] floats scratch;  workspace: lmkd_bn_bwd_workspace(C) bytes;  tickets: lmkd_ticket_words() zeroed words (zero again on
 // return; one buffer per stream that may run this concurrently);  accumulate_param_grads: dgamma / dbeta += (see bn_bwd_coef_kernel)
+extern "C" int lmkd_bn_backward_seg(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dx,
+                                    float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows,
+                                    long rows0, int C, int mask_mode, int accumulate_param_grads, void* stream);
 extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma,
                                 float* dx, float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets,
                                 long rows, int C, int mask_mode, int accumulate_param_grads, void* stream) {
+  return lmkd_bn_backward_seg(dy, x, yact, stats, gamma, dx, g_out, dgamma, dbeta, coef, workspace, tickets, rows, rows, C, mask_mode,
+                              accumulate_param_grads, stream);
+}
+// lmkd_bn_backward over two frame segments [0, rows0) | [rows0, rows) of one tensor (both trunk calls of an episode, resnet18_2fc.py:41-42,
+// each with its own batch statistics): stats = [2][5][C], coef = [2][5][C] floats of scratch, workspace = 2 * lmkd_bn_bwd_workspace(C)
+// bytes; dx / g_out of a segment are bit-identical to a launch on that segment alone; dgamma / dbeta (+)= segment 0's sums + segment 1's.
+// rows0 = rows (or 0): one segment, coef [3][C], the plain lmkd_bn_backward.
+extern "C" int lmkd_bn_backward_seg(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dx,
+                                    float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows,
+                                    long rows0, int C, int mask_mode, int accumulate_param_grads, void* stream) {
   LMKD_REQUIRE(dx, "lmkd_bn_backward: null pointer");
   hipStream_t s = (hipStream_t)stream;
+  if (rows0 <= 0 || rows0 >= rows) rows0 = rows;
   const int rc = bn_bwd_stats_impl(dy, x, yact, stats, gamma, dgamma, dbeta, coef, workspace, tickets, rows, rows, C, mask_mode,
-                                   accumulate_param_grads, s, "lmkd_bn_backward");
+                                   accumulate_param_grads, s, "lmkd_bn_backward", rows0, rows0);
   if (rc) return rc;
-  const long n4 = rows * C / 4;
+  const long n4 = rows * C / 4, n4_0 = rows0 * C / 4;
+  ParamGradSeg pg;
+  pg.dgamma = dgamma; pg.dbeta = dbeta; pg.accumulate = accumulate_param_grads;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<lmkd_bf16_t>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, (const lmkd_bf16_t*)dy, (const lmkd_bf16_t*)x,
-                       (const lmkd_bf16_t*)yact, stats, (const float*)coef, (lmkd_bf16_t*)dx, (lmkd_bf16_t*)g_out, n4, C, mask_mode);
+                       (const lmkd_bf16_t*)yact, stats, (const float*)coef, (lmkd_bf16_t*)dx, (lmkd_bf16_t*)g_out, n4, C, mask_mode, n4_0, pg);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, dy, x, yact, stats, (const float*)coef, dx, g_out,
-                       n4, C, mask_mode);
+                       n4, C, mask_mode, n4_0, pg);
   LMKD_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return LMKD_OK;
 }
 
 // lmkd_bn_backward whose reduction pass already happened in the epilogue of the data gradient that produced dy
 // (lmkd_conv2d_bwd_data_bn): part = [T][C][2] per-row-tile sums (sum g, sum g * xhat) of mask mode 2.  Coefficient kernel + apply pass.
+extern "C" int lmkd_bn_backward_part_seg(const float* part, int T, int T0, const float* dy, const float* x, const float* stats, const float* gamma,
+                                         float* dx, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows,
+                                         long rows0, int C, int accumulate_param_grads, void* stream);
 extern "C" int lmkd_bn_backward_part(const float* part, int T, const float* dy, const float* x, const float* stats, const float* gamma,
                                      float* dx, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, int C,
                                      int accumulate_param_grads, void* stream) {
+  return lmkd_bn_backward_part_seg(part, T, T, dy, x, stats, gamma, dx, dgamma, dbeta, coef, workspace, tickets, rows, rows, C,
+                                   accumulate_param_grads, stream);
+}
+// two frame segments: partial rows [0, T0) | [T0, T) of lmkd_conv2d_bwd_data_seg, tensor rows [0, rows0) | [rows0, rows); tables as
+// lmkd_bn_backward_seg.  T0 = T (rows0 = rows): one segment.
+extern "C" int lmkd_bn_backward_part_seg(const float* part, int T, int T0, const float* dy, const float* x, const float* stats, const float* gamma,
+                                         float* dx, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows,
+                                         long rows0, int C, int accumulate_param_grads, void* stream) {
   LMKD_REQUIRE(part && T > 0 && dy && x && stats && dx && coef && workspace && tickets, "lmkd_bn_backward_part: null pointer");
   LMKD_REQUIRE(!g_lmkd_act_bf16 && C % 4 == 0, "lmkd_bn_backward_part: fp32 tensors, C %% 4 == 0");
-  LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS, "lmkd_bn_backward_part: C=%d exceeds the ticket buffer", C);
+  const bool seg = T0 > 0 && T0 < T && rows0 > 0 && rows0 < rows;
+  LMKD_REQUIRE(seg || (T0 == T && rows0 == rows), "lmkd_bn_backward_part_seg: T0 / rows0 must both name a split or both the whole");
+  LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS / (seg ? 2 : 1), "lmkd_bn_backward_part: C=%d exceeds the ticket buffer", C);
   hipStream_t s = (hipStream_t)stream;
   double* dscr = (double*)((char*)workspace + (((long)2048 * 2 * C * sizeof(float) + 63) / 64) * 64);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(2 * C, CS_COLS), cs_slices(T)), dim3(CS_COLS, CS_LANES), 0, s, part, T, C, (double)rows, gamma,
-                     stats, coef, dgamma, dbeta, accumulate_param_grads, dscr, tickets);
+  CoefSeg cs;
+  cs.T1 = T - T0; cs.pstride = (long)T0 * 2 * C; cs.count1 = (double)(rows - rows0); cs.S0 = cs_slices(T0); cs.S1 = seg ? cs_slices(T - T0) : 0;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(2 * C, CS_COLS), std::max(cs.S0, cs.S1), seg ? 2 : 1), dim3(CS_COLS, CS_LANES), 0, s, part, T0, C,
+                     (double)rows0, gamma, stats, coef, dgamma, dbeta, accumulate_param_grads, dscr, tickets, cs);
   LMKD_CHECK_LAUNCH("bn_bwd_coef_kernel");
   const long n4 = rows * C / 4;
+  ParamGradSeg pg;
+  pg.dgamma = dgamma; pg.dbeta = dbeta; pg.accumulate = accumulate_param_grads;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, dy, x, (const float*)nullptr, stats, (const float*)coef,
-                     dx, (float*)nullptr, n4, C, 2);
+                     dx, (float*)nullptr, n4, C, 2, rows0 * C / 4, pg);
   LMKD_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return LMKD_OK;
 }
@@ -660,6 +785,15 @@ extern "C" int lmkd_bn_backward_stats(const float* dy, const float* cmax, const 
   LMKD_REQUIRE(pooled_rows > 0 && count >= pooled_rows, "lmkd_bn_backward_stats: bad row counts");
   return bn_bwd_stats_impl(dy, cmax, nullptr, stats, gamma, dgamma, dbeta, coef, workspace, tickets, pooled_rows, count, C, 2,
                            accumulate_param_grads, (hipStream_t)stream, "lmkd_bn_backward_stats");
+}
+// two frame segments: pooled rows [0, pooled_rows0) | [.., pooled_rows) with count0 | count - count0 pre-pooling elements per channel;
+// stats / coef [2][5][C], workspace 2 * lmkd_bn_bwd_workspace(C).  The parameter gradients are written by lmkd_stem_unpool_bn_bwd_seg.
+extern "C" int lmkd_bn_backward_stats_seg(const float* dy, const float* cmax, const float* stats, const float* gamma, float* coef, void* workspace,
+                                          unsigned* tickets, long pooled_rows, long pooled_rows0, long count, long count0, int C, void* stream) {
+  LMKD_REQUIRE(pooled_rows0 > 0 && pooled_rows0 < pooled_rows && count0 >= pooled_rows0 && count - count0 >= pooled_rows - pooled_rows0,
+               "lmkd_bn_backward_stats_seg: bad row counts");
+  return bn_bwd_stats_impl(dy, cmax, nullptr, stats, gamma, nullptr, nullptr, coef, workspace, tickets, pooled_rows, count, C, 2, 0,
+                           (hipStream_t)stream, "lmkd_bn_backward_stats_seg", pooled_rows0, count0);
 }
 
 // plain ReLU backward (eval-mode / no-BN paths): g = dy * (y > 0)
@@ -686,7 +820,7 @@ extern "C" int lmkd_relu_backward(const float* dy, const float* y, float* g, lon
 // ---------------------------------------------------------------------------------
 template <typename T>
 __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ stats, T* __restrict__ y,
-                                       uchar4* __restrict__ idx, T* __restrict__ cmax, int N, int H, int W, int C, int OH, int OW) {
+                                       uchar4* __restrict__ idx, T* __restrict__ cmax, int N, int H, int W, int C, int OH, int OW, int N0) {
   // a thread owns U groups of 4 consecutive channels of one output pixel (U = 2 with bf16 tensors: every access 16 bytes; with 8-byte
   // accesses the bf16 instance took as long as the fp32 one on half the bytes - 260 vs 280 us at 200 frames)
   constexpr int U = ActU<T>::U;
@@ -702,8 +836,9 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __r
     uchar4 am[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      sc[u] = *reinterpret_cast<const float4*>(stats + 2 * C + (cq * U + u) * 4);
-      sh[u] = *reinterpret_cast<const float4*>(stats + 3 * C + (cq * U + u) * 4);
+      const float* st = stats + (n >= N0 ? 5 * C : 0);      // frames from N0 on: the second segment's table
+      sc[u] = *reinterpret_cast<const float4*>(st + 2 * C + (cq * U + u) * 4);
+      sh[u] = *reinterpret_cast<const float4*>(st + 3 * C + (cq * U + u) * 4);
       m[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
       cm[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       am[u] = make_uchar4(255, 255, 255, 255);
@@ -739,17 +874,25 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __r
   }
 }
 
+extern "C" int lmkd_bn_relu_maxpool_fwd_seg(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int N0, int H,
+                                            int W, int C, void* stream);
 extern "C" int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int H, int W,
                                         int C, void* stream) {
+  return lmkd_bn_relu_maxpool_fwd_seg(x, stats, y, idx, cmax, N, N, H, W, C, stream);
+}
+// two frame segments: frames [0, N0) use stats[0], frames [N0, N) stats[1] ([2][5][C])
+extern "C" int lmkd_bn_relu_maxpool_fwd_seg(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int N0, int H,
+                                            int W, int C, void* stream) {
   LMKD_REQUIRE(x && stats && y && idx && C % (g_lmkd_act_bf16 ? 8 : 4) == 0, "lmkd_bn_relu_maxpool_fwd: bad arguments");
+  if (N0 <= 0 || N0 > N) N0 = N;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long total = (long)N * OH * OW * C / (g_lmkd_act_bf16 ? 8 : 4);
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<lmkd_bf16_t>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)x,
-                       stats, (lmkd_bf16_t*)y, (uchar4*)idx, (lmkd_bf16_t*)cmax, N, H, W, C, OH, OW);
+                       stats, (lmkd_bf16_t*)y, (uchar4*)idx, (lmkd_bf16_t*)cmax, N, H, W, C, OH, OW, N0);
   else
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, stats, y, (uchar4*)idx,
-                       cmax, N, H, W, C, OH, OW);
+                       cmax, N, H, W, C, OH, OW, N0);
   LMKD_CHECK_LAUNCH("bn_relu_maxpool_kernel");
   return LMKD_OK;
 }
@@ -800,17 +943,18 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uchar4* __res
 template <typename T>
 __global__ void stem_unpool_bn_bwd_kernel(const T* __restrict__ dy, const uchar4* __restrict__ idx, const T* __restrict__ c,
                                           const float* __restrict__ stats, const float* __restrict__ coef, T* __restrict__ dc, int N,
-                                          int H, int W, int C, int OH, int OW) {
+                                          int H, int W, int C, int OH, int OW, int N0, ParamGradSeg pg) {
   const int C4 = C >> 2;
   const int HB = (H + 1) >> 1, WB = (W + 1) >> 1;
   const long total = (long)N * HB * WB * C4;
+  if (N0 < N) bn_param_grads_seg(coef, C, pg);      // two frame segments: tables [2][5][C], parameter gradients from both (bn_bwd_coef_kernel)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cq = (int)(i % C4);
     long r = i / C4;
     const int b = (int)(r % WB); r /= WB;
     const int a = (int)(r % HB);
     const int n = (int)(r / HB);
-    const int ch = cq * 4;
+    const int ch = cq * 4 + (n >= N0 ? 5 * C : 0);
     const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * C + ch);
     const float4 sh = *reinterpret_cast<const float4*>(stats + 3 * C + ch);
     const float4 mean = *reinterpret_cast<const float4*>(stats + ch);
@@ -875,17 +1019,30 @@ __global__ void stem_unpool_bn_bwd_kernel(const T* __restrict__ dy, const uchar4
 
 // dy, idx: [N, OH, OW, C] (pooled gradient, arg-max bytes of lmkd_bn_relu_maxpool_fwd); c: [N, H, W, C] convolution output;
 // stats: its [5][C] table; coef: [3][C] from lmkd_bn_backward_stats; dc: [N, H, W, C] gradient w.r.t. the convolution output
+extern "C" int lmkd_stem_unpool_bn_bwd_seg(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef,
+                                           float* dc, float* dgamma, float* dbeta, int accumulate_param_grads, int N, int N0, int H, int W, int C,
+                                           void* stream);
 extern "C" int lmkd_stem_unpool_bn_bwd(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef,
                                        float* dc, int N, int H, int W, int C, void* stream) {
+  return lmkd_stem_unpool_bn_bwd_seg(dy, idx, c, stats, coef, dc, nullptr, nullptr, 0, N, N, H, W, C, stream);
+}
+// two frame segments [0, N0) | [N0, N): stats / coef = the [2][5][C] tables of lmkd_bn_backward_stats_seg; dgamma / dbeta (nullable) (+)= the
+// sums of both segments (rows 3 / 4 of coef).  N0 = N: one segment, the plain form (coef [3][C], dgamma / dbeta ignored).
+extern "C" int lmkd_stem_unpool_bn_bwd_seg(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef,
+                                           float* dc, float* dgamma, float* dbeta, int accumulate_param_grads, int N, int N0, int H, int W, int C,
+                                           void* stream) {
   LMKD_REQUIRE(dy && idx && c && stats && coef && dc && C % 4 == 0 && N > 0 && H > 0 && W > 0, "lmkd_stem_unpool_bn_bwd: bad arguments");
+  if (N0 <= 0 || N0 > N) N0 = N;
+  ParamGradSeg pg;
+  pg.dgamma = dgamma; pg.dbeta = dbeta; pg.accumulate = accumulate_param_grads;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * C / 4;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(stem_unpool_bn_bwd_kernel<lmkd_bf16_t>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream,
-                       (const lmkd_bf16_t*)dy, (const uchar4*)idx, (const lmkd_bf16_t*)c, stats, coef, (lmkd_bf16_t*)dc, N, H, W, C, OH, OW);
+                       (const lmkd_bf16_t*)dy, (const uchar4*)idx, (const lmkd_bf16_t*)c, stats, coef, (lmkd_bf16_t*)dc, N, H, W, C, OH, OW, N0, pg);
   else
     hipLaunchKernelGGL(stem_unpool_bn_bwd_kernel<float>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, dy, (const uchar4*)idx, c,
-                       stats, coef, dc, N, H, W, C, OH, OW);
+                       stats, coef, dc, N, H, W, C, OH, OW, N0, pg);
   LMKD_CHECK_LAUNCH("stem_unpool_bn_bwd_kernel");
   return LMKD_OK;
 }

@@ -30,9 +30,12 @@ struct WgradWinArgs {
   int N, H, W, Cs, Co, Kp;
   int Mpix, steps_total, steps_per_split, splits;
   int n_ct, n_it;      // output-channel tiles, input-channel tiles (32 channels each)
+  // two frame segments (ConvGemmArgs::seg_m0; only needed with PRE, whose [2][5][Cs] table differs per segment): pixels [0, seg_pix0) are
+  // covered by the splits [0, seg_splits0) of steps_per_split steps each, pixels [seg_pix0, Mpix) by the remaining splits of sps1 steps,
+  // the first of which STARTS at pixel seg_pix0 - no slab straddles the boundary.  One segment: seg_pix0 = Mpix, seg_splits0 = splits.
+  int seg_pix0, seg_splits0, sps1;
   FastDiv div_hw, div_w;
 };
-
 template <int COB, int NPROD, bool ACT16, int R, bool PRE = false, int TPW = 9>
 __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_win_kernel(WgradWinArgs a) {
   constexpr int NPL = NPROD == 1 ? 1 : 3;
@@ -55,9 +58,8 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
   if (z >= a.splits) return;
   const int tz = xj - (xj / tiles) * tiles;
   const int co0 = (tz % a.n_ct) * BM, ci0 = (tz / a.n_ct) * 32;
-  const int s0 = z * a.steps_per_split;
-  int nk = a.steps_total - s0;
-  if (nk > a.steps_per_split) nk = a.steps_per_split;
+  const WinSlab sl = win_slab(z, a.Mpix, a.steps_per_split, a.seg_pix0, a.seg_splits0, a.sps1);
+  const int nk = sl.nk, kend = sl.kend;      // kend: this slab's segment ends here - pixels past it are not this slab's
   const int halo = a.W + 1;
 
   const __amdgpu_buffer_rsrc_t rs_dy = x3_rsrc(a.dy, (long)a.Mpix * a.Co * ESZ);
@@ -71,14 +73,14 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
   unsigned x_ok = 0;      // PRE: which of the prefetched x rows are real pixels (rows outside the tensor stay zero)
   float4 psc = float4(), psh = float4();
   if (PRE) {
-    psc = *reinterpret_cast<const float4*>(a.pre_stats + 2 * a.Cs + ci0 + x_c);
-    psh = *reinterpret_cast<const float4*>(a.pre_stats + 3 * a.Cs + ci0 + x_c);
+    psc = *reinterpret_cast<const float4*>(a.pre_stats + (long)sl.seg * 5 * a.Cs + 2 * a.Cs + ci0 + x_c);
+    psh = *reinterpret_cast<const float4*>(a.pre_stats + (long)sl.seg * 5 * a.Cs + 3 * a.Cs + ci0 + x_c);
   }
   auto load_dy = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_NI; ++i) {
       const int p = k0 + a_r + A_RPP * i;
-      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (a_cin && a_r + A_RPP * i < LMKD_BK && p < a.Mpix) ? (unsigned)((p * a.Co + co0 + a_c) * ESZ) : X3_OOB, 0, 0);
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (a_cin && a_r + A_RPP * i < LMKD_BK && p < kend) ? (unsigned)((p * a.Co + co0 + a_c) * ESZ) : X3_OOB, 0, 0);
     }
   };
   auto load_x = [&](int q0) {      // the 32 pixel rows q0 .. q0 + 31 (rows outside the tensor read as zeros)
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
       const int tp = e >> 5, r = e & 31;
       const int p = k0 + r;
       unsigned adr = (unsigned)(R * LDX);
-      if (p < a.Mpix) {
+      if (p < kend) {
         const int n = fdiv(p, a.div_hw);
         const int rem = p - n * a.H * a.W;
         const int h = fdiv(rem, a.div_w), w = rem - h * a.W;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
   if (nk > 0) {
-    const int kfirst = s0 * LMKD_BK;
+    const int kfirst = sl.kfirst;
     for (int j = tid; j < NPL * LDX / 4; j += THREADS)      // the zero row of every plane
       reinterpret_cast<unsigned*>(s_x + (j / (LDX / 4)) * X_PLANE + R * LDX)[j % (LDX / 4)] = 0u;
     // warm-up: rows [k0 - halo, k0 + halo) in chunks of 32 (a chunk may run into the rows of step 0: rewritten with the same data)
@@ -264,9 +266,8 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
   if (z >= a.splits) return;
   const int tz = xj - (xj / tiles) * tiles;
   const int co0 = (tz % a.n_ct) * BM, ci0 = (tz / a.n_ct) * 32;
-  const int s0 = z * a.steps_per_split;
-  int nk = a.steps_total - s0;
-  if (nk > a.steps_per_split) nk = a.steps_per_split;
+  const WinSlab sl = win_slab(z, a.Mpix, a.steps_per_split, a.seg_pix0, a.seg_splits0, a.sps1);
+  const int nk = sl.nk, kend = sl.kend;      // kend: this slab's segment ends here - pixels past it are not this slab's
   const int halo = a.W + 1;
 
   const __amdgpu_buffer_rsrc_t rs_dy = x3_rsrc(a.dy, (long)a.Mpix * a.Co * 4);
@@ -278,14 +279,14 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
   unsigned x_ok = 0;
   float4 psc = float4(), psh = float4();
   if (PRE) {
-    psc = *reinterpret_cast<const float4*>(a.pre_stats + 2 * a.Cs + ci0 + x_c);
-    psh = *reinterpret_cast<const float4*>(a.pre_stats + 3 * a.Cs + ci0 + x_c);
+    psc = *reinterpret_cast<const float4*>(a.pre_stats + (long)sl.seg * 5 * a.Cs + 2 * a.Cs + ci0 + x_c);
+    psh = *reinterpret_cast<const float4*>(a.pre_stats + (long)sl.seg * 5 * a.Cs + 3 * a.Cs + ci0 + x_c);
   }
   auto load_dy = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_NI; ++i) {
       const int p = k0 + a_r + A_RPP * i;
-      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (a_cin && a_r + A_RPP * i < LMKD_BK && p < a.Mpix) ? (unsigned)((p * a.Co + co0 + a_c) * 4) : X3_OOB, 0, 0);
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (a_cin && a_r + A_RPP * i < LMKD_BK && p < kend) ? (unsigned)((p * a.Co + co0 + a_c) * 4) : X3_OOB, 0, 0);
     }
   };
   auto load_x = [&](int q0) {
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
       const int tp = e >> 5, r = e & 31;
       const int p = k0 + r;
       unsigned adr = (unsigned)(R * LDX);
-      if (p < a.Mpix) {
+      if (p < kend) {
         const int n = fdiv(p, a.div_hw);
         const int rem = p - n * a.H * a.W;
         const int h = fdiv(rem, a.div_w), w = rem - h * a.W;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
       for (int j = 0; j < JW; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) {
-    const int kfirst = s0 * LMKD_BK;
+    const int kfirst = sl.kfirst;
     for (int j = tid; j < NPL * LDX / 4; j += THREADS)      // the zero row of every plane
       reinterpret_cast<unsigned*>(s_x + (j / (LDX / 4)) * X_PLANE + R * LDX)[j % (LDX / 4)] = 0u;
     for (int q0 = kfirst - halo; q0 < kfirst + halo; q0 += LMKD_BK) {

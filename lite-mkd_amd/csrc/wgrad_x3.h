@@ -168,11 +168,18 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
   const int m0 = (tz % a.n_mt) * Cfg::BM, j0 = (tz / a.n_mt) * Cfg::BN;
   LA la;
   LB lb;
-  la.init(a.dy, a.Co, m0, a.Co, a.Mpix);
+  // two frame segments (WgradArgs::seg_pix0): the slab's pixel range lies inside ONE segment, whose BatchNorm table the PRE loader uses
+  const WinSlab sl = win_slab(z, a.Mpix, a.steps_per_split, a.seg_pix0, a.seg_splits0, a.sps1);
+  const int nk = sl.nk, kb = sl.kfirst;
+  la.init(a.dy, a.Co, m0, a.Co, sl.kend);
   lb.init(a, j0);
-  const int s0 = z * a.steps_per_split;
-  int nk = a.steps_total - s0;
-  if (nk > a.steps_per_split) nk = a.steps_per_split;
+  lb.Mpix = sl.kend;
+  if constexpr (PRE) {
+    if (sl.seg && lb.tap_ok) {
+      lb.psc = *reinterpret_cast<const float4*>(a.pre_stats + 5 * a.Cs + 2 * a.Cs + lb.coff);
+      lb.psh = *reinterpret_cast<const float4*>(a.pre_stats + 5 * a.Cs + 3 * a.Cs + lb.coff);
+    }
+  }
   // (The directional truncation of the MFMA's mixed-magnitude additions - conv_x3.h, X3FragB::init - is left alone here: a slab is a
   // sum over ~2.5 K pixels, the bias of a weight-gradient element is ~1e-6 of the tensor's rms and nothing sums weight gradients
   // coherently over 10^5 terms afterwards.  Alternating the accumulation sign per pixel split was measured: it removes the bias, but
@@ -257,14 +264,14 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
   if (nk > 0) {
     unsigned char* A0 = smem;
     unsigned char* B0 = smem + A_BYTES;
-    la.load((s0 + 0) * LMKD_BK);
-    lb.load((s0 + 0) * LMKD_BK);
+    la.load(kb);
+    lb.load(kb);
     for (int t = 0; t < nk; ++t) {
       store_tiles(A0, B0);                    // waits for the prefetched registers of step t
       __syncthreads();
       if (t + 1 < nk) {
-        la.load((s0 + t + 1) * LMKD_BK);
-        lb.load((s0 + t + 1) * LMKD_BK);
+        la.load(kb + (t + 1) * LMKD_BK);
+        lb.load(kb + (t + 1) * LMKD_BK);
       }
       kstep(A0, B0);
       __syncthreads();                        // every wave has read the tile before it is overwritten

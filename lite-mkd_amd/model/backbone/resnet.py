@@ -47,7 +47,8 @@ class _Block(nn.Module):
             self.downsample.add_module("0", _Conv(cin, cout, 1))
             self.downsample.add_module("1", _BN(cout))
 
-    def forward(self, x):
+    def forward(self, x, seg=0):
+        """seg = F0 > 0: x holds both trunk calls of an episode, frames [0, F0) | [F0, F) (merged_trunk_call)"""
         tr = self.training
         ops.mark_cacheable(self.conv1.weight)
         ops.mark_cacheable(self.conv2.weight)
@@ -57,7 +58,7 @@ class _Block(nn.Module):
         else:
             ds = (None, None, None, None, None)
         return ops.BasicBlockFn.apply(x, self.stride, tr, self.conv1.weight, *self.bn1.args(),
-                                      self.conv2.weight, *self.bn2.args(), *ds)
+                                      self.conv2.weight, *self.bn2.args(), *ds, seg)
 
 
 class _Bottleneck(nn.Module):
@@ -79,7 +80,7 @@ class _Bottleneck(nn.Module):
             self.downsample.add_module("0", _Conv(cin, cout, 1))
             self.downsample.add_module("1", _BN(cout))
 
-    def forward(self, x):
+    def forward(self, x, seg=0):
         for c in (self.conv1, self.conv2, self.conv3):
             ops.mark_cacheable(c.weight)
         if self.downsample is not None:
@@ -88,7 +89,7 @@ class _Bottleneck(nn.Module):
         else:
             ds = (None, None, None, None, None)
         return ops.BottleneckFn.apply(x, self.stride, self.training, self.conv1.weight, *self.bn1.args(),
-                                      self.conv2.weight, *self.bn2.args(), self.conv3.weight, *self.bn3.args(), *ds)
+                                      self.conv2.weight, *self.bn2.args(), self.conv3.weight, *self.bn3.args(), *ds, seg)
 
 
 class ResNet18Trunk(nn.Module):
@@ -146,11 +147,70 @@ class ResNet50Trunk(ResNet18Trunk):
 OVERLAP_TRUNK_CALLS = True
 _BN_UPDATE_EVENT = {}
 
+# Round 4: both trunk calls as ONE launch per layer.  The support and the query frames travel through the trunk as one NHWC tensor
+# [Fs + Fq, H, W, C] with a frame split ("two frame segments", include/lmkd.h lmkd_*_seg): every convolution / BatchNorm / pooling kernel
+# is launched once for both calls, each call still normalises with its OWN batch statistics ([2][5][C] tables; the row tiles of the
+# convolutions are dealt per segment, so activations and activation gradients are bit-identical to two separate calls), weight and
+# BatchNorm-parameter gradients are summed over both calls in one pass.  Half the trunk's launches (431 -> ~250 per episode), grids of
+# twice the size, no second stream / shadow gradient buffer for the query call.  The default wherever the arithmetic has the two-segment
+# kernels (the bf16-plane modes: fp32-as-3xbf16 and bf16); the native fp32 MFMA mode keeps the two-call schedule below.
+MERGE_TRUNK_CALLS = True
+
+
+def merge_supported(trunk, context_frames, target_frames):
+    return (MERGE_TRUNK_CALLS and isinstance(trunk, ResNet18Trunk) and context_frames.is_cuda and ops.get_conv_compute_dtype() != "fp32"
+            and context_frames.shape[1:] == target_frames.shape[1:] and context_frames.dtype == target_frames.dtype)
+
+
+def merged_trunk_call(trunk, head, context_frames, target_frames):
+    """-> head(trunk([context_frames; target_frames])) as ONE [Fs + Fq, ...] tensor plus Fs: the trunk runs once over both frame sets
+    (resnet18_2fc.py:41-42 calls it twice; train-mode BatchNorm statistics stay per call)."""
+    Fs = context_frames.shape[0]
+    x4 = ops.frames_pair_to_nhwc4(context_frames, target_frames)
+    training = trunk.training
+    seg = Fs if training else 0      # eval: the running statistics serve every frame alike
+    upd = []
+    ops.mark_cacheable(getattr(trunk, "0").weight)
+    try:
+        if training:
+            ops.set_defer(upd)
+        y = ops.StemFn.apply(x4, getattr(trunk, "0").weight, *getattr(trunk, "1").args(), training, seg)
+        for name, _, _, _ in STAGES:
+            for blk in getattr(trunk, name):
+                y = blk(y, seg)
+        feat = head(y)
+    finally:
+        ops.set_defer(None)
+    if training:
+        main = torch.cuda.current_stream()
+        key = context_frames.device.index
+        prev = _BN_UPDATE_EVENT.get(key)
+        if prev is not None:
+            main.wait_event(prev)
+        ops.apply_deferred(upd)      # entries come in (support, query) pairs per BatchNorm: applied in the reference's order
+        trunk.bump_counters(2)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        _BN_UPDATE_EVENT[key] = ev
+    return feat, Fs
+
+
+def trunk_features(trunk, head, context_frames, target_frames):
+    """-> (X, Fs): X = head(trunk(.)) of the support frames (rows [0, Fs)) followed by the query frames' - from the merged trunk call
+    where the arithmetic has it, else from the two-call schedule"""
+    if merge_supported(trunk, context_frames, target_frames):
+        return merged_trunk_call(trunk, head, context_frames, target_frames)
+    cf, tf = two_trunk_calls(trunk, head, context_frames, target_frames)
+    return torch.cat([cf, tf], 0), cf.shape[0]
+
 
 def two_trunk_calls(trunk, head, context_frames, target_frames):
     """-> (head(trunk(context_frames)), head(trunk(target_frames))).  The two calls are enqueued layer by layer,
     alternating between the two streams, so both queues stay fed (and autograd, which walks the graph in reverse creation
     order, alternates between them in the backward as well)."""
+    if merge_supported(trunk, context_frames, target_frames):
+        feat, Fs = merged_trunk_call(trunk, head, context_frames, target_frames)
+        return feat[:Fs], feat[Fs:]
     if not (OVERLAP_TRUNK_CALLS and context_frames.is_cuda):
         return head(trunk(context_frames)), head(trunk(target_frames))
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)

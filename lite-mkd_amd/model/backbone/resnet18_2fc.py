@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from ... import ops
-from .resnet import Linear, ResNet18Trunk, two_trunk_calls
+from .resnet import Linear, ResNet18Trunk, trunk_features
 
 
 class resnet18_2fc(nn.Module):
@@ -17,9 +17,9 @@ class resnet18_2fc(nn.Module):
 
     def forward(self, context_feature, context_labels, target_feature):
         # two separate trunk calls = two separate BatchNorm batches (resnet18_2fc.py:41-42)
-        cf, tf = two_trunk_calls(self.resnet, ops.PoolHeadFn.apply, context_feature, target_feature)     # :41-54
+        X, Fs = trunk_features(self.resnet, ops.PoolHeadFn.apply, context_feature, target_feature)     # :41-54: both calls, one launch per layer
         L, D = self.args.seq_len, self.args.trans_linear_in_dim
-        c1, t1, c2, t2 = ops.two_head_linear(cf, tf, self.fc1, self.fc2)      # :56-64, one autograd node for the four calls
+        c1, t1, c2, t2 = ops.two_head_linear_x(X, Fs, self.fc1, self.fc2)      # :56-64, one autograd node for the four calls
         context_feature_dict = {
             "context_features_1": c1.reshape(-1, L, D),
             "context_features_2": c2.reshape(-1, L, D),

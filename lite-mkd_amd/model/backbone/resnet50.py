@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from ... import ops
-from .resnet import Linear, ResNet50Trunk, two_trunk_calls
+from .resnet import Linear, ResNet50Trunk, trunk_features, two_trunk_calls
 
 
 class resnet50_2fc(nn.Module):
@@ -16,9 +16,9 @@ class resnet50_2fc(nn.Module):
         self.fc2 = Linear(2048, 2048)
 
     def forward(self, context_feature, context_labels, target_feature):
-        cf, tf = two_trunk_calls(self.resnet, ops.PoolHeadFn.apply, context_feature, target_feature)     # :40-57
+        X, Fs = trunk_features(self.resnet, ops.PoolHeadFn.apply, context_feature, target_feature)     # :40-57
         L, D = self.args.seq_len, self.args.trans_linear_in_dim
-        c1, t1, c2, t2 = ops.two_head_linear(cf, tf, self.fc1, self.fc2)
+        c1, t1, c2, t2 = ops.two_head_linear_x(X, Fs, self.fc1, self.fc2)
         return ({"context_features_1": c1.reshape(-1, L, D), "context_features_2": c2.reshape(-1, L, D)},
                 {"target_features_1": t1.reshape(-1, L, D), "target_features_2": t2.reshape(-1, L, D)})
 

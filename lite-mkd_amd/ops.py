@@ -283,10 +283,11 @@ FUSE_TWO_HEAD_LINEAR = True
 
 
 class TwoHeadLinearFn(torch.autograd.Function):
+    """X = the pooled features of the support frames (rows [0, Nc)) followed by those of the query frames"""
+
     @staticmethod
-    def forward(ctx, cf, tf, w1, b1, w2, b2):
-        Nc = cf.shape[0]
-        X = torch.cat([cf, tf], 0).contiguous()
+    def forward(ctx, X, Nc, w1, b1, w2, b2):
+        X = X.contiguous()
         M, K = X.shape
         N = w1.shape[0]
         Y1, Y2 = _empty((M, N), X), _empty((M, N), X)
@@ -313,7 +314,7 @@ class TwoHeadLinearFn(torch.autograd.Function):
             return torch.cat([gc, gt], 0).contiguous()
         G = [full(g1c, g1t), full(g2c, g2t)]
         dX = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[0]:
             live = [(g, w) for g, w in zip(G, (w1, w2)) if g is not None]
             dX = _empty((M, K), X)
             if len(live) == 2:      # dX = [G1 | G2] @ [W1; W2]: one GEMM over K = 2 N
@@ -324,7 +325,7 @@ class TwoHeadLinearFn(torch.autograd.Function):
                 gemm("K", "N", M, K, N, live[0][0], N, live[0][1], K, dX, K)
             else:
                 dX.zero_()
-        outs = [None, None]
+        outs = [dX if ctx.needs_input_grad[0] else None, None]
         for g, pw, pb in zip(G, (pw1, pw2), (pb1, pb2)):
             dw = db = None
             if g is not None:
@@ -343,16 +344,20 @@ class TwoHeadLinearFn(torch.autograd.Function):
                     else:
                         db = colsum(g)
             outs += [dw, db]
-        outs[0] = dX[:Nc] if dX is not None and ctx.needs_input_grad[0] else None
-        outs[1] = dX[Nc:] if dX is not None and ctx.needs_input_grad[1] else None
         return tuple(outs)
+
+
+def two_head_linear_x(X, Nc, fc1, fc2):
+    """X [Nc + Nt, K] = support-frame rows followed by query-frame rows -> fc1(X[:Nc]), fc1(X[Nc:]), fc2(X[:Nc]), fc2(X[Nc:])"""
+    if FUSE_TWO_HEAD_LINEAR and X.is_cuda and X.dim() == 2 and fc1.weight.shape == fc2.weight.shape and fc1.bias is not None and fc2.bias is not None:
+        return TwoHeadLinearFn.apply(X, Nc, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+    cf, tf = X[:Nc], X[Nc:]
+    return fc1(cf), fc1(tf), fc2(cf), fc2(tf)
 
 
 def two_head_linear(cf, tf, fc1, fc2):
     """-> fc1(cf), fc1(tf), fc2(cf), fc2(tf)"""
-    if FUSE_TWO_HEAD_LINEAR and cf.is_cuda and cf.dim() == 2 and fc1.weight.shape == fc2.weight.shape and fc1.bias is not None and fc2.bias is not None:
-        return TwoHeadLinearFn.apply(cf.contiguous(), tf.contiguous(), fc1.weight, fc1.bias, fc2.weight, fc2.bias)
-    return fc1(cf), fc1(tf), fc2(cf), fc2(tf)
+    return two_head_linear_x(torch.cat([cf, tf], 0), cf.shape[0], fc1, fc2)
 
 
 # ------------------------------------------------------------------------------------------
@@ -547,25 +552,37 @@ def _conv_family(kind, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad):
     return "conv_patch_kernel" if info[4] == 1 else "conv_gemm_kernel"
 
 
-def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None):
+def _seg_frames(seg, N):
+    """frame split of a two-segment tensor (both trunk calls of an episode as one [F0 + F1, ...] tensor), 0 = one segment"""
+    seg = int(seg or 0)
+    return seg if 0 < seg < N else 0
+
+
+def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None, seg=0):
     """x NHWC [N,H,W,Cs] -> (y [N,Ho,Wo,Cout], stat partial [T,Cout,2] | None).  pre_stats: x is the RAW output of the previous
-    convolution and the loader applies relu(BatchNorm(x)) with that layer's [5][Cs] table (lmkd_conv2d_fwd_pre)."""
+    convolution and the loader applies relu(BatchNorm(x)) with that layer's [5][Cs] table (lmkd_conv2d_fwd_pre).
+    seg = F0 > 0: frames [0, F0) and [F0, N) are two BatchNorm batches (lmkd_conv2d_fwd_seg): pre_stats is [2, 5, Cs] and the result is
+    (y, part, T0) - the first T0 rows of part belong to segment 0."""
     _chk(x, wp, pre_stats)
     N, H, W, Cs = x.shape
+    seg = _seg_frames(seg, N)
     Ho, Wo = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
     y = _empty_act((N, Ho, Wo, Cout), x)
     part = None
+    t0 = (ctypes.c_int * 1)()
     if want_stats:
-        T = lib().value("lmkd_conv2d_fwd_row_tiles_cs", N, H, W, Cs, Cout, KH, KW, stride, pad)
+        T = lib().value("lmkd_conv2d_fwd_row_tiles_seg", N, H, W, Cs, Cout, KH, KW, stride, pad, seg, t0)
         part = _empty((T, Cout, 2), x)
     cin = 3 if Cs == 4 else Cs
     with _timed(_conv_family(0, N, H, W, Cs, cin, Cout, KH, KW, stride, pad), 2.0 * N * Ho * Wo * Cout * cin * KH * KW,
                 x.element_size() * x.numel() + y.element_size() * y.numel() + 4 * wp.numel()):
-        if pre_stats is not None:
+        if seg:
+            lib().call("lmkd_conv2d_fwd_seg", _p(x), _p(pre_stats), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, seg, _stream())
+        elif pre_stats is not None:
             lib().call("lmkd_conv2d_fwd_pre", _p(x), _p(pre_stats), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, _stream())
         else:
             lib().call("lmkd_conv2d_fwd", _p(x), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, _stream())
-    return y, part
+    return (y, part, int(t0[0])) if seg else (y, part)
 
 
 # The data gradient that feeds relu + BatchNorm backward leaves that backward's reduction in its epilogue (lmkd_conv2d_bwd_data_bn) where
@@ -576,24 +593,32 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None):
 DGRAD_BN_STATS = True
 
 
-def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumulate=False, bn=None):
+def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumulate=False, bn=None, seg=0):
     """bn = (x_bn, stats): the gradient feeds relu(BatchNorm(x_bn)) backward -> (dx, part | None), part = the [T, Cin, 2] partial sums
-    bn_backward(part=...) takes in place of its reduction pass (None: this launch has no fused form)"""
+    bn_backward(part=...) takes in place of its reduction pass (None: this launch has no fused form).
+    seg = F0 > 0: two frame segments (lmkd_conv2d_bwd_data_seg); stats is [2, 5, Cin] and part becomes (part, T0)."""
     N, H, W, Cin = x_shape
+    seg = _seg_frames(seg, N)
     _chk(dy, wd, out)
     if accumulate and out is None:
         raise ValueError("accumulate needs an output buffer")
     dx = out if out is not None else _empty_act((N, H, W, Cin), dy)
     part = None
+    t0 = (ctypes.c_int * 1)()
     if bn is not None and DGRAD_BN_STATS and not accumulate:
-        T = lib().value("lmkd_conv2d_bwd_data_bn_tiles", N, H, W, Cin, Cout, KH, KW, stride, pad)
+        T = lib().value("lmkd_conv2d_bwd_data_bn_tiles_seg", N, H, W, Cin, Cout, KH, KW, stride, pad, seg, t0)
         if T > 0:
             _chk(bn[0], bn[1])
             part = _empty((T, Cin, 2), dy)
     with _timed(_conv_family(1, N, H, W, Cin, Cin, Cout, KH, KW, stride, pad), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
                 dy.element_size() * dy.numel() + dx.element_size() * dx.numel() * (2 if accumulate else 1) + 4 * wd.numel()
                 + (bn[0].element_size() * bn[0].numel() if part is not None else 0)):      # the fused form also reads the BatchNorm input
-        if part is not None:
+        if seg:
+            lib().call("lmkd_conv2d_bwd_data_seg", _p(dy), _p(wd), _p(dx), _p(bn[0]) if part is not None else None,
+                       _p(bn[1]) if part is not None else None, _p(part), N, H, W, Cin, Cout, KH, KW, stride, pad, int(accumulate), seg, _stream())
+            if part is not None:
+                part = (part, int(t0[0]))
+        elif part is not None:
             lib().call("lmkd_conv2d_bwd_data_bn", _p(dy), _p(wd), _p(dx), _p(bn[0]), _p(bn[1]), _p(part), N, H, W, Cin, Cout, KH, KW, stride,
                        pad, _stream())
         else:
@@ -601,18 +626,23 @@ def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumula
     return (dx, part) if bn is not None else dx
 
 
-def conv_bwd_weight(x, dy, w_shape, stride, pad, pre_stats=None, acc_into=None):
+def conv_bwd_weight(x, dy, w_shape, stride, pad, pre_stats=None, acc_into=None, seg=0):
     """pre_stats: x is a raw conv output, relu(BatchNorm(x)) is recomputed in the loader (lmkd_conv2d_bwd_weight_pre).
-    acc_into: a contiguous OIHW tensor (the weight's .grad) that receives `+= dW` in the slab-reduce kernel itself."""
+    acc_into: a contiguous OIHW tensor (the weight's .grad) that receives `+= dW` in the slab-reduce kernel itself.
+    seg = F0 > 0: two frame segments, pre_stats [2, 5, Cs] (lmkd_conv2d_bwd_weight_seg: one launch over all frames)."""
     Cout, Cin, KH, KW = w_shape
     N, H, W, Cs = x.shape
+    seg = _seg_frames(seg, N)
     _chk(x, dy, pre_stats, acc_into)
-    nbytes = lib().value("lmkd_conv2d_bwd_weight_workspace", N, H, W, Cs, Cout, KH, KW, stride, pad)
+    nbytes = lib().value("lmkd_conv2d_bwd_weight_workspace_seg", N, H, W, Cs, Cout, KH, KW, stride, pad, seg)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     dw = acc_into if acc_into is not None else _empty(w_shape, x)
     with _timed("conv_wgrad_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
                 x.element_size() * x.numel() + dy.element_size() * dy.numel() + 4 * dw.numel()):
-        if acc_into is not None:
+        if seg:
+            lib().call("lmkd_conv2d_bwd_weight_seg", _p(x), _p(pre_stats), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW,
+                       stride, pad, int(acc_into is not None), seg, _stream())
+        elif acc_into is not None:
             lib().call("lmkd_conv2d_bwd_weight_acc", _p(x), _p(pre_stats), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW,
                        stride, pad, _stream())
         elif pre_stats is not None:
@@ -696,17 +726,17 @@ def side_accumulate(param, fn, *reads):
     return True
 
 
-def weight_grad(w, x, dy, stride, pad, pre_stats=None):
+def weight_grad(w, x, dy, stride, pad, pre_stats=None, seg=0):
     """dW of a convolution for autograd — or None after accumulating it into w.grad on the weight-gradient stream."""
     if not (SIDE_WGRAD and w.is_leaf and w.requires_grad) or _has_hooks(w):
-        return conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats)
+        return conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats, seg=seg)
     sw = _wgrad_stream(x.device)
     sw.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(sw):
         if w.grad is not None and w.grad.is_contiguous() and w.grad.dtype == torch.float32:
-            conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats, acc_into=w.grad)      # += in the slab reduce
+            conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats, acc_into=w.grad, seg=seg)      # += in the slab reduce
         else:
-            dw = conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats)
+            dw = conv_bwd_weight(x, dy, tuple(w.shape), stride, pad, pre_stats, seg=seg)
             if w.grad is None:
                 w.grad = dw
             else:
@@ -723,8 +753,19 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
-def bn_stats_train(part, count, gamma, beta, running_mean, running_var):
+def bn_stats_train(part, count, gamma, beta, running_mean, running_var, seg=None):
+    """seg = (T0, count0): two frame segments - partial rows [0, T0) / [T0, T), count0 / count - count0 elements per channel ->
+    stats [2, 5, C]; the running statistics are not touched (the caller defers both updates: apply_deferred)"""
     T, C, _ = part.shape
+    if seg is not None:
+        T0, count0 = seg
+        if running_mean is not None or running_var is not None:
+            raise ValueError("two frame segments: the running-statistics updates are deferred (ops.set_defer)")
+        stats = _empty((2, 5, C), part)
+        scratch = torch.empty(2 * 64 * 2 * C, dtype=torch.float64, device=part.device)
+        lib().call("lmkd_bn_finalize_seg", _p(part), T, T0, C, count0, count - count0, _p(gamma), _p(beta), _f32(BN_EPS), _p(stats), _p(scratch),
+                   _p(_tickets(part)), _stream())
+        return stats
     stats = _empty((5, C), part)
     scratch = torch.empty(64 * 2 * C, dtype=torch.float64, device=part.device)
     lib().call("lmkd_bn_finalize", _p(part), T, C, count, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
@@ -739,25 +780,35 @@ def bn_stats_eval(gamma, beta, running_mean, running_var):
     return stats
 
 
-def bn_apply(x, stats, relu, res=None, rstats=None, want_bits=False):
-    """-> y, or (y, bits) with want_bits: the packed ReLU mask (y > 0), one bit per element, for bn_backward(mask_mode 3)"""
+def _rows0(t, seg):
+    """rows (pixels) of frame segment 0 of the NHWC tensor t; its row count when there is one segment"""
+    rows = t.numel() // t.shape[-1]
+    seg = _seg_frames(seg, t.shape[0])
+    return seg * (rows // t.shape[0]) if seg else rows
+
+
+def bn_apply(x, stats, relu, res=None, rstats=None, want_bits=False, seg=0):
+    """-> y, or (y, bits) with want_bits: the packed ReLU mask (y > 0), one bit per element, for bn_backward(mask_mode 3).
+    seg = F0 > 0: stats (and rstats) are [2, 5, C], one table per frame segment"""
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty_like(x)
     mode = 0 if res is None else (2 if rstats is not None else 1)
     _chk(x, stats, res, rstats)
     bits = torch.empty(x.numel() // 32, dtype=torch.int32, device=x.device) if want_bits else None
-    lib().call("lmkd_bn_apply", _p(x), _p(stats), _p(res), _p(rstats), _p(y), rows, C, int(relu), mode, _p(bits), _stream())
+    lib().call("lmkd_bn_apply_seg", _p(x), _p(stats), _p(res), _p(rstats), _p(y), rows, _rows0(x, seg), C, int(relu), mode, _p(bits), _stream())
     return (y, bits) if want_bits else y
 
 
-def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None, beta=None, part=None):
+def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None, beta=None, part=None, seg=0):
     """-> dx, g (masked dy) | None, dgamma, dbeta.  mask_mode 1: yact = the activation output; 3: yact = its packed bit mask.
     beta (the BatchNorm bias parameter) given and DIRECT_PARAM_GRAD on: dgamma / dbeta are added into gamma.grad / beta.grad (or
     their side-stream shadows) by the coefficient kernel and None is returned for both.
     part: the reduction already happened in the data gradient that produced dy (conv_bwd_data(bn=...); mask_mode 2, no g)"""
     C = x.shape[-1]
     rows = x.numel() // C
+    seg = _seg_frames(seg, x.shape[0])      # two frame segments: stats [2, 5, C]; part = (tensor, T0)
+    rows0 = _rows0(x, seg)
     _chk(dy, x, yact, stats, gamma)
     dx = dx_out if dx_out is not None else torch.empty_like(x)
     g = torch.empty_like(x) if want_g else None
@@ -765,17 +816,18 @@ def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None,
     tb = _grad_target(beta) if tg is not None else None
     direct = tg is not None and tb is not None
     dgamma, dbeta = (tg, tb) if direct else (_empty((C,), x), _empty((C,), x))
-    coef = _empty((3, C), x)
-    ws = torch.empty(lib().value("lmkd_bn_bwd_workspace", C), dtype=torch.uint8, device=x.device)
+    coef = _empty((2, 5, C) if seg else (3, C), x)
+    ws = torch.empty(lib().value("lmkd_bn_bwd_workspace", C) * (2 if seg else 1), dtype=torch.uint8, device=x.device)
     if part is not None:
         if mask_mode != 2 or want_g:
             raise ValueError("partial sums of the data gradient: mask_mode 2 without g")
+        part, T0 = part if isinstance(part, tuple) else (part, part.shape[0])
         _chk(part)
-        lib().call("lmkd_bn_backward_part", _p(part), part.shape[0], _p(dy), _p(x), _p(stats), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
-                   _p(coef), _p(ws), _p(_tickets(x)), rows, C, int(direct), _stream())
+        lib().call("lmkd_bn_backward_part_seg", _p(part), part.shape[0], T0, _p(dy), _p(x), _p(stats), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
+                   _p(coef), _p(ws), _p(_tickets(x)), rows, rows0, C, int(direct), _stream())
     else:
-        lib().call("lmkd_bn_backward", _p(dy), _p(x), _p(yact), _p(stats), _p(gamma), _p(dx), _p(g), _p(dgamma), _p(dbeta),
-                   _p(coef), _p(ws), _p(_tickets(x)), rows, C, mask_mode, int(direct), _stream())
+        lib().call("lmkd_bn_backward_seg", _p(dy), _p(x), _p(yact), _p(stats), _p(gamma), _p(dx), _p(g), _p(dgamma), _p(dbeta),
+                   _p(coef), _p(ws), _p(_tickets(x)), rows, rows0, C, mask_mode, int(direct), _stream())
     return (dx, g, None, None) if direct else (dx, g, dgamma, dbeta)
 
 
@@ -917,9 +969,21 @@ def _train_pre():
             and (FUSE_PRE_ALL_MODES or cd == 0 or (cd in (2, 3) and PRE_IN_PLANE_MODES)))
 
 
-def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training, pre_stats=None):
+def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training, pre_stats=None, seg=0):
     Cout, _, KH, KW = w.shape
     wp = pack_weights(w, Cs, 0)
+    seg = _seg_frames(seg, x.shape[0]) if training else 0      # eval: one table (the running statistics) for every frame
+    if seg:
+        # both trunk calls of the episode in this launch: per-segment batch statistics -> [2, 5, C]; the two running-statistics updates are
+        # deferred and applied in the reference's order (support call, then query call) by apply_deferred
+        if _DEFER is None:
+            raise RuntimeError("two frame segments need deferred running-statistics updates (ops.set_defer)")
+        y, part, T0 = conv_fwd(x, wp, Cout, KH, KW, stride, pad, True, pre_stats, seg=seg)
+        count = y.numel() // Cout
+        stats = bn_stats_train(part, count, gamma, beta, None, None, seg=(T0, seg * (count // y.shape[0])))
+        _DEFER.append((rm, rv, stats[0]))
+        _DEFER.append((rm, rv, stats[1]))
+        return y, stats
     y, part = conv_fwd(x, wp, Cout, KH, KW, stride, pad, training, pre_stats)
     if training:
         if _DEFER is not None:
@@ -940,7 +1004,8 @@ class StemFn(torch.autograd.Function):
     Input NCHW [F,3,H,W] (the reference's frame layout), output NHWC [F,H/4,W/4,64]."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, rm, rv, training):
+    def forward(ctx, x, w, gamma, beta, rm, rv, training, seg=0):
+        """seg = F0 > 0: frames [0, F0) and [F0, F) of x are the two trunk calls of an episode (two BatchNorm batches, one launch per kernel)"""
         _chk(x, w, gamma, beta, rm, rv)
         if x.dim() == 4 and x.shape[-1] == 4 and x.shape[1] != 3:
             x4 = x.contiguous()                      # already NHWC4 (frames_u8_to_nhwc4)
@@ -951,21 +1016,23 @@ class StemFn(torch.autograd.Function):
                 raise RuntimeError("stem expects 3-channel frames")
             x4 = _empty((F_, H, W, 4), x)
             lib().call("lmkd_nchw3_to_nhwc4", _p(x.contiguous()), _p(x4), F_, H, W, _stream())
-        c, stats = _conv_bn_train_or_eval(x4, w, 4, 2, 3, gamma, beta, rm, rv, training)
+        seg = _seg_frames(seg, F_) if training else 0
+        c, stats = _conv_bn_train_or_eval(x4, w, 4, 2, 3, gamma, beta, rm, rv, training, seg=seg)
         N, Hc, Wc, C = c.shape
         Ho, Wo = conv_out_size(Hc, 3, 2, 1), conv_out_size(Wc, 3, 2, 1)
         y = _empty_act((N, Ho, Wo, C), x)
         idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
         # training: also the raw convolution output at each window's arg-max - the BatchNorm backward then takes its sums from the
         # pooled tensors (lmkd_bn_backward_stats) instead of the 4x larger pre-pooling ones
-        cmax = torch.empty_like(y) if (training and STEM_POOLED_BWD) else None
-        lib().call("lmkd_bn_relu_maxpool_fwd", _p(c), _p(stats), _p(y), _p(idx), _p(cmax), N, Hc, Wc, C, _stream())
+        cmax = torch.empty_like(y) if (training and (STEM_POOLED_BWD or seg)) else None
+        lib().call("lmkd_bn_relu_maxpool_fwd_seg", _p(c), _p(stats), _p(y), _p(idx), _p(cmax), N, seg if seg else N, Hc, Wc, C, _stream())
         if BLOCK_TAPS is not None:
-            BLOCK_TAPS.append({"stem_c": c, "stem_st": stats, "stem_idx": idx})
+            BLOCK_TAPS.append({"stem_c": c, "stem_st": stats, "stem_idx": idx, "seg": seg})
         if training:
             ctx.save_for_backward(x4, c, stats, idx, gamma, w, cmax)
             ctx.beta = beta
         ctx.training = training
+        ctx.seg = seg
         return y
 
     @staticmethod
@@ -975,7 +1042,25 @@ class StemFn(torch.autograd.Function):
         x4, c, stats, idx, gamma, w, cmax = ctx.saved_tensors
         dy = dy.contiguous()
         N, Hc, Wc, C = c.shape
-        if cmax is not None:
+        seg = ctx.seg
+        if seg:
+            # both trunk calls: sums per segment in one reduce + one coefficient launch, then one fused un-pool + BatchNorm-backward pass
+            # that also adds (segment 0 + segment 1) into the BatchNorm parameter gradients
+            tg = _grad_target(gamma)
+            tb = _grad_target(ctx.beta) if tg is not None else None
+            direct = tg is not None and tb is not None
+            dgamma, dbeta = (tg, tb) if direct else (_empty((C,), c), _empty((C,), c))
+            coef = _empty((2, 5, C), c)
+            ws = torch.empty(2 * lib().value("lmkd_bn_bwd_workspace", C), dtype=torch.uint8, device=c.device)
+            prow, crow = dy.numel() // C // N, c.numel() // C // N
+            lib().call("lmkd_bn_backward_stats_seg", _p(dy), _p(cmax), _p(stats), _p(gamma), _p(coef), _p(ws), _p(_tickets(c)),
+                       N * prow, seg * prow, N * crow, seg * crow, C, _stream())
+            dc = torch.empty_like(c)
+            lib().call("lmkd_stem_unpool_bn_bwd_seg", _p(dy), _p(idx), _p(c), _p(stats), _p(coef), _p(dc), _p(dgamma), _p(dbeta), int(direct),
+                       N, seg, Hc, Wc, C, _stream())
+            if direct:
+                dgamma = dbeta = None
+        elif cmax is not None:
             # sums of the BatchNorm backward over the pooled tensors, then max-pool backward + BatchNorm backward apply in one pass:
             # the 642 MB pre-pooling gradient is never written
             tg = _grad_target(gamma)
@@ -995,7 +1080,31 @@ class StemFn(torch.autograd.Function):
             lib().call("lmkd_maxpool_bwd", _p(dy), _p(idx), _p(g), N, Hc, Wc, C, _stream())
             dc, _, dgamma, dbeta = bn_backward(g, c, None, stats, gamma, 2, dx_out=g, beta=ctx.beta)
         dw = weight_grad(w, x4, dc, 2, 3)
-        return None, dw, dgamma, dbeta, None, None, None
+        return None, dw, dgamma, dbeta, None, None, None, None
+
+
+def frames_pair_to_nhwc4(a, b):
+    """the support frames followed by the query frames as ONE NHWC4 tensor [Fa + Fb, H, W, 4] (the stem's input layout; merged trunk call).
+    Either input may be NCHW [F, 3, H, W] float frames (the reference's layout) or already NHWC4."""
+    _chk(a, b)
+
+    def geom(t):
+        if t.dim() == 4 and t.shape[-1] == 4 and t.shape[1] != 3:
+            return t.shape[0], t.shape[1], t.shape[2], True
+        if t.dim() != 4 or t.shape[1] != 3:
+            raise RuntimeError("stem expects 3-channel frames")
+        return t.shape[0], t.shape[2], t.shape[3], False
+    Fa, H, W, a4 = geom(a)
+    Fb, Hb, Wb, b4 = geom(b)
+    if (H, W) != (Hb, Wb):
+        raise RuntimeError("support and query frames differ in size")
+    out = _empty((Fa + Fb, H, W, 4), a)
+    for t, is4, dst, F_ in ((a, a4, out[:Fa], Fa), (b, b4, out[Fa:], Fb)):
+        if is4:
+            dst.copy_(t)
+        else:
+            lib().call("lmkd_nchw3_to_nhwc4", _p(t.contiguous()), _p(dst), F_, H, W, _stream())
+    return out
 
 
 def frames_u8_to_nhwc4(frames_u8, crop_y, crop_x, flip, size, frames_per_video=8, out=None):
@@ -1068,13 +1177,33 @@ def resize_frames_u8(frames_u8, size):
 BLOCK_TAPS = None
 
 
+def split_block_taps(taps):
+    """taps of a merged trunk call (entries over both frame segments, "seg" = frames of the first) -> the list two separate calls would
+    have left: every entry of the support-frame call, then every entry of the query-frame call (tensors sliced, [2, 5, C] tables split)"""
+    if not any(t.get("seg") for t in taps):
+        return [{k: v for k, v in t.items() if k != "seg"} for t in taps]
+    calls = ([], [])
+    for t in taps:
+        s = t["seg"]
+        for k in (0, 1):
+            d = {}
+            for key, v in t.items():
+                if key == "seg":
+                    continue
+                d[key] = v[k] if key in ("stem_st", "st1") else (v[:s] if k == 0 else v[s:])
+            calls[k].append(d)
+    return calls[0] + calls[1]
+
+
 class BasicBlockFn(torch.autograd.Function):
     """torchvision BasicBlock: conv3x3-BN-ReLU-conv3x3-BN (+1x1/2 conv-BN downsample) + add + ReLU.
     One autograd node per block; backward is hand-scheduled so that the masked gradient buffer
     of the residual branch is reused as the block-input gradient accumulator."""
 
     @staticmethod
-    def forward(ctx, x, stride, training, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, wd, gd, bd, rmd, rvd):
+    def forward(ctx, x, stride, training, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, wd, gd, bd, rmd, rvd, seg=0):
+        """seg = F0 > 0: frames [0, F0) | [F0, F) of x are the two trunk calls of an episode - one launch per kernel for both, per-segment
+        BatchNorm statistics ([2, 5, C] tables), bit-identical activations and activation gradients to two calls"""
         _chk(x, w1, w2, wd)
         Cs = x.shape[-1]
         if not training and _eval_fused():
@@ -1084,30 +1213,32 @@ class BasicBlockFn(torch.autograd.Function):
             return conv_bn_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, True, r)
         fused = training and _train_fused()
         pre = training and _train_pre()
-        c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, stride, 1, g1, b1, rm1, rv1, training)
+        seg = _seg_frames(seg, x.shape[0]) if training else 0
+        c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, stride, 1, g1, b1, rm1, rv1, training, seg=seg)
         if pre:         # conv2 normalises + rectifies c1 in its loader: a1 = relu(bn1(c1)) is never stored
             a1 = None
-            c2, st2 = _conv_bn_train_or_eval(c1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training, pre_stats=st1)
+            c2, st2 = _conv_bn_train_or_eval(c1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training, pre_stats=st1, seg=seg)
         else:
-            a1 = bn_apply(c1, st1, True)
-            c2, st2 = _conv_bn_train_or_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training)
+            a1 = bn_apply(c1, st1, True, seg=seg)
+            c2, st2 = _conv_bn_train_or_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training, seg=seg)
         if wd is not None:
-            cd, std = _conv_bn_train_or_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, training)
+            cd, std = _conv_bn_train_or_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, training, seg=seg)
             res, rst = cd, std
         else:
             cd = std = None
             res, rst = x, None
         if fused:
-            y, ybits = bn_apply(c2, st2, True, res, rst, want_bits=True)
+            y, ybits = bn_apply(c2, st2, True, res, rst, want_bits=True, seg=seg)
         else:
-            y, ybits = bn_apply(c2, st2, True, res, rst), None
+            y, ybits = bn_apply(c2, st2, True, res, rst, seg=seg), None
         ctx.training = training
+        ctx.seg = seg
         ctx.stride = stride
         ctx.has_ds = wd is not None
         ctx.fused = fused
         ctx.betas = (b1, b2, bd)      # BatchNorm biases: the backward may add their gradients straight into .grad (DIRECT_PARAM_GRAD)
         if BLOCK_TAPS is not None:
-            BLOCK_TAPS.append({"c1": c1, "st1": st1, "y": y})
+            BLOCK_TAPS.append({"c1": c1, "st1": st1, "y": y, "seg": seg})
         if training:
             # fused: the backward needs neither a1 (recomputed from c1 in the weight-gradient loader) nor y (its mask travels as bits)
             ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, ybits if fused else y, wd, gd, cd, std)
@@ -1120,33 +1251,34 @@ class BasicBlockFn(torch.autograd.Function):
         x, w1, g1, c1, st1, a1, w2, g2, c2, st2, y, wd, gd, cd, std = ctx.saved_tensors
         dy = dy.contiguous()
         stride = ctx.stride
+        seg = ctx.seg
         Cmid = w1.shape[0]
         # bn2 (+ReLU mask from y, or from its bits); g = masked dy = gradient of both residual branches
-        dc2, g, dg2, db2 = bn_backward(dy, c2, y, st2, g2, 3 if ctx.fused else 1, want_g=True, beta=ctx.betas[1])
+        dc2, g, dg2, db2 = bn_backward(dy, c2, y, st2, g2, 3 if ctx.fused else 1, want_g=True, beta=ctx.betas[1], seg=seg)
         wd2 = pack_weights(w2, Cmid, 1)
         # first: its stream then waits for the BatchNorm backward only, not for the data gradient
-        dw2 = weight_grad(w2, c1, dc2, 1, 1, st1) if a1 is None else weight_grad(w2, a1, dc2, 1, 1)
-        da1, part1 = conv_bwd_data(dc2, wd2, c1.shape, Cmid, 3, 3, 1, 1, bn=(c1, st1))      # + bn1's backward sums where the launch has the form
+        dw2 = weight_grad(w2, c1, dc2, 1, 1, st1, seg=seg) if a1 is None else weight_grad(w2, a1, dc2, 1, 1, seg=seg)
+        da1, part1 = conv_bwd_data(dc2, wd2, c1.shape, Cmid, 3, 3, 1, 1, bn=(c1, st1), seg=seg)      # + bn1's backward sums where the launch has the form
         del dc2
-        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1, beta=ctx.betas[0], part=part1)    # mask from c1*scale+shift > 0
-        dw1 = weight_grad(w1, x, dc1, stride, 1)
+        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1, beta=ctx.betas[0], part=part1, seg=seg)    # mask from c1*scale+shift > 0
+        dw1 = weight_grad(w1, x, dc1, stride, 1, seg=seg)
         dwd = dgd = dbd = None
         need_dx = ctx.needs_input_grad[0]
         dx = None
         if ctx.has_ds:
-            dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g, beta=ctx.betas[2])
-            dwd = weight_grad(wd, x, dcd, stride, 0)
+            dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g, beta=ctx.betas[2], seg=seg)
+            dwd = weight_grad(wd, x, dcd, stride, 0, seg=seg)
             if need_dx:
                 # the 3x3 gradient writes every input pixel; the 1x1 stride-2 one then accumulates onto the quarter of the
                 # pixels it reaches (parity classes without a tap launch nothing) instead of writing three quarters of zeros
-                dx = conv_bwd_data(dc1, pack_weights(w1, Cmid, 1), x.shape, Cmid, 3, 3, stride, 1)
-                conv_bwd_data(dcd, pack_weights(wd, Cmid, 1), x.shape, Cmid, 1, 1, stride, 0, out=dx, accumulate=True)
+                dx = conv_bwd_data(dc1, pack_weights(w1, Cmid, 1), x.shape, Cmid, 3, 3, stride, 1, seg=seg)
+                conv_bwd_data(dcd, pack_weights(wd, Cmid, 1), x.shape, Cmid, 1, 1, stride, 0, out=dx, accumulate=True, seg=seg)
         else:
             dx = g                                    # identity branch
             if need_dx:
-                conv_bwd_data(dc1, pack_weights(w1, Cmid, 1), x.shape, Cmid, 3, 3, stride, 1, out=dx, accumulate=True)   # dx += dgrad(conv1)
+                conv_bwd_data(dc1, pack_weights(w1, Cmid, 1), x.shape, Cmid, 3, 3, stride, 1, out=dx, accumulate=True, seg=seg)   # dx += dgrad(conv1)
         return (dx if need_dx else None, None, None, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None,
-                dwd, dgd, dbd, None, None)
+                dwd, dgd, dbd, None, None, None)
 
 
 class BottleneckFn(torch.autograd.Function):
@@ -1155,7 +1287,7 @@ class BottleneckFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, stride, training, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3,
-                wd, gd, bd, rmd, rvd):
+                wd, gd, bd, rmd, rvd, seg=0):
         _chk(x, w1, w2, w3, wd)
         Cs = x.shape[-1]
         Cm = w1.shape[0]
@@ -1167,27 +1299,29 @@ class BottleneckFn(torch.autograd.Function):
             return conv_bn_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, True, r)
         fused = training and _train_fused()
         pre = training and _train_pre()
-        c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, 1, 0, g1, b1, rm1, rv1, training)
+        seg = _seg_frames(seg, x.shape[0]) if training else 0      # two frame segments (BasicBlockFn)
+        c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, 1, 0, g1, b1, rm1, rv1, training, seg=seg)
         if pre:         # conv2 / conv3 normalise + rectify their raw inputs in the loader (BasicBlockFn)
             a1 = a2 = None
-            c2, st2 = _conv_bn_train_or_eval(c1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training, pre_stats=st1)
-            c3, st3 = _conv_bn_train_or_eval(c2, w3, Cm, 1, 0, g3, b3, rm3, rv3, training, pre_stats=st2)
+            c2, st2 = _conv_bn_train_or_eval(c1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training, pre_stats=st1, seg=seg)
+            c3, st3 = _conv_bn_train_or_eval(c2, w3, Cm, 1, 0, g3, b3, rm3, rv3, training, pre_stats=st2, seg=seg)
         else:
-            a1 = bn_apply(c1, st1, True)
-            c2, st2 = _conv_bn_train_or_eval(a1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training)
-            a2 = bn_apply(c2, st2, True)
-            c3, st3 = _conv_bn_train_or_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, training)
+            a1 = bn_apply(c1, st1, True, seg=seg)
+            c2, st2 = _conv_bn_train_or_eval(a1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training, seg=seg)
+            a2 = bn_apply(c2, st2, True, seg=seg)
+            c3, st3 = _conv_bn_train_or_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, training, seg=seg)
         if wd is not None:
-            cd, std = _conv_bn_train_or_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, training)
+            cd, std = _conv_bn_train_or_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, training, seg=seg)
             res, rst = cd, std
         else:
             cd = std = None
             res, rst = x, None
         if fused:
-            y, ybits = bn_apply(c3, st3, True, res, rst, want_bits=True)
+            y, ybits = bn_apply(c3, st3, True, res, rst, want_bits=True, seg=seg)
         else:
-            y, ybits = bn_apply(c3, st3, True, res, rst), None
+            y, ybits = bn_apply(c3, st3, True, res, rst, seg=seg), None
         ctx.training, ctx.stride, ctx.has_ds, ctx.fused = training, stride, wd is not None, fused
+        ctx.seg = seg
         ctx.betas = (b1, b2, b3, bd)
         if training:
             ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, a2, w3, g3, c3, st3, ybits if fused else y, wd, gd, cd, std)
@@ -1201,32 +1335,33 @@ class BottleneckFn(torch.autograd.Function):
         dy = dy.contiguous()
         stride = ctx.stride
         fused = ctx.fused
+        seg = ctx.seg
         Cm, Co = w1.shape[0], w3.shape[0]
-        dc3, g, dg3, db3 = bn_backward(dy, c3, y, st3, g3, 3 if fused else 1, want_g=True, beta=ctx.betas[2])
-        dw3 = weight_grad(w3, c2, dc3, 1, 0, st2) if a2 is None else weight_grad(w3, a2, dc3, 1, 0)       # weight gradients first (BasicBlockFn)
-        da2, part2 = conv_bwd_data(dc3, pack_weights(w3, Cm, 1), c2.shape, Co, 1, 1, 1, 0, bn=(c2, st2))
+        dc3, g, dg3, db3 = bn_backward(dy, c3, y, st3, g3, 3 if fused else 1, want_g=True, beta=ctx.betas[2], seg=seg)
+        dw3 = weight_grad(w3, c2, dc3, 1, 0, st2, seg=seg) if a2 is None else weight_grad(w3, a2, dc3, 1, 0, seg=seg)       # weight gradients first (BasicBlockFn)
+        da2, part2 = conv_bwd_data(dc3, pack_weights(w3, Cm, 1), c2.shape, Co, 1, 1, 1, 0, bn=(c2, st2), seg=seg)
         del dc3
-        dc2, _, dg2, db2 = bn_backward(da2, c2, None, st2, g2, 2, dx_out=da2, beta=ctx.betas[1], part=part2)
-        dw2 = weight_grad(w2, c1, dc2, stride, 1, st1) if a1 is None else weight_grad(w2, a1, dc2, stride, 1)
-        da1, part1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), c1.shape, Cm, 3, 3, stride, 1, bn=(c1, st1))
+        dc2, _, dg2, db2 = bn_backward(da2, c2, None, st2, g2, 2, dx_out=da2, beta=ctx.betas[1], part=part2, seg=seg)
+        dw2 = weight_grad(w2, c1, dc2, stride, 1, st1, seg=seg) if a1 is None else weight_grad(w2, a1, dc2, stride, 1, seg=seg)
+        da1, part1 = conv_bwd_data(dc2, pack_weights(w2, Cm, 1), c1.shape, Cm, 3, 3, stride, 1, bn=(c1, st1), seg=seg)
         del dc2, da2
-        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1, beta=ctx.betas[0], part=part1)
-        dw1 = weight_grad(w1, x, dc1, 1, 0)
+        dc1, _, dg1, db1 = bn_backward(da1, c1, None, st1, g1, 2, dx_out=da1, beta=ctx.betas[0], part=part1, seg=seg)
+        dw1 = weight_grad(w1, x, dc1, 1, 0, seg=seg)
         dwd = dgd = dbd = None
         need_dx = ctx.needs_input_grad[0]
         dx = None
         if ctx.has_ds:
-            dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g, beta=ctx.betas[3])
-            dwd = weight_grad(wd, x, dcd, stride, 0)
+            dcd, _, dgd, dbd = bn_backward(g, cd, None, std, gd, 0, dx_out=g, beta=ctx.betas[3], seg=seg)
+            dwd = weight_grad(wd, x, dcd, stride, 0, seg=seg)
             if need_dx:      # conv1's gradient first (writes every pixel), the strided downsample one accumulates (BasicBlockFn)
-                dx = conv_bwd_data(dc1, pack_weights(w1, x.shape[-1], 1), x.shape, Cm, 1, 1, 1, 0)
-                conv_bwd_data(dcd, pack_weights(wd, x.shape[-1], 1), x.shape, Co, 1, 1, stride, 0, out=dx, accumulate=True)
+                dx = conv_bwd_data(dc1, pack_weights(w1, x.shape[-1], 1), x.shape, Cm, 1, 1, 1, 0, seg=seg)
+                conv_bwd_data(dcd, pack_weights(wd, x.shape[-1], 1), x.shape, Co, 1, 1, stride, 0, out=dx, accumulate=True, seg=seg)
         else:
             dx = g
             if need_dx:
-                conv_bwd_data(dc1, pack_weights(w1, x.shape[-1], 1), x.shape, Cm, 1, 1, 1, 0, out=dx, accumulate=True)
+                conv_bwd_data(dc1, pack_weights(w1, x.shape[-1], 1), x.shape, Cm, 1, 1, 1, 0, out=dx, accumulate=True, seg=seg)
         return (dx if need_dx else None, None, None, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None,
-                dw3, dg3, db3, None, None, dwd, dgd, dbd, None, None)
+                dw3, dg3, db3, None, None, dwd, dgd, dbd, None, None, None)
 
 
 class PoolHeadFn(torch.autograd.Function):

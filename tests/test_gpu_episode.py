@@ -127,7 +127,7 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
     ops.BLOCK_TAPS = [] if impose else None
     try:
         out = student(ep["support_set"].to(dev), ep["support_labels"].to(dev), ep["target_set"].to(dev))
-        taps = ops.BLOCK_TAPS
+        taps = ops.split_block_taps(ops.BLOCK_TAPS) if impose else None      # merged trunk call (the default): per-call entries, oracle order
     finally:
         R.OVERLAP_TRUNK_CALLS, ops.BLOCK_TAPS = overlap, None
     tl = teacher(ep["support_set_feature_teacher"].to(dev), ep["support_labels"].to(dev), ep["target_set_feature_teacher"].to(dev))["logits"]
