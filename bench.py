@@ -116,6 +116,7 @@ def main():
     from litemkd_amd.utils import aggregate_accuracy
     from litemkd_amd.model.backbone import resnet as R
     R.OVERLAP_TRUNK_CALLS = (not a.serial) and os.environ.get("LMKD_OVERLAP", "1") != "0"
+    R.MERGE_TRUNK_CALLS = os.environ.get("LMKD_MERGE", "0") == "1"      # both trunk calls as one launch per layer (round 4; measured slower than the two-stream two-call schedule: resnet.py)
     ops.SIDE_WGRAD = (not a.serial) and os.environ.get("LMKD_SIDE_WGRAD", "1") != "0"   # weight gradients on a third stream
     ops.SYNC_WGRAD_AT_BACKWARD_END = os.environ.get("LMKD_SYNC_WG", "0") == "1"           # FusedOptimizer waits for them itself
     TL.TEACHER_STREAM = os.environ.get("LMKD_TEACHER_STREAM", "1") != "0"                  # tuning switches of the round-3 schedule changes
@@ -265,6 +266,7 @@ def main():
     t_enq = time.perf_counter() - t0                 # host time to enqueue the timed region (before the fence)
     fence()
     dt = time.perf_counter() - t0
+    opt_steps_timed = opt.steps - steps0             # read HERE: the repeat and host-idle passes below step the optimizer too
     timed_events, ops.CONV_TIMING = (ops.CONV_TIMING or []), None
     # the same K steps once more, timed the same way (barrier + synchronize on both sides), WITHOUT the per-launch HIP events of the
     # roofline bookkeeping: reported as `repeat` (never as `value`) - two figures that agree say the timed region was undisturbed
@@ -288,7 +290,6 @@ def main():
     fence()
     host_idle /= 4
     ar_events, PAR.ALLREDUCE_TIMING = PAR.ALLREDUCE_TIMING, None
-    opt_steps_timed = opt.steps - steps0
     dist_info = {"backend": None, "world": world, "devices": [torch.cuda.get_device_name(dev)], "allreduce_ms_per_optimizer_step": None,
                  "optimizer_steps_in_timed_region": opt_steps_timed, "allreduce_bucket_bytes": opt.bucket.numel * 4}
     if world > 1:

@@ -152,9 +152,18 @@ _BN_UPDATE_EVENT = {}
 # is launched once for both calls, each call still normalises with its OWN batch statistics ([2][5][C] tables; the row tiles of the
 # convolutions are dealt per segment, so activations and activation gradients are bit-identical to two separate calls), weight and
 # BatchNorm-parameter gradients are summed over both calls in one pass.  Half the trunk's launches (431 -> ~250 per episode), grids of
-# twice the size, no second stream / shadow gradient buffer for the query call.  The default wherever the arithmetic has the two-segment
-# kernels (the bf16-plane modes: fp32-as-3xbf16 and bf16); the native fp32 MFMA mode keeps the two-call schedule below.
-MERGE_TRUNK_CALLS = True
+# twice the size, no second stream / shadow gradient buffer for the query call.  Exists wherever the arithmetic has the two-segment
+# kernels (the bf16-plane modes: fp32-as-3xbf16 and bf16).
+# OFF by default - measured, same box, alternating processes (profiles/r04_merge_ab.txt): 36.0 episodes/s merged against 36.8 on the
+# two-call two-stream schedule (bf16 tensors: 70.7 against 75.7), although the serialized patch-kernel rate rises from 0.447 to 0.478 of its
+# roofline and the host enqueues an episode in 7 ms instead of 11.  The kernel trace says why (profiles/r04_merge_trace.txt): no single
+# kernel fills the chip (MFMA busy 54 - 62 %), and three streams of half-size launches co-schedule complementary kernels (one call's
+# convolutions beside the other's BatchNorm passes and the weight gradients) all the time, while the merged chain has a partner only
+# during the backward pass: its main stream is busy 96 % of the wall time - it IS the critical path - with the weight-gradient stream
+# idle 42 %.  tools/tail_probe.py had predicted it per layer (profiles/r04_tail_probe.txt: one 400-frame launch = two concurrent
+# 200-frame launches +- 3 %, layer 3 excepted).  For hosts short of cores (7 ms instead of 11 per episode) and as the base of a
+# persistent-kernel schedule; tests/test_gpu_merged.py keeps it bit-identical to the two-call path.
+MERGE_TRUNK_CALLS = False
 
 
 def merge_supported(trunk, context_frames, target_frames):

@@ -162,7 +162,7 @@ def _trunk_pair(dev, bb, Fs, Fq, img, mode, act, seed=0):
             assert n0 == Fs
             X.backward(gout)
         finally:
-            R.MERGE_TRUNK_CALLS, R.OVERLAP_TRUNK_CALLS = True, True
+            R.MERGE_TRUNK_CALLS, R.OVERLAP_TRUNK_CALLS = False, True
         torch.cuda.synchronize()
         out[merged] = (X.detach().clone(), {n: p.grad.clone() for n, p in trunk.named_parameters()},
                        {n: b.clone() for n, b in trunk.named_buffers()})

@@ -1,6 +1,6 @@
 """Reads a rocprofv3 kernel-trace CSV of the (overlapped, three-stream) benchmark and reports, for the last `--episodes` episodes'
 worth of time: GPU busy time (union of kernel intervals), sum of kernel durations, and the per-kernel totals.
-usage: python tools/overlap_trace.py <r_kernel_trace.csv> [t_skip_fraction]"""
+usage: python tools/overlap_trace.py <r_kernel_trace.csv> [t_skip_fraction [t_end_fraction]]"""
 import csv, sys, collections
 rows = []
 with open(sys.argv[1]) as f:
@@ -9,7 +9,8 @@ with open(sys.argv[1]) as f:
 rows.sort()
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
 t_lo = rows[0][0] + (rows[-1][1] - rows[0][0]) * skip
-rows = [r for r in rows if r[0] >= t_lo]
+t_hi = rows[0][0] + (rows[-1][1] - rows[0][0]) * (float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
+rows = [r for r in rows if t_lo <= r[0] <= t_hi]
 span = rows[-1][1] - rows[0][0]
 busy, cur_s, cur_e = 0, rows[0][0], rows[0][1]
 for s, e, _ in rows[1:]:

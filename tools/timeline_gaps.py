@@ -1,12 +1,13 @@
 """GPU busy/idle from a rocprofv3 --kernel-trace csv: union of kernel intervals, gaps, per-stream busy.
-usage: timeline_gaps.py kernel_trace.csv [skip_fraction]"""
+usage: timeline_gaps.py kernel_trace.csv [skip_fraction [end_fraction]]"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "0"))) for r in rows))
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
 t0, t1 = ev[0][0], max(e[1] for e in ev)
 lo = t0 + (t1 - t0) * skip
-ev = [e for e in ev if e[0] >= lo]
+hi = t0 + (t1 - t0) * (float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
+ev = [e for e in ev if lo <= e[0] <= hi]
 span = max(e[1] for e in ev) - ev[0][0]
 busy, cur_s, cur_e, gaps = 0, ev[0][0], ev[0][1], []
 for s, e, n, q in ev[1:]:
