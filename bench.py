@@ -115,13 +115,13 @@ def main():
     from litemkd_amd.options import default_args
     from litemkd_amd.utils import aggregate_accuracy
     from litemkd_amd.model.backbone import resnet as R
-    R.OVERLAP_TRUNK_CALLS = (not a.serial) and os.environ.get("LMKD_OVERLAP", "1") != "0"
-    R.MERGE_TRUNK_CALLS = os.environ.get("LMKD_MERGE", "0") == "1"      # both trunk calls as one launch per layer (round 4; measured slower than the two-stream two-call schedule: resnet.py)
-    ops.SIDE_WGRAD = (not a.serial) and os.environ.get("LMKD_SIDE_WGRAD", "1") != "0"   # weight gradients on a third stream
-    ops.SYNC_WGRAD_AT_BACKWARD_END = os.environ.get("LMKD_SYNC_WG", "0") == "1"           # FusedOptimizer waits for them itself
-    TL.TEACHER_STREAM = os.environ.get("LMKD_TEACHER_STREAM", "1") != "0"                  # tuning switches of the round-3 schedule changes
-    ops.HEADS_ON_TWO_STREAMS = os.environ.get("LMKD_HEADS2", "1") != "0"
-    ops.STEM_POOLED_BWD = os.environ.get("LMKD_STEM_POOLED", "1") != "0"
+    # the schedule the benchmark times: ONE object (lite-mkd_amd/schedule.py; defaults = Schedule.bench(), LMKD_* variables override single
+    # switches for A/B runs) - tests/test_gpu_schedule.py compares exactly this schedule with the serial one at the benchmark's size
+    from litemkd_amd.schedule import Schedule
+    SCHED = Schedule.from_env()
+    if a.serial:
+        SCHED.overlap_trunk_calls = SCHED.side_wgrad = False
+    SCHED.apply(arithmetic=False)
     if os.environ.get("LMKD_PRIO"):                                                         # stream priorities "lane0,lane1,wgrad" (-1 high, 0 default)
         pr = [int(v) for v in os.environ["LMKD_PRIO"].split(",")]
         ops.STREAM_PRIORITY.update({0: pr[0], 1: pr[1], "wgrad": pr[2]})
@@ -131,15 +131,6 @@ def main():
         ops.lib().call("lmkd_conv_set_s2_patch", 0)
     if os.environ.get("LMKD_WIN16", "1") == "0":                                          # rolling-window weight gradient back on the 32x32x16 MFMA
         ops.lib().call("lmkd_conv_set_wgrad_win16", 0)
-    ops.TRX_PROJ_ON_CONV = os.environ.get("LMKD_TRX_CONV", "0") == "1"                        # TRX projections + their input gradient as 1x1 convolutions
-    TL.REPACK_AT_STEP = os.environ.get("LMKD_REPACK", "1") != "0"                             # all weight packs re-packed by one launch at the optimizer step
-    ops.FUSE_TWO_HEAD_LINEAR = os.environ.get("LMKD_FC_FUSED", "1") != "0"                    # fc1 / fc2 of both trunk calls as one autograd node
-    ops.SIDE_LINEAR_WGRAD = os.environ.get("LMKD_SIDE_LINEAR", "1") != "0"                   # Linear / TRX weight-gradient GEMMs on the weight-gradient stream
-    ops.GEMM_SPLIT_K = os.environ.get("LMKD_GEMM_SPLIT", "0") == "1"                         # split-K for the head's small GEMMs
-    ops.DGRAD_BN_STATS = os.environ.get("LMKD_DGRAD_BN", "1") != "0"                       # BatchNorm-backward sums in the data gradient's epilogue
-    ops.PRE_IN_PLANE_MODES = os.environ.get("LMKD_PRE_X3", "1") != "0"
-    ops.FUSE_PRE_ALL_MODES = os.environ.get("LMKD_FUSE_PRE", "0") == "1"                   # inner BatchNorm + ReLU in the consumers' loaders also in the plane modes
-    ops.DIRECT_PARAM_GRAD = os.environ.get("LMKD_DIRECT_GRAD", "1") != "0"               # BatchNorm / Linear / TRX parameter gradients added into .grad by the kernels
 
     from litemkd_amd import parallel as PAR
     rank, world, dev = init_distributed()
@@ -331,8 +322,8 @@ def main():
         opt.zero_grad()
         fence()
         rec, ops.CONV_TIMING = ops.CONV_TIMING, None
-        R.OVERLAP_TRUNK_CALLS = True
-        ops.SIDE_WGRAD = os.environ.get("LMKD_SIDE_WGRAD", "1") != "0"
+        R.OVERLAP_TRUNK_CALLS = SCHED.overlap_trunk_calls
+        ops.SIDE_WGRAD = SCHED.side_wgrad
         return rec
 
     def families(rec):

@@ -678,6 +678,21 @@ def wait_weight_grads():
             torch.cuda.default_stream(dev).wait_stream(sw)
 
 
+def join_all_streams():
+    """make the current stream wait for EVERY stream this module has created on its device - the weight-gradient stream, the side /
+    auxiliary / lane-main streams of every lane.  The optimizer calls it before it reads or zeroes the gradient buffers (and their
+    shadow): kernels on the side and auxiliary streams add parameter gradients directly (DIRECT_PARAM_GRAD), hand autograd None, and are
+    therefore NOT joined to the caller's stream by the autograd engine; that the stem's weight gradient happens to order the side stream
+    before the weight-gradient stream is not something to rely on (a frozen or hooked stem weight breaks it)."""
+    cur = torch.cuda.current_stream()
+    dev = cur.device.index if hasattr(cur, "device") and cur.device is not None else torch.cuda.current_device()
+    wait_weight_grads()
+    for table in (_side_streams, _aux_streams, _lane_mains):
+        for key, s in table.items():
+            if key[1] == dev and s.cuda_stream != cur.cuda_stream:
+                cur.wait_stream(s)
+
+
 def _end_of_backward():
     _WG_CB[0] = None
     wait_weight_grads()

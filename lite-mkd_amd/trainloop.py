@@ -30,14 +30,14 @@ class FusedOptimizer:
             raise KeyError(opt)
 
     def zero_grad(self):
-        ops.wait_weight_grads()             # weight gradients accumulate on their own stream (ops.SIDE_WGRAD)
+        ops.join_all_streams()              # weight gradients (ops.SIDE_WGRAD) and direct parameter gradients (side / auxiliary streams) in flight
         self.bucket.zero_grad()
 
     def step(self):
         b = self.bucket
-        ops.wait_weight_grads()
-        if ops.DIRECT_PARAM_GRAD:
-            b.fold_shadow()                 # gradients the side stream's kernels accumulated directly (ops.DIRECT_PARAM_GRAD)
+        ops.join_all_streams()              # every stream that writes the gradient buffer or its shadow, or reads the packs re-packed below
+        b.fold_shadow()                     # gradients the side / auxiliary streams' kernels accumulated directly (ops.DIRECT_PARAM_GRAD);
+                                            # unconditionally: the flag may have been switched off since they were written
         b.allreduce_grads()
         self.steps += 1
         ops.WEIGHT_EPOCH[0] += 1            # invalidates the packed-weight cache (raw-pointer update below)
@@ -242,8 +242,15 @@ class PipelinedEpisodes:
                 if self.bwd_done is not None:
                     main.wait_event(self.bwd_done)       # gradients accumulate in episode order
                 loss.backward(retain_graph=False)
+                # the lane's side / auxiliary streams wrote parameter gradients directly (autograd got None and joined nothing): the
+                # event that orders the NEXT backward's accumulations must cover them
+                d = torch.device(dev)
+                for table in (ops._side_streams, ops._aux_streams):
+                    s = table.get((d.type, d.index if d.index is not None else torch.cuda.current_device(), lane))
+                    if s is not None:
+                        main.wait_stream(s)
                 ev = torch.cuda.Event()
-                ev.record(main)                          # (the autograd engine has joined the lane's other streams into `main`)
+                ev.record(main)
                 self.bwd_done = ev
         finally:
             ops.set_lane(0)
@@ -273,7 +280,7 @@ class TestAccuracies:
         self.datasets = list(test_sets)
 
 
-def make(config, video_loader=None, base_seed=0):
+def make(config, video_loader=None, base_seed=0, schedule=None):
     """trainwandb.py:78-109: everything the training loop needs, built from the reference's args namespace in the reference's order -
     -> (student, teacher, video_loader, distillers, accuracy_fn, test_accuracies, optimizer, scheduler), the reference's tuple.
     Differences that are the point of this build: the optimizer is FusedOptimizer (SGD / Adam kernels on the flat parameter and
@@ -283,6 +290,8 @@ def make(config, video_loader=None, base_seed=0):
     from .distillers import Distiller
     from .parallel import rank as _rank
     from .utils import aggregate_accuracy
+    if schedule is not None:      # the arithmetic mode and every schedule switch in one object (schedule.Schedule), installed process-wide
+        schedule.apply()
     student, teacher = init_model(config)
     test_set = [config.dataset]
     if video_loader is None:
@@ -359,8 +368,10 @@ class GraphedEpisode:
         finally:
             ops.SEED_SLOTS = None
             ops.SYNC_WGRAD_AT_BACKWARD_END = prev_sync
+        # the entry HOLDS the episode's tensors (their addresses cannot be recycled while it lives) and remembers their in-place
+        # versions: a replay is only valid for these very tensors with unchanged contents (_resident)
         ent = {"graph": g, "slots": slots, "loss": loss, "acc": acc, "prepared": prepared, "plan": plan, "counts": tuple(plan.counts),
-               "task": task_dict}
+               "task": task_dict, "versions": tuple(task_dict[k]._version for k in self.KEYS)}
         self.graphs[key] = ent
         return ent
 
@@ -368,13 +379,21 @@ class GraphedEpisode:
         self.eager += 1
         return train_task(task_dict, self.student, self.teacher, self.distiller, self.accuracy_fn, self.config)
 
+    def _resident(self, ent, task_dict):
+        """is this call about the very tensors the entry was captured on, unmodified since?  (The key is made of addresses: a loader that
+        hands out FRESH device tensors gets recycled allocator addresses, and one that refills static buffers in place keeps them - in
+        both cases the captured class plan, label copies and host-side label derivations would be stale.)"""
+        return (all(task_dict[k] is ent["task"][k] for k in self.KEYS)
+                and tuple(task_dict[k]._version for k in self.KEYS) == ent["versions"])
+
     def _replay(self, ent):
         ops.wait_weight_grads()                                        # an eager episode's weight gradients may still be in flight
         ops.refresh_packs()
         ent["slots"].stage(self._seeds(ent["slots"].used))
         ent["graph"].replay()
         self.replays += 1
-        return ent["loss"], ent["acc"], {"accuracy": ent["acc"]}
+        loss, acc = ent["loss"].clone(), ent["acc"].clone()            # the graph's output tensors are overwritten by the next replay
+        return loss, acc, {"accuracy": acc}
 
     def _generic(self, task_dict):
         """episodes that arrive in NEW tensors (a data loader): one graph on static copies of the inputs; the new episode's tensors are
@@ -423,7 +442,8 @@ class GraphedEpisode:
         ent["slots"].stage(self._seeds(ent["slots"].used))
         ent["graph"].replay()
         self.replays += len(task_dicts)
-        return [(l, a, {"accuracy": a}) for l, a in ent["out"]]
+        out = [(l.clone(), a.clone()) for l, a in ent["out"]]
+        return [(l, a, {"accuracy": a}) for l, a in out]
 
     def _capture_interval(self, task_dicts, ikey):
         cfg = self.config
@@ -471,6 +491,11 @@ class GraphedEpisode:
             if sum(1 for k in self.graphs if k[0] != "generic") >= self.max_graphs:
                 return self._generic(task_dict)
             ent = self._capture(task_dict, key)
+        elif not self._resident(ent, task_dict):
+            # same addresses, other tensors or modified contents: not the resident episode this graph was captured on
+            del self.graphs[key]
+            self.seen.discard(key)
+            return self._generic(task_dict)
         return self._replay(ent)
 
 
@@ -503,7 +528,7 @@ def _crossed(n_before, n_after, period):
     return period > 0 and n_after // period > n_before // period
 
 
-def train(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log=None):
+def train(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log=None, schedule=None):
     """trainwandb.py:111-188 (optimizer cadence, print, checkpoint every save_freq, test at test_iters).
     Returns (losses, accuracies) as python floats.
 
@@ -512,6 +537,10 @@ def train(student, teacher, video_loader, distiller, optimizer, scheduler, accur
     tasks_per_batch / W local iterations (tasks_per_batch global episodes; W must divide it), MultiStepLR advances by W per
     local iteration, and print_freq / save_freq / test_iters trigger when the global count (local iteration x W) passes them.
     At W = 1 all of this reduces to the reference's conditions literally."""
+    if schedule is not None:      # run the loop under this schedule.Schedule (restored afterwards); without one: the three switches below
+        with schedule.applied():
+            cfg2 = _with(config, side_wgrad=schedule.side_wgrad, direct_param_grad=schedule.direct_param_grad)
+            return train(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, cfg2, log)
     losses, accuracies = [], []
     world = world_size()
     if config.tasks_per_batch % world != 0:
@@ -531,10 +560,18 @@ def train(student, teacher, video_loader, distiller, optimizer, scheduler, accur
         return _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log, losses,
                            accuracies, total_iterations, every, iteration, world)
     finally:
-        ops.wait_weight_grads()
-        if ops.DIRECT_PARAM_GRAD and isinstance(optimizer, FusedOptimizer):
+        ops.join_all_streams()
+        if isinstance(optimizer, FusedOptimizer):
             optimizer.bucket.fold_shadow()          # leave complete gradients in .grad for whoever reads them next
         ops.SYNC_WGRAD_AT_BACKWARD_END, ops.SIDE_WGRAD, ops.DIRECT_PARAM_GRAD = sync_prev, side_prev, direct_prev
+
+
+def _with(config, **kw):
+    import copy
+    c = copy.copy(config)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
 
 
 def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log, losses, accuracies,

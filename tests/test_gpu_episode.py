@@ -191,7 +191,7 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
         return p, o, ot, ol
     _, o, ot, ol = oracle(torch.float32, False)                  # forward values, logits, loss: the plain oracle
     sp32, _, _, _ = oracle(torch.float32, impose)               # gradients: both precisions with the HIP masks imposed
-    sp64, _, _, ol64 = oracle(torch.float64, impose)
+    sp64, o64, ot64, ol64 = oracle(torch.float64, impose)
     assert flips[0] <= max(8, flips[1] // ((500 if O.ACT_BF16 else 2000) if bf16 else 100000)), flips
     if bf16:
         # bf16 convolution operands: two fp32 implementations of this arithmetic agree only to ~1e-4 RMS (an activation within
@@ -205,14 +205,20 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
             anchored("logits " + k, out["logits"][k], o["logits"][k], o64["logits"][k], 3.0, 1e-5)
         assert abs(loss.item() - ol64u.item()) <= 3 * abs(ol.item() - ol64u.item()) + 1e-3 * abs(ol64u.item()), (loss.item(), ol.item(), ol64u.item())
     else:
-        # features: rel 2e-3 of max; logits O(1e2..1e3): abs 2e-2 + rel 2e-3; loss rel 1e-3 (fp32, different summation order)
+        # round 4: the forward is fp64-ANCHORED like the gradients (before: features rel 2e-3, logits 2e-3 / 2e-2, loss 1e-3 - twenty times
+        # looser than what is measured): per tensor, relative-L2 error against the oracle in fp64 <= 3 x the fp32 oracle's own + 1e-5.  (The
+        # fp64 run carries the HIP path's ReLU masks / pooling selections where they are imposed: they differ from the natural ones only at
+        # values within 1e-5 of zero / of a tie - checked above - which moves no forward value by more than that.)
+        fwd = {}
         for k in ("context_features_1", "context_features_2"):
-            assert _rel(out["context_features"][k], o["context_features"][k]) < 2e-3, k
+            fwd[k] = anchored(k, out["context_features"][k], o["context_features"][k], o64["context_features"][k], 3.0, 1e-5)
         for k in ("kl", "ce", "sup"):
-            a, b = out["logits"][k].detach().cpu(), o["logits"][k].detach()
-            assert torch.allclose(a, b, rtol=2e-3, atol=2e-2), (k, float((a - b).abs().max()))
-            assert torch.allclose(tl[k].cpu(), ot[k], rtol=1e-4, atol=2e-2) if k != "ce" else True
-        assert abs(loss.item() - ol.item()) < 1e-3 * max(1.0, abs(ol.item()))
+            fwd["logits " + k] = anchored("logits " + k, out["logits"][k], o["logits"][k], o64["logits"][k], 3.0, 1e-5)
+            if k != "ce":
+                anchored("teacher logits " + k, tl[k], ot[k], ot64[k], 3.0, 1e-5)
+        assert abs(loss.item() - ol64.item()) <= 3 * abs(ol.item() - ol64.item()) + 1e-5 * abs(ol64.item()), (loss.item(), ol.item(), ol64.item())
+        from _anchor import record as _rec
+        _rec("episode forward %d-shot %d-query %dpx %s %s [%s]" % (shot, query, img, clf, bb, ops.get_conv_compute_dtype()), fwd)
     # argmax bit-exact wherever the oracle's top-2 margin exceeds the logit tolerance
     lg = o["logits"]["kl"].detach() + o["logits"]["ce"].detach()
     srt = torch.sort(lg, -1).values
@@ -452,6 +458,9 @@ def test_packed_weight_cache_follows_optimizer(dev):
     assert torch.equal(trunk(x), fresh(x))
 
 
+_FULL64 = {}
+
+
 @pytest.mark.parametrize("mode", ["fp32x3", "fp32"])
 def test_full_size_episode_matches_oracle(dev, mode):
     """BASELINE configs[1] at full size (5-way 5-shot, 5 queries/class, 400 frames of 224x224): logits, loss and class
@@ -480,12 +489,25 @@ def test_full_size_episode_matches_oracle(dev, mode):
         o = O.student_forward(ep, sp, 5, 5)
         ot = O.clf_TRX_2fcsup_fixed(ep["support_set_feature_teacher"], ep["support_labels"], ep["target_set_feature_teacher"], tp, 5, 5)
         ol = O.distill_fc_2_sup_dist(o["logits"], ot, labels)["loss"]
+        # the same forward in fp64 (once per session: both arithmetic modes start from the same seeded weights and episode)
+        if "o64" not in _FULL64:
+            e64 = {k: (v.double() if v.is_floating_point() else v) for k, v in ep.items()}
+            o64 = O.student_forward(e64, {k: (v.double() if v.is_floating_point() else v) for k, v in sp.items()}, 5, 5)
+            ot64 = O.clf_TRX_2fcsup_fixed(e64["support_set_feature_teacher"], e64["support_labels"], e64["target_set_feature_teacher"],
+                                          {k: v.double() for k, v in tp.items()}, 5, 5)
+            _FULL64.update(o64=o64, ol64=O.distill_fc_2_sup_dist(o64["logits"], ot64, labels)["loss"], w0=sp["backbone.resnet.0.weight"].clone())
+        assert torch.equal(_FULL64["w0"], sp["backbone.resnet.0.weight"])
+        o64, ol64 = _FULL64["o64"], _FULL64["ol64"]
+    # fp64-anchored (round 4; before: 2e-3 / 2e-2 / 1e-3): relative-L2 error vs fp64 <= 3 x the fp32 oracle's own + 1e-5
+    from _anchor import anchored, record
+    fwd = {}
     for k in ("context_features_1", "context_features_2"):
-        assert _rel(out["context_features"][k], o["context_features"][k]) < 2e-3, k
+        fwd[k] = anchored(k, out["context_features"][k], o["context_features"][k], o64["context_features"][k], 3.0, 1e-5)
     for k in ("kl", "ce", "sup"):
-        a, b = out["logits"][k].cpu(), o["logits"][k]
-        assert torch.allclose(a, b, rtol=2e-3, atol=2e-2), (k, float((a - b).abs().max()))
-    assert abs(loss.item() - ol.item()) < 1e-3 * max(1.0, abs(ol.item()))
+        fwd["logits " + k] = anchored("logits " + k, out["logits"][k], o["logits"][k], o64["logits"][k], 3.0, 1e-5)
+    assert abs(loss.item() - ol64.item()) <= 3 * abs(ol.item() - ol64.item()) + 1e-5 * abs(ol64.item()), (loss.item(), ol.item(), ol64.item())
+    fwd["loss abs"] = (abs(loss.item() - ol64.item()), abs(ol.item() - ol64.item()))
+    record("full-size episode forward (400 frames of 224^2) [%s]" % mode, fwd)
     lg = o["logits"]["kl"] + o["logits"]["ce"]
     srt = torch.sort(lg, -1).values
     clear = (srt[:, -1] - srt[:, -2]) > 5e-2
