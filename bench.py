@@ -219,6 +219,8 @@ def main():
                 ns = cfg.way * cfg.shot
                 ep = dict(ep, support_set_feature_teacher=fused[:ns].unsqueeze(0), target_set_feature_teacher=fused[ns:].unsqueeze(0))
             graphed = graph_runner()
+            if (it + 1) % every == 0 and graphed is None and pipe is None:
+                opt.expect_step()                      # world > 1: the bucket's tail is all-reduced under this episode's backward pass
             if pipe is not None and state.get("pipe", True):
                 pipe.push(ep)
             elif graphed is not None:
@@ -296,10 +298,14 @@ def main():
         chk = torch.tensor([float(rank + 1)], device=dev)
         dist.all_reduce(chk)
         assert int(chk.item()) == world * (world + 1) // 2, "all-reduce checksum: %s" % chk.item()
-        ar = torch.tensor([sum(e0.elapsed_time(e1) for e0, e1 in ar_events) / max(len(ar_events), 1)], device=dev, dtype=torch.float64)
+        # per optimizer step: the part issued under the backward pass (EarlyAllReduce: overlapped with it) and the rest, issued at the step
+        n_steps = max(1, sum(1 for e in ar_events if e[2] == "at step"))
+        ms = {k: sum(e[0].elapsed_time(e[1]) for e in ar_events if e[2] == k) / n_steps for k in ("early", "at step")}
+        ar = torch.tensor([ms["early"] + ms["at step"], ms["early"], ms["at step"]], device=dev, dtype=torch.float64)
         dist.all_reduce(ar, op=dist.ReduceOp.MAX)
-        dist_info.update({"backend": dist.get_backend(), "devices": names, "allreduce_ms_per_optimizer_step": float(ar.item()),
-                          "allreduce_checksum_ok": True})
+        dist_info.update({"backend": dist.get_backend(), "devices": names, "allreduce_ms_per_optimizer_step": float(ar[0].item()),
+                          "allreduce_ms_overlapped_with_backward": float(ar[1].item()), "allreduce_ms_at_step": float(ar[2].item()),
+                          "allreduce_early_elements": opt.bucket.numel - opt.early.split, "allreduce_checksum_ok": True})
     conv_flops_timed = sum(r[1] for r in timed_events)
     # the same HIP-event measurement inside the timed region: with two streams a launch's interval also contains the other
     # stream's kernels, so this is a lower bound of the kernel's own rate (reported next to the serialized figure)

@@ -113,6 +113,8 @@ class ResNet18Trunk(nn.Module):
         ops.mark_cacheable(conv.weight)
         y = ops.StemFn.apply(x, conv.weight, *bn.args(), self.training)
         for name, _, _, _ in STAGES:
+            if name == "7":
+                y = _grad_ready(y)
             for blk in getattr(self, name):
                 y = blk(y)
         if self.training and not ops.deferring():
@@ -146,6 +148,14 @@ class ResNet50Trunk(ResNet18Trunk):
 # (support, then query).  autograd runs each call's backward on the stream of its forward, so the backward overlaps too.
 OVERLAP_TRUNK_CALLS = True
 _BN_UPDATE_EVENT = {}
+
+
+def _grad_ready(y):
+    """the input of the last stage: when its gradient arrives, the backward pass has finished the last stage, the heads and the matcher
+    (ops.GRAD_READY_HOOK = parallel.EarlyAllReduce.hook while an optimizer step is due)"""
+    if ops.GRAD_READY_HOOK is not None and torch.is_grad_enabled() and y.requires_grad:
+        y.register_hook(ops.GRAD_READY_HOOK)
+    return y
 
 # Round 4: both trunk calls as ONE launch per layer.  The support and the query frames travel through the trunk as one NHWC tensor
 # [Fs + Fq, H, W, C] with a frame split ("two frame segments", include/lmkd.h lmkd_*_seg): every convolution / BatchNorm / pooling kernel
@@ -185,6 +195,8 @@ def merged_trunk_call(trunk, head, context_frames, target_frames):
             ops.set_defer(upd)
         y = ops.StemFn.apply(x4, getattr(trunk, "0").weight, *getattr(trunk, "1").args(), training, seg)
         for name, _, _, _ in STAGES:
+            if name == "7":
+                y = _grad_ready(y)
             for blk in getattr(trunk, name):
                 y = blk(y, seg)
         feat = head(y)
@@ -232,6 +244,8 @@ def two_trunk_calls(trunk, head, context_frames, target_frames):
     ops.mark_cacheable(getattr(trunk, "0").weight)
     layers = [lambda t: ops.StemFn.apply(t, getattr(trunk, "0").weight, *getattr(trunk, "1").args(), trunk.training)]
     for name, _, _, _ in STAGES:
+        if name == "7":
+            layers.append(_grad_ready)
         layers += list(getattr(trunk, name))
     layers.append(head)
     cf, tf = context_frames, target_frames

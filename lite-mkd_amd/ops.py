@@ -684,6 +684,8 @@ def join_all_streams():
     shadow): kernels on the side and auxiliary streams add parameter gradients directly (DIRECT_PARAM_GRAD), hand autograd None, and are
     therefore NOT joined to the caller's stream by the autograd engine; that the stem's weight gradient happens to order the side stream
     before the weight-gradient stream is not something to rely on (a frozen or hooked stem weight breaks it)."""
+    if not (_WG_STREAM or _side_streams or _aux_streams or _lane_mains):
+        return      # nothing was ever forked (this includes every CPU-side caller)
     cur = torch.cuda.current_stream()
     dev = cur.device.index if hasattr(cur, "device") and cur.device is not None else torch.cuda.current_device()
     wait_weight_grads()
@@ -1184,6 +1186,11 @@ def resize_frames_u8(frames_u8, size):
         lib().call("lmkd_resize_pass_u8", _p(x), _p(t), _p(b), _p(k), ks, F_, H, oh, ow * C, _stream())
         x = t
     return x
+
+
+# parallel.EarlyAllReduce: while set, the trunk's forward registers this tensor hook on the input of its last stage - it fires when the
+# backward pass has left that stage (the gradients of the last stage, the heads and the matcher are final)
+GRAD_READY_HOOK = None
 
 
 # Test aid: with BLOCK_TAPS set to a list, every BasicBlockFn / StemFn training forward appends its BatchNorm inputs and

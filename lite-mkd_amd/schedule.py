@@ -105,15 +105,10 @@ class Schedule:
     def applied(self):
         from . import ops
         prev = Schedule.current()
-        ops.join_all_streams() if _cuda_ready() else None
+        ops.join_all_streams()
         self.apply()
         try:
             yield self
         finally:
-            ops.join_all_streams() if _cuda_ready() else None
+            ops.join_all_streams()
             prev.apply()
-
-
-def _cuda_ready():
-    import torch
-    return torch.cuda.is_available()

@@ -9,12 +9,13 @@ import numpy as np
 import torch
 
 from . import ops
-from .parallel import FlatParams, world_size
+from .parallel import EarlyAllReduce, FlatParams, world_size
 from ._lib import lib
 import ctypes
 
 
 REPACK_AT_STEP = True
+EARLY_ALLREDUCE = True      # world > 1: all-reduce the bucket's tail under the last backward pass of an optimizer interval (parallel.EarlyAllReduce)
 
 
 class FusedOptimizer:
@@ -23,11 +24,23 @@ class FusedOptimizer:
     def __init__(self, module, opt="sgd", lr=1e-4):
         self.bucket = FlatParams(module)
         self.opt, self.lr, self.steps = opt, float(lr), 0
+        self.early = EarlyAllReduce(self.bucket, module)      # tail of the gradient bucket all-reduced under the last backward pass (world > 1)
         if opt == "adam":
             self.m = torch.zeros_like(self.bucket.flat)
             self.v = torch.zeros_like(self.bucket.flat)
         elif opt != "sgd":
             raise KeyError(opt)
+
+    def expect_step(self):
+        """call before the LAST episode of an optimizer interval (the loop knows: (iteration + 1) % every == 0 after it): under episode
+        parallelism the all-reduce of the bucket's tail - last trunk stage, heads, matcher - is then issued as soon as the backward pass
+        has left the last stage, and runs beside the rest of it (parallel.EarlyAllReduce).  Harmless on one process."""
+        if EARLY_ALLREDUCE and world_size() > 1:
+            from .model.backbone import resnet as R
+            self.early.arm(1 if R.MERGE_TRUNK_CALLS else 2)
+            ops.GRAD_READY_HOOK = self.early.hook
+        else:
+            ops.GRAD_READY_HOOK = None
 
     def zero_grad(self):
         ops.join_all_streams()              # weight gradients (ops.SIDE_WGRAD) and direct parameter gradients (side / auxiliary streams) in flight
@@ -36,9 +49,12 @@ class FusedOptimizer:
     def step(self):
         b = self.bucket
         ops.join_all_streams()              # every stream that writes the gradient buffer or its shadow, or reads the packs re-packed below
+        ops.GRAD_READY_HOOK = None
+        upto = self.early.finish()          # the tail went out during the backward pass: wait for it, all-reduce the rest here
         b.fold_shadow()                     # gradients the side / auxiliary streams' kernels accumulated directly (ops.DIRECT_PARAM_GRAD);
                                             # unconditionally: the flag may have been switched off since they were written
-        b.allreduce_grads()
+                                            # (the early part folded and zeroed its own tail of the shadow)
+        b.allreduce_grads(upto)
         self.steps += 1
         ops.WEIGHT_EPOCH[0] += 1            # invalidates the packed-weight cache (raw-pointer update below)
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -581,6 +597,8 @@ def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler,
             break
         iteration += 1
         torch.set_grad_enabled(True)
+        if (((iteration + 1) % every == 0) or (iteration == (total_iterations - 1))) and hasattr(optimizer, "expect_step"):
+            optimizer.expect_step()          # this episode's backward completes the interval's gradients
         task_loss, task_accuracy, _ = train_task(task_dict, student, teacher, distiller, accuracy_fn, config)
         losses.append(task_loss)
         accuracies.append(task_accuracy)

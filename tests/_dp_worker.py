@@ -29,9 +29,13 @@ def main():
     w0 = opt.bucket.flat.clone()
     src = TL.SyntheticEpisodes(cfg, base_seed=808, rank=0, device=dev)          # ONE global stream, dealt round-robin
     ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END = True, False
-    for e in range(G):
-        if e % world == rank:
-            TL.train_task(src.episode(e), student, teacher, distiller, aggregate_accuracy, cfg)
+    mine = [e for e in range(G) if e % world == rank]
+    for e in mine:
+        if e == mine[-1]:
+            opt.expect_step()      # world > 1: the tail of the gradient bucket is all-reduced under this backward pass (parallel.EarlyAllReduce)
+        TL.train_task(src.episode(e), student, teacher, distiller, aggregate_accuracy, cfg)
+    if world > 1 and os.environ.get("LMKD_EXPECT_EARLY", "1") == "1":
+        assert opt.early.work is not None and opt.early.split < opt.bucket.numel, "the early all-reduce did not fire"
     opt.step()
     torch.cuda.synchronize()
     bn = {k: v.detach().cpu() for k, v in student.state_dict().items() if "running_" in k}

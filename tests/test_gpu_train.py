@@ -409,3 +409,81 @@ def test_pipelined_episodes_bit_identical_to_sequential(dev):
     assert torch.equal(g_s, g_p), float((g_s - g_p).abs().max())
     for k in s_s:
         assert torch.equal(s_s[k], s_p[k]), k
+
+
+def test_rccl_world2_when_two_gpus_are_visible(dev, tmp_path):
+    """RCCL readiness.  Needs >= 2 visible GPUs - skips on the 1-GPU test boxes, so the suite stays green - and
+    then runs the REAL `nccl` (= RCCL) backend twice: (a) the data-parallel worker of test_data_parallel_world2_equals_world1 with one GPU
+    per rank - world-2 weights after the all-reduce + SGD step equal the world-1 run, the early all-reduce of the bucket's tail fires;
+    (b) `python bench.py --gpus 2` through its own launcher (bench.self_launch: torchrun as a child process, started before any GPU call)
+    - the JSON line reports backend nccl, two distinct devices, a correct all-reduce checksum and the optimizer step's collective."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: RCCL needs one device per rank")
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "_dp_worker.py")
+
+    def launch(world):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       LMKD_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+            procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path), "16"], env=env))
+        for p in procs:
+            assert p.wait(timeout=900) == 0
+    launch(1)
+    launch(2)
+    a, b = torch.load(str(tmp_path / "flat_w1.pt")), torch.load(str(tmp_path / "flat_w2.pt"))
+    assert torch.equal(a["w0"], b["w0"])
+    d1, d2 = (a["w1"] - a["w0"]).double(), (b["w1"] - b["w0"]).double()
+    assert float(d1.norm()) > 0 and float((d1 - d2).norm() / d1.norm()) < 1e-5
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(here), "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-other-modes"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    d = line["distributed"]
+    assert line["n_gpus"] == 2 and d["backend"] == "nccl" and d["world"] == 2 and d["allreduce_checksum_ok"]
+    assert len(set(d["devices"])) == 2 and d["optimizer_steps_in_timed_region"] >= 1
+    assert d["allreduce_ms_per_optimizer_step"] > 0 and d["allreduce_early_elements"] > 0
+
+
+def test_train_cli_synthetic_and_clip_directory(dev, tmp_path):
+    """python -m litemkd_amd.train (reference flags, options.py:7-76): a few iterations on synthetic episodes with a checkpoint in the
+    reference's format, then on a directory of decoded uint8 clips through the GPU frame transform (video_reader.py:398-485 sampling)"""
+    import glob
+    import json
+    import numpy as np
+    from litemkd_amd import train as T
+    ck = tmp_path / "ckpt"
+    log = tmp_path / "log.jsonl"
+    losses, accs = T.main(["--shot", "1", "--query_per_class", "1", "--img_size", "64", "--tasks_per_batch", "2", "--training_iterations", "6",
+                           "--print_freq", "2", "--checkpoint_dir", str(ck), "--learning_rate", "0.001", "--log_jsonl", str(log), "--test_iters", "100"])
+    assert len(losses) == 6 and all(np.isfinite(losses))
+    recs = [json.loads(ln) for ln in open(log)]
+    assert recs and all("loss" in r and "lr" in r for r in recs)
+    files = glob.glob(str(ck / "*.pt"))
+    assert len(files) == 1
+    sd = torch.load(files[0])["model_state_dict"]
+    assert "backbone.resnet.4.0.conv1.weight" in sd and "classifier.transformers.k_linear.weight" in sd      # the reference's keys
+    # a tiny dataset of decoded clips: 6 classes x 3 videos of 11 frames of 100 x 130, teacher features next to them
+    root = tmp_path / "clips"
+    g = np.random.default_rng(0)
+    for c in range(6):
+        d = root / ("class%02d" % c)
+        d.mkdir(parents=True)
+        for v in range(3):
+            np.save(d / ("v%d.npy" % v), g.integers(0, 256, size=(11, 100, 130, 3), dtype=np.uint8))
+            np.save(d / ("v%d.feature.npy" % v), g.standard_normal((8, 2048)).astype(np.float32))
+    losses, accs = T.main(["--shot", "1", "--query_per_class", "1", "--img_size", "84", "--tasks_per_batch", "2", "--training_iterations", "4",
+                           "--no_save", "--data_dir", str(root), "--dtype", "bf16", "--test_iters", "100", "--seed", "3"])
+    assert len(losses) == 4 and all(np.isfinite(losses))

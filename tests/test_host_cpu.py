@@ -277,3 +277,62 @@ def test_make_returns_the_reference_tuple():
     assert p0.data_ptr() == optimizer.bucket.flat.data_ptr() and float(optimizer.bucket.grad.abs().max()) == 0.0
     with pytest.raises(KeyError):
         TL.make(default_args(device=torch.device("cpu"), opt="rmsprop"))
+
+
+# the command line of the reference's train_wandb.sh (its exported variables substituted; a literal copy of the FLAG NAMES AND VALUES the
+# script passes to trainwandb.py - data, not code)
+_TRAIN_WANDB_SH = ("--dataset hmdb --shot 5 --debug False --num_gpus 1 --mode hmdb --test_model student --num_test_tasks 10000 "
+                   "--learning_rate 0.0001 --checkpoint_dir hmdb_ckpt/ --training_iterations 70010 --model_backbone resnet18_2fc "
+                   "--model_classifier TRX_2fcsup --model_teacher test_teacher_TRX_2fcsup_fixed --teacher_checkpoint /data/hmdb/teacher/checkpoint35000.pt "
+                   "--distill_name fc_2_sup_dist --temp_set 2 --trans_linear_in_dim 2048")
+
+
+def test_train_cli_parses_the_reference_command_line():
+    """python -m litemkd_amd.train takes the flags of options.py:7-76 under their own names: train_wandb.sh's command line parses
+    unchanged, and every option the reference's parser declares exists here with the reference's default (plugin names excepted)"""
+    from litemkd_amd import train as T
+    p = T.build_parser()
+    a = p.parse_args(_TRAIN_WANDB_SH.split())
+    assert (a.dataset, a.shot, a.debug, a.num_gpus, a.mode, a.test_model, a.num_test_tasks) == ("hmdb", 5, False, 1, "hmdb", "student", 10000)
+    assert (a.learning_rate, a.training_iterations, a.model_backbone, a.model_classifier) == (1e-4, 70010, "resnet18_2fc", "TRX_2fcsup")
+    assert (a.model_teacher, a.distill_name, a.temp_set, a.trans_linear_in_dim) == ("test_teacher_TRX_2fcsup_fixed", "fc_2_sup_dist", [2], 2048)
+    d = p.parse_args([])
+    ref_defaults = dict(way=5, shot=5, query_per_class=5, query_per_class_test=1, tasks_per_batch=16, print_freq=10, seq_len=8, num_workers=1,
+                        trans_linear_out_dim=1152, trans_linear_in_dim=2048, img_size=224, temp_set=[2], trans_dropout=0.1, save_freq=10000,
+                        split=3, sch=[20000, 40000], num_test_tasks=5000, method="resnet18", num_gpus=1, dataset="kinetics", mode="KD_KL_meta",
+                        debug=False, soft_loss_weight=1, hard_loss_weight=1, test=False, checkpoint_dir=None, training_iterations=100010,
+                        resume_from_checkpoint=False, learning_rate=0.0001, opt="sgd",
+                        test_iters=[10000, 15000, 20000, 30000, 35000, 40000, 50000, 60000, 70000, 80000, 90000, 100000])
+    for k, v in ref_defaults.items():
+        assert getattr(d, k) == v, k
+    assert d.cfg["temperature"] == 4 and d.cfg["soft_loss_weight"] == 2
+    # when the reference tree is at hand (the build container), every `--flag` its parser and its script name is known here
+    ref = "/root/reference"
+    if os.path.isdir(ref):
+        import re
+        known = set(p._option_string_actions)
+        for f in ("options.py", "train_wandb.sh"):
+            txt = open(os.path.join(ref, f)).read()
+            if f == "options.py":      # the training parser: parse_common_args + parse_train_args
+                txt = txt[:txt.index("def parse_test_args")]
+            for flag in re.findall(r"(--[a-z_]+)", txt):
+                assert flag in known, (f, flag)
+    with pytest.raises(SystemExit):
+        T.args_check(p.parse_args([]))          # "need to specify a checkpoint dir" (options.py:89-91)
+
+
+def test_schedule_object_on_cpu():
+    from litemkd_amd.schedule import Schedule
+    s = Schedule.from_env({"LMKD_MERGE": "1", "LMKD_SIDE_WGRAD": "0"})
+    assert s.merge_trunk_calls and not s.side_wgrad and s.overlap_trunk_calls
+    ser = Schedule.serial()
+    assert not ser.overlap_trunk_calls and not ser.direct_param_grad and ser.sync_wgrad_at_backward_end
+    before = Schedule.current()
+    ser.apply()
+    try:
+        from litemkd_amd import ops, trainloop
+        from litemkd_amd.model.backbone import resnet
+        assert not ops.SIDE_WGRAD and not resnet.OVERLAP_TRUNK_CALLS and not trainloop.TEACHER_STREAM
+        assert Schedule.current() == ser
+    finally:
+        before.apply()
