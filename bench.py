@@ -89,10 +89,11 @@ def main():
                          "default: on one MI355X with a free host the replay is 5 %% slower on the GPU side than the eager three-stream "
                          "launches (31.4 vs 33.0 episodes/s; bf16 66.5 vs 72.3) - for hosts with less than ~1 core per rank")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
-    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=os.environ.get("LMKD_PIPELINE", "0") == "1",
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=None,
                     help="software pipelining across episodes (trainloop.PipelinedEpisodes): the forward of episode i + 1 runs beside the "
-                         "backward of episode i on a second stream set; same kernels, bit-identical results, same optimizer cadence.  OFF by "
-                         "default: measured 6 %% SLOWER on one MI355X (31.0 vs 32.9 episodes/s) - more kernels side by side disturb each other's L2 working sets")
+                         "backward of episode i on a second stream set; same kernels, bit-identical results, same optimizer cadence.  Default: "
+                         "the schedule's (Schedule.bench(): ON together with the merged trunk call - 37.5 vs 37.0 episodes/s; with the "
+                         "two-call schedule it is 5 %% slower, six streams of half-size launches disturb each other)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false")
     ap.add_argument("--graph-interval", action="store_true", help="with --graph: capture the episodes between two optimizer steps as ONE graph "
                     "(the weight-gradient stream keeps running under the next episode's forward, as in the eager loop)")
@@ -165,7 +166,9 @@ def main():
         mods = [{k: torch.randn(nv, cfg.seq_len, 2048, generator=g, device=dev).abs() for k in ("rgb", "depth", "flow")}
                 for _ in range(a.pool)]
     every = max(1, cfg.tasks_per_batch // (a.emulate_world if a.emulate_world > 0 else world))
-    use_pipe = a.pipeline and not a.serial and mfm is None
+    if a.pipeline is not None:
+        SCHED.pipeline_episodes = a.pipeline
+    use_pipe = SCHED.pipeline_episodes and not a.serial and mfm is None
     use_graph = a.graph and not a.serial and mfm is None and not use_pipe
     pipe = TL.PipelinedEpisodes(student, teacher, distiller, aggregate_accuracy, cfg) if use_pipe else None
     runners = {}      # one GraphedEpisode per arithmetic mode: a captured graph holds that mode's kernels and packed-weight buffers
@@ -464,6 +467,9 @@ def main():
         for name in ("f32native", "bf16"):
             set_mode(name)
             state["mode"] = name
+            # the native fp32 MFMA mode has no two-segment kernels (resnet.merge_supported): it runs round 3's schedule - two trunk calls on
+            # two streams, no pipelining (Schedule.two_call()), which is the faster one there
+            state["pipe"] = name != "f32native"
             it = run(2 * len(pool) + 1 if use_graph else 2, it)
             fence()
             t1 = time.perf_counter()
@@ -480,6 +486,7 @@ def main():
                                         "wgrad_kernel_tflops": w2[0] / w2[1] / 1e12}}
         set_mode("f32")
         state["mode"] = "f32"
+        state["pipe"] = True
         other["f32native"]["what"] = "round 1's headline arithmetic: every convolution on the fp32 MFMA (157.3 TFLOP/s peak)"
         other["bf16"]["what"] = "BASELINE configs[2]: bf16 tensors in HBM (activations and their gradients), bf16 MFMA, fp32 accumulate / statistics / weights"
         # configs[2] sits at the ridge of the bf16 roofline: report the HBM side as well, on algorithmic bytes

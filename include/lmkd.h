@@ -39,6 +39,12 @@ int lmkd_gemm_f32(char layA, char layB, int M, int N, int K, float alpha, const 
 /* the same with split-K for launches of at most 64 output tiles (the fc layers' 200-row calls): given a workspace the K range is split
    over more workgroups and the last-arriving block of each output tile adds the partial tiles in split order (deterministic).  workspace: any size (the split count adapts), tickets: lmkd_gemm_ticket_words() zeroed words (left zeroed); both
    private to the stream while its launches may be in flight. */
+/* arithmetic of lmkd_gemm_f32: -1 (default) = that of the convolutions (lmkd_conv_set_compute_dtype 0: native fp32 MFMA; 1-3: every fp32
+   product from the exact 3-way bf16 split of both operands on the bf16 matrix pipe, six products, fp32-class error - csrc/gemm_x3.h),
+   0 = always native fp32 MFMA, 1 = always 3 x bf16, 2 = one RNE bf16 plane per operand with fp32 accumulation (the reference's
+   autocast arithmetic for nn.Linear / matmul, trainwandb.py:20,126).  Process-wide, like lmkd_conv_set_compute_dtype. */
+int lmkd_gemm_set_mode(int mode);
+int lmkd_gemm_set_tile(int t); /* tuning (modes 1 / 2): 0 auto, 2 = 64 x 128 tiles, 3 = 64 x 64 */
 long lmkd_gemm_ticket_words(void);
 int lmkd_gemm_f32_splitk(char layA, char layB, int M, int N, int K, float alpha, const float* A, long lda, long sA,
                          const float* B, long ldb, long sB, float beta, float* C, long ldc, long sC, const float* bias,

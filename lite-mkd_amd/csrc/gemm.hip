@@ -114,6 +114,27 @@ __global__ __launch_bounds__(LMKD_THREADS) void gemm_kernel(GemmArgs g) {
   }
 }
 
+#include "gemm_x3.h"
+
+// Which arithmetic the GEMMs run in: -1 (default) follows the convolutions' (lmkd_conv_set_compute_dtype: native fp32 MFMA in mode 0, the
+// exact 3-way bf16 split - six products, fp32-class error - in modes 1-3: the heads stay fp32-class also when the trunk runs in bf16),
+// 0 = always the native fp32 MFMA kernel, 1 = always the three-plane kernel, 2 = ONE bf16 plane per operand (RNE), fp32 accumulation.
+static int g_gemm_mode = -1;
+static int g_gemm_tile = 0;      // tuning: 0 auto, 1 = 128 x 128 where it fills the chip, 2 = 64 x 128, 3 = 64 x 64
+extern "C" int lmkd_gemm_set_tile(int t) { g_gemm_tile = t; return LMKD_OK; }
+extern "C" int lmkd_gemm_set_mode(int mode) {
+  LMKD_REQUIRE(mode >= -1 && mode <= 2, "lmkd_gemm_set_mode: -1 follow the convolutions, 0 fp32 MFMA, 1 fp32 as 3 x bf16, 2 bf16");
+  g_gemm_mode = mode;
+  return LMKD_OK;
+}
+extern "C" int lmkd_conv_get_compute_dtype(void);
+static inline int gemm_planes(int M, int N, int K) {
+  int m = g_gemm_mode;
+  if (m < 0) m = lmkd_conv_get_compute_dtype() == 0 ? 0 : 1;
+  if (m == 0 || (long)M * N * K < (1L << 18)) return 0;      // tiny products (the 5 x 4 / 25 x 5 matcher tables) stay where they are
+  return m == 2 ? 1 : 3;
+}
+
 template <class Cfg>
 static int launch_gemm(const GemmArgs& g, int batch, int ak, int bk, hipStream_t s) {
   dim3 grid(cdiv(g.M, Cfg::BM), cdiv(g.N, Cfg::BN), batch * (g.splits > 1 ? g.splits : 1));
@@ -174,6 +195,14 @@ static int gemm_impl(char layA, char layB, int M, int N, int K, float alpha, con
   const int ak = layA == 'K', bk = layB == 'K';
   // tile choice: big tiles only when they still give >= ~1.5 waves of workgroups over 256 CUs
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128) * batch;
+  if (g.splits == 1) {
+    if (const int npl = gemm_planes(M, N, K)) {      // the bf16 matrix pipe (gemm_x3.h): 128 x 128 tiles once they fill the chip, else 64 x 128
+      if (t128 >= 256 && g_gemm_tile != 2 && g_gemm_tile != 3) return npl == 3 ? launch_gemm_x3<G3Cfg<128, 128, 2, 2>, 3>(g, batch, ak, bk, s) : launch_gemm_x3<G3Cfg<128, 128, 2, 2>, 1>(g, batch, ak, bk, s);
+      const long t64 = (long)cdiv(M, 64) * cdiv(N, 128) * batch;
+      if ((t64 >= 400 && g_gemm_tile != 3) || g_gemm_tile == 2) return npl == 3 ? launch_gemm_x3<G3Cfg<64, 128, 1, 4>, 3>(g, batch, ak, bk, s) : launch_gemm_x3<G3Cfg<64, 128, 1, 4>, 1>(g, batch, ak, bk, s);
+      return npl == 3 ? launch_gemm_x3<G3Cfg<64, 64, 2, 2>, 3>(g, batch, ak, bk, s) : launch_gemm_x3<G3Cfg<64, 64, 2, 2>, 1>(g, batch, ak, bk, s);
+    }
+  }
   if (t128 >= 384) return launch_gemm<TileCfg<128, 128, 2, 2>>(g, batch, ak, bk, s);
   return launch_gemm<TileCfg<64, 64, 2, 2>>(g, batch, ak, bk, s);
 }

@@ -12,7 +12,7 @@ JSON-lines log instead, --log_jsonl), JPEG decoding (episodes come from Syntheti
 uint8 clips through the GPU frame transform).  One process per GPU: under torchrun every rank runs this script on its own episode stream
 and the optimizer step all-reduces the gradient bucket (parallel.py).
 
-Extra flags (not in the reference): --dtype, --merge_trunk_calls, --serial (schedule.Schedule), --data_dir / --feature_dir, --log_jsonl,
+Extra flags (not in the reference): --dtype, --two_call, --serial (schedule.Schedule), --data_dir / --feature_dir, --log_jsonl,
 --seed, --no_save."""
 import argparse
 import json
@@ -87,7 +87,8 @@ def build_parser():
     p.add_argument("--dtype", choices=["f32", "f32native", "bf16"], default="f32", help="arithmetic: f32 = fp32 as 3 x bf16 on the matrix pipe (default), "
                    "f32native = v_mfma_f32_32x32x2_f32, bf16 = bf16 tensors + bf16 MFMA (the reference's autocast path, trainwandb.py:20,126)")
     p.add_argument("--serial", action="store_true", help="single-stream schedule (Schedule.serial())")
-    p.add_argument("--merge_trunk_calls", action="store_true", help="both trunk calls as one launch per layer")
+    p.add_argument("--two_call", action="store_true", help="round 3's schedule (two trunk calls on two streams, no cross-episode pipelining) instead of "
+                   "the default merged + pipelined one (Schedule.bench())")
     p.add_argument("--data_dir", default=None, help="directory of decoded clips: <data_dir>/<class>/<video>.npy, uint8 [T, H, W, 3]")
     p.add_argument("--feature_dir", default=None, help="teacher features: <feature_dir>/<class>/<video>.npy, float [seq_len, 2048] (default: next to the clips, <video>.feature.npy)")
     p.add_argument("--log_jsonl", default=None, help="append one JSON line per print_freq iterations (the reference logs to wandb)")
@@ -185,8 +186,11 @@ class ClipDirectoryEpisodes:
 def schedule_from_args(args):
     conv = {"f32": "fp32x3", "f32native": "fp32", "bf16": "bf16"}[args.dtype]
     act = "bf16" if args.dtype == "bf16" else "fp32"
-    base = Schedule.serial if args.serial else Schedule.from_env
-    return base(conv_dtype=conv, act_dtype=act, merge_trunk_calls=bool(args.merge_trunk_calls))
+    if args.serial:
+        return Schedule.serial(conv_dtype=conv, act_dtype=act)
+    if args.two_call or conv == "fp32":          # the native fp32 MFMA mode has no two-segment kernels
+        return Schedule.two_call(conv_dtype=conv, act_dtype=act)
+    return Schedule.from_env(conv_dtype=conv, act_dtype=act)
 
 
 def main(argv=None):

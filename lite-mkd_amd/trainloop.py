@@ -555,7 +555,8 @@ def train(student, teacher, video_loader, distiller, optimizer, scheduler, accur
     At W = 1 all of this reduces to the reference's conditions literally."""
     if schedule is not None:      # run the loop under this schedule.Schedule (restored afterwards); without one: the three switches below
         with schedule.applied():
-            cfg2 = _with(config, side_wgrad=schedule.side_wgrad, direct_param_grad=schedule.direct_param_grad)
+            cfg2 = _with(config, side_wgrad=schedule.side_wgrad, direct_param_grad=schedule.direct_param_grad,
+                         pipeline_episodes=schedule.pipeline_episodes)
             return train(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, cfg2, log)
     losses, accuracies = [], []
     world = world_size()
@@ -592,6 +593,15 @@ def _with(config, **kw):
 
 def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler, accuracy_fn, config, log, losses, accuracies,
                 total_iterations, every, iteration, world=1):
+    # cross-episode pipelining (schedule.Schedule.pipeline_episodes): the forward of this episode is queued BEFORE the backward of the
+    # previous one; results arrive one episode late and are bit-identical to the sequential loop (PipelinedEpisodes)
+    pipe = (PipelinedEpisodes(student, teacher, distiller, accuracy_fn, config)
+            if getattr(config, "pipeline_episodes", False) and torch.device(config.device).type == "cuda" else None)
+
+    def took(res):
+        if res is not None:
+            losses.append(res[0])
+            accuracies.append(res[1])
     for task_dict in video_loader:
         if iteration >= total_iterations:
             break
@@ -599,10 +609,13 @@ def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler,
         torch.set_grad_enabled(True)
         if (((iteration + 1) % every == 0) or (iteration == (total_iterations - 1))) and hasattr(optimizer, "expect_step"):
             optimizer.expect_step()          # this episode's backward completes the interval's gradients
-        task_loss, task_accuracy, _ = train_task(task_dict, student, teacher, distiller, accuracy_fn, config)
-        losses.append(task_loss)
-        accuracies.append(task_accuracy)
+        if pipe is not None:
+            took(pipe.push(task_dict))
+        else:
+            took(train_task(task_dict, student, teacher, distiller, accuracy_fn, config)[:2])
         if ((iteration + 1) % every == 0) or (iteration == (total_iterations - 1)):
+            if pipe is not None:
+                took(pipe.flush())           # the step needs the gradients of every episode up to this one
             optimizer.step()
             optimizer.zero_grad()
         scheduler.step()
@@ -615,9 +628,13 @@ def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler,
         if _crossed(g0, g1, config.save_freq) and not last:
             checkpoint_all_ranks(student, iteration, config)
         if any(g0 < t <= g1 for t in getattr(config, "test_iters", ())) and not last:
+            if pipe is not None:
+                took(pipe.flush())
             accuracy_dict = test(student, video_loader, accuracy_fn, config)
             if log is not None:
                 log(iteration, accuracy_dict, None)
+    if pipe is not None:
+        took(pipe.flush())
     return [float(x) for x in losses], [float(x) for x in accuracies]
 
 

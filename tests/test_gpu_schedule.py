@@ -1,8 +1,10 @@
 """GPU: the schedule the benchmark TIMES against the serial schedule, at the benchmark's size.
 
-bench.py runs the episode loop under schedule.Schedule.bench(): two trunk calls on two streams, weight gradients on a third, the frozen
-teacher head and the second TRX head on auxiliary streams, BatchNorm / Linear / TRX parameter gradients added into .grad (or its
-per-stream shadow) by the kernels, all weight packs re-packed in place at the optimizer step.  The oracle tests run the SERIAL schedule
+bench.py runs the episode loop under schedule.Schedule.bench(): both trunk calls as one launch per layer, the forward of episode i + 1
+queued beside the backward of episode i (two stream sets), weight gradients on a third stream, the frozen teacher head and the second
+TRX head on auxiliary streams, BatchNorm / Linear / TRX parameter gradients added into .grad (or its per-stream shadow) by the
+kernels, all weight packs re-packed in place at the optimizer step (round 3's schedule - two trunk calls on two streams, no
+pipelining - is Schedule.two_call()).  The oracle tests run the SERIAL schedule
 (one stream, every gradient through autograd).  A missing event wait between streams is size dependent - at 64 px a kernel lasts
 microseconds and nothing can overtake it - so the identity of the two schedules is checked HERE at 400 frames of 224^2
 (trainwandb.py:122-143: two accumulated episodes, then optimizer.step()), and in the small cases that bend the dependency structure
@@ -43,9 +45,17 @@ def _run(dev, sched, shot, img, episodes, freeze=(), opt="sgd", lr=1e-2, seed=3)
         pool = [src.episode(e) for e in range(episodes)]
         torch.manual_seed(seed + 1)                      # the TRX dropout seeds are drawn from torch's generator, in program order
         losses = []
-        for ep in pool:
-            loss, _, _ = TL.train_task(ep, student, teacher, distiller, aggregate_accuracy, cfg)
-            losses.append(loss)
+        if sched.pipeline_episodes:                      # the forward of episode i + 1 is queued before the backward of episode i (bench.py's loop)
+            pipe = TL.PipelinedEpisodes(student, teacher, distiller, aggregate_accuracy, cfg)
+            for ep in pool:
+                r = pipe.push(ep)
+                if r is not None:
+                    losses.append(r[0])
+            losses.append(pipe.flush()[0])
+        else:
+            for ep in pool:
+                loss, _, _ = TL.train_task(ep, student, teacher, distiller, aggregate_accuracy, cfg)
+                losses.append(loss)
         ops.join_all_streams()
         optim.bucket.fold_shadow()
         grad = optim.bucket.grad.clone()
@@ -74,26 +84,34 @@ def _compare(a, b, grad_tol, lr):
     assert float((pa - pb).abs().max()) <= 1e-4 * float(pb.abs().max()), "forward after the step"
 
 
-@pytest.mark.parametrize("which", ["bench", "merged"])
-def test_bench_schedule_equals_serial_full_size(dev, which):
-    """two accumulated 400-frame episodes (5-way 5-shot, 224^2) + one SGD step: Schedule.bench() - what bench.py times - and the merged
-    trunk call against Schedule.serial(): losses identical, flat gradient bucket within 2e-6 of its maximum, weights after the step
-    equal to that precision, running statistics identical"""
+def _sched(which):
     from litemkd_amd.schedule import Schedule
-    ref = _run(dev, Schedule.serial(), 5, 224, 2)
-    tst = _run(dev, Schedule.bench() if which == "bench" else Schedule.bench(merge_trunk_calls=True), 5, 224, 2)
+    return {"bench": Schedule.bench, "two_call": Schedule.two_call, "merged": lambda: Schedule.bench(pipeline_episodes=False),
+            "two_call_pipelined": lambda: Schedule.two_call(pipeline_episodes=True)}[which]()
+
+
+@pytest.mark.parametrize("which", ["bench", "two_call", "merged"])
+def test_bench_schedule_equals_serial_full_size(dev, which):
+    """three accumulated 400-frame episodes (5-way 5-shot, 224^2) + one SGD step under Schedule.bench() - what bench.py times: merged trunk
+    call + cross-episode pipelining - under round 3's two-call three-stream schedule and under the merged call alone, against
+    Schedule.serial(): losses identical, flat gradient bucket within 2e-6 of its maximum, weights after the step equal to that precision,
+    running statistics identical"""
+    from litemkd_amd.schedule import Schedule
+    assert Schedule.bench().merge_trunk_calls and Schedule.bench().pipeline_episodes
+    ref = _run(dev, Schedule.serial(), 5, 224, 3)
+    tst = _run(dev, _sched(which), 5, 224, 3)
     _compare(tst, ref, 2e-6, 1e-2)
 
 
-@pytest.mark.parametrize("which", ["bench", "merged"])
+@pytest.mark.parametrize("which", ["bench", "two_call", "two_call_pipelined"])
 @pytest.mark.parametrize("freeze", [(), ("backbone.resnet.0.weight",), ("backbone.resnet.0.weight", "backbone.resnet.1.weight", "backbone.resnet.1.bias")])
 def test_bench_schedule_equals_serial_frozen_stem(dev, which, freeze):
     """the same identity on a small episode with the stem's weight (and BatchNorm) frozen: the stem's weight gradient is then NOT the
     last thing on the side stream that the weight-gradient stream waits for - the optimizer has to join every stream itself
     (ops.join_all_streams)"""
     from litemkd_amd.schedule import Schedule
-    ref = _run(dev, Schedule.serial(), 1, 64, 3, freeze)
-    tst = _run(dev, Schedule.bench() if which == "bench" else Schedule.bench(merge_trunk_calls=True), 1, 64, 3, freeze)
+    ref = _run(dev, Schedule.serial(), 1, 64, 4, freeze)
+    tst = _run(dev, _sched(which), 1, 64, 4, freeze)
     _compare(tst, ref, 5e-6, 1e-2)
 
 
