@@ -44,7 +44,7 @@ int lmkd_gemm_f32(char layA, char layB, int M, int N, int K, float alpha, const 
    0 = always native fp32 MFMA, 1 = always 3 x bf16, 2 = one RNE bf16 plane per operand with fp32 accumulation (the reference's
    autocast arithmetic for nn.Linear / matmul, trainwandb.py:20,126).  Process-wide, like lmkd_conv_set_compute_dtype. */
 int lmkd_gemm_set_mode(int mode);
-int lmkd_gemm_set_tile(int t); /* tuning (modes 1 / 2): 0 auto, 2 = 64 x 128 tiles, 3 = 64 x 64 */
+int lmkd_gemm_set_tile(int t); /* tuning (modes 1 / 2): 0 auto (64 x 64 tiles), 1 = 128 x 128, 2 = 64 x 128 */
 long lmkd_gemm_ticket_words(void);
 int lmkd_gemm_f32_splitk(char layA, char layB, int M, int N, int K, float alpha, const float* A, long lda, long sA,
                          const float* B, long ldb, long sB, float beta, float* C, long ldc, long sC, const float* bias,
@@ -157,6 +157,10 @@ int lmkd_bn_running_update(float* running_mean, float* running_var, const float*
    null) stats_second[i] - the two trunk calls of an episode in the reference's order */
 int lmkd_bn_running_update_multi(float* const* running_mean, float* const* running_var, const float* const* stats_first,
                                  const float* const* stats_second, const int* C, int n, float momentum, void* stream);
+/* the same + nn.BatchNorm2d's num_batches_tracked (int64 device scalars; the array and single entries are nullable): += 1 per update applied */
+int lmkd_bn_running_update_multi_nbt(float* const* running_mean, float* const* running_var, const float* const* stats_first,
+                                     const float* const* stats_second, long long* const* num_batches_tracked, const int* C, int n,
+                                     float momentum, void* stream);
 int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                        float* stats, void* stream);
 /* y = act(x*scale+shift [+res | +res*rscale+rshift]); res_mode 0 none, 1 plain, 2 affine.  mask_bits (nullable; needs

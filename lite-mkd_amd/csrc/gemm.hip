@@ -196,10 +196,12 @@ static int gemm_impl(char layA, char layB, int M, int N, int K, float alpha, con
   // tile choice: big tiles only when they still give >= ~1.5 waves of workgroups over 256 CUs
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128) * batch;
   if (g.splits == 1) {
-    if (const int npl = gemm_planes(M, N, K)) {      // the bf16 matrix pipe (gemm_x3.h): 128 x 128 tiles once they fill the chip, else 64 x 128
-      if (t128 >= 256 && g_gemm_tile != 2 && g_gemm_tile != 3) return npl == 3 ? launch_gemm_x3<G3Cfg<128, 128, 2, 2>, 3>(g, batch, ak, bk, s) : launch_gemm_x3<G3Cfg<128, 128, 2, 2>, 1>(g, batch, ak, bk, s);
-      const long t64 = (long)cdiv(M, 64) * cdiv(N, 128) * batch;
-      if ((t64 >= 400 && g_gemm_tile != 3) || g_gemm_tile == 2) return npl == 3 ? launch_gemm_x3<G3Cfg<64, 128, 1, 4>, 3>(g, batch, ak, bk, s) : launch_gemm_x3<G3Cfg<64, 128, 1, 4>, 1>(g, batch, ak, bk, s);
+    if (const int npl = gemm_planes(M, N, K)) {      // the bf16 matrix pipe (gemm_x3.h)
+      // 64 x 64 tiles throughout: measured on every head GEMM of the episode (tools/gemm_x3_bench.py, profiles/r04_gemm_x3_bench.txt) they
+      // beat 64 x 128 and 128 x 128 - these launches have 100 - 600 tiles, and five small workgroups per CU hide the load latency of
+      // each other where one or two big ones expose it (projection dW: 40 us against 66 with 128 x 128; prototypes 20 against 40)
+      if (g_gemm_tile == 1) return npl == 3 ? launch_gemm_x3<G3Cfg<128, 128, 2, 2>, 3>(g, batch, ak, bk, s) : launch_gemm_x3<G3Cfg<128, 128, 2, 2>, 1>(g, batch, ak, bk, s);
+      if (g_gemm_tile == 2) return npl == 3 ? launch_gemm_x3<G3Cfg<64, 128, 1, 4>, 3>(g, batch, ak, bk, s) : launch_gemm_x3<G3Cfg<64, 128, 1, 4>, 1>(g, batch, ak, bk, s);
       return npl == 3 ? launch_gemm_x3<G3Cfg<64, 64, 2, 2>, 3>(g, batch, ak, bk, s) : launch_gemm_x3<G3Cfg<64, 64, 2, 2>, 1>(g, batch, ak, bk, s);
     }
   }

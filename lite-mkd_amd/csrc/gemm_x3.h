@@ -114,6 +114,16 @@ __global__ __launch_bounds__(LMKD_THREADS) void gemm_x3_kernel(GemmArgs g) {
     for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // The MFMA's addition of products 2^-8 .. 2^-16 smaller than its accumulator truncates toward -inf (conv_x3.h, X3FragB::init: a mean
+  // error of -4e-11 x K x rms per element in the three-plane arithmetic - half an ulp at most, but of ONE sign, and the consumers of these
+  // GEMMs sum their outputs over hundreds of rows: the last BatchNorm's bias gradient sums the fc input gradient over 400 x 49 pixels).
+  // So the 32-row blocks of the output alternate in sign, checkerboard-wise with the wave's column block: a negated block accumulates
+  // -(A B) from sign-flipped A fragments (one v_xor per register) and flips back in the epilogue - the truncation then has either sign
+  // on half the rows and half the columns and cancels in any sum over them.
+  unsigned sgn[Cfg::TM];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+    sgn[i] = (NPL == 3 && (((m0 >> 5) + wm * Cfg::TM + i + (n0 >> 5) + wn * Cfg::TN) & 1)) ? 0x80008000u : 0u;
   const int nk = (g.K + LMKD_BK - 1) / LMKD_BK;
   // TWO register sets: the tile of step t + 2 is requested while step t is multiplied (a launch of these GEMMs is one or two workgroups
   // per CU - M = 400 rows - so nothing but the prefetch distance hides the ~1 us of an L2 / HBM round trip: with one set a K-step
@@ -133,7 +143,12 @@ __global__ __launch_bounds__(LMKD_THREADS) void gemm_x3_kernel(GemmArgs g) {
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-          for (int i = 0; i < Cfg::TM; ++i) fa[gq][p][i] = IA::frag(sa, offA, i, gq, p);
+          for (int i = 0; i < Cfg::TM; ++i) {
+            union { bf16x8 b; unsigned u[4]; } c;
+            c.b = IA::frag(sa, offA, i, gq, p);
+            if (NPL == 3) { c.u[0] ^= sgn[i]; c.u[1] ^= sgn[i]; c.u[2] ^= sgn[i]; c.u[3] ^= sgn[i]; }
+            fa[gq][p][i] = c.b;
+          }
 #pragma unroll
           for (int j = 0; j < Cfg::TN; ++j) fb[gq][p][j] = IB::frag(sb, offB, j, gq, p);
         }
@@ -192,7 +207,8 @@ __global__ __launch_bounds__(LMKD_THREADS) void gemm_x3_kernel(GemmArgs g) {
         const int row = m0 + wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane);
         if (row < g.M) {
           float* c = C + (long)row * g.ldc + col;
-          float v = g.alpha * acc[i][j][e] + bv;      // the operations of gemm_kernel's epilogue, in its order
+          const float a = sgn[i] ? -acc[i][j][e] : acc[i][j][e];
+          float v = g.alpha * a + bv;      // the operations of gemm_kernel's epilogue, in its order
           if (g.beta != 0.f) v += g.beta * *c;
           if (g.relu) v = fmaxf(v, 0.f);
           *c = v;

@@ -304,11 +304,13 @@ struct BnMultiArgs {
   float* rv[BN_MULTI_MAX];
   const float* st0[BN_MULTI_MAX];
   const float* st1[BN_MULTI_MAX];
+  long long* nbt[BN_MULTI_MAX];      // num_batches_tracked of the layer (nullable): += one per update applied
   int C[BN_MULTI_MAX];
 };
 __global__ void bn_running_update_multi_kernel(BnMultiArgs a, float momentum) {
   const int b = blockIdx.x;
   const int C = a.C[b];
+  if (threadIdx.x == 0 && a.nbt[b]) *a.nbt[b] += a.st1[b] ? 2 : 1;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float m = a.rm[b][c], v = a.rv[b][c];
     m = (1.f - momentum) * m + momentum * a.st0[b][c];
@@ -322,8 +324,17 @@ __global__ void bn_running_update_multi_kernel(BnMultiArgs a, float momentum) {
   }
 }
 // rm / rv / stats_first / stats_second / C: HOST arrays of n entries (device pointers inside); stats_second[i] may be null
+extern "C" int lmkd_bn_running_update_multi_nbt(float* const* running_mean, float* const* running_var, const float* const* stats_first,
+                                                const float* const* stats_second, long long* const* num_batches_tracked, const int* C, int n,
+                                                float momentum, void* stream);
 extern "C" int lmkd_bn_running_update_multi(float* const* running_mean, float* const* running_var, const float* const* stats_first,
                                             const float* const* stats_second, const int* C, int n, float momentum, void* stream) {
+  return lmkd_bn_running_update_multi_nbt(running_mean, running_var, stats_first, stats_second, nullptr, C, n, momentum, stream);
+}
+// the same + nn.BatchNorm2d's num_batches_tracked counters (int64 scalars; array or entries nullable): += 1 per update applied to the layer
+extern "C" int lmkd_bn_running_update_multi_nbt(float* const* running_mean, float* const* running_var, const float* const* stats_first,
+                                                const float* const* stats_second, long long* const* num_batches_tracked, const int* C, int n,
+                                                float momentum, void* stream) {
   LMKD_REQUIRE(running_mean && running_var && stats_first && stats_second && C && n > 0, "lmkd_bn_running_update_multi: bad arguments");
   for (int i0 = 0; i0 < n; i0 += BN_MULTI_MAX) {
     BnMultiArgs a;
@@ -333,6 +344,7 @@ extern "C" int lmkd_bn_running_update_multi(float* const* running_mean, float* c
       LMKD_REQUIRE(running_mean[i0 + i] && running_var[i0 + i] && stats_first[i0 + i] && C[i0 + i] > 0, "lmkd_bn_running_update_multi: null entry %d", i0 + i);
       a.rm[i] = running_mean[i0 + i]; a.rv[i] = running_var[i0 + i];
       a.st0[i] = stats_first[i0 + i]; a.st1[i] = stats_second[i0 + i];
+      a.nbt[i] = num_batches_tracked ? num_batches_tracked[i0 + i] : nullptr;
       a.C[i] = C[i0 + i];
     }
     hipLaunchKernelGGL(bn_running_update_multi_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, a, momentum);

@@ -121,6 +121,10 @@ class ResNet18Trunk(nn.Module):
             self.bump_counters(1)
         return y
 
+    def counters(self):
+        """{running_mean.data_ptr(): num_batches_tracked} of every BatchNorm (ops.apply_deferred bumps them in its own launch)"""
+        return {m.running_mean.data_ptr(): m.num_batches_tracked for m in self.modules() if isinstance(m, _BN)}
+
     def bump_counters(self, n):
         """num_batches_tracked += n for every BatchNorm (one fused launch)"""
         bufs = [m.num_batches_tracked for m in self.modules() if isinstance(m, _BN)]
@@ -208,8 +212,8 @@ def merged_trunk_call(trunk, head, context_frames, target_frames):
         prev = _BN_UPDATE_EVENT.get(key)
         if prev is not None:
             main.wait_event(prev)
-        ops.apply_deferred(upd)      # entries come in (support, query) pairs per BatchNorm: applied in the reference's order
-        trunk.bump_counters(2)
+        # entries come in (support, query) pairs per BatchNorm: applied in the reference's order; num_batches_tracked += 2 in the same launch
+        ops.apply_deferred(upd, trunk.counters())
         ev = torch.cuda.Event()
         ev.record(main)
         _BN_UPDATE_EVENT[key] = ev
@@ -269,8 +273,7 @@ def two_trunk_calls(trunk, head, context_frames, target_frames):
         prev = _BN_UPDATE_EVENT.get(key)
         if prev is not None:
             main.wait_event(prev)
-        ops.apply_deferred(s_upd + q_upd)
-        trunk.bump_counters(2)
+        ops.apply_deferred(s_upd + q_upd, trunk.counters())
         ev = torch.cuda.Event()
         ev.record(main)
         _BN_UPDATE_EVENT[key] = ev

@@ -117,6 +117,17 @@ def _gemm_workspace(like):
     return e
 
 
+def stack_rows(a, b):
+    """[a; b] along dim 0 for 2-D row-major tensors.  When b starts exactly where a ends in the SAME storage (the two halves of one
+    tensor: the support / query rows of the pooled features and of the fc outputs, which autograd hands back as two views) the result is
+    a view of that storage - no cat launch, no copy; otherwise torch.cat."""
+    if (a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1] and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+            and a.numel() > 0 and b.numel() > 0 and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and a.storage_offset() + a.numel() == b.storage_offset()):
+        return torch.as_strided(a, (a.shape[0] + b.shape[0], a.shape[1]), (a.shape[1], 1), a.storage_offset())
+    return torch.cat([a, b], 0)
+
+
 def linear_fwd(x, w, b):
     """y[M,N] = x[M,K] w[N,K]^T + b"""
     M, K = x.shape
@@ -311,18 +322,15 @@ class TwoHeadLinearFn(torch.autograd.Function):
                 return None
             gc = gc if gc is not None else torch.zeros((Nc, N), dtype=X.dtype, device=X.device)
             gt = gt if gt is not None else torch.zeros((M - Nc, N), dtype=X.dtype, device=X.device)
-            return torch.cat([gc, gt], 0).contiguous()
+            return stack_rows(gc.contiguous(), gt.contiguous())      # the TRX head returns the two halves of ONE gradient tensor: a view
         G = [full(g1c, g1t), full(g2c, g2t)]
         dX = None
         if ctx.needs_input_grad[0]:
             live = [(g, w) for g, w in zip(G, (w1, w2)) if g is not None]
             dX = _empty((M, K), X)
-            if len(live) == 2:      # dX = [G1 | G2] @ [W1; W2]: one GEMM over K = 2 N
-                Gc = torch.cat(G, 1).contiguous()
-                Wc = torch.cat([w1, w2], 0).contiguous()
-                gemm("K", "N", M, K, 2 * N, Gc, 2 * N, Wc, K, dX, K, split_k=True)
-            elif live:
-                gemm("K", "N", M, K, N, live[0][0], N, live[0][1], K, dX, K)
+            if live:                # dX = G1 @ W1 (+ G2 @ W2 accumulated in the second GEMM's epilogue: no cat of the gradients / weights)
+                for i, (g, w) in enumerate(live):
+                    gemm("K", "N", M, K, N, g, N, w, K, dX, K, beta=0.0 if i == 0 else 1.0)
             else:
                 dX.zero_()
         outs = [dX if ctx.needs_input_grad[0] else None, None]
@@ -863,9 +871,10 @@ def deferring():
     return _DEFER is not None
 
 
-def apply_deferred(entries):
+def apply_deferred(entries, counters=None):
     """entries: [(running_mean, running_var, stats)] in program order; updates of the same BatchNorm (the two trunk calls of an
-    episode) are applied in that order.  One launch for all layers (lmkd_bn_running_update_multi)."""
+    episode) are applied in that order.  One launch for all layers (lmkd_bn_running_update_multi_nbt).
+    counters: {running_mean.data_ptr(): num_batches_tracked tensor} - bumped by the same launch, once per update applied."""
     if not entries:
         return
     layers, order = {}, []
@@ -885,7 +894,8 @@ def apply_deferred(entries):
         s0 = P(*[layers[k][2][r0].data_ptr() for k in ks])
         s1 = P(*[(layers[k][2][r0 + 1].data_ptr() if len(layers[k][2]) > r0 + 1 else None) for k in ks])
         C = (ctypes.c_int * n)(*[layers[k][0].shape[0] for k in ks])
-        lib().call("lmkd_bn_running_update_multi", rm, rv, s0, s1, C, n, _f32(BN_MOMENTUM), _stream())
+        nbt = P(*[(counters[k].data_ptr() if counters and k in counters else None) for k in ks])
+        lib().call("lmkd_bn_running_update_multi_nbt", rm, rv, s0, s1, nbt, C, n, _f32(BN_MOMENTUM), _stream())
 
 
 # Stream sets ("lanes").  An episode uses up to three forward streams: the caller's (support-frame trunk call, heads, loss), a side
@@ -1539,7 +1549,7 @@ def _trx_forward(sup, qry, plan, wk, bk, wv, bv, gamma, beta, pe, mask, want_gra
     D = wk.shape[0]
     T = L * (L - 1) // 2
     NV = Ns + Nq
-    X = torch.cat([sup.reshape(Ns * L, Din), qry.reshape(Nq * L, Din)], 0).contiguous()
+    X = stack_rows(sup.reshape(Ns * L, Din), qry.reshape(Nq * L, Din))      # (the fc head's output halves: a view, no copy)
     Xp = torch.empty_like(X)
     lib().call("lmkd_add_pe", _p(X), _p(pe), _p(mask), _p(Xp), NV * L, Din, L, _stream())
     # per-frame projections: P = Xp @ [Wk[:, :Din] | Wk[:, Din:] | Wv[:, :Din] | Wv[:, Din:]]^T
@@ -1842,25 +1852,30 @@ class D2MLossFn(torch.autograd.Function):
         if labels is not None and labels.dtype != torch.int64:
             raise RuntimeError("labels must be int64 (the reference casts with .type(torch.LongTensor), trainwandb.py:441)")
         out = _empty((4,), ref)
-        g_kl = torch.empty_like(s_kl) if s_kl is not None else None
-        g_ce = torch.empty_like(s_ce) if s_ce is not None else None
-        g_sup = torch.empty_like(s_sup) if s_sup is not None else None
+        # the three logits gradients live in ONE buffer: the backward scales them with one launch
+        sizes = [t.numel() if t is not None else 0 for t in (s_kl, s_ce, s_sup)]
+        gbuf = _empty((sum(sizes),), ref)
+        g_kl = gbuf[:sizes[0]].view_as(s_kl) if s_kl is not None else None
+        g_ce = gbuf[sizes[0]:sizes[0] + sizes[1]].view_as(s_ce) if s_ce is not None else None
+        g_sup = gbuf[sizes[0] + sizes[1]:].view_as(s_sup) if s_sup is not None else None
         q = s_kl if s_kl is not None else s_ce
         Rq, C = (q.shape if q is not None else (0, 0))
         Rs, Cs = (s_sup.shape if s_sup is not None else (0, 0))
         lib().call("lmkd_d2m_loss", _p(s_kl), _p(t_kl), _p(s_ce), _p(labels), _p(s_sup), _p(t_sup), Rq, C, Rs, Cs, _f32(T),
                    _f32(w_kl), _f32(w_sup), _f32(w_ce), _p(out), _p(g_kl), _p(g_ce), _p(g_sup), _stream())
-        ctx.grads = (g_kl, g_ce, g_sup)
+        ctx.grads = (gbuf, sizes, tuple(t.shape if t is not None else None for t in (s_kl, s_ce, s_sup)))
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        g_kl, g_ce, g_sup = ctx.grads
-        s = gout[0]                                # only the total carries gradient
+        gbuf, sizes, shapes = ctx.grads
+        g = gbuf * gout[0]                         # only the total carries gradient; one launch for the three tensors
+        o0, o1 = sizes[0], sizes[0] + sizes[1]
+        parts = (g[:o0], g[o0:o1], g[o1:])
 
-        def sc(t):
-            return None if t is None else t * s
-        return sc(g_kl), None, sc(g_ce), None, sc(g_sup), None, None, None, None, None
+        def sc(i):
+            return None if shapes[i] is None else parts[i].view(shapes[i])
+        return sc(0), None, sc(1), None, sc(2), None, None, None, None, None
 
 
 class MSELossFn(torch.autograd.Function):

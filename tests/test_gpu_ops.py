@@ -1727,3 +1727,43 @@ def test_trx_projections_on_conv_kernels_match_gemm(dev, mode):
         ops.reset_compute_dtypes()
     for i, (a, b) in enumerate(zip(res[False], res[True])):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12, (i, float((a - b).abs().max()), float(a.abs().max()))
+
+
+@pytest.mark.parametrize("layA,layB", [("K", "K"), ("K", "N"), ("M", "N"), ("M", "K")])
+@pytest.mark.parametrize("M,N,K,batch", [(400, 1152, 2048, 2), (700, 140, 1152, 5), (1152, 2048, 400, 1), (100, 68, 36, 1), (64, 64, 4608, 1)])
+def test_gemm_on_the_bf16_pipe(dev, layA, layB, M, N, K, batch):
+    """lmkd_gemm_f32 in its three arithmetics (lmkd_gemm_set_mode; csrc/gemm_x3.h) against an fp64 product: the native fp32 MFMA kernel
+    (mode 0), fp32 as 3 x bf16 with six products (mode 1: fp32-class error AND no coherent bias - the sign-alternating 32-row blocks
+    cancel the MFMA's directional truncation), one bf16 plane per operand (mode 2: the fp64 product of the bf16-ROUNDED operands).
+    All four operand layouts, ragged sizes (M, N not multiples of the tile, K not a multiple of 32), strided batches, alpha / beta / bias."""
+    import litemkd_amd
+    from litemkd_amd import ops
+    lib = litemkd_amd.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(batch, M, K, generator=g) if layA == "K" else torch.randn(batch, K, M, generator=g)
+    B = torch.randn(batch, N, K, generator=g) if layB == "K" else torch.randn(batch, K, N, generator=g)
+    A = A + 0.5                                            # a mean, so that the sums are not centred on zero
+    bias = torch.randn(N, generator=g)
+    C0 = torch.randn(batch, M, N, generator=g)
+    A64 = (A if layA == "K" else A.transpose(1, 2)).double()
+    B64 = (B if layB == "K" else B.transpose(1, 2)).double()
+    r16 = lambda t: t.float().bfloat16().double()      # noqa: E731
+
+    def ref(a, b):
+        return 0.5 * (a @ b.transpose(1, 2)) + 0.25 * C0.double() + bias.double()
+    Ad, Bd = A.to(dev), B.to(dev)
+    lda, ldb = (K if layA == "K" else M), (K if layB == "K" else N)
+    try:
+        tiny = M * N * K < (1 << 18)      # such products stay on the fp32 MFMA kernel in every mode (gemm.hip gemm_planes)
+        for mode, want in ((0, ref(A64, B64)), (1, ref(A64, B64)), (2, ref(A64, B64) if tiny else ref(r16(A64), r16(B64)))):
+            lib.call("lmkd_gemm_set_mode", mode)
+            C = C0.clone().to(dev)
+            ops.gemm(layA, layB, M, N, K, Ad, lda, Bd, ldb, C, N, alpha=0.5, beta=0.25, bias=bias.to(dev), batch=batch,
+                     sA=A[0].numel(), sB=B[0].numel(), sC=M * N)
+            err = (C.cpu().double() - want)
+            rel = float(err.norm() / want.norm())
+            assert rel < 2e-6, (mode, rel)
+            if mode == 1 and M * N >= 64 * 64 * 4:      # the coherent part of the error: far below the per-element error
+                assert abs(float(err.mean())) < 0.1 * float(err.abs().mean()) + 1e-9, (float(err.mean()), float(err.abs().mean()))
+    finally:
+        lib.call("lmkd_gemm_set_mode", -1)

@@ -18,8 +18,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 dev = torch.device("cuda:0")
 ops.set_conv_compute_dtype({"f32": "fp32x3", "bf16": "bf16"}[mode])
 ops.set_activation_dtype("bf16" if mode == "bf16" else "fp32")
-ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END = True, False
-ops.DIRECT_PARAM_GRAD = os.environ.get("LMKD_DIRECT_GRAD", "1") != "0"
+from litemkd_amd.schedule import Schedule
+Schedule.from_env().apply(arithmetic=False)      # the benchmark's schedule (merged trunk call; the episodes here are not pipelined: one at a time)
 cfg = default_args(shot=5, device=dev, trans_dropout=0.1, training_iterations=10 ** 9, print_freq=10 ** 9)
 torch.manual_seed(1234)
 student, teacher = Student(cfg).to(dev), Teacher(cfg).to(dev)

@@ -22,7 +22,7 @@ def run(name, layA, layB, M, N, K, batch=1, **kw):
     lda = K if layA == "K" else M
     ldb = K if layB == "K" else N
     out = []
-    for mode, tile in ((0, 0), (1, 0), (1, 2), (1, 3), (2, 0), (2, 3)):
+    for mode, tile in ((0, 0), (1, 0), (1, 2), (1, 1), (2, 0), (2, 1)):
         lib.call("lmkd_gemm_set_mode", mode)
         lib.call("lmkd_gemm_set_tile", tile)
         f = lambda: ops.gemm(layA, layB, M, N, K, A, lda, B, ldb, C, N, batch=batch, sA=A[0].numel(), sB=B[0].numel(), sC=M * N)
@@ -42,7 +42,7 @@ def run(name, layA, layB, M, N, K, batch=1, **kw):
         out.append("%6.1f us %5.1f TF %.0e" % (best, 2.0 * M * N * K * batch / best / 1e6, err))
     lib.call("lmkd_gemm_set_mode", -1)
     lib.call("lmkd_gemm_set_tile", 0)
-    print("%-34s %s%s M %4d N %4d K %4d x%d | fp32 %s | x3 auto %s | x3 64x128 %s | x3 64x64 %s | bf16 auto %s | bf16 64x64 %s" % ((name, layA, layB, M, N, K, batch) + tuple(out)))
+    print("%-34s %s%s M %4d N %4d K %4d x%d | fp32 %s | x3 64x64 %s | x3 64x128 %s | x3 128x128 %s | bf16 64x64 %s | bf16 128x128 %s" % ((name, layA, layB, M, N, K, batch) + tuple(out)))
 
 
 run("TRX projection (per k / v weight)", "K", "K", 400, 1152, 2048, 2)
