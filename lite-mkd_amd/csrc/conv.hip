@@ -717,14 +717,15 @@ extern "C" int lmkd_conv2d_repack_multi(const float* const* ws, void* const* wfs
 // Workgroups per CU by LDS: 2 / 2 / 4 / 2 / 2.
 static int g_tile_override = 0;
 extern "C" int lmkd_conv_set_tile(int id) {
-  LMKD_REQUIRE(id >= 0 && id <= 12, "lmkd_conv_set_tile: id must be 0 (auto) .. 12");
+  LMKD_REQUIRE(id >= 0 && id <= 14, "lmkd_conv_set_tile: id must be 0 (auto) .. 14");
   g_tile_override = id;
   return LMKD_OK;
 }
 // 7..10: the bf16-plane kernels (conv_x3.h, conv_patch.h), 8 waves: 7 = 256x64, 8 = 128x128, 9 = 128x64, 10 = 256x128 (patch kernel only)
 // 11 / 12 (patch kernel only): 128x64 / 128x128 with FOUR waves, three / two workgroups per CU
-static inline int cfg_bm(int id) { return (id == 7 || id == 10) ? 256 : ((id <= 2 || id >= 5) ? 128 : 64); }
-static inline int cfg_bn(int id) { return (id == 1 || id == 4 || id == 5 || id == 8 || id == 10 || id == 12) ? 128 : 64; }
+// 13 / 14 (patch kernel, one-plane modes only): 256x128 / 256x64 with FOUR waves (wave tiles 128x64 / 128x32)
+static inline int cfg_bm(int id) { return (id == 7 || id == 10 || id == 13 || id == 14) ? 256 : ((id <= 2 || id >= 5) ? 128 : 64); }
+static inline int cfg_bn(int id) { return (id == 1 || id == 4 || id == 5 || id == 8 || id == 10 || id == 12 || id == 13) ? 128 : 64; }
 static inline int cfg_wg_per_cu(int id) { return id == 1 ? 2 : (id == 3 ? 4 : 3); }
 
 // Pick the tile that minimises ceil(tiles / 256 CUs) * work per tile: at 64 cycles per fp32 MFMA every configuration is
@@ -737,7 +738,9 @@ static int pick_conv_cfg(long rows_per_class, int nclass, int ncols, bool same =
       if (id == 10 && !same) id = 8;
       if (id == 11 && !same) id = 9;
       if (id == 12 && !same) id = 8;
-      if (ncols <= 64 && cfg_bn(id) == 128) id = id == 10 ? 7 : (id == 12 ? 11 : 9);
+      if ((id == 13 || id == 14) && (!same || !g_conv_bf16)) id = id == 13 ? 10 : 7;
+      if (id == 10 && !same) id = 8;
+      if (ncols <= 64 && cfg_bn(id) == 128) id = id == 10 ? 7 : (id == 12 ? 11 : (id == 13 ? 14 : 9));
       return id;
     }
     if (same) {
@@ -924,6 +927,30 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
 #undef LMKD_PATCH
 }
 
+// one-plane modes only (tile ids 13 / 14: 256-row tiles with four waves)
+template <class Cfg>
+static void launch_conv_patch_1p(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
+  conv_set_tiles(a, Cfg::BM);
+  a.n_ct = cdiv(ncols, Cfg::BN);
+  a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
+  if (g_xcd_mode == 0) a.xcd_mode = 0;
+  const dim3 grid(xcd_grid(a.n_rt, a.n_ct, a.xcd_mode));
+  a.halo = halo;
+  const size_t lds = patch_lds_bytes(Cfg::BM, halo, 1);
+#define LMKD_PATCH1(PRE, IO)                                                                                                   \
+  do {                                                                                                                         \
+    static std::atomic<unsigned long long> attr_done{0};                                                                       \
+    lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, 1, PRE, IO>),                       \
+                       (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 1));                                                      \
+    hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, 1, PRE, IO>), grid, dim3(Cfg::THREADS), lds, s, a);                          \
+  } while (0)
+  if (a.ep_stats) LMKD_PATCH1(false, 4);
+  else if (g_lmkd_act_bf16) LMKD_PATCH1(false, 3);
+  else if (a.pre_stats) LMKD_PATCH1(true, 0);
+  else LMKD_PATCH1(false, 0);
+#undef LMKD_PATCH1
+}
+
 template <class Cfg, bool SMALLC, bool STATS>
 static void launch_conv_x3(ConvGemmArgs a, int ncols, hipStream_t s) {
   conv_set_tiles(a, Cfg::BM);
@@ -970,6 +997,7 @@ static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
       if (halo < 0 && id == 10) id = 7;
       if (halo < 0 && id == 11) id = 9;
       if (halo < 0 && id == 12) id = 8;      // same tile height (the BatchNorm partials' row count) on the gather kernel
+      if (halo < 0 && (id == 13 || id == 14)) id = 7;
       if (halo >= 0) {
         switch (id) {
           case 7: launch_conv_patch<X3Cfg<256, 64, 4, 2>>(a, ncols, halo, s); break;
@@ -977,6 +1005,8 @@ static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
           case 10: launch_conv_patch<X3Cfg<256, 128, 2, 4>>(a, ncols, halo, s); break;
           case 11: launch_conv_patch<X3Cfg<128, 64, 2, 2, 3>>(a, ncols, halo, s); break;
           case 12: launch_conv_patch<X3Cfg<128, 128, 2, 2, 2>>(a, ncols, halo, s); break;
+          case 13: launch_conv_patch_1p<X3Cfg<256, 128, 2, 2, 2>>(a, ncols, halo, s); break;
+          case 14: launch_conv_patch_1p<X3Cfg<256, 64, 2, 2, 2>>(a, ncols, halo, s); break;
           default: launch_conv_patch<X3Cfg<128, 64, 4, 2>>(a, ncols, halo, s); break;
         }
         LMKD_CHECK_LAUNCH("conv_patch_x3_kernel");

@@ -173,14 +173,51 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
   };
   bf16x8 dbg_av[2][NPL][Cfg::TM];      // (dead unless DBG & 2)
   int k_tp = 0, k_cc = 0;      // (tap, chunk) of the current K-step
+  // One-plane modes (round 4): the A fragments of K-step t + 1 are read from LDS while the MFMAs of step t run (two register sets,
+  // passed to step() in alternation like the weight sets).  With one plane a K-step is 4 MFMAs (128 cycles) per wave behind 4
+  // ds_read_b128 whose latency (+ bank conflicts) is as long: read-then-multiply left the matrix pipe 31 % busy (PMC, tools/pmc_patch.sh)
+  // with every tile shape.  Across a chunk boundary nothing can be prefetched (the next chunk's patch is not in LDS yet).
+  constexpr bool PIPE = NPL == 1 && DBG == 0;
+  bf16x8 avp0[2][NPL][Cfg::TM], avp1[2][NPL][Cfg::TM];
+  auto read_tap = [&](int tp, bf16x8 (&dst)[2][NPL][Cfg::TM]) {
+    const unsigned sh = (unsigned)s_tap_shift[tp];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+      const unsigned ad = ((a_mask[i] >> tp) & 1u) ? a_base[i] + sh : zero_addr;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) dst[g][p][i] = *reinterpret_cast<const bf16x8*>(psm + ad + p * 64 + g * 32);
+    }
+  };
   // K-step t: MFMAs with the B set `rb`; afterwards the set fetched before them (`rbn`, step t+1) is landed - every load in flight
   // is then one MFMA phase old - and `rb` is refilled with step t+2.  At a chunk boundary the patch is replaced first.
-  auto step = [&](int t, u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR]) {
+  auto step = [&](int t, u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR], bf16x8 (&avc)[2][NPL][Cfg::TM], bf16x8 (&avn)[2][NPL][Cfg::TM]) {
     if (k_tp == 0) {
       __syncthreads();                       // every wave has finished reading the previous chunk
       if (!(DBG & 4) || t == 0) store_patch();
       __syncthreads();
       if (k_cc + 1 < a.cps) issue_patch(k_cc + 1);
+      if constexpr (PIPE) read_tap(0, avc);
+    }
+    if constexpr (PIPE) {
+      if (k_tp + 1 < ntap) read_tap(k_tp + 1, avn);      // lands under this step's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+          const bf16x8 b0 = x3_as_bf16(rb[j * 2 + g]);
+#pragma unroll
+          for (int i = 0; i < Cfg::TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avc[g][0][i], b0, acc[i][j], 0, 0, 0);
+        }
+      if (++k_tp == ntap) { k_tp = 0; ++k_cc; }
+      __builtin_amdgcn_sched_barrier(0);
+      x3_landed(rbn);
+      x3_landed(rp);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < nk) issue_b(rb);
+      return;
     }
     const unsigned sh = (unsigned)s_tap_shift[k_tp];
     unsigned ad[Cfg::TM];
@@ -281,10 +318,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     // MFMAs with s_waitcnt vmcnt(5..0) - which on the real path wait for the loads issued just before them
     int t = 0;
     for (; t + 1 < nk; t += 2) {
-      step(t, rb0, rb1);
-      step(t + 1, rb1, rb0);
+      step(t, rb0, rb1, avp0, avp1);
+      step(t + 1, rb1, rb0, avp1, avp0);
     }
-    if (t < nk) step(t, rb0, rb1);
+    if (t < nk) step(t, rb0, rb1, avp0, avp1);
   }
   if (DBG & 16) {      // ablation: the same bytes written with 16-byte stores (wrong element mapping): what would a transposed epilogue buy?
 #pragma unroll

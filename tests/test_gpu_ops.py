@@ -1645,7 +1645,9 @@ def test_stem_pooled_backward_matches_materialised_path(dev, N, H, W, mode):
 
 def test_two_head_linear_matches_four_linear_calls(dev):
     """ops.TwoHeadLinearFn (fc1 / fc2 over both trunk calls' features as one autograd node, resnet18_2fc.py:56-64) against four
-    LinearFn calls: outputs bit-identical (the same GEMM rows), gradients equal to fp32 rounding of the re-ordered sums"""
+    LinearFn calls: outputs equal to fp32 rounding (the same GEMM rows; bit-identical on the native fp32 MFMA, while the 3 x bf16 GEMM
+    alternates the accumulation sign per 32-row block of the launch - gemm_x3.h - and the query rows sit in other blocks of the stacked
+    call), gradients equal to fp32 rounding of the re-ordered sums"""
     from litemkd_amd import ops
     from litemkd_amd.model.backbone.resnet import Linear
     torch.manual_seed(5)
@@ -1666,7 +1668,7 @@ def test_two_head_linear_matches_four_linear_calls(dev):
             ops.FUSE_TWO_HEAD_LINEAR = True
     for i, (a, b) in enumerate(zip(res[False], res[True])):
         if i < 4:
-            assert torch.equal(a, b), i
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), i
         else:
             assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (i, float((a - b).abs().max()), float(a.abs().max()))
 

@@ -34,6 +34,8 @@ for mode in modes:
         fl = 2.0 * N * H * H * Cout * C * 9
         res, best = {}, {}
         cfgs = [(0, 0), (1, 0)] + [(1, t) for t in ((9, 7, 11) if Cout <= 64 else (8, 10, 11, 12))]
+        if mode.startswith("bf16"):
+            cfgs += [(1, 14)] if Cout <= 64 else [(1, 13), (1, 14)]
         for rnd_ in range(3):      # interleaved rounds, best time per configuration: the clock the chip holds drifts between launches
             for patch, tile in cfgs:
                 lib().call("lmkd_conv_set_patch", patch)
