@@ -170,6 +170,8 @@ def main():
         SCHED.pipeline_episodes = a.pipeline
     use_pipe = SCHED.pipeline_episodes and not a.serial and mfm is None
     use_graph = a.graph and not a.serial and mfm is None and not use_pipe
+    if os.environ.get("LMKD_PIPE_DEPTH"):
+        TL.PIPELINE_DEPTH = int(os.environ["LMKD_PIPE_DEPTH"])
     pipe = TL.PipelinedEpisodes(student, teacher, distiller, aggregate_accuracy, cfg) if use_pipe else None
     runners = {}      # one GraphedEpisode per arithmetic mode: a captured graph holds that mode's kernels and packed-weight buffers
     state = {"mode": a.dtype}

@@ -14,6 +14,7 @@ from ._lib import lib
 import ctypes
 
 
+PIPELINE_DEPTH = 1          # PipelinedEpisodes: forwards queued ahead of the oldest pending backward
 REPACK_AT_STEP = True
 EARLY_ALLREDUCE = True      # world > 1: all-reduce the bucket's tail under the last backward pass of an optimizer interval (parallel.EarlyAllReduce)
 
@@ -225,16 +226,24 @@ class PipelinedEpisodes:
             if optimizer step due: pipe.flush(); optimizer.step(); optimizer.zero_grad()
         pipe.flush()                             # -> (loss, accuracy) of the last episode; the caller's stream waits for everything"""
 
-    def __init__(self, student, teacher, distiller, accuracy_fn, config):
+    def __init__(self, student, teacher, distiller, accuracy_fn, config, depth=None):
         self.student, self.teacher, self.distiller, self.accuracy_fn, self.config = student, teacher, distiller, accuracy_fn, config
-        self.pending = None
+        # depth: how many forwards may be queued ahead of the oldest pending backward (1: the forward of episode i + 1 beside the backward
+        # of episode i; 2: the forward of episode i + 2 starts as soon as that of i + 1 is queued - it fills the stretch in which the
+        # longer backward of episode i is still running - at the price of a third episode's activations in memory)
+        self.depth = int(depth if depth is not None else PIPELINE_DEPTH)
+        self.queue = []
         self.bwd_done = None
         self.count = 0
+
+    @property
+    def pending(self):
+        return self.queue[-1] if self.queue else None
 
     def push(self, task_dict):
         dev = self.config.device
         caller = torch.cuda.current_stream(dev)
-        lane = self.count & 1
+        lane = self.count % (self.depth + 1)
         self.count += 1
         ops.set_lane(lane)
         try:
@@ -243,8 +252,8 @@ class PipelinedEpisodes:
             with torch.cuda.stream(main):
                 prepared = prepare_task(task_dict, dev)
                 loss, acc = _episode_forward(prepared, self.student, self.teacher, self.distiller, self.accuracy_fn, self.config)
-            prev, self.pending = self.pending, (loss, acc, lane)
-            return self._backward(prev) if prev is not None else None
+            self.queue.append((loss, acc, lane))
+            return self._backward(self.queue.pop(0)) if len(self.queue) > self.depth else None
         finally:
             ops.set_lane(0)
 
@@ -273,13 +282,16 @@ class PipelinedEpisodes:
         return loss.detach(), acc
 
     def flush(self):
-        """run the pending backward; afterwards the caller's current stream waits for every episode pushed so far"""
-        out = None
-        if self.pending is not None:
-            out, self.pending = self._backward(self.pending), None
+        """run the pending backward passes (oldest first); afterwards the caller's current stream waits for every episode pushed so far.
+        -> (loss, accuracy) of the last episode, or a list of them when more than one was pending, or None"""
+        outs = []
+        while self.queue:
+            outs.append(self._backward(self.queue.pop(0)))
         if self.bwd_done is not None:
             torch.cuda.current_stream(self.config.device).wait_event(self.bwd_done)
-        return out
+        if not outs:
+            return None
+        return outs[0] if len(outs) == 1 else outs
 
 
 def init_model(config):
@@ -599,9 +611,10 @@ def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler,
             if getattr(config, "pipeline_episodes", False) and torch.device(config.device).type == "cuda" else None)
 
     def took(res):
-        if res is not None:
-            losses.append(res[0])
-            accuracies.append(res[1])
+        for r in (res if isinstance(res, list) else [res]):
+            if r is not None:
+                losses.append(r[0])
+                accuracies.append(r[1])
     for task_dict in video_loader:
         if iteration >= total_iterations:
             break

@@ -51,7 +51,8 @@ def _run(dev, sched, shot, img, episodes, freeze=(), opt="sgd", lr=1e-2, seed=3)
                 r = pipe.push(ep)
                 if r is not None:
                     losses.append(r[0])
-            losses.append(pipe.flush()[0])
+            r = pipe.flush()
+            losses += [x[0] for x in (r if isinstance(r, list) else [r])]
         else:
             for ep in pool:
                 loss, _, _ = TL.train_task(ep, student, teacher, distiller, aggregate_accuracy, cfg)
