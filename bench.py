@@ -67,9 +67,12 @@ def main():
                     "mode under rocprofv3 so per-kernel durations are not inflated by concurrent kernels")
     ap.add_argument("--roofline-episodes", type=int, default=2)
     ap.add_argument("--dtype", choices=["f32", "f32native", "bf16", "bf16conv", "f32x3"], default="f32", help="f32 (headline, BASELINE "
-                    "configs[1]; the library's default arithmetic): fp32 tensors, fp32 accumulation, the convolution products on the bf16 "
+                    "configs[1]): fp32 tensors, fp32 accumulation; f32x3's arithmetic with the 3x3 convolutions (forward, data gradient, "
+                    "window weight gradient: 93 %% of the trunk's flops) on TWO fp16 planes + power-of-two scales, three products per fp32 "
+                    "product ('fp32h2', csrc/conv_patch16.h) - error vs fp64 at or below f32x3's on every layer (tests/test_gpu_h2.py, "
+                    "profiles/r04_h2_error.txt); f32x3 (rounds 2-3's headline, the library default): the convolution products on the bf16 "
                     "matrix pipe from an EXACT 3-way bf16 split of both operands, 6 products per fp32 product (csrc/conv_x3.h, wgrad_x3.h; "
-                    "error vs fp64 of the class of the native fp32 MFMA: tests/test_gpu_fullsize.py); f32x3: alias of f32; f32native: the same "
+                    "error vs fp64 of the class of the native fp32 MFMA: tests/test_gpu_fullsize.py); f32native: the same "
                     "job on v_mfma_f32_32x32x2_f32 (round 1's headline arithmetic, reported under other_modes by default); "
                     "bf16 (configs[2]): bf16 tensors in HBM for every activation / activation gradient of the trunk, bf16 MFMA with "
                     "fp32 accumulation, fp32 statistics, weights and heads; bf16conv: round 1's variant (fp32 tensors, only the "
@@ -142,9 +145,7 @@ def main():
     litemkd_amd.lib().call("lmkd_conv_set_xcd_mode", a.xcd_mode)
     if a.ew_wg > 0:
         litemkd_amd.lib().call("lmkd_set_elementwise_wg_per_cu", a.ew_wg)
-    if a.dtype == "f32x3":
-        a.dtype = "f32"
-    MODE = {"f32": "fp32x3", "f32native": "fp32", "bf16": "bf16", "bf16conv": "bf16"}
+    MODE = {"f32": "fp32h2", "f32x3": "fp32x3", "f32native": "fp32", "bf16": "bf16", "bf16conv": "bf16"}
 
     def set_mode(name):
         ops.set_conv_compute_dtype(MODE[name])
@@ -375,19 +376,21 @@ def main():
     wg = fam.get("conv_wgrad_kernel", ZERO)
     achieved = cg[0] / cg[1] / 1e12
     # dense MFMA peaks (MI355X_MICROARCH.md); the 3xbf16 arithmetic issues 6 bf16 MFMA flops per algorithmic fp32 flop
-    PEAK = {"f32": 2500.0 / 6, "f32native": PEAK_FP32_MFMA_TFLOPS, "bf16": 2500.0, "bf16conv": 2500.0}
-    ARITH = {"f32": "v_mfma_f32_16x16x32_bf16 x6 per fp32 product, exact 3-way bf16 operand split, fp32 accumulate; peak = dense bf16 MFMA peak / 6",
+    PEAK = {"f32": 2500.0 / 3, "f32x3": 2500.0 / 6, "f32native": PEAK_FP32_MFMA_TFLOPS, "bf16": 2500.0, "bf16conv": 2500.0}
+    ARITH = {"f32": "v_mfma_f32_16x16x32_f16 x3 per fp32 product, two fp16 planes per operand (h0 + h1 = x 2^s to 2^-24, 2^s from the tensor's "
+                    "maximum), fp32 accumulate; peak = dense fp16 MFMA peak / 3",
+             "f32x3": "v_mfma_f32_16x16x32_bf16 x6 per fp32 product, exact 3-way bf16 operand split, fp32 accumulate; peak = dense bf16 MFMA peak / 6",
              "f32native": "v_mfma_f32_32x32x2_f32",
              "bf16": "one bf16 plane, bf16 tensors, v_mfma_f32_32x32x16_bf16",
              "bf16conv": "one bf16 plane, fp32 tensors, v_mfma_f32_32x32x16_bf16"}
 
     def kernel_name(mode, patch):
         if patch:
-            return ("conv_patch16_x3_kernel" if mode == "f32" else "conv_patch_x3_kernel") + \
+            return ("conv_patch16_x3_kernel" if mode in ("f32", "f32x3") else "conv_patch_x3_kernel") + \
                 " (3x3 conv fwd + dgrad from an LDS-resident input patch; stride-2 launches as parity classes): " + ARITH[mode]
         return ("conv_gemm_kernel" if mode == "f32native" else "conv_gemm_x3_kernel") + " (implicit-GEMM conv fwd + dgrad): " + ARITH[mode]
     KERNEL = {a.dtype: kernel_name(a.dtype, patch_dom)}
-    PMC_KEY = ("conv_patch16_x3_kernel" if a.dtype == "f32" else "conv_patch_x3_kernel") if patch_dom else ("conv_gemm_kernel" if a.dtype == "f32native" else "conv_gemm_x3_kernel")
+    PMC_KEY = ("conv_patch16_x3_kernel" if a.dtype in ("f32", "f32x3") else "conv_patch_x3_kernel") if patch_dom else ("conv_gemm_kernel" if a.dtype == "f32native" else "conv_gemm_x3_kernel")
     peak = PEAK[a.dtype]
     # HBM-side traffic of the same kernel family: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950) of `bench.py --serial`,
@@ -415,8 +418,19 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "HMDB-shape 5-way %d-shot %s + TRX_2fcsup + D2M fc_2_sup_dist training episode%s, %s"
                                % (a.shot, a.backbone, " + live MFM fusion" if a.live_mfm else "",
-                                  {"f32": "fp32", "f32native": "fp32", "bf16": "bf16 tensors / fp32 accumulate", "bf16conv": "bf16 conv operands / fp32 tensors"}[a.dtype]),
-                   "conv_arithmetic": {"f32": "the library default: fp32 tensors and accumulation; every convolution (forward, data and weight "
+                                  {"f32": "fp32", "f32x3": "fp32", "f32native": "fp32", "bf16": "bf16 tensors / fp32 accumulate", "bf16conv": "bf16 conv operands / fp32 tensors"}[a.dtype]),
+                   "conv_arithmetic": {"f32": "fp32 tensors and accumulation.  The 3x3 convolutions - forward, data gradient, stride-1 weight gradient: 93 % of "
+                                              "the trunk's flops - split each fp32 operand x into TWO fp16 planes, h0 = fp16(x 2^s), h1 = fp16(x 2^s - h0) "
+                                              "(|x 2^s - h0 - h1| <= 2^-24 |x 2^s|: half an fp32 ulp; 2^s a power of two from max |tensor|, which the kernel "
+                                              "that writes the tensor records, so the scaling is exact) and form h0 w0 + h0 w1 + h1 w0 on "
+                                              "v_mfma_f32_16x16x32_f16 with fp32 accumulation (the dropped h1 w1 <= 2^-24 of the product; the three-plane "
+                                              "bf16 form drops 2^-23).  Everything else (stem, 1x1 / stride-2 weight gradients, heads) runs f32x3's "
+                                              "arithmetic.  Relative-L2 error vs fp64 on the trunk's four 3x3 shapes: forward 2.7e-7 .. 7.0e-7, data gradient "
+                                              "2.7e-7 .. 7.1e-7, weight gradient 2.3e-7 .. 5.5e-7 - BELOW f32x3's (3.5e-7 .. 9.6e-7 | 3.6e-7 .. 1.0e-6 | 2.9e-7 .. "
+                                              "8.2e-7) and at torch's fp32 convolution's on every one (profiles/r04_h2_error.txt; tests/test_gpu_h2.py holds "
+                                              "it to the fp64-anchored criterion of the f32x3 tests).  The same job in f32x3 (rounds 2-3's headline): "
+                                              "other_modes.f32x3",
+                                       "f32x3": "the library default: fp32 tensors and accumulation; every convolution (forward, data and weight "
                                               "gradient, stem included) forms its products on the bf16 matrix pipe from an exact 3-way bf16 split of "
                                               "both operands, 6 of 9 cross products; half the row tiles of a launch accumulate -y so that the MFMA's "
                                               "directional truncation cancels in sums over pixels (DESIGN 8.5).  Relative-L2 error vs fp64 at the "
@@ -466,7 +480,7 @@ def main():
         # short timed regions right here, same process, same resident episodes, each with its own per-kernel roofline pass
         other = {}
         ALG_BYTES_PER_EPISODE = 3 * 12.9e6 * frames      # 12.9 MB of bf16 activation traffic per frame forward, x3 for a step
-        for name in ("f32native", "bf16"):
+        for name in ("f32x3", "f32native", "bf16"):
             set_mode(name)
             state["mode"] = name
             # the native fp32 MFMA mode has no two-segment kernels (resnet.merge_supported): it runs round 3's schedule - two trunk calls on
@@ -489,6 +503,8 @@ def main():
         set_mode("f32")
         state["mode"] = "f32"
         state["pipe"] = True
+        other["f32x3"]["what"] = ("rounds 2-3's headline arithmetic (the library default): every fp32 product from an exact 3-way bf16 split, "
+                                  "six bf16 MFMA products")
         other["f32native"]["what"] = "round 1's headline arithmetic: every convolution on the fp32 MFMA (157.3 TFLOP/s peak)"
         other["bf16"]["what"] = "BASELINE configs[2]: bf16 tensors in HBM (activations and their gradients), bf16 MFMA, fp32 accumulate / statistics / weights"
         # configs[2] sits at the ridge of the bf16 roofline: report the HBM side as well, on algorithmic bytes

@@ -67,11 +67,32 @@ int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound 
    accumulation (csrc/conv_x3.h; fp32-class error, the arithmetic of the benchmark's headline line), 3 = the same with all nine
    products, 0 = native fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16 MFMA inputs + fp32 accumulation (BASELINE configs[2]).
    In modes 1/2/3 the packed-weight arguments of lmkd_conv2d_fwd / lmkd_conv2d_bwd_data point at the buffer written by
-   lmkd_conv2d_split_weights (in that mode). */
+   lmkd_conv2d_split_weights (in that mode).
+   4 (round 4) = mode 2 with the kernels that carry 93 % of the trunk's flops - the 3x3 convolutions' forward and data gradient
+   (conv_patch16_x3_kernel) and the 3x3 / stride-1 weight gradient (conv_wgrad_win16_kernel) - on TWO fp16 planes and THREE
+   v_mfma_f32_16x16x32_f16 products per fp32 product: x 2^s = h0 + h1 with h0 = fp16(x 2^s), h1 = fp16(x 2^s - h0) represents x to
+   2^-24 (half an fp32 ulp), the dropped h1 h1' term is <= 2^-24 of the product (mode 2 drops 2^-23), accumulation stays fp32, and 2^s
+   is a power of two taken from the tensor's maximum (lmkd_conv_operand_amax), so the scaling is exact.  Measured error against fp64
+   at or below mode 2's on every layer (profiles/r04_h2_error.txt).  A launch whose operand maxima are not named runs mode 2. */
 int lmkd_conv_set_compute_dtype(int mode);
+/* mode 4: the maxima of the operands of the NEXT convolution launch of this host thread (forward: x; data gradient: dy; weight gradient:
+   both), one-shot - consumed and cleared by that launch.  Each is a device word holding the fp32 bits of max |tensor| (any upper bound
+   is valid), complete in stream order before the launch; null = unknown.  Ignored in the other modes. */
+int lmkd_conv_operand_amax(const void* x_word, const void* dy_word);
+/* the NEXT launch of lmkd_bn_apply(_seg) / lmkd_bn_relu_maxpool_fwd(_seg) / lmkd_bn_backward(_seg) / lmkd_bn_backward_part(_seg) on this
+   host thread also folds max |y| (backward: max |dx|) into *word with an atomic max on the fp32 bits; the caller zeroes the word.
+   One-shot.  This is how a trunk tensor gets the word lmkd_conv_operand_amax names, without a pass of its own. */
+int lmkd_amax_next(void* word);
+/* max |x[0 .. n)| -> *word (zeroed here first): a pass of its own, for tensors no kernel of this library wrote */
+int lmkd_amax(const float* x, long n, void* word, void* stream);
+/* 16-bit elements of the plane buffer lmkd_conv2d_split_weights fills for a packed weight [ncols][Kp] in the current mode:
+   ncols Kp (mode 1), 12 ncols Kp (2 / 3), 16 ncols Kp + 32 (4: + the two fp16 planes of W and of -W in the 16x16x32 order and, in the
+   last 64 bytes, max |w|) */
+long lmkd_conv2d_plane_elems(int ncols, int Kp);
+long lmkd_conv_h2_launches(void); /* launches that took the two-plane form so far (tests) */
 /* re-pack n convolution weights in ONE launch (after an optimizer step; trainwandb.py:142): entry i = OIHW weight ws[i] -> wfs[i], the
    buffer lmkd_conv2d_pack_weights + lmkd_conv2d_split_weights would fill for dims[6 i ..] = (Cout, Cin, Cs, KH, KW, mode), bit for bit.
-   Modes 1-3 of lmkd_conv_set_compute_dtype.  The pointer / dims arrays are host memory. */
+   Modes 1-4 of lmkd_conv_set_compute_dtype.  The pointer / dims arrays are host memory. */
 int lmkd_conv2d_repack_multi(const float* const* ws, void* const* wfs, const int* dims, int n, void* stream);
 /* wp: fp32 K-major packed weights [ncols][Kp] (lmkd_conv2d_pack_weights; ncols = Cout forward, Cin data gradient)
    -> wf: bf16 in MFMA fragment order: mode 1: ncols * Kp (one round-to-nearest plane); modes 2/3: 12 * ncols * Kp = the three planes

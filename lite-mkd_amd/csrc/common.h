@@ -55,6 +55,17 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
   return (t + ((n - t) >> 1)) >> (f.sh - 1);
 }
 
+// max |x| of a tensor, folded into a device word by the kernel that writes the tensor (lmkd_amax_next; read by the two-plane fp16
+// convolutions, conv_patch16.h): the fp32 bits of a non-negative number order like unsigned integers, so the fold is an atomicMax
+__device__ __forceinline__ float amax4(float m, const float4& v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ __forceinline__ void amax_commit(unsigned* __restrict__ word, float m) {      // call with the whole wave active
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(word, __float_as_uint(m));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -54,6 +54,7 @@ struct ConvGemmArgs {
   // tiles (with their -W halves, x3_neg_tile) are exactly those of two separate launches: bit-identical results.
   // Unsegmented launch: seg_m0 = rows_per_class, seg_t0 = tiles_per_class (conv_set_tiles).
   int seg_m0, seg_t0;
+  const unsigned* h2_xw;      // two-plane fp16 arithmetic (compute dtype 4): the word holding max |operand| (lmkd_conv_operand_amax); null: three bf16 planes
   FastDiv div_hw, div_w;
   int ntap[LMKD_MAX_CLASSES];
   Tap taps[LMKD_MAX_CLASSES][LMKD_MAX_TAPS];
@@ -600,13 +601,50 @@ static int g_conv_bf16 = 0;
 static int g_conv_patch = 1;   // same-size convolutions of the bf16-plane modes from an LDS-resident patch (conv_patch.h); 0 = im2col gather
 extern "C" int lmkd_conv_set_patch(int on) { g_conv_patch = on ? 1 : 0; return LMKD_OK; }
 static int g_conv_x3 = 6;   // 0 | 6 | 9 bf16 MFMA products per fp32 product (conv_x3.h); library default: 6
+// mode 4: fp32 as TWO fp16 planes, three products (conv_patch16.h: h2_split4) in the kernels that carry 93 % of the trunk's flops - the 3x3
+// convolutions' forward / data gradient (conv_patch16_x3_kernel) and the window weight gradient (conv_wgrad_win16_kernel) - wherever the
+// caller names the operands' maxima (lmkd_conv_operand_amax); every other launch, and every launch without them, runs mode 2.
+static int g_conv_h2 = 0;
+static long g_h2_launches = 0;      // launches that took the two-plane form (tests)
+extern "C" long lmkd_conv_h2_launches(void) { return g_h2_launches; }
 extern "C" int lmkd_conv_set_compute_dtype(int mode) {
-  LMKD_REQUIRE(mode >= 0 && mode <= 3, "lmkd_conv_set_compute_dtype: 0 fp32 MFMA, 1 bf16, 2 fp32 as 3xbf16 (6 products), 3 (9 products)");
+  LMKD_REQUIRE(mode >= 0 && mode <= 4, "lmkd_conv_set_compute_dtype: 0 fp32 MFMA, 1 bf16, 2 fp32 as 3xbf16 (6 products), 3 (9 products), 4 fp32 as 2xfp16 (3 products) over mode 2");
   g_conv_bf16 = mode == 1;
-  g_conv_x3 = mode == 2 ? 6 : (mode == 3 ? 9 : 0);
+  g_conv_x3 = (mode == 2 || mode == 4) ? 6 : (mode == 3 ? 9 : 0);
+  g_conv_h2 = mode == 4;
   return LMKD_OK;
 }
-extern "C" int lmkd_conv_get_compute_dtype(void) { return g_conv_bf16 ? 1 : (g_conv_x3 == 6 ? 2 : (g_conv_x3 == 9 ? 3 : 0)); }
+extern "C" int lmkd_conv_get_compute_dtype(void) { return g_conv_bf16 ? 1 : (g_conv_h2 ? 4 : (g_conv_x3 == 6 ? 2 : (g_conv_x3 == 9 ? 3 : 0))); }
+// the maxima of the NEXT convolution launch's operands on this host thread (one-shot: consumed - and cleared - by that launch):
+// x_word / dy_word: device words holding the fp32 bits of max |x| / max |dy| over the whole tensor (upper bounds are valid: a larger word
+// costs range, not correctness), complete in stream order before the launch.  Either may be null.  Only mode 4 reads them.
+static thread_local const unsigned* g_amax_x = nullptr;
+static thread_local const unsigned* g_amax_dy = nullptr;
+extern "C" int lmkd_conv_operand_amax(const void* x_word, const void* dy_word) {
+  g_amax_x = (const unsigned*)x_word;
+  g_amax_dy = (const unsigned*)dy_word;
+  return LMKD_OK;
+}
+static inline const unsigned* take_amax_x() { const unsigned* p = g_amax_x; g_amax_x = nullptr; return p; }
+static inline const unsigned* take_amax_dy() { const unsigned* p = g_amax_dy; g_amax_dy = nullptr; return p; }
+// elements (16-bit) of the plane buffer of a packed weight of ncols x Kp in the current mode
+extern "C" long lmkd_conv2d_plane_elems(int ncols, int Kp) {
+  const long n = (long)ncols * Kp;
+  return g_conv_bf16 ? n : (g_conv_h2 ? 16 * n + 32 : 12 * n);
+}
+// max |x| of n floats into *word (zeroed here first).  The fallback for a tensor whose producer did not record it.
+extern "C" int lmkd_amax(const float* x, long n, void* word, void* stream) {
+  LMKD_REQUIRE(x && word && n > 0, "lmkd_amax: bad arguments");
+  if (hipMemsetAsync(word, 0, 4, (hipStream_t)stream) != hipSuccess) {
+    lmkd_set_error("lmkd_amax: hipMemsetAsync failed");
+    return LMKD_EHIP;
+  }
+  int grid = cdiv(n, 256 * 16);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(amax_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, (unsigned*)word);
+  LMKD_CHECK_LAUNCH("amax_kernel");
+  return LMKD_OK;
+}
 
 extern "C" int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, int Kp, void* stream) {
   LMKD_REQUIRE(wp && wf, "lmkd_conv2d_split_weights: null pointer");
@@ -620,6 +658,13 @@ extern "C" int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, i
   if (!g_conv_bf16) {      // three-plane modes: the 16x16x32 fragment order behind the two 32x32x16 copies (conv_patch16.h)
     hipLaunchKernelGGL(split_weights16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wp, (unsigned short*)wf + (long)ncols * Kp * 6, ncols, Kp);
     LMKD_CHECK_LAUNCH("split_weights16_kernel");
+  }
+  if (g_conv_h2) {         // + the two fp16 planes (16x16x32 order) and max |w| behind them
+    unsigned short* wh = (unsigned short*)wf + (long)ncols * Kp * 12;
+    const int rc = lmkd_amax(wp, (long)ncols * Kp, wh + (long)ncols * Kp * 4, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(split_weights16_h2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wp, wh, ncols, Kp);
+    LMKD_CHECK_LAUNCH("split_weights16_h2_kernel");
   }
   return LMKD_OK;
 }
@@ -637,24 +682,61 @@ struct RepackArgs {
   RepackEntry e[LMKD_REPACK_MAX];
   int npl;
 };
+// element (col, k) of the packed weight of entry e (pack_weights_kernel)
+__device__ __forceinline__ float repack_fetch(const RepackEntry& e, int col, int k) {
+  if (e.mode == 0) {      // mode 0: col = co, k = (kh * KWp + kw) * Cs + ci
+    const int ci = k % e.Cs;
+    const int r = k / e.Cs;
+    const int kw = r % e.KWp, kh = r / e.KWp;
+    return (ci < e.Cin && kw < e.KW) ? e.w[(((long)col * e.Cin + ci) * e.KH + kh) * e.KW + kw] : 0.f;
+  }
+  // mode 1: col = ci, k = (kh * KW + kw) * Co + co
+  const int co = k % e.Co;
+  const int r = k / e.Co;
+  const int kw = r % e.KW, kh = r / e.KW;
+  return e.w[(((long)co * e.Cin + col) * e.KH + kh) * e.KW + kw];
+}
+// mode 4: the fp16 planes behind the bf16 ones, in three launches: phase 0 zeroes the entries' max |w| words, 1 folds the maxima, 2 splits
+__global__ void repack_h2_kernel(RepackArgs a, int phase) {
+  const RepackEntry& e = a.e[blockIdx.y];
+  const long total = (long)e.ncols * e.Kp;
+  unsigned short* wh = e.wf + total * 12;
+  unsigned* word = reinterpret_cast<unsigned*>(wh + total * 4);
+  if (phase == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *word = 0u;
+    return;
+  }
+  if (phase == 1) {
+    float m = 0.f;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+      const int col = (int)(idx / e.Kp), k = (int)(idx - (long)col * e.Kp);
+      m = fmaxf(m, fabsf(repack_fetch(e, col, k)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(word, __float_as_uint(m));
+    return;
+  }
+  const float s = h2_scale(*word);
+  const int G16 = e.Kp >> 5;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx / e.Kp), k = (int)(idx - (long)col * e.Kp);
+    const int lane16 = (col & 15) + 16 * patch16_kslot((k >> 3) & 3);
+    const long q = ((((long)(col >> 4) * G16 + (k >> 5)) * 2) * 64 + lane16) * 8 + (k & 7);
+    unsigned short p0, p1;
+    h2_split1(repack_fetch(e, col, k) * s, p0, p1);
+    wh[q] = p0; wh[q + 512] = p1;
+    const long q2 = q + total * 2;
+    wh[q2] = p0 ^ 0x8000u; wh[q2 + 512] = p1 ^ 0x8000u;
+  }
+}
 __global__ void repack_multi_kernel(RepackArgs a) {
   const RepackEntry& e = a.e[blockIdx.y];
   const long total = (long)e.ncols * e.Kp;
   const int G = e.Kp >> 4, G16 = e.Kp >> 5;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int col = (int)(idx / e.Kp), k = (int)(idx - (long)col * e.Kp);
-    float x;
-    if (e.mode == 0) {      // pack_weights_kernel mode 0: col = co, k = (kh * KWp + kw) * Cs + ci
-      const int ci = k % e.Cs;
-      const int r = k / e.Cs;
-      const int kw = r % e.KWp, kh = r / e.KWp;
-      x = (ci < e.Cin && kw < e.KW) ? e.w[(((long)col * e.Cin + ci) * e.KH + kh) * e.KW + kw] : 0.f;
-    } else {                // mode 1: col = ci, k = (kh * KW + kw) * Co + co
-      const int co = k % e.Co;
-      const int r = k / e.Co;
-      const int kw = r % e.KW, kh = r / e.KW;
-      x = e.w[(((long)co * e.Cin + col) * e.KH + kh) * e.KW + kw];
-    }
+    const float x = repack_fetch(e, col, k);
     const int lane = (col & 31) + 32 * ((k >> 3) & 1);
     const long o = ((((long)(col >> 5) * G + (k >> 4)) * a.npl) * 64 + lane) * 8 + (k & 7);
     if (a.npl == 1) {
@@ -708,6 +790,12 @@ extern "C" int lmkd_conv2d_repack_multi(const float* const* ws, void* const* wfs
     if (gx > 512) gx = 512;
     hipLaunchKernelGGL(repack_multi_kernel, dim3(gx, m), dim3(256), 0, (hipStream_t)stream, a);
     LMKD_CHECK_LAUNCH("repack_multi_kernel");
+    if (g_conv_h2) {
+      for (int phase = 0; phase < 3; ++phase) {
+        hipLaunchKernelGGL(repack_h2_kernel, dim3(phase == 0 ? 1 : gx, m), dim3(256), 0, (hipStream_t)stream, a, phase);
+        LMKD_CHECK_LAUNCH("repack_h2_kernel");
+      }
+    }
   }
   return LMKD_OK;
 }
@@ -899,12 +987,14 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
     hipLaunchKernelGGL((conv_patch16_x3_kernel<Cfg, NPROD, false, EP, true>), grid, dim3(Cfg::THREADS), lds, s, a);            \
   } while (0)
         if (a.ep_stats) { if (g_conv_x3 == 9) LMKD_PATCH16S(9, true); else LMKD_PATCH16S(6, true); }
+        else if (g_conv_h2 && a.h2_xw) { LMKD_PATCH16S(3, false); ++g_h2_launches; }
         else { if (g_conv_x3 == 9) LMKD_PATCH16S(9, false); else LMKD_PATCH16S(6, false); }
 #undef LMKD_PATCH16S
         return;
       }
       if (a.ep_stats) { if (g_conv_x3 == 9) LMKD_PATCH16(9, false, true); else LMKD_PATCH16(6, false, true); }
       else if (a.pre_stats) { if (g_conv_x3 == 9) LMKD_PATCH16(9, true, false); else LMKD_PATCH16(6, true, false); }
+      else if (g_conv_h2 && a.h2_xw) { LMKD_PATCH16(3, false, false); ++g_h2_launches; }
       else { if (g_conv_x3 == 9) LMKD_PATCH16(9, false, false); else LMKD_PATCH16(6, false, false); }
 #undef LMKD_PATCH16
       return;
@@ -1094,6 +1184,7 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
   ConvGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.src = x; a.wpk = wp; a.out = y; a.stat_partial = stat_partial;
+  a.h2_xw = take_amax_x(); (void)take_amax_dy();
   a.ep_stats = ep_stats; a.ep_res = ep_res; a.ep_relu = ep_relu;
   a.pre_stats = pre_stats;
   LMKD_REQUIRE(!pre_stats || (stat_partial && !smallc && !g_lmkd_act_bf16),
@@ -1220,6 +1311,7 @@ static int bwd_data_args(ConvGemmArgs& a, const float* dy, const float* wd, floa
                "lmkd_conv2d_bwd_data: dy exceeds the 4 GiB buffer range of the bf16-plane kernels");
   memset(&a, 0, sizeof(a));
   a.src = dy; a.wpk = wd; a.out = dx; a.stat_partial = nullptr; a.accum = accumulate;
+  a.h2_xw = take_amax_dy(); (void)take_amax_x();
   a.N = N; a.Hs = Ho; a.Ws = Wo; a.Cs = Cout;
   a.Ho = H; a.Wo = W; a.Co = Cin;
   a.Kp = KH * KW * Cout; a.cps = Cout / 32;
@@ -1434,6 +1526,8 @@ extern "C" long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, in
 static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const float* dy, float* dw_oihw, float* workspace,
                                   long ws_bytes, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                   void* stream, int accumulate = 0, int seg_n0 = 0) {
+  const unsigned* amax_x = take_amax_x();
+  const unsigned* amax_dy = take_amax_dy();
   LMKD_REQUIRE(x && dy && dw_oihw && workspace, "lmkd_conv2d_bwd_weight: null pointer");
   // two frame segments: each is split into the slabs a launch of its own would use (same partial sums, same accumulation error), the
   // PRE loader takes the segment's BatchNorm table, ONE slab reduce sums everything
@@ -1501,6 +1595,7 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
     WgradWinArgs w;
     memset(&w, 0, sizeof(w));
     w.dy = dy; w.x = x; w.slab = workspace; w.pre_stats = pre_stats;
+    w.h2_xw = amax_x; w.h2_dyw = amax_dy;
     w.N = N; w.H = H; w.W = W; w.Cs = Cs; w.Co = Cout; w.Kp = a.Kp; w.Mpix = a.Mpix;
     w.steps_total = cdiv(a.Mpix, LMKD_BK);
     int cob;
@@ -1540,6 +1635,7 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   do {                                                                                                                  \
     if (g_wgrad_win16 && g_conv_x3 && !g_lmkd_act_bf16) {      /* three-plane modes, fp32 tensors: the 16x16x32 MFMA form */ \
       if (g_conv_x3 == 9) { if (pre_stats) LMKD_WIN16(COB, 9, true); else LMKD_WIN16(COB, 9, false); }                  \
+      else if (g_conv_h2 && !pre_stats && w.h2_xw && w.h2_dyw) { LMKD_WIN16(COB, 3, false); ++g_h2_launches; }          \
       else { if (pre_stats) LMKD_WIN16(COB, 6, true); else LMKD_WIN16(COB, 6, false); }                                 \
       break;                                                                                                            \
     }                                                                                                                   \

@@ -40,28 +40,31 @@ __device__ __forceinline__ float row16_sum(float v) {
   return dpp_add<0x140>(v);
 }
 
-template <int TN>
+// NPW = 3: the bf16 planes; NPW = 2: the fp16 planes of the two-plane arithmetic (lmkd_conv_set_compute_dtype(4)), a third region of the
+// weight buffer:  [32x32x16 order: W x 3 | -W x 3][16x16x32 order: W x 3 | -W x 3][16x16x32 order, fp16: W x 2 | -W x 2][max |w| : 64 bytes]
+template <int TN, int NPW = 3>
 struct X3FragB16 {
   static constexpr int NT = 2 * TN;      // 16-channel blocks of this wave
-  static constexpr int NR = NT * 3;
+  static constexpr int NR = NT * NPW;
   __amdgpu_buffer_rsrc_t rs;
   unsigned off[NT];
   __device__ __forceinline__ void init(const void* wf, int ncols, int Kp, int col0 /* of this wave */, int lane, bool neg) {
-    const long copy_bytes = (long)ncols * Kp * 2 * 3;
-    // buffer: [32x32x16 order: W planes | -W planes][16x16x32 order: W planes | -W planes]
-    rs = x3_rsrc(reinterpret_cast<const unsigned char*>(wf) + (neg ? 3 : 2) * copy_bytes, copy_bytes);
+    const long plane_bytes = (long)ncols * Kp * 2;
+    const long copy_bytes = plane_bytes * NPW;
+    const long base = NPW == 3 ? (neg ? 9 : 6) * plane_bytes : (neg ? 14 : 12) * plane_bytes;
+    rs = x3_rsrc(reinterpret_cast<const unsigned char*>(wf) + base, copy_bytes);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int nt = (col0 >> 4) + j;
-      off[j] = (nt * 16 < ncols) ? (unsigned)(((long)nt * (Kp >> 5) * 3 * 64 + lane) * 16) : X3_OOB;
+      off[j] = (nt * 16 < ncols) ? (unsigned)(((long)nt * (Kp >> 5) * NPW * 64 + lane) * 16) : X3_OOB;
     }
   }
   __device__ __forceinline__ void load(int koff /* multiple of 32 */, u32x4 (&reg)[NR]) const {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        reg[j * 3 + p] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j] == X3_OOB ? X3_OOB : off[j] + (unsigned)(((koff >> 5) * 3 + p) * 1024), 0, 0);
+      for (int p = 0; p < NPW; ++p)
+        reg[j * NPW + p] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j] == X3_OOB ? X3_OOB : off[j] + (unsigned)(((koff >> 5) * NPW + p) * 1024), 0, 0);
   }
 };
 
@@ -89,6 +92,70 @@ __global__ void split_weights16_kernel(const float* __restrict__ wp, unsigned sh
   }
 }
 
+// ---- fp32 as TWO fp16 planes (NPROD == 3; lmkd_conv_set_compute_dtype(4)) ----
+// x 2^s = h0 + h1 + e with h0 = fp16_rne(x 2^s), h1 = fp16_rne(x 2^s - h0): |e| <= 2^-24 |x 2^s| - HALF an fp32 ulp - wherever h1 is a normal
+// fp16 number (|x 2^s| >= 1/2), and <= 2^-25 absolutely below that.  Three products h0 w0 + h0 w1 + h1 w0 on v_mfma_f32_16x16x32_f16 with fp32
+// accumulation; the dropped h1 w1 is <= 2^-24 of the product (the three-plane bf16 form drops 2^-23).  2^s is a power of two taken from
+// the tensor's maximum (the producer of the tensor folds max |x| into a word, lmkd_amax_next; the weight packs carry max |w|), so the
+// scaling is exact: max |x| 2^s lies in (2^14, 2^15], elements down to 2^-16 of the maximum keep the full 2^-24, and what an element
+// below that loses is < 2^-40 of the tensor's maximum - 2^-16 of the rounding of the fp32 accumulator it is added into.
+// Measured against fp64 (tools/h2_error.py, profiles/r04_h2_error.txt): rel-L2 2.7e-7 .. 7.0e-7 on the four 3x3 layers, BELOW the
+// three-plane form's 3.5e-7 .. 9.6e-7 and torch's fp32 convolution's 3.1e-7 .. 8.1e-7, at half the MFMA work.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// 2^s for a tensor whose max |x| has the fp32 bits `amax`: max |x| 2^s in (2^14, 2^15]; s clamped to +-60 (zero / denormal / inf maxima)
+__device__ __forceinline__ float h2_scale(unsigned amax) {
+  const int e = (int)((amax >> 23) & 0xffu) - 127 + ((amax & 0x7fffffu) ? 1 : 0);      // ceil(log2(max))
+  int s = 15 - e;
+  s = s < -60 ? -60 : (s > 60 ? 60 : s);
+  if (amax == 0u) s = 0;
+  return __uint_as_float((unsigned)(s + 127) << 23);
+}
+__device__ __forceinline__ void h2_split4(const float4& v, float s, uint2& p0, uint2& p1) {
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+  union { _Float16 h[4]; uint2 u; } c0, c1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c0.h[j] = (_Float16)x[j];
+    c1.h[j] = (_Float16)(x[j] - (float)c0.h[j]);
+  }
+  p0 = c0.u;
+  p1 = c1.u;
+}
+__device__ __forceinline__ void h2_split1(float x, unsigned short& p0, unsigned short& p1) {
+  union { _Float16 h; unsigned short u; } c0, c1;
+  c0.h = (_Float16)x;
+  c1.h = (_Float16)(x - (float)c0.h);
+  p0 = c0.u;
+  p1 = c1.u;
+}
+// the fp16 planes of the packed weights: split_weights16_kernel's fragment order with two planes per slot (W, then -W), scaled by the
+// power of two of the word behind them (max |w|, written by amax_kernel before this launch)
+__global__ void split_weights16_h2_kernel(const float* __restrict__ wp, unsigned short* __restrict__ wh, int ncols, int Kp) {
+  const long total = (long)ncols * Kp;
+  const int G = Kp >> 5;
+  const float s = h2_scale(*reinterpret_cast<const unsigned*>(wh + total * 4));
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx / Kp), k = (int)(idx - (long)col * Kp);
+    const int lane = (col & 15) + 16 * patch16_kslot((k >> 3) & 3);
+    const long o = ((((long)(col >> 4) * G + (k >> 5)) * 2) * 64 + lane) * 8 + (k & 7);
+    unsigned short p0, p1;
+    h2_split1(wp[idx] * s, p0, p1);
+    wh[o] = p0;
+    wh[o + 512] = p1;
+    const long o2 = o + total * 2;
+    wh[o2] = p0 ^ 0x8000u;
+    wh[o2 + 512] = p1 ^ 0x8000u;
+  }
+}
+// max |x| over n floats folded into *word (the fp32 bits of a non-negative number order like unsigned integers); *word zeroed by the caller
+__global__ void amax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ word) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(word, __float_as_uint(m));
+}
+
 // SRC2: a stride-2 FORWARD convolution (3x3 / pad 1 on an even-sized input).  The input's four parity classes x[:, sph::2, spw::2] are
 // images of the OUTPUT's size, and a tap (kh, kw) reads one of them at a shift of -1 or 0 pixels: the convolution is the sum of four
 // same-size convolutions with 4 + 2 + 2 + 1 taps.  The K loop runs (chunk, class, tap of the class); the patch of a (chunk, class) is the
@@ -97,15 +164,17 @@ __global__ void split_weights16_kernel(const float* __restrict__ wp, unsigned sh
 // (before: conv_gemm_x3_kernel's im2col gather, 125-135 TFLOP/s on the three stride-2 3x3 layers.)
 template <class Cfg, int NPROD, bool PRE, bool EP, bool SRC2 = false>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kernel(ConvGemmArgs a) {
-  static_assert(NPROD == 6 || NPROD == 9, "three-plane modes");
+  static_assert(NPROD == 6 || NPROD == 9 || NPROD == 3, "three bf16 planes (6 / 9 products) or two fp16 planes (3 products)");
+  static_assert(NPROD != 3 || !PRE, "two-plane form: the operand's maximum comes from its producer, a BatchNorm applied in the loader has none");
   static_assert(!SRC2 || !PRE, "the stride-2 source form has no BatchNorm loader");
   constexpr int NPL = 3;
+  constexpr int NPU = NPROD == 3 ? 2 : 3;      // planes stored / read / multiplied (the LDS rows keep their three-plane pitch)
   constexpr int ROWB = PatchRow<NPL>::BYTES;
   constexpr int LPR = 8;                                  // lanes per patch row (16 bytes each)
   constexpr int RPP = Cfg::THREADS / LPR;                 // patch rows per pass
   constexpr int NI = (Cfg::BM + 2 * PATCH_HALO_MAX + RPP - 1) / RPP;
   constexpr int NB = 2 * Cfg::TM, NC = 2 * Cfg::TN;       // 16-pixel blocks / 16-channel blocks of a wave
-  using LB = X3FragB16<Cfg::TN>;
+  using LB = X3FragB16<Cfg::TN, NPU>;
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   __shared__ int s_out[Cfg::BM];
   __shared__ int s_tap_shift[LMKD_MAX_TAPS], s_tap_kofs[LMKD_MAX_TAPS];
@@ -160,6 +229,12 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     }
   }
   const int lane = tid & 63, wave = tid >> 6;
+  float h2_sx = 1.f, h2_inv = 1.f;
+  if constexpr (NPROD == 3) {
+    h2_sx = h2_scale(*a.h2_xw);
+    const float sw = h2_scale(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(a.wpk) + (long)a.Co * a.Kp * 16));
+    h2_inv = 1.f / (h2_sx * sw);      // both powers of two within 2^+-60
+  }
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int kq = lane >> 4;                               // lane group: result rows 4 kq .. 4 kq + 3; k-slot patch16_kslot(kq) of a 32-k step
   const int ksl = patch16_kslot(kq);
@@ -229,10 +304,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
         v.z = fmaxf(fmaf(v.z, psc.z, psh.z), 0.f); v.w = fmaxf(fmaf(v.w, psc.w, psh.w), 0.f);
       }
       uint2 q0, q1, q2;
-      x3_split4(v, q0, q1, q2);
+      if constexpr (NPROD == 3) h2_split4(v, h2_sx, q0, q1); else x3_split4(v, q0, q1, q2);
       *reinterpret_cast<uint2*>(d) = q0;
       *reinterpret_cast<uint2*>(d + 64) = q1;
-      *reinterpret_cast<uint2*>(d + 128) = q2;
+      if (NPU == 3) *reinterpret_cast<uint2*>(d + 128) = q2;
     }
   };
   const bool neg = x3_neg_tile(sg.ltile, sg.ltiles);      // half the row tiles (of the segment) accumulate -y: X3FragB::init
@@ -275,7 +350,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     bf16x8 av[NPL][HB];
     auto read_a = [&](int hf) {
 #pragma unroll
-      for (int p = 0; p < NPL; ++p)
+      for (int p = 0; p < NPU; ++p)
 #pragma unroll
         for (int b = 0; b < HB; ++b) av[p][b] = *reinterpret_cast<const bf16x8*>(psm + ad[hf * HB + b] + p * 64);
     };
@@ -290,10 +365,17 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       }
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const bf16x8 w0 = x3_as_bf16(rb[c * 3 + 0]), w1 = x3_as_bf16(rb[c * 3 + 1]), w2 = x3_as_bf16(rb[c * 3 + 2]);
+        const bf16x8 w0 = x3_as_bf16(rb[c * NPU + 0]), w1 = x3_as_bf16(rb[c * NPU + 1]), w2 = x3_as_bf16(rb[c * NPU + (NPU - 1)]);
 #pragma unroll
         for (int b = 0; b < HB; ++b) {
           f32x4 d = acc[hf * HB + b][c];
+          if constexpr (NPROD == 3) {      // two fp16 planes, three products, smallest terms first
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w1), __builtin_bit_cast(f16x8, av[0][b]), d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, av[1][b]), d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, av[0][b]), d, 0, 0, 0);
+            acc[hf * HB + b][c] = d;
+            continue;
+          }
           // rows = channels (weights), columns = pixels (patch); smallest terms first, as in conv_patch.h
           if (NPROD == 9) {
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, av[2][b], d, 0, 0, 0);
@@ -374,6 +456,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       const int col = ch0 + 16 * c;
       float4 v = make_float4(acc[b][c][0], acc[b][c][1], acc[b][c][2], acc[b][c][3]);
       if (neg) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
+      if constexpr (NPROD == 3) { v.x *= h2_inv; v.y *= h2_inv; v.z *= h2_inv; v.w *= h2_inv; }      // 2^-(sx + sw): exact
       const bool ok = ob >= 0 && col < a.Co;
       if (EP) {      // inference: the operations of bn_apply_kernel in its order (x3_epilogue<EP>)
         v.x = fmaf(v.x, esc[c].x, esh[c].x); v.y = fmaf(v.y, esc[c].y, esh[c].y); v.z = fmaf(v.z, esc[c].z, esh[c].z); v.w = fmaf(v.w, esc[c].w, esh[c].w);

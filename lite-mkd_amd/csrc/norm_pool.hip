@@ -160,6 +160,13 @@ extern "C" int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst,
 #define CS_MAX_SLICES 64
 #define LMKD_TICKET_WORDS 512      // two segments (blockIdx.z) x cdiv(2 C, CS_COLS) words: C <= 4096
 extern "C" long lmkd_ticket_words(void) { return LMKD_TICKET_WORDS; }
+
+// One-shot, per host thread: the NEXT launch of lmkd_bn_apply(_seg), lmkd_bn_relu_maxpool_fwd(_seg), lmkd_bn_backward(_seg) or
+// lmkd_bn_backward_part(_seg) on this thread also folds max |y| (max |dx| for the backward) into *word (fp32 bits, atomic max: the caller
+// zeroes the word).  The two-plane fp16 convolutions scale their operands by a power of two taken from it (lmkd_conv_operand_amax).
+static thread_local unsigned* g_amax_next = nullptr;
+extern "C" int lmkd_amax_next(void* word) { g_amax_next = (unsigned*)word; return LMKD_OK; }
+static inline unsigned* take_amax_next() { unsigned* p = g_amax_next; g_amax_next = nullptr; return p; }
 static inline int cs_slices(int T) { return T <= 64 ? 1 : std::min(CS_MAX_SLICES, cdiv(T, 64)); }
 
 // -> true in the block that holds the totals of its CS_COLS columns in tot[] (every thread of the block gets the same answer)
@@ -414,11 +421,12 @@ extern "C" int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, 
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const T* __restrict__ res,
                                 const float* __restrict__ rstats, T* __restrict__ y, long n4, int C, int relu, int res_mode,
-                                unsigned* __restrict__ mask_bits, long n4_0) {
+                                unsigned* __restrict__ mask_bits, long n4_0, unsigned* __restrict__ amax) {
   // n4_0: groups of 4 elements in frame segment 0 (rows0 * C / 4; = n4 for one segment): elements past it use the second [5][C] table
   constexpr int U = ActU<T>::U;
   const int C4 = C >> 2;
   const long nu = n4 / U;
+  float am = 0.f;
   for (long iu = (long)blockIdx.x * blockDim.x + threadIdx.x; iu < nu; iu += (long)gridDim.x * blockDim.x) {
     float4 v[U], r[U];
     ldv<T, U>(x, iu, v);
@@ -442,6 +450,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
       }
       if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
       nibs |= ((w.x > 0.f ? 1u : 0u) | (w.y > 0.f ? 2u : 0u) | (w.z > 0.f ? 4u : 0u) | (w.w > 0.f ? 8u : 0u)) << (4 * u);
+      am = amax4(am, w);
     }
     stv<T, U>(y, iu, v);      // bf16 storage: a positive value never rounds to zero, so the mask equals (stored y > 0)
     if (mask_bits) {
@@ -453,6 +462,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
       if ((threadIdx.x & (LPW - 1)) == 0) mask_bits[iu / LPW] = wbits;
     }
   }
+  if (amax) amax_commit(amax, am);
 }
 
 extern "C" int lmkd_bn_apply_seg(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows, long rows0,
@@ -464,6 +474,7 @@ extern "C" int lmkd_bn_apply(const float* x, const float* stats, const float* re
 // two frame segments: rows [0, rows0) use stats[0] (and rstats[0]), rows [rows0, rows) stats[1] / rstats[1] ([2][5][C] tables)
 extern "C" int lmkd_bn_apply_seg(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows, long rows0,
                                  int C, int relu, int res_mode, unsigned* mask_bits, void* stream) {
+  unsigned* amax = take_amax_next();
   LMKD_REQUIRE(x && stats && y && rows > 0 && C > 0 && C % 4 == 0, "lmkd_bn_apply: bad arguments (C=%d)", C);
   if (rows0 <= 0 || rows0 > rows) rows0 = rows;
   LMKD_REQUIRE(res_mode == 0 || res, "lmkd_bn_apply: residual pointer missing");
@@ -473,10 +484,10 @@ extern "C" int lmkd_bn_apply_seg(const float* x, const float* stats, const float
   const long n4 = rows * C / 4;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_apply_kernel<lmkd_bf16_t>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)x, stats,
-                       (const lmkd_bf16_t*)res, rstats, (lmkd_bf16_t*)y, n4, C, relu, res_mode, mask_bits, rows0 * C / 4);
+                       (const lmkd_bf16_t*)res, rstats, (lmkd_bf16_t*)y, n4, C, relu, res_mode, mask_bits, rows0 * C / 4, amax);
   else
     hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, stats, res, rstats, y, n4, C,
-                       relu, res_mode, mask_bits, rows0 * C / 4);
+                       relu, res_mode, mask_bits, rows0 * C / 4, amax);
   LMKD_CHECK_LAUNCH("bn_apply_kernel");
   return LMKD_OK;
 }
@@ -624,12 +635,14 @@ __device__ __forceinline__ void bn_param_grads_seg(const float* __restrict__ coe
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
                                     const float* __restrict__ stats, const float* __restrict__ coef, T* __restrict__ dx,
-                                    T* __restrict__ g_out, long n4, int C, int mask_mode, long n4_0, ParamGradSeg pg) {
+                                    T* __restrict__ g_out, long n4, int C, int mask_mode, long n4_0, ParamGradSeg pg,
+                                    unsigned* __restrict__ amax) {
   // n4_0 < n4: two frame segments - elements from n4_0 on use stats[1] / coef[1] ([2][5][C] tables), and pg carries the parameter gradients
   constexpr int U = ActU<T>::U;
   const int C4 = C >> 2;
   const long nu = n4 / U;
   if (n4_0 < n4) bn_param_grads_seg(coef, C, pg);
+  float am = 0.f;
   for (long iu = (long)blockIdx.x * blockDim.x + threadIdx.x; iu < nu; iu += (long)gridDim.x * blockDim.x) {
     float4 xv[U], dv[U], o[U], gq[U];
     ldv<T, U>(x, iu, xv);
@@ -652,10 +665,12 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
       o[u].z = A.z * (g.z - mg.z - (xv[u].z - mean.z) * istd.z * mgx.z);
       o[u].w = A.w * (g.w - mg.w - (xv[u].w - mean.w) * istd.w * mgx.w);
       gq[u] = g;
+      am = amax4(am, o[u]);
     }
     stv<T, U>(dx, iu, o);
     if (g_out) stv<T, U>(g_out, iu, gq);
   }
+  if (amax) amax_commit(amax, am);
 }
 
 extern "C" long lmkd_bn_bwd_workspace(int C) { return (long)(2048 * 2 * C) * sizeof(float) + (long)(66 * 2 * C) * sizeof(double) + 64; }
@@ -729,6 +744,7 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
 extern "C" int lmkd_bn_backward_seg(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dx,
                                     float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows,
                                     long rows0, int C, int mask_mode, int accumulate_param_grads, void* stream) {
+  unsigned* amax = take_amax_next();
   LMKD_REQUIRE(dx, "lmkd_bn_backward: null pointer");
   hipStream_t s = (hipStream_t)stream;
   if (rows0 <= 0 || rows0 >= rows) rows0 = rows;
@@ -740,10 +756,10 @@ extern "C" int lmkd_bn_backward_seg(const float* dy, const float* x, const float
   pg.dgamma = dgamma; pg.dbeta = dbeta; pg.accumulate = accumulate_param_grads;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<lmkd_bf16_t>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, (const lmkd_bf16_t*)dy, (const lmkd_bf16_t*)x,
-                       (const lmkd_bf16_t*)yact, stats, (const float*)coef, (lmkd_bf16_t*)dx, (lmkd_bf16_t*)g_out, n4, C, mask_mode, n4_0, pg);
+                       (const lmkd_bf16_t*)yact, stats, (const float*)coef, (lmkd_bf16_t*)dx, (lmkd_bf16_t*)g_out, n4, C, mask_mode, n4_0, pg, amax);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, dy, x, yact, stats, (const float*)coef, dx, g_out,
-                       n4, C, mask_mode, n4_0, pg);
+                       n4, C, mask_mode, n4_0, pg, amax);
   LMKD_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return LMKD_OK;
 }
@@ -764,6 +780,7 @@ extern "C" int lmkd_bn_backward_part(const float* part, int T, const float* dy, 
 extern "C" int lmkd_bn_backward_part_seg(const float* part, int T, int T0, const float* dy, const float* x, const float* stats, const float* gamma,
                                          float* dx, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows,
                                          long rows0, int C, int accumulate_param_grads, void* stream) {
+  unsigned* amax = take_amax_next();
   LMKD_REQUIRE(part && T > 0 && dy && x && stats && dx && coef && workspace && tickets, "lmkd_bn_backward_part: null pointer");
   LMKD_REQUIRE(!g_lmkd_act_bf16 && C % 4 == 0, "lmkd_bn_backward_part: fp32 tensors, C %% 4 == 0");
   const bool seg = T0 > 0 && T0 < T && rows0 > 0 && rows0 < rows;
@@ -780,7 +797,7 @@ extern "C" int lmkd_bn_backward_part_seg(const float* part, int T, int T0, const
   ParamGradSeg pg;
   pg.dgamma = dgamma; pg.dbeta = dbeta; pg.accumulate = accumulate_param_grads;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, dy, x, (const float*)nullptr, stats, (const float*)coef,
-                     dx, (float*)nullptr, n4, C, 2, rows0 * C / 4, pg);
+                     dx, (float*)nullptr, n4, C, 2, rows0 * C / 4, pg, amax);
   LMKD_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return LMKD_OK;
 }
@@ -832,12 +849,14 @@ extern "C" int lmkd_relu_backward(const float* dy, const float* y, float* g, lon
 // ---------------------------------------------------------------------------------
 template <typename T>
 __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ stats, T* __restrict__ y,
-                                       uchar4* __restrict__ idx, T* __restrict__ cmax, int N, int H, int W, int C, int OH, int OW, int N0) {
+                                       uchar4* __restrict__ idx, T* __restrict__ cmax, int N, int H, int W, int C, int OH, int OW, int N0,
+                                       unsigned* __restrict__ amax) {
   // a thread owns U groups of 4 consecutive channels of one output pixel (U = 2 with bf16 tensors: every access 16 bytes; with 8-byte
   // accesses the bf16 instance took as long as the fp32 one on half the bytes - 260 vs 280 us at 200 frames)
   constexpr int U = ActU<T>::U;
   const int CU = C / (4 * U);
   const long total = (long)N * OH * OW * CU;
+  float amx = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cq = (int)(i % CU);
     long r = i / CU;
@@ -881,9 +900,13 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __r
     }
     stv<T, U>(y, i, m);
 #pragma unroll
-    for (int u = 0; u < U; ++u) idx[i * U + u] = am[u];
+    for (int u = 0; u < U; ++u) {
+      idx[i * U + u] = am[u];
+      amx = amax4(amx, m[u]);
+    }
     if (cmax) stv<T, U>(cmax, i, cm);
   }
+  if (amax) amax_commit(amax, amx);
 }
 
 extern "C" int lmkd_bn_relu_maxpool_fwd_seg(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int N0, int H,
@@ -895,16 +918,17 @@ extern "C" int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, floa
 // two frame segments: frames [0, N0) use stats[0], frames [N0, N) stats[1] ([2][5][C])
 extern "C" int lmkd_bn_relu_maxpool_fwd_seg(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int N0, int H,
                                             int W, int C, void* stream) {
+  unsigned* amax = take_amax_next();
   LMKD_REQUIRE(x && stats && y && idx && C % (g_lmkd_act_bf16 ? 8 : 4) == 0, "lmkd_bn_relu_maxpool_fwd: bad arguments");
   if (N0 <= 0 || N0 > N) N0 = N;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long total = (long)N * OH * OW * C / (g_lmkd_act_bf16 ? 8 : 4);
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<lmkd_bf16_t>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)x,
-                       stats, (lmkd_bf16_t*)y, (uchar4*)idx, (lmkd_bf16_t*)cmax, N, H, W, C, OH, OW, N0);
+                       stats, (lmkd_bf16_t*)y, (uchar4*)idx, (lmkd_bf16_t*)cmax, N, H, W, C, OH, OW, N0, amax);
   else
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, stats, y, (uchar4*)idx,
-                       cmax, N, H, W, C, OH, OW, N0);
+                       cmax, N, H, W, C, OH, OW, N0, amax);
   LMKD_CHECK_LAUNCH("bn_relu_maxpool_kernel");
   return LMKD_OK;
 }

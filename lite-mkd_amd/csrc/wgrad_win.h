@@ -35,6 +35,8 @@ struct WgradWinArgs {
   // the first of which STARTS at pixel seg_pix0 - no slab straddles the boundary.  One segment: seg_pix0 = Mpix, seg_splits0 = splits.
   int seg_pix0, seg_splits0, sps1;
   FastDiv div_hw, div_w;
+  const unsigned* h2_xw;       // two-plane fp16 form (NPROD == 3, conv_patch16.h): the words holding max |x| / max |dy|
+  const unsigned* h2_dyw;
 };
 template <int COB, int NPROD, bool ACT16, int R, bool PRE = false, int TPW = 9>
 __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_win_kernel(WgradWinArgs a) {
@@ -248,8 +250,9 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
 template <int COB, int NPROD, int R, bool PRE = false, int TPW = 9, int JW = 2>
 __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void conv_wgrad_win16_kernel(WgradWinArgs a) {
   static_assert(JW == 2 || (JW == 1 && TPW == 9), "the channel-block split exists for nine taps per wave");
-  static_assert(NPROD == 6 || NPROD == 9, "three-plane modes");
-  constexpr int NPL = 3;
+  static_assert(NPROD == 6 || NPROD == 9 || NPROD == 3, "three bf16 planes (6 / 9 products) or two fp16 planes (3 products: conv_patch16.h)");
+  static_assert(NPROD != 3 || !PRE, "two-plane form: no BatchNorm in the loader (the operand's maximum comes from its producer)");
+  constexpr int NPL = NPROD == 3 ? 2 : 3;
   constexpr int THREADS = 64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW), BM = 32 * COB;
   constexpr int LDA = BM * 2 + 32, A_PLANE = LMKD_BK * LDA;      // dy image [k][co], bytes
   constexpr int LDX = 64, X_PLANE = (R + 1) * LDX;               // x ring [slot][32 ci]; slot R = the zero row
@@ -277,6 +280,11 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
   const int x_c = (tid % X_LPR) * 4, x_r = tid / X_LPR;
   u32x4 ra[A_NI], rx[X_NI];
   unsigned x_ok = 0;
+  float h2_sx = 1.f, h2_sdy = 1.f;
+  if constexpr (NPROD == 3) {
+    h2_sx = h2_scale(*a.h2_xw);
+    h2_sdy = h2_scale(*a.h2_dyw);
+  }
   float4 psc = float4(), psh = float4();
   if (PRE) {
     psc = *reinterpret_cast<const float4*>(a.pre_stats + (long)sl.seg * 5 * a.Cs + 2 * a.Cs + ci0 + x_c);
@@ -303,7 +311,15 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
 #pragma unroll
     for (int i = 0; i < A_NI; ++i) {
       if (a_r + A_RPP * i >= LMKD_BK) continue;
-      tr_store4<NPL, LDA, A_PLANE>(s_dy, a_r + A_RPP * i, a_c, as_f4(ra[i]));
+      if constexpr (NPROD == 3) {
+        uint2 p0, p1;
+        h2_split4(as_f4(ra[i]), h2_sdy, p0, p1);
+        unsigned char* d = s_dy + (a_r + A_RPP * i) * LDA + a_c * 2;
+        *reinterpret_cast<uint2*>(d) = p0;
+        *reinterpret_cast<uint2*>(d + A_PLANE) = p1;
+      } else {
+        tr_store4<NPL, LDA, A_PLANE>(s_dy, a_r + A_RPP * i, a_c, as_f4(ra[i]));
+      }
     }
   };
   auto store_x = [&](int q0) {
@@ -317,11 +333,11 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
         v.z = fmaxf(fmaf(v.z, psc.z, psh.z), 0.f); v.w = fmaxf(fmaf(v.w, psc.w, psh.w), 0.f);
       }
       uint2 p0, p1, p2;
-      x3_split4(v, p0, p1, p2);
+      if constexpr (NPROD == 3) h2_split4(v, h2_sx, p0, p1); else x3_split4(v, p0, p1, p2);
       unsigned char* d = s_x + slot * LDX + ((x_c * 2) ^ (((slot >> 2) & 1) << 5));      // halves swapped in the slots with bit 2 set
       *reinterpret_cast<uint2*>(d) = p0;
       *reinterpret_cast<uint2*>(d + X_PLANE) = p1;
-      *reinterpret_cast<uint2*>(d + 2 * X_PLANE) = p2;
+      if constexpr (NPL == 3) *reinterpret_cast<uint2*>(d + 2 * X_PLANE) = p2;
     }
   };
   auto fill_adr = [&](unsigned* tab, int k0) {
@@ -408,14 +424,21 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             f32x4 c = acc[ti][i][j];
+            if constexpr (NPROD == 3) {      // two fp16 planes: smallest terms first
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[i][1]), __builtin_bit_cast(f16x8, fb[0]), c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, fb[1]), c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, fb[0]), c, 0, 0, 0);
+              acc[ti][i][j] = c;
+              continue;
+            }
             if (NPROD == 9) {
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][2], fb[2], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[2], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][2], fb[1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][NPL - 1], fb[NPL - 1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[NPL - 1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][NPL - 1], fb[1], c, 0, 0, 0);
             }
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[1], c, 0, 0, 0);     // smallest terms first
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][2], fb[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[NPL - 1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][NPL - 1], fb[0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[1], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[0], c, 0, 0, 0);
@@ -428,6 +451,7 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
   }
 
   float* C = a.slab + (long)z * a.Co * a.Kp;
+  const float h2_inv = NPROD == 3 ? 1.f / (h2_sx * h2_sdy) : 1.f;      // 2^-(sx + sdy): exact
 #pragma unroll
   for (int ti = 0; ti < TPW; ++ti) {
     if (9 % TPW != 0 && tap0 + ti >= 9) break;
@@ -439,7 +463,7 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = co0 + cw * 32 + 16 * i + 4 * q4 + e;
-          if (row < a.Co) C[(long)row * a.Kp + col] = acc[ti][i][j][e];
+          if (row < a.Co) C[(long)row * a.Kp + col] = NPROD == 3 ? acc[ti][i][j][e] * h2_inv : acc[ti][i][j][e];
         }
       }
   }

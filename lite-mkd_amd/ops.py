@@ -461,6 +461,65 @@ def refresh_packs(streams=()):
     return n
 
 
+# ---- fp32 as two fp16 planes ('fp32h2', lmkd_conv_set_compute_dtype(4); csrc/conv_patch16.h) ----
+# The kernels scale an operand by a power of two taken from max |operand|.  The maximum of a trunk tensor is folded into a device word
+# by the kernel that WRITES the tensor (BatchNorm apply, BatchNorm backward apply, the stem's pooling: lmkd_amax_next) and travels with
+# the tensor as the attribute `_lmkd_amax`; a convolution whose operands carry it runs the two-plane form (lmkd_conv_operand_amax), any
+# other launch - a tensor from elsewhere, a view - the three-plane form: both fp32-class, so a lost word costs time, never correctness.
+_AMAX_POOLS = {}
+_AMAX_POOL_WORDS = 4096
+
+
+def _h2_mode():
+    return lib().value("lmkd_conv_get_compute_dtype") == 4
+
+
+def _amax_slot(dev):
+    """a zeroed device word (a 1-element int32 view of a pool; the pool is zeroed once, on the stream that first needs it - every other
+    stream waits for that - and inside a hipGraph capture it is a pool of the capture, so a replay zeroes it again)"""
+    cap = torch.cuda.is_current_stream_capturing()
+    cur = torch.cuda.current_stream(dev)
+    p = _AMAX_POOLS.get(dev.index)
+    if p is None or p["next"] >= _AMAX_POOL_WORDS or p["cap"] != cap:
+        buf = torch.zeros(_AMAX_POOL_WORDS, dtype=torch.int32, device=dev)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        p = _AMAX_POOLS[dev.index] = {"buf": buf, "next": 0, "cap": cap, "event": ev, "seen": {cur.cuda_stream}}
+    if cur.cuda_stream not in p["seen"]:
+        cur.wait_event(p["event"])
+        p["seen"].add(cur.cuda_stream)
+    i = p["next"]
+    p["next"] = i + 1
+    return p["buf"][i:i + 1]
+
+
+def _amax_record(t):
+    """call immediately before the launch that writes t (lmkd_amax_next is one-shot): that launch also folds max |t| into a fresh word"""
+    if t.dtype is torch.float32 and _h2_mode():
+        w = _amax_slot(t.device)
+        lib().call("lmkd_amax_next", w.data_ptr())
+        t._lmkd_amax = w
+
+
+def _amax_ptr(t):
+    w = getattr(t, "_lmkd_amax", None) if t is not None else None
+    return w.data_ptr() if w is not None else None
+
+
+def _amax_operands(x, dy):
+    """call immediately before a convolution launch (one-shot): the words of its operands, where they are known"""
+    if _h2_mode():
+        lib().call("lmkd_conv_operand_amax", _amax_ptr(x), _amax_ptr(dy))
+
+
+def amax_compute(t):
+    """max |t| by a reduction pass of its own (tensors that no kernel of this library wrote: tests, tools)"""
+    w = torch.zeros(1, dtype=torch.int32, device=t.device)
+    lib().call("lmkd_amax", _p(t), t.numel(), w.data_ptr(), _stream())
+    t._lmkd_amax = w
+    return t
+
+
 def _pack_weights(w, Cs, mode, out=None):
     Cout, Cin, KH, KW = w.shape
     n = lib().value("lmkd_conv2d_packed_weight_elems", Cout, Cin, Cs, KH, KW, mode)
@@ -475,7 +534,7 @@ def _pack_weights(w, Cs, mode, out=None):
     lib().call("lmkd_conv2d_pack_weights", _p(w), _p(wp), Cout, Cin, Cs, KH, KW, mode, _stream())
     ncols = Cout if mode == 0 else Cin
     # one RNE plane, or the planes of W and of -W in both fragment orders (lmkd_conv2d_split_weights: 2 orders x 2 signs x 3 planes)
-    planes = out if out is not None else torch.empty(((1 if cd == 1 else 12) * n,), dtype=torch.int16, device=w.device)
+    planes = out if out is not None else torch.empty((lib().value("lmkd_conv2d_plane_elems", ncols, n // ncols),), dtype=torch.int16, device=w.device)
     lib().call("lmkd_conv2d_split_weights", _p(wp), planes.data_ptr(), ncols, n // ncols, _stream())
     return planes
 
@@ -488,9 +547,11 @@ def set_conv_compute_dtype(dtype):
     """Process-wide arithmetic of the convolutions (lmkd_conv_set_compute_dtype; one process per GPU, set before launching):
     'fp32x3' (DEFAULT): fp32 tensors and accumulation, each fp32 product formed on the bf16 matrix pipe from an exact 3-way
     bf16 split of both operands (6 of the 9 cross products; 'fp32x3_9': all nine) - fp32-class error (tests/test_gpu_fullsize.py).
+    'fp32h2': 'fp32x3' with the 3x3 convolutions' forward / data gradient / window weight gradient on TWO fp16 planes and three products
+    (power-of-two scales from the tensors' maxima; csrc/conv_patch16.h) - the same error class at half the MFMA work.
     'fp32': native fp32 MFMA (v_mfma_f32_32x32x2_f32).  'bf16' (BASELINE configs[2]): operands rounded to bf16, fp32 accumulation;
     with set_activation_dtype('bf16') the trunk's tensors in HBM are bf16 as well."""
-    modes = {"fp32": 0, "bf16": 1, "fp32x3": 2, "fp32x3_9": 3}
+    modes = {"fp32": 0, "bf16": 1, "fp32x3": 2, "fp32x3_9": 3, "fp32h2": 4}
     if dtype not in modes:
         raise ValueError(dtype)
     lib().call("lmkd_conv_set_compute_dtype", modes[dtype])   # (the packed-weight cache keeps one buffer per mode)
@@ -499,7 +560,7 @@ def set_conv_compute_dtype(dtype):
 
 
 def get_conv_compute_dtype():
-    return ("fp32", "bf16", "fp32x3", "fp32x3_9")[lib().value("lmkd_conv_get_compute_dtype")]
+    return ("fp32", "bf16", "fp32x3", "fp32x3_9", "fp32h2")[lib().value("lmkd_conv_get_compute_dtype")]
 
 
 def reset_compute_dtypes():
@@ -584,6 +645,7 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None, seg=0
     cin = 3 if Cs == 4 else Cs
     with _timed(_conv_family(0, N, H, W, Cs, cin, Cout, KH, KW, stride, pad), 2.0 * N * Ho * Wo * Cout * cin * KH * KW,
                 x.element_size() * x.numel() + y.element_size() * y.numel() + 4 * wp.numel()):
+        _amax_operands(x if pre_stats is None else None, None)
         if seg:
             lib().call("lmkd_conv2d_fwd_seg", _p(x), _p(pre_stats), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, seg, _stream())
         elif pre_stats is not None:
@@ -621,6 +683,7 @@ def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumula
     with _timed(_conv_family(1, N, H, W, Cin, Cin, Cout, KH, KW, stride, pad), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
                 dy.element_size() * dy.numel() + dx.element_size() * dx.numel() * (2 if accumulate else 1) + 4 * wd.numel()
                 + (bn[0].element_size() * bn[0].numel() if part is not None else 0)):      # the fused form also reads the BatchNorm input
+        _amax_operands(None, dy)
         if seg:
             lib().call("lmkd_conv2d_bwd_data_seg", _p(dy), _p(wd), _p(dx), _p(bn[0]) if part is not None else None,
                        _p(bn[1]) if part is not None else None, _p(part), N, H, W, Cin, Cout, KH, KW, stride, pad, int(accumulate), seg, _stream())
@@ -647,6 +710,7 @@ def conv_bwd_weight(x, dy, w_shape, stride, pad, pre_stats=None, acc_into=None, 
     dw = acc_into if acc_into is not None else _empty(w_shape, x)
     with _timed("conv_wgrad_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
                 x.element_size() * x.numel() + dy.element_size() * dy.numel() + 4 * dw.numel()):
+        _amax_operands(x if pre_stats is None else None, dy)
         if seg:
             lib().call("lmkd_conv2d_bwd_weight_seg", _p(x), _p(pre_stats), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW,
                        stride, pad, int(acc_into is not None), seg, _stream())
@@ -821,6 +885,7 @@ def bn_apply(x, stats, relu, res=None, rstats=None, want_bits=False, seg=0):
     mode = 0 if res is None else (2 if rstats is not None else 1)
     _chk(x, stats, res, rstats)
     bits = torch.empty(x.numel() // 32, dtype=torch.int32, device=x.device) if want_bits else None
+    _amax_record(y)
     lib().call("lmkd_bn_apply_seg", _p(x), _p(stats), _p(res), _p(rstats), _p(y), rows, _rows0(x, seg), C, int(relu), mode, _p(bits), _stream())
     return (y, bits) if want_bits else y
 
@@ -848,9 +913,11 @@ def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None,
             raise ValueError("partial sums of the data gradient: mask_mode 2 without g")
         part, T0 = part if isinstance(part, tuple) else (part, part.shape[0])
         _chk(part)
+        _amax_record(dx)
         lib().call("lmkd_bn_backward_part_seg", _p(part), part.shape[0], T0, _p(dy), _p(x), _p(stats), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
                    _p(coef), _p(ws), _p(_tickets(x)), rows, rows0, C, int(direct), _stream())
     else:
+        _amax_record(dx)
         lib().call("lmkd_bn_backward_seg", _p(dy), _p(x), _p(yact), _p(stats), _p(gamma), _p(dx), _p(g), _p(dgamma), _p(dbeta),
                    _p(coef), _p(ws), _p(_tickets(x)), rows, rows0, C, mask_mode, int(direct), _stream())
     return (dx, g, None, None) if direct else (dx, g, dgamma, dbeta)
@@ -1052,6 +1119,7 @@ class StemFn(torch.autograd.Function):
         # training: also the raw convolution output at each window's arg-max - the BatchNorm backward then takes its sums from the
         # pooled tensors (lmkd_bn_backward_stats) instead of the 4x larger pre-pooling ones
         cmax = torch.empty_like(y) if (training and (STEM_POOLED_BWD or seg)) else None
+        _amax_record(y)
         lib().call("lmkd_bn_relu_maxpool_fwd_seg", _p(c), _p(stats), _p(y), _p(idx), _p(cmax), N, seg if seg else N, Hc, Wc, C, _stream())
         if BLOCK_TAPS is not None:
             BLOCK_TAPS.append({"stem_c": c, "stem_st": stats, "stem_idx": idx, "seg": seg})
@@ -1274,6 +1342,7 @@ class BasicBlockFn(torch.autograd.Function):
         if training:
             # fused: the backward needs neither a1 (recomputed from c1 in the weight-gradient loader) nor y (its mask travels as bits)
             ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, ybits if fused else y, wd, gd, cd, std)
+            ctx.amax = (getattr(x, "_lmkd_amax", None), getattr(a1, "_lmkd_amax", None) if a1 is not None else None)
         return y
 
     @staticmethod
@@ -1281,6 +1350,9 @@ class BasicBlockFn(torch.autograd.Function):
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         x, w1, g1, c1, st1, a1, w2, g2, c2, st2, y, wd, gd, cd, std = ctx.saved_tensors
+        for t, wm in zip((x, a1), ctx.amax):      # the maxima recorded in the forward (saved tensors may come back as new objects)
+            if t is not None and wm is not None:
+                t._lmkd_amax = wm
         dy = dy.contiguous()
         stride = ctx.stride
         seg = ctx.seg
