@@ -76,11 +76,13 @@ int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound 
    at or below mode 2's on every layer (profiles/r04_h2_error.txt).  A launch whose operand maxima are not named runs mode 2. */
 int lmkd_conv_set_compute_dtype(int mode);
 /* mode 4: the maxima of the operands of the NEXT convolution launch of this host thread (forward: x; data gradient: dy; weight gradient:
-   both), one-shot - consumed and cleared by that launch.  Each is a device word holding the fp32 bits of max |tensor| (any upper bound
-   is valid), complete in stream order before the launch; null = unknown.  Ignored in the other modes. */
+   both), one-shot - consumed and cleared by that launch.  Each points at TWO device words holding the fp32 bits of max |tensor| over
+   frame segment 0 / segment 1 (the *_seg entry points; one segment: word 0) - any upper bound is valid - complete in stream order
+   before the launch; null = unknown.  Ignored in the other modes. */
 int lmkd_conv_operand_amax(const void* x_word, const void* dy_word);
 /* the NEXT launch of lmkd_bn_apply(_seg) / lmkd_bn_relu_maxpool_fwd(_seg) / lmkd_bn_backward(_seg) / lmkd_bn_backward_part(_seg) on this
-   host thread also folds max |y| (backward: max |dx|) into *word with an atomic max on the fp32 bits; the caller zeroes the word.
+   host thread also folds max |y| (backward: max |dx|) into word[0] - the elements of frame segment 1 into word[1] - with an atomic max
+   on the fp32 bits; the caller zeroes both words.
    One-shot.  This is how a trunk tensor gets the word lmkd_conv_operand_amax names, without a pass of its own. */
 int lmkd_amax_next(void* word);
 /* max |x[0 .. n)| -> *word (zeroed here first): a pass of its own, for tensors no kernel of this library wrote */

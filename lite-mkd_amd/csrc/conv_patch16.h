@@ -102,11 +102,12 @@ __global__ void split_weights16_kernel(const float* __restrict__ wp, unsigned sh
 // Measured against fp64 (tools/h2_error.py, profiles/r04_h2_error.txt): rel-L2 2.7e-7 .. 7.0e-7 on the four 3x3 layers, BELOW the
 // three-plane form's 3.5e-7 .. 9.6e-7 and torch's fp32 convolution's 3.1e-7 .. 8.1e-7, at half the MFMA work.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// 2^s for a tensor whose max |x| has the fp32 bits `amax`: max |x| 2^s in (2^14, 2^15]; s clamped to +-60 (zero / denormal / inf maxima)
+// 2^s for a tensor whose max |x| has the fp32 bits `amax`: max |x| 2^s in (2^14, 2^15]; s clamped to +-126 (2^s and 2^-s stay normal
+// fp32 numbers; the epilogue undoes the two operands' scales by two separate multiplications, so no product of scales is ever formed)
 __device__ __forceinline__ float h2_scale(unsigned amax) {
   const int e = (int)((amax >> 23) & 0xffu) - 127 + ((amax & 0x7fffffu) ? 1 : 0);      // ceil(log2(max))
   int s = 15 - e;
-  s = s < -60 ? -60 : (s > 60 ? 60 : s);
+  s = s < -126 ? -126 : (s > 126 ? 126 : s);
   if (amax == 0u) s = 0;
   return __uint_as_float((unsigned)(s + 127) << 23);
 }
@@ -229,11 +230,12 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     }
   }
   const int lane = tid & 63, wave = tid >> 6;
-  float h2_sx = 1.f, h2_inv = 1.f;
+  float h2_sx = 1.f, h2_ix = 1.f, h2_iw = 1.f;
   if constexpr (NPROD == 3) {
-    h2_sx = h2_scale(*a.h2_xw);
+    h2_sx = h2_scale(a.h2_xw[sg.seg]);      // two words: the operand's maximum per frame segment
     const float sw = h2_scale(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(a.wpk) + (long)a.Co * a.Kp * 16));
-    h2_inv = 1.f / (h2_sx * sw);      // both powers of two within 2^+-60
+    h2_ix = 1.f / h2_sx;      // exact: powers of two within 2^+-126
+    h2_iw = 1.f / sw;
   }
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int kq = lane >> 4;                               // lane group: result rows 4 kq .. 4 kq + 3; k-slot patch16_kslot(kq) of a 32-k step
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       const int col = ch0 + 16 * c;
       float4 v = make_float4(acc[b][c][0], acc[b][c][1], acc[b][c][2], acc[b][c][3]);
       if (neg) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
-      if constexpr (NPROD == 3) { v.x *= h2_inv; v.y *= h2_inv; v.z *= h2_inv; v.w *= h2_inv; }      // 2^-(sx + sw): exact
+      if constexpr (NPROD == 3) { v.x = v.x * h2_ix * h2_iw; v.y = v.y * h2_ix * h2_iw; v.z = v.z * h2_ix * h2_iw; v.w = v.w * h2_ix * h2_iw; }      // 2^-sx, 2^-sw: exact
       const bool ok = ob >= 0 && col < a.Co;
       if (EP) {      // inference: the operations of bn_apply_kernel in its order (x3_epilogue<EP>)
         v.x = fmaf(v.x, esc[c].x, esh[c].x); v.y = fmaf(v.y, esc[c].y, esh[c].y); v.z = fmaf(v.z, esc[c].z, esh[c].z); v.w = fmaf(v.w, esc[c].w, esh[c].w);

@@ -162,8 +162,9 @@ extern "C" int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst,
 extern "C" long lmkd_ticket_words(void) { return LMKD_TICKET_WORDS; }
 
 // One-shot, per host thread: the NEXT launch of lmkd_bn_apply(_seg), lmkd_bn_relu_maxpool_fwd(_seg), lmkd_bn_backward(_seg) or
-// lmkd_bn_backward_part(_seg) on this thread also folds max |y| (max |dx| for the backward) into *word (fp32 bits, atomic max: the caller
-// zeroes the word).  The two-plane fp16 convolutions scale their operands by a power of two taken from it (lmkd_conv_operand_amax).
+// lmkd_bn_backward_part(_seg) on this thread also folds max |y| (max |dx| for the backward) into word[0] - frame segment 1's elements
+// into word[1] (two words: the two trunk calls of an episode keep the scales they would have as two launches) - fp32 bits, atomic max:
+// the caller zeroes both.  The two-plane fp16 convolutions scale their operands by a power of two taken from it (lmkd_conv_operand_amax).
 static thread_local unsigned* g_amax_next = nullptr;
 extern "C" int lmkd_amax_next(void* word) { g_amax_next = (unsigned*)word; return LMKD_OK; }
 static inline unsigned* take_amax_next() { unsigned* p = g_amax_next; g_amax_next = nullptr; return p; }
@@ -426,7 +427,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
   constexpr int U = ActU<T>::U;
   const int C4 = C >> 2;
   const long nu = n4 / U;
-  float am = 0.f;
+  float am = 0.f, am1 = 0.f;      // max |y| of segment 0 / segment 1
   for (long iu = (long)blockIdx.x * blockDim.x + threadIdx.x; iu < nu; iu += (long)gridDim.x * blockDim.x) {
     float4 v[U], r[U];
     ldv<T, U>(x, iu, v);
@@ -450,7 +451,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
       }
       if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
       nibs |= ((w.x > 0.f ? 1u : 0u) | (w.y > 0.f ? 2u : 0u) | (w.z > 0.f ? 4u : 0u) | (w.w > 0.f ? 8u : 0u)) << (4 * u);
-      am = amax4(am, w);
+      if (so) am1 = amax4(am1, w); else am = amax4(am, w);
     }
     stv<T, U>(y, iu, v);      // bf16 storage: a positive value never rounds to zero, so the mask equals (stored y > 0)
     if (mask_bits) {
@@ -462,7 +463,10 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
       if ((threadIdx.x & (LPW - 1)) == 0) mask_bits[iu / LPW] = wbits;
     }
   }
-  if (amax) amax_commit(amax, am);
+  if (amax) {
+    amax_commit(amax, am);
+    if (n4_0 < n4) amax_commit(amax + 1, am1);
+  }
 }
 
 extern "C" int lmkd_bn_apply_seg(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows, long rows0,
@@ -642,7 +646,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
   const int C4 = C >> 2;
   const long nu = n4 / U;
   if (n4_0 < n4) bn_param_grads_seg(coef, C, pg);
-  float am = 0.f;
+  float am = 0.f, am1 = 0.f;
   for (long iu = (long)blockIdx.x * blockDim.x + threadIdx.x; iu < nu; iu += (long)gridDim.x * blockDim.x) {
     float4 xv[U], dv[U], o[U], gq[U];
     ldv<T, U>(x, iu, xv);
@@ -665,12 +669,15 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
       o[u].z = A.z * (g.z - mg.z - (xv[u].z - mean.z) * istd.z * mgx.z);
       o[u].w = A.w * (g.w - mg.w - (xv[u].w - mean.w) * istd.w * mgx.w);
       gq[u] = g;
-      am = amax4(am, o[u]);
+      if (so) am1 = amax4(am1, o[u]); else am = amax4(am, o[u]);
     }
     stv<T, U>(dx, iu, o);
     if (g_out) stv<T, U>(g_out, iu, gq);
   }
-  if (amax) amax_commit(amax, am);
+  if (amax) {
+    amax_commit(amax, am);
+    if (n4_0 < n4) amax_commit(amax + 1, am1);
+  }
 }
 
 extern "C" long lmkd_bn_bwd_workspace(int C) { return (long)(2048 * 2 * C) * sizeof(float) + (long)(66 * 2 * C) * sizeof(double) + 64; }
@@ -856,7 +863,7 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __r
   constexpr int U = ActU<T>::U;
   const int CU = C / (4 * U);
   const long total = (long)N * OH * OW * CU;
-  float amx = 0.f;
+  float amx = 0.f, amx1 = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cq = (int)(i % CU);
     long r = i / CU;
@@ -902,11 +909,14 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __r
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       idx[i * U + u] = am[u];
-      amx = amax4(amx, m[u]);
+      if (n >= N0) amx1 = amax4(amx1, m[u]); else amx = amax4(amx, m[u]);
     }
     if (cmax) stv<T, U>(cmax, i, cm);
   }
-  if (amax) amax_commit(amax, amx);
+  if (amax) {
+    amax_commit(amax, amx);
+    if (N0 < N) amax_commit(amax + 1, amx1);
+  }
 }
 
 extern "C" int lmkd_bn_relu_maxpool_fwd_seg(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int N0, int H,

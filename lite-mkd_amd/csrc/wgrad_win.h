@@ -35,7 +35,7 @@ struct WgradWinArgs {
   // the first of which STARTS at pixel seg_pix0 - no slab straddles the boundary.  One segment: seg_pix0 = Mpix, seg_splits0 = splits.
   int seg_pix0, seg_splits0, sps1;
   FastDiv div_hw, div_w;
-  const unsigned* h2_xw;       // two-plane fp16 form (NPROD == 3, conv_patch16.h): the words holding max |x| / max |dy|
+  const unsigned* h2_xw;       // two-plane fp16 form (NPROD == 3, conv_patch16.h): max |x| / max |dy| per frame segment (two words each)
   const unsigned* h2_dyw;
 };
 template <int COB, int NPROD, bool ACT16, int R, bool PRE = false, int TPW = 9>
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
   unsigned x_ok = 0;
   float h2_sx = 1.f, h2_sdy = 1.f;
   if constexpr (NPROD == 3) {
-    h2_sx = h2_scale(*a.h2_xw);
-    h2_sdy = h2_scale(*a.h2_dyw);
+    h2_sx = h2_scale(a.h2_xw[sl.seg]);      // two words each: the maxima per frame segment (a slab lies in one segment)
+    h2_sdy = h2_scale(a.h2_dyw[sl.seg]);
   }
   float4 psc = float4(), psh = float4();
   if (PRE) {
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
   }
 
   float* C = a.slab + (long)z * a.Co * a.Kp;
-  const float h2_inv = NPROD == 3 ? 1.f / (h2_sx * h2_sdy) : 1.f;      // 2^-(sx + sdy): exact
+  const float h2_ix = 1.f / h2_sx, h2_idy = 1.f / h2_sdy;      // exact (powers of two within 2^+-126), applied one after the other
 #pragma unroll
   for (int ti = 0; ti < TPW; ++ti) {
     if (9 % TPW != 0 && tap0 + ti >= 9) break;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = co0 + cw * 32 + 16 * i + 4 * q4 + e;
-          if (row < a.Co) C[(long)row * a.Kp + col] = NPROD == 3 ? acc[ti][i][j][e] * h2_inv : acc[ti][i][j][e];
+          if (row < a.Co) C[(long)row * a.Kp + col] = NPROD == 3 ? acc[ti][i][j][e] * h2_ix * h2_idy : acc[ti][i][j][e];
         }
       }
   }

@@ -475,12 +475,13 @@ def _h2_mode():
 
 
 def _amax_slot(dev):
-    """a zeroed device word (a 1-element int32 view of a pool; the pool is zeroed once, on the stream that first needs it - every other
-    stream waits for that - and inside a hipGraph capture it is a pool of the capture, so a replay zeroes it again)"""
+    """two zeroed device words - max |tensor| per frame segment - as a 2-element int32 view of a pool; the pool is zeroed once, on the
+    stream that first needs it (every other stream waits for that), and inside a hipGraph capture it is a pool of the capture, so a
+    replay zeroes it again"""
     cap = torch.cuda.is_current_stream_capturing()
     cur = torch.cuda.current_stream(dev)
     p = _AMAX_POOLS.get(dev.index)
-    if p is None or p["next"] >= _AMAX_POOL_WORDS or p["cap"] != cap:
+    if p is None or p["next"] + 2 > _AMAX_POOL_WORDS or p["cap"] != cap:
         buf = torch.zeros(_AMAX_POOL_WORDS, dtype=torch.int32, device=dev)
         ev = torch.cuda.Event()
         ev.record(cur)
@@ -489,8 +490,8 @@ def _amax_slot(dev):
         cur.wait_event(p["event"])
         p["seen"].add(cur.cuda_stream)
     i = p["next"]
-    p["next"] = i + 1
-    return p["buf"][i:i + 1]
+    p["next"] = i + 2
+    return p["buf"][i:i + 2]
 
 
 def _amax_record(t):
@@ -512,10 +513,14 @@ def _amax_operands(x, dy):
         lib().call("lmkd_conv_operand_amax", _amax_ptr(x), _amax_ptr(dy))
 
 
-def amax_compute(t):
-    """max |t| by a reduction pass of its own (tensors that no kernel of this library wrote: tests, tools)"""
-    w = torch.zeros(1, dtype=torch.int32, device=t.device)
-    lib().call("lmkd_amax", _p(t), t.numel(), w.data_ptr(), _stream())
+def amax_compute(t, seg=0):
+    """max |t| by a reduction pass of its own (tensors that no kernel of this library wrote: tests, tools); seg = F0: per frame segment"""
+    w = torch.zeros(2, dtype=torch.int32, device=t.device)
+    seg = _seg_frames(seg, t.shape[0])
+    n0 = (t.numel() // t.shape[0]) * seg if seg else t.numel()
+    lib().call("lmkd_amax", _p(t), n0, w.data_ptr(), _stream())
+    if seg:
+        lib().call("lmkd_amax", t.data_ptr() + 4 * n0, t.numel() - n0, w.data_ptr() + 4, _stream())
     t._lmkd_amax = w
     return t
 

@@ -30,13 +30,19 @@ def _rel(a, b):
                                                              (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3"),
                                                              (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3"),
                                                              (1, 1, 64, "TRX_2fcsup", "fc_2_sup_dist", "resnet50_2fc", "fp32x3"),
+                                                             (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32h2"),
+                                                             (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc", "fp32h2"),
                                                              (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "bf16"),
                                                              (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "bf16act"),
                                                              # BASELINE configs[1] at FULL SIZE in the benchmark's arithmetic: 400 frames of
                                                              # 224^2, forward, loss and every parameter gradient (three oracle runs, ~2 min)
-                                                             (5, 5, 224, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3")])
+                                                             (5, 5, 224, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3"),
+                                                             # ... and in bench.py's headline arithmetic (two fp16 planes in the 3x3 kernels)
+                                                             (5, 5, 224, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32h2")])
 def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode):
-    """mode fp32x3 (the library default and bench.py's headline arithmetic): the convolutions (forward, data and weight gradient) in the 3xbf16 arithmetic, under the same fp32 criteria.
+    """mode fp32h2 (bench.py's headline arithmetic): fp32x3 with the 3x3 convolutions on two fp16 planes (csrc/conv_patch16.h); the test
+    asserts that those kernels ran.
+    mode fp32x3 (the library default): the convolutions (forward, data and weight gradient) in the 3xbf16 arithmetic, under the same fp32 criteria.
     mode bf16 (BASELINE configs[2]): against the ORACLE RUN ON BF16-ROUNDED CONVOLUTION OPERANDS (oracle.CONV_BF16: forward
     conv(r(x), r(w)), data gradient from r(dy), r(w), weight gradient from r(x), r(dy), fp32 everywhere else) - the same
     arithmetic on the CPU, not the GPU's own fp32 run."""
@@ -46,8 +52,12 @@ def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode):
     if mode == "bf16act":      # + every stored activation / activation gradient of the trunk as bf16: oracle.ACT_BF16 rounds at the same places
         ops.set_activation_dtype("bf16")
         O.ACT_BF16 = True
+    import litemkd_amd
+    h2_before = litemkd_amd.lib().value("lmkd_conv_h2_launches")
     try:
         _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode in ("bf16", "bf16act"))
+        if mode == "fp32h2":      # 16 forward + 16 data-gradient + 13 weight-gradient launches per trunk call (one merged call here)
+            assert litemkd_amd.lib().value("lmkd_conv_h2_launches") - h2_before >= (45 if img == 224 else 20), "the two-plane kernels did not run"
     finally:
         O.ACT_BF16 = False
         ops.set_activation_dtype("fp32")
@@ -461,7 +471,7 @@ def test_packed_weight_cache_follows_optimizer(dev):
 _FULL64 = {}
 
 
-@pytest.mark.parametrize("mode", ["fp32x3", "fp32"])
+@pytest.mark.parametrize("mode", ["fp32h2", "fp32x3", "fp32"])
 def test_full_size_episode_matches_oracle(dev, mode):
     """BASELINE configs[1] at full size (5-way 5-shot, 5 queries/class, 400 frames of 224x224): logits, loss and class
     predictions of the HIP path against the CPU oracle on the same episode and weights (~10 s of oracle time), in the library

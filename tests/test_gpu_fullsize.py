@@ -100,6 +100,9 @@ def _run_shape(dev, name, H, Cs, Cin, Cout, K, s, p, N=FRAMES, check_wgrad=True,
         dy = _r16(dy)
     xk = x.to(torch.bfloat16) if (act16 and Cs != 4) else x      # what the kernels are given
     dyk = dy.to(torch.bfloat16) if act16 else dy
+    if ops.get_conv_compute_dtype() == "fp32h2":      # the operands' maxima (inside the trunk: recorded by the kernels that write them)
+        ops.amax_compute(xk)
+        ops.amax_compute(dyk)
     sub = list(range(4)) + list(range(N - 4, N))                 # first / last row tiles of the launch
     xs64 = nchw(x[sub][..., :Cin]).cpu().double()
     w64 = (_r16(w) if act16 else w).cpu().double()
@@ -194,6 +197,28 @@ def test_conv_benchmark_shapes_x3_mode_vs_fp64(dev, shape):
         _run_shape(dev, *shape)
         SEEN.setdefault("x3_mode", set()).update(SEEN["x3"])
         SEEN.setdefault("x3w_mode", set()).update(SEEN["x3w"])
+    finally:
+        ops.reset_compute_dtypes()
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[s[0] for s in SHAPES])
+def test_conv_benchmark_shapes_h2_mode_vs_fp64(dev, shape):
+    """bench.py's headline arithmetic ('fp32h2'): the 3x3 launches - forward, data gradient (+ its accumulate form), stride-1 weight
+    gradient - on two fp16 planes with power-of-two scales, three v_mfma_f32_16x16x32_f16 products (csrc/conv_patch16.h), everything
+    else in fp32x3; all under the SAME fp64-anchored criterion as the native fp32 MFMA kernels.  Asserts that the two-plane instances
+    are what ran."""
+    import litemkd_amd
+    from litemkd_amd import ops
+    ops.set_conv_compute_dtype("fp32h2")
+    n0 = litemkd_amd.lib().value("lmkd_conv_h2_launches")
+    try:
+        _run_shape(dev, *shape)
+        ran = litemkd_amd.lib().value("lmkd_conv_h2_launches") - n0
+        name, H, Cs, Cin, Cout, K, s, p = shape
+        # 3x3: forward, data gradient, its accumulate form (+ the window weight gradient at stride 1); the 1x1 / stride-2 downsample
+        # convolution's data gradient (and its accumulate form) runs on the same patch kernel as four parity classes with one tap
+        want = (2 if (K == 1 and Cs % 32 == 0) else 0) if K != 3 else (4 if s == 1 else 3)
+        assert ran == want, (name, ran, want)
     finally:
         ops.reset_compute_dtypes()
 

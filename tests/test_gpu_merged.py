@@ -29,7 +29,7 @@ def _conv_w(co, ci, k, dev, g):
     return torch.nn.Parameter((torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5).to(dev))
 
 
-@pytest.mark.parametrize("mode,act", [("fp32x3", "fp32"), ("bf16", "fp32"), ("bf16", "bf16")])
+@pytest.mark.parametrize("mode,act", [("fp32x3", "fp32"), ("fp32h2", "fp32"), ("bf16", "fp32"), ("bf16", "bf16")])
 @pytest.mark.parametrize("F0,F1,H,cin,cout,stride", [(3, 5, 14, 64, 64, 1),      # 588 | 980 rows: neither a multiple of the 128-row tile
                                                       (5, 3, 14, 64, 128, 2),     # downsample branch, stride-2 forward / data gradient
                                                       (2, 7, 7, 256, 256, 1),     # 98 rows in segment 0: less than one tile
@@ -37,10 +37,12 @@ def _conv_w(co, ci, k, dev, g):
                                                       (6, 2, 56, 64, 64, 1)])     # the widest halo (W = 56)
 def test_basic_block_two_segments_equal_two_calls(dev, mode, act, F0, F1, H, cin, cout, stride):
     """ops.BasicBlockFn over [F0 + F1] frames with seg = F0 against two calls on the halves: block output, input gradient and the
-    deferred BatchNorm tables bit-identical; parameter gradients equal to the sum of the two calls' to fp32 rounding"""
-    import litemkd_amd  # noqa: F401
+    deferred BatchNorm tables bit-identical; parameter gradients equal to the sum of the two calls' to fp32 rounding.
+    fp32h2: the operand maxima are kept per frame segment, so the two-plane kernels scale each segment as its own launch would"""
+    import litemkd_amd
     from litemkd_amd import ops
     ops.set_conv_compute_dtype(mode)
+    h2_before = litemkd_amd.lib().value("lmkd_conv_h2_launches")
     ops.set_activation_dtype(act)
     g = torch.Generator().manual_seed(F0 * 100 + F1 * 10 + H)
     adt = torch.bfloat16 if act == "bf16" else torch.float32
@@ -65,10 +67,15 @@ def test_basic_block_two_segments_equal_two_calls(dev, mode, act, F0, F1, H, cin
         try:
             if seg:
                 xs = [x.clone().requires_grad_()]
+                if mode == "fp32h2":
+                    ops.amax_compute(xs[0], seg=F0)      # (inside the trunk the producer of the block input records it)
                 ys = [ops.BasicBlockFn.apply(xs[0], stride, True, *ps, F0)]
                 ys[0].backward(gy)
             else:
                 xs = [x[:F0].clone().requires_grad_(), x[F0:].clone().requires_grad_()]
+                if mode == "fp32h2":
+                    ops.amax_compute(xs[0])
+                    ops.amax_compute(xs[1])
                 ys = [ops.BasicBlockFn.apply(xs[0], stride, True, *ps), ops.BasicBlockFn.apply(xs[1], stride, True, *ps)]
                 ys[0].backward(gy[:F0])
                 ys[1].backward(gy[F0:])
@@ -82,6 +89,8 @@ def test_basic_block_two_segments_equal_two_calls(dev, mode, act, F0, F1, H, cin
         return y, dx, grads, tabs
     y2, dx2, g2, t2 = run(False)
     y1, dx1, g1, t1 = run(True)
+    if mode == "fp32h2":      # the 3x3 launches of both runs took the two-plane form (7 per call without a downsample branch: 2 fwd, 3 dgrad, 2 wgrad)
+        assert litemkd_amd.lib().value("lmkd_conv_h2_launches") - h2_before >= (3 * 5 if stride != 1 else 3 * 6), "two-plane kernels did not run"
     assert torch.equal(y1, y2), _rel(y1.float(), y2.float())
     assert torch.equal(dx1, dx2), _rel(dx1.float(), dx2.float())
     # deferred tables: the two-call run lists (conv1, conv2, [ds]) of call 0 then of call 1; the merged run lists (seg 0, seg 1) per BatchNorm
@@ -170,6 +179,7 @@ def _trunk_pair(dev, bb, Fs, Fq, img, mode, act, seed=0):
 
 
 @pytest.mark.parametrize("bb,Fs,Fq,img,mode,act", [("r18", 8, 40, 64, "fp32x3", "fp32"), ("r18", 40, 40, 96, "fp32x3", "fp32"),
+                                                     ("r18", 8, 40, 64, "fp32h2", "fp32"), ("r18", 40, 40, 96, "fp32h2", "fp32"),
                                                      ("r18", 8, 40, 64, "bf16", "bf16"), ("r18", 24, 8, 64, "bf16", "fp32"),
                                                      ("r50", 8, 16, 64, "fp32x3", "fp32"), ("r50", 8, 16, 64, "bf16", "bf16")])
 def test_merged_trunk_equals_two_calls(dev, bb, Fs, Fq, img, mode, act):
@@ -182,8 +192,9 @@ def test_merged_trunk_equals_two_calls(dev, bb, Fs, Fq, img, mode, act):
     assert worst[0] < 2e-5, worst
 
 
-@pytest.mark.parametrize("Fs,Fq,tile", [(200, 200, 0), (40, 200, 11), (40, 200, 0)])
-def test_merged_trunk_equals_two_calls_full_size(dev, Fs, Fq, tile):
+@pytest.mark.parametrize("Fs,Fq,tile,mode", [(200, 200, 0, "fp32x3"), (40, 200, 11, "fp32x3"), (40, 200, 0, "fp32x3"), (200, 200, 0, "fp32h2"),
+                                              (40, 200, 11, "fp32h2")])
+def test_merged_trunk_equals_two_calls_full_size(dev, Fs, Fq, tile, mode):
     """BASELINE configs[1] (5-way 5-shot: 200 | 200 frames of 224^2) and configs[0] (1-shot: 40 | 200) in the benchmark's arithmetic:
     forward bit-identical, accumulated parameter gradients within 2e-6 (relative L2) of the two-call path's.
     Bit-identity needs the SAME tile instance in both schedules: the launcher picks the tile from the launch's row count, and a 40-frame
@@ -193,7 +204,7 @@ def test_merged_trunk_equals_two_calls_full_size(dev, Fs, Fq, tile):
     import litemkd_amd
     litemkd_amd.lib().call("lmkd_conv_set_tile", tile)
     try:
-        out = _trunk_pair(dev, "r18", Fs, Fq, 224, "fp32x3", "fp32", seed=5)
+        out = _trunk_pair(dev, "r18", Fs, Fq, 224, mode, "fp32", seed=5)
     finally:
         litemkd_amd.lib().call("lmkd_conv_set_tile", 0)
     (X2, g2, b2), (X1, g1, b1) = out[False], out[True]
