@@ -46,6 +46,10 @@ class _Lib:
             raise RuntimeError(
                 "liblmkd_hip.so not found at %s: build it with `python lite-mkd_amd/build.py` "
                 "(there is no CPU or PyTorch fallback for the hot path)" % LIB_PATH)
+        # torch first: its wheel bundles its own libamdhip64, and a process must not end up with two HIP runtimes - loaded after torch,
+        # liblmkd_hip.so binds to the runtime torch brought (loaded before it, the library initialises /opt/rocm's copy and the devices
+        # are then invisible to one of the two)
+        import torch  # noqa: F401
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         for name, (restype, argtypes) in self.protos.items():

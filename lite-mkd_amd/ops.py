@@ -494,6 +494,11 @@ def _amax_slot(dev):
     return p["buf"][i:i + 2]
 
 
+def amax_pool_reset():
+    """the next word comes from a new pool (a hipGraph capture: each graph zeroes the pool its own words live in)"""
+    _AMAX_POOLS.clear()
+
+
 def _amax_record(t):
     """call immediately before the launch that writes t (lmkd_amax_next is one-shot): that launch also folds max |t| into a fresh word"""
     if t.dtype is torch.float32 and _h2_mode():

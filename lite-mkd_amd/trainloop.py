@@ -389,6 +389,7 @@ class GraphedEpisode:
         torch.cuda.synchronize()
         ops.SEED_SLOTS = slots
         ops.SYNC_WGRAD_AT_BACKWARD_END = True                      # every forked stream joins the capture stream before it ends
+        ops.amax_pool_reset()                                      # fp32h2: the words of the tensors' maxima come from a pool zeroed inside THIS graph
         try:
             with torch.cuda.graph(g):
                 loss, acc, _ = _train_task_prepared(prepared, self.student, self.teacher, self.distiller, self.accuracy_fn, cfg)
@@ -490,6 +491,7 @@ class GraphedEpisode:
         torch.cuda.synchronize()
         ops.SEED_SLOTS = slots
         ops.SYNC_WGRAD_AT_BACKWARD_END = False                     # the weight-gradient stream runs on under the next episode's forward ...
+        ops.amax_pool_reset()
         out = []
         try:
             with torch.cuda.graph(g):

@@ -85,34 +85,45 @@ def _compare(a, b, grad_tol, lr):
     assert float((pa - pb).abs().max()) <= 1e-4 * float(pb.abs().max()), "forward after the step"
 
 
-def _sched(which):
+def _sched(which, conv="fp32x3"):
     from litemkd_amd.schedule import Schedule
-    return {"bench": Schedule.bench, "two_call": Schedule.two_call, "merged": lambda: Schedule.bench(pipeline_episodes=False),
-            "two_call_pipelined": lambda: Schedule.two_call(pipeline_episodes=True)}[which]()
+    return {"bench": lambda: Schedule.bench(conv_dtype=conv), "two_call": lambda: Schedule.two_call(conv_dtype=conv),
+            "merged": lambda: Schedule.bench(pipeline_episodes=False, conv_dtype=conv),
+            "two_call_pipelined": lambda: Schedule.two_call(pipeline_episodes=True, conv_dtype=conv)}[which]()
 
 
-@pytest.mark.parametrize("which", ["bench", "two_call", "merged"])
-def test_bench_schedule_equals_serial_full_size(dev, which):
+@pytest.mark.parametrize("which,conv", [("bench", "fp32h2"), ("bench", "fp32x3"), ("two_call", "fp32x3"), ("merged", "fp32x3")])
+def test_bench_schedule_equals_serial_full_size(dev, which, conv):
     """three accumulated 400-frame episodes (5-way 5-shot, 224^2) + one SGD step under Schedule.bench() - what bench.py times: merged trunk
     call + cross-episode pipelining - under round 3's two-call three-stream schedule and under the merged call alone, against
     Schedule.serial(): losses identical, flat gradient bucket within 2e-6 of its maximum, weights after the step equal to that precision,
     running statistics identical"""
     from litemkd_amd.schedule import Schedule
+    import litemkd_amd
     assert Schedule.bench().merge_trunk_calls and Schedule.bench().pipeline_episodes
-    ref = _run(dev, Schedule.serial(), 5, 224, 3)
-    tst = _run(dev, _sched(which), 5, 224, 3)
+    n0 = litemkd_amd.lib().value("lmkd_conv_h2_launches")
+    ref = _run(dev, Schedule.serial(conv_dtype=conv), 5, 224, 3)
+    n1 = litemkd_amd.lib().value("lmkd_conv_h2_launches")
+    tst = _run(dev, _sched(which, conv), 5, 224, 3)
+    n2 = litemkd_amd.lib().value("lmkd_conv_h2_launches")
+    if conv == "fp32h2":      # bench.py's headline arithmetic: the two-plane kernels ran - 48 launches per trunk call (16 forward, 16 + 3 data gradient,
+        # 13 weight gradient) x 2 calls x 3 episodes in the serial run, once per episode in the merged one, + the 16 forward launches per
+        # call of _run's probe - i.e. every maximum reached its consumer
+        assert n1 - n0 == 2 * (n2 - n1) and n2 - n1 == 3 * 48 + 16, (n1 - n0, n2 - n1)
+    else:
+        assert n2 == n0
     _compare(tst, ref, 2e-6, 1e-2)
 
 
-@pytest.mark.parametrize("which", ["bench", "two_call", "two_call_pipelined"])
+@pytest.mark.parametrize("which,conv", [("bench", "fp32x3"), ("two_call", "fp32x3"), ("two_call_pipelined", "fp32x3"), ("bench", "fp32h2")])
 @pytest.mark.parametrize("freeze", [(), ("backbone.resnet.0.weight",), ("backbone.resnet.0.weight", "backbone.resnet.1.weight", "backbone.resnet.1.bias")])
-def test_bench_schedule_equals_serial_frozen_stem(dev, which, freeze):
+def test_bench_schedule_equals_serial_frozen_stem(dev, which, conv, freeze):
     """the same identity on a small episode with the stem's weight (and BatchNorm) frozen: the stem's weight gradient is then NOT the
     last thing on the side stream that the weight-gradient stream waits for - the optimizer has to join every stream itself
     (ops.join_all_streams)"""
     from litemkd_amd.schedule import Schedule
-    ref = _run(dev, Schedule.serial(), 1, 64, 4, freeze)
-    tst = _run(dev, _sched(which), 1, 64, 4, freeze)
+    ref = _run(dev, Schedule.serial(conv_dtype=conv), 1, 64, 4, freeze)
+    tst = _run(dev, _sched(which, conv), 1, 64, 4, freeze)
     _compare(tst, ref, 5e-6, 1e-2)
 
 

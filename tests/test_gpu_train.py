@@ -250,15 +250,17 @@ def test_data_parallel_world2_equals_world1(dev, tmp_path):
     assert not torch.equal(r0["backbone.resnet.1.running_mean"], r1["backbone.resnet.1.running_mean"])
 
 
-@pytest.mark.parametrize("fresh_tensors", [False, True])
-def test_graphed_episode_bit_identical_to_eager(dev, fresh_tensors):
+@pytest.mark.parametrize("fresh_tensors,conv", [(False, "fp32x3"), (True, "fp32x3"), (False, "fp32h2"), (True, "fp32h2")])
+def test_graphed_episode_bit_identical_to_eager(dev, fresh_tensors, conv):
     """trainloop.GraphedEpisode: the episode captured into a hipGraph (forward + loss + backward on three streams, dropout seeds and
     class plan in device memory, packed weights refreshed in place) replays the SAME kernels on the same data: losses, accuracies,
     accumulated gradients, BatchNorm running statistics and the weights after an optimizer step are bit-identical to the eager loop
     over the same episodes with the same RNG state (dropout 0.1 active).
     fresh_tensors False: a resident pool of episodes - one graph per episode, captured on the episode's own tensors (bench.py);
-    True: every episode arrives in new tensors (a data loader) - ONE graph on static copies, inputs and class plan copied in."""
+    True: every episode arrives in new tensors (a data loader) - ONE graph on static copies, inputs and class plan copied in.
+    conv fp32h2 (bench.py's headline arithmetic): the words that carry the tensors' maxima are zeroed INSIDE the graph (ops._amax_slot)."""
     from litemkd_amd import ops, trainloop as TL
+    ops.set_conv_compute_dtype(conv)
     from litemkd_amd.model.model_select import Student, Teacher
     from litemkd_amd.distillers import Distiller
     from litemkd_amd.options import default_args
@@ -296,8 +298,11 @@ def test_graphed_episode_bit_identical_to_eager(dev, fresh_tensors):
             ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD = prev
         stats = {k: v.clone() for k, v in student.state_dict().items() if "running" in k or "num_batches" in k}
         return out, opt.bucket.grad.clone(), opt.bucket.flat.clone(), stats, runner
-    o_e, g_e, w_e, s_e, _ = run(False)
-    o_g, g_g, w_g, s_g, runner = run(True)
+    try:
+        o_e, g_e, w_e, s_e, _ = run(False)
+        o_g, g_g, w_g, s_g, runner = run(True)
+    finally:
+        ops.reset_compute_dtypes()
     if fresh_tensors:      # two new keys eager (max_graphs), then the generic graph: its first episode eager, captured on the next
         assert runner.replays == len(order) - 3 and runner.eager == 3 and len(runner.graphs) == 1, (runner.replays, runner.eager)
     else:                  # first sight of each of the two episodes eager, then their own graphs
