@@ -377,7 +377,7 @@ def main():
     achieved = cg[0] / cg[1] / 1e12
     # dense MFMA peaks (MI355X_MICROARCH.md); the 3xbf16 arithmetic issues 6 bf16 MFMA flops per algorithmic fp32 flop
     PEAK = {"f32": 2500.0 / 3, "f32x3": 2500.0 / 6, "f32native": PEAK_FP32_MFMA_TFLOPS, "bf16": 2500.0, "bf16conv": 2500.0}
-    ARITH = {"f32": "v_mfma_f32_16x16x32_f16 x3 per fp32 product, two fp16 planes per operand (h0 + h1 = x 2^s to 2^-24, 2^s from the tensor's "
+    ARITH = {"f32": "v_mfma_f32_16x16x32_f16 x3 per fp32 product, two fp16 planes per operand (h0 + h1 = x 2^s to 2^-23, 2^s from the tensor's "
                     "maximum), fp32 accumulate; peak = dense fp16 MFMA peak / 3",
              "f32x3": "v_mfma_f32_16x16x32_bf16 x6 per fp32 product, exact 3-way bf16 operand split, fp32 accumulate; peak = dense bf16 MFMA peak / 6",
              "f32native": "v_mfma_f32_32x32x2_f32",
@@ -421,10 +421,10 @@ def main():
                                   {"f32": "fp32", "f32x3": "fp32", "f32native": "fp32", "bf16": "bf16 tensors / fp32 accumulate", "bf16conv": "bf16 conv operands / fp32 tensors"}[a.dtype]),
                    "conv_arithmetic": {"f32": "fp32 tensors and accumulation.  The 3x3 convolutions - forward, data gradient, stride-1 weight gradient: 93 % of "
                                               "the trunk's flops - split each fp32 operand x into TWO fp16 planes, h0 = fp16(x 2^s), h1 = fp16(x 2^s - h0) "
-                                              "(|x 2^s - h0 - h1| <= 2^-24 |x 2^s|: half an fp32 ulp; 2^s a power of two from max |tensor|, which the kernel "
+                                              "(round to nearest: |x 2^s - h0 - h1| <= 2^-23 |x 2^s|, one fp32 ulp, zero for at least half of all fp32 values; 2^s a power of two from max |tensor|, which the kernel "
                                               "that writes the tensor records, so the scaling is exact) and form h0 w0 + h0 w1 + h1 w0 on "
-                                              "v_mfma_f32_16x16x32_f16 with fp32 accumulation (the dropped h1 w1 <= 2^-24 of the product; the three-plane "
-                                              "bf16 form drops 2^-23).  Everything else (stem, 1x1 / stride-2 weight gradients, heads) runs f32x3's "
+                                              "v_mfma_f32_16x16x32_f16 with fp32 accumulation (the dropped h1 w1 <= 2^-22 of the product, zero-mean; the three-plane "
+                                              "bf16 form drops <= 2^-23, all of one sign).  Everything else (stem, 1x1 / stride-2 weight gradients, heads) runs f32x3's "
                                               "arithmetic.  Relative-L2 error vs fp64 on the trunk's four 3x3 shapes: forward 2.7e-7 .. 7.0e-7, data gradient "
                                               "2.7e-7 .. 7.1e-7, weight gradient 2.3e-7 .. 5.5e-7 - BELOW f32x3's (3.5e-7 .. 9.6e-7 | 3.6e-7 .. 1.0e-6 | 2.9e-7 .. "
                                               "8.2e-7) and at torch's fp32 convolution's on every one (profiles/r04_h2_error.txt; tests/test_gpu_h2.py holds "

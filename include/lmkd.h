@@ -70,8 +70,9 @@ int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound 
    lmkd_conv2d_split_weights (in that mode).
    4 (round 4) = mode 2 with the kernels that carry 93 % of the trunk's flops - the 3x3 convolutions' forward and data gradient
    (conv_patch16_x3_kernel) and the 3x3 / stride-1 weight gradient (conv_wgrad_win16_kernel) - on TWO fp16 planes and THREE
-   v_mfma_f32_16x16x32_f16 products per fp32 product: x 2^s = h0 + h1 with h0 = fp16(x 2^s), h1 = fp16(x 2^s - h0) represents x to
-   2^-24 (half an fp32 ulp), the dropped h1 h1' term is <= 2^-24 of the product (mode 2 drops 2^-23), accumulation stays fp32, and 2^s
+   v_mfma_f32_16x16x32_f16 products per fp32 product: x 2^s = h0 + h1 with h0 = fp16(x 2^s), h1 = fp16(x 2^s - h0) (round to nearest)
+   represents x to 2^-23 (one fp32 ulp; exactly for at least half of all fp32 values; zero-mean), the dropped h1 h1' term is <= 2^-22
+   of the product with zero mean (mode 2 drops <= 2^-23, all of one sign: its planes are truncations), accumulation stays fp32, and 2^s
    is a power of two taken from the tensor's maximum (lmkd_conv_operand_amax), so the scaling is exact.  Measured error against fp64
    at or below mode 2's on every layer (profiles/r04_h2_error.txt).  A launch whose operand maxima are not named runs mode 2. */
 int lmkd_conv_set_compute_dtype(int mode);

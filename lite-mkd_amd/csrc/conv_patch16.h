@@ -59,12 +59,16 @@ struct X3FragB16 {
       off[j] = (nt * 16 < ncols) ? (unsigned)(((long)nt * (Kp >> 5) * NPW * 64 + lane) * 16) : X3_OOB;
     }
   }
-  __device__ __forceinline__ void load(int koff /* multiple of 32 */, u32x4 (&reg)[NR]) const {
+  __device__ __forceinline__ void load(int koff /* multiple of 32, wave-uniform */, u32x4 (&reg)[NR]) const {
+    // the K offset is the same for every lane: it travels in the SCALAR offset of the buffer load (the range check looks at the vector
+    // offset alone, so an out-of-range column block - off = X3_OOB - still reads zeros), and the loop-invariant off[j] is the whole
+    // vector offset: no vector instruction per load (before: an add and a select each - the kernel is bound by vector-instruction issue)
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((koff >> 5) * NPW * 1024));
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int p = 0; p < NPW; ++p)
-        reg[j * NPW + p] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j] == X3_OOB ? X3_OOB : off[j] + (unsigned)(((koff >> 5) * NPW + p) * 1024), 0, 0);
+        reg[j * NPW + p] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], so + (unsigned)(p * 1024), 0);
   }
 };
 
@@ -93,12 +97,15 @@ __global__ void split_weights16_kernel(const float* __restrict__ wp, unsigned sh
 }
 
 // ---- fp32 as TWO fp16 planes (NPROD == 3; lmkd_conv_set_compute_dtype(4)) ----
-// x 2^s = h0 + h1 + e with h0 = fp16_rne(x 2^s), h1 = fp16_rne(x 2^s - h0): |e| <= 2^-24 |x 2^s| - HALF an fp32 ulp - wherever h1 is a normal
-// fp16 number (|x 2^s| >= 1/2), and <= 2^-25 absolutely below that.  Three products h0 w0 + h0 w1 + h1 w0 on v_mfma_f32_16x16x32_f16 with fp32
-// accumulation; the dropped h1 w1 is <= 2^-24 of the product (the three-plane bf16 form drops 2^-23).  2^s is a power of two taken from
-// the tensor's maximum (the producer of the tensor folds max |x| into a word, lmkd_amax_next; the weight packs carry max |w|), so the
-// scaling is exact: max |x| 2^s lies in (2^14, 2^15], elements down to 2^-16 of the maximum keep the full 2^-24, and what an element
-// below that loses is < 2^-40 of the tensor's maximum - 2^-16 of the rounding of the fp32 accumulator it is added into.
+// X = x 2^s = h0 + h1 + e with h0 = fp16_rne(X), h1 = fp16_rne(X - h0) (the subtraction is exact in fp32): |e| <= 2^-23 |X| - one fp32
+// ulp - and e = 0 for the fp32 values whose residual X - h0 fits 11 bits (at least half of them); e has zero mean (round to nearest).
+// That holds wherever fp16's grid is fine enough for h1, |X| >= 1/4 (h1 may be a subnormal fp16 number: the matrix pipe takes those as
+// they are, tests/test_gpu_h2.py); below that |e| <= 2^-25 absolutely.  Three products h0 w0 + h0 w1 + h1 w0 on v_mfma_f32_16x16x32_f16
+// with fp32 accumulation; the dropped h1 w1 is <= 2^-22 of the product with zero mean (the three-plane bf16 form drops <= 2^-23, but its
+// planes are TRUNCATIONS: its dropped terms all have the sign of the product).  2^s is a power of two taken from the tensor's maximum
+// (the producer of the tensor folds max |x| into a word, lmkd_amax_next; the weight packs carry max |w|), so the scaling is exact:
+// max |X| lies in (2^14, 2^15], elements down to 2^-17 of the maximum keep the full precision, and what an element below that loses is
+// < 2^-40 of the tensor's maximum - 2^-16 of the rounding of the fp32 accumulator it is added into.
 // Measured against fp64 (tools/h2_error.py, profiles/r04_h2_error.txt): rel-L2 2.7e-7 .. 7.0e-7 on the four 3x3 layers, BELOW the
 // three-plane form's 3.5e-7 .. 9.6e-7 and torch's fp32 convolution's 3.1e-7 .. 8.1e-7, at half the MFMA work.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -111,14 +118,18 @@ __device__ __forceinline__ float h2_scale(unsigned amax) {
   if (amax == 0u) s = 0;
   return __uint_as_float((unsigned)(s + 127) << 23);
 }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void h2_split4(const float4& v, float s, uint2& p0, uint2& p1) {
-  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
-  union { _Float16 h[4]; uint2 u; } c0, c1;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    c0.h[j] = (_Float16)x[j];
-    c1.h[j] = (_Float16)(x[j] - (float)c0.h[j]);
-  }
+  // on pairs: v_pk_mul_f32, v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32 - three vector instructions per element
+  // (the kernels that call this are bound by vector-instruction issue)
+  union { f16x2_t h[2]; uint2 u; } c0, c1;
+  const f32x2_t sv = {s, s};
+  const f32x2_t xa = f32x2_t{v.x, v.y} * sv, xb = f32x2_t{v.z, v.w} * sv;
+  c0.h[0] = __builtin_convertvector(xa, f16x2_t);
+  c0.h[1] = __builtin_convertvector(xb, f16x2_t);
+  c1.h[0] = __builtin_convertvector(xa - __builtin_convertvector(c0.h[0], f32x2_t), f16x2_t);
+  c1.h[1] = __builtin_convertvector(xb - __builtin_convertvector(c0.h[1], f32x2_t), f16x2_t);
   p0 = c0.u;
   p1 = c1.u;
 }
@@ -178,7 +189,12 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   using LB = X3FragB16<Cfg::TN, NPU>;
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   __shared__ int s_out[Cfg::BM];
-  __shared__ int s_tap_shift[LMKD_MAX_TAPS], s_tap_kofs[LMKD_MAX_TAPS];
+  __shared__ int s_tap_kofs[LMKD_MAX_TAPS];
+  // s_adp[tap][wave row][lane % 16][pixel block]: byte offset, inside the patch, of the row a (tap, output pixel) reads - the zero row
+  // where the tap leaves the image.  A lane's NB = 4 entries of a tap are one 8-byte read per K-step (before: a mask test, an add and a
+  // select per pixel block and step - the kernel is bound by vector-instruction issue)
+  static_assert(NB == 4 && PatchRow<NPL>::BYTES * (Cfg::BM + 2 * PATCH_HALO_MAX + 1) < 65536, "four 16-bit patch offsets per lane and tap");
+  __shared__ __attribute__((aligned(8))) unsigned short s_adp[LMKD_MAX_TAPS * Cfg::BM];
   __shared__ float s_red[Cfg::WM * Cfg::BN * 2];
   __shared__ int s_src[SRC2 ? Cfg::BM + 2 * PATCH_HALO_MAX : 1];      // SRC2: byte offset of patch row j's pixel in class (0, 0), -1 outside
   const int tid = threadIdx.x;
@@ -196,7 +212,6 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   const int row0 = sg.row0, n0 = ct * Cfg::BN;
   if (tid < ntap) {
     const Tap tp = taps[tid];
-    s_tap_shift[tid] = (tp.dh * a.Ws + tp.dw) * ROWB;
     s_tap_kofs[tid] = tp.kofs;
   }
   for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
@@ -231,35 +246,40 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   }
   const int lane = tid & 63, wave = tid >> 6;
   float h2_sx = 1.f, h2_ix = 1.f, h2_iw = 1.f;
+  bool h2_one = true;
   if constexpr (NPROD == 3) {
     h2_sx = h2_scale(a.h2_xw[sg.seg]);      // two words: the operand's maximum per frame segment
     const float sw = h2_scale(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(a.wpk) + (long)a.Co * a.Kp * 16));
     h2_ix = 1.f / h2_sx;      // exact: powers of two within 2^+-126
     h2_iw = 1.f / sw;
+    const int ex = (int)((__float_as_uint(h2_ix) >> 23) & 0xffu) + (int)((__float_as_uint(h2_iw) >> 23) & 0xffu) - 254;
+    h2_one = ex >= -126 && ex <= 126;      // (uniform) the product of the two is a normal number: one multiplication in the epilogue
+    if (h2_one) h2_ix *= h2_iw;
   }
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int kq = lane >> 4;                               // lane group: result rows 4 kq .. 4 kq + 3; k-slot patch16_kslot(kq) of a 32-k step
   const int ksl = patch16_kslot(kq);
   const int pxl = patch16_pixel(lane & 15);               // this lane's pixel of each 16-pixel block
-  // per 16-pixel block of this lane: LDS byte address of its own pixel's row (tap shift 0) and one validity bit per tap
-  unsigned a_base[NB], a_mask[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int r = wm * (Cfg::TM * 32) + 16 * b + pxl, m = row0 + r;
-    a_base[b] = (unsigned)((r + halo) * ROWB + 16 * ksl);
-    unsigned mk = 0;
+  for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {      // the offset table (s_adp): row r of the tile, every tap
+    const int m = row0 + r;
+    const int within = r % (Cfg::TM * 32), px = within & 15;
+    const int l16 = (px & 1) ? ((px >> 1) + (px < 8 ? 0 : 8)) : (px >> 1) + 4;      // the lane (mod 16) whose pixel this is: patch16_pixel(l16) == px
+    unsigned short* dst = s_adp + ((r / (Cfg::TM * 32)) * 16 + l16) * NB + (within >> 4);
+    int hh = -0x40000000, ww = 0;      // rows past the tile's segment: every tap reads the zero row
     if (m < M) {
       const int n = fdiv(m, a.div_hw);
       const int rem = m - n * a.Hs * a.Ws;
-      const int hh = fdiv(rem, a.div_w), ww = rem - hh * a.Ws;
-      for (int tp = 0; tp < ntap; ++tp) {
-        const int y = hh + taps[tp].dh, x = ww + taps[tp].dw;
-        if ((unsigned)y < (unsigned)a.Hs && (unsigned)x < (unsigned)a.Ws) mk |= 1u << tp;
-      }
+      hh = fdiv(rem, a.div_w);
+      ww = rem - hh * a.Ws;
     }
-    a_mask[b] = mk;
+    for (int tp = 0; tp < ntap; ++tp) {
+      const int y = hh + taps[tp].dh, x = ww + taps[tp].dw;
+      const bool in = (unsigned)y < (unsigned)a.Hs && (unsigned)x < (unsigned)a.Ws;
+      dst[tp * Cfg::BM] = (unsigned short)(in ? (r + halo + taps[tp].dh * a.Ws + taps[tp].dw) * ROWB : P * ROWB);
+    }
   }
-  const unsigned zero_addr = (unsigned)(P * ROWB + 16 * ksl);
+  const unsigned lane_off = (unsigned)(16 * ksl);      // this lane group's k-slot inside a patch row
+  const unsigned short* adp_lane = s_adp + (wm * 16 + (lane & 15)) * NB;
   // patch loader (conv_patch.h): LPR lanes x 16 B per pixel row
   const __amdgpu_buffer_rsrc_t prs = x3_rsrc(a.src, (long)a.N * a.Hs * a.Ws * a.Cs * 4 * (SRC2 ? 4 : 1));
   const int pk = (tid & (LPR - 1)) * 4;
@@ -313,6 +333,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     }
   };
   const bool neg = x3_neg_tile(sg.ltile, sg.ltiles);      // half the row tiles (of the segment) accumulate -y: X3FragB::init
+  if (NPROD == 3 && neg) h2_ix = -h2_ix;      // the epilogue's one multiplication also undoes the sign of a -W tile
   LB lb;
   lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, neg);
   f32x4 acc[NB][NC];
@@ -342,10 +363,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
         if (k_cc + 1 < a.cps) issue_patch(k_cc + 1);
       }
     }
-    const unsigned sh = (unsigned)s_tap_shift[k_tp];
-    unsigned ad[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) ad[b] = ((a_mask[b] >> k_tp) & 1u) ? a_base[b] + sh : zero_addr;
+    const uint2 pk2 = *reinterpret_cast<const uint2*>(adp_lane + k_tp * Cfg::BM);
+    const unsigned ad[NB] = {(pk2.x & 0xffffu) + lane_off, (pk2.x >> 16) + lane_off, (pk2.y & 0xffffu) + lane_off, (pk2.y >> 16) + lane_off};
     // the pixel blocks in two halves (conv_patch.h's two k-groups): one register set, the second half's fragments are read after the
     // first half's MFMAs (the set that would hold both halves costs the third workgroup per CU)
     constexpr int HB = NB / 2;
@@ -457,8 +476,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     for (int c = 0; c < NC; ++c) {
       const int col = ch0 + 16 * c;
       float4 v = make_float4(acc[b][c][0], acc[b][c][1], acc[b][c][2], acc[b][c][3]);
-      if (neg) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
-      if constexpr (NPROD == 3) { v.x = v.x * h2_ix * h2_iw; v.y = v.y * h2_ix * h2_iw; v.z = v.z * h2_ix * h2_iw; v.w = v.w * h2_ix * h2_iw; }      // 2^-sx, 2^-sw: exact
+      if constexpr (NPROD == 3) {      // 2^-sx, 2^-sw (exact), the sign of the -W tiles folded in
+        if (h2_one) { v.x *= h2_ix; v.y *= h2_ix; v.z *= h2_ix; v.w *= h2_ix; }
+        else { v.x = v.x * h2_ix * h2_iw; v.y = v.y * h2_ix * h2_iw; v.z = v.z * h2_ix * h2_iw; v.w = v.w * h2_ix * h2_iw; }
+      } else if (neg) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
       const bool ok = ob >= 0 && col < a.Co;
       if (EP) {      // inference: the operations of bn_apply_kernel in its order (x3_epilogue<EP>)
         v.x = fmaf(v.x, esc[c].x, esh[c].x); v.y = fmaf(v.y, esc[c].y, esh[c].y); v.z = fmaf(v.z, esc[c].z, esh[c].z); v.w = fmaf(v.w, esc[c].w, esh[c].w);

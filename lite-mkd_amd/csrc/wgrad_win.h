@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW)) void conv_wgrad_w
 // waves takes the OTHER 16 input channels of all nine taps (TPW = 9, JW = 1: 108 MFMAs per wave and step for every wave) instead of
 // four of the nine taps (TPW = 5: 120 / 96 - the 4-tap waves idle a fifth of the time): 244 -> measured in DESIGN 8.8.
 template <int COB, int NPROD, int R, bool PRE = false, int TPW = 9, int JW = 2>
-__global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void conv_wgrad_win16_kernel(WgradWinArgs a) {
+__global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW), JW == 2 ? 2 : 3) void conv_wgrad_win16_kernel(WgradWinArgs a) {
   static_assert(JW == 2 || (JW == 1 && TPW == 9), "the channel-block split exists for nine taps per wave");
   static_assert(NPROD == 6 || NPROD == 9 || NPROD == 3, "three bf16 planes (6 / 9 products) or two fp16 planes (3 products: conv_patch16.h)");
   static_assert(NPROD != 3 || !PRE, "two-plane form: no BatchNorm in the loader (the operand's maximum comes from its producer)");
@@ -404,6 +404,64 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW)) void c
           u.s[0] = lo; u.s[1] = hi;
           fa[i][p] = u.b;
         }
+      if constexpr (NPROD == 3 && JW == 2) {
+        // two planes, three products: half the MFMAs per fragment read of the three-plane form, so the reads no longer hide behind the
+        // MFMAs of their own tap - the fragments of tap ti + 1 are read while tap ti multiplies (one read per MFMA gap): 379 -> 284, 352 -> 251,
+        // 365 -> 265 us on layers 2-4 at 400 frames.  (JW = 1, layer 1: six MFMAs per tap - the plain loop is faster there, 334 vs 359 us)
+        static_assert(NPROD != 3 || TPW == 9, "all nine taps per wave");
+        auto read_fb = [&](int tp, bf16x8 (&fb)[JW][NPL]) {
+          const uint2 a2 = *reinterpret_cast<const uint2*>(&s_adr[t & 1][tp * LMKD_BK + (4 * q4 + (idx >> 2)) * 2]);
+#pragma unroll
+          for (int j = 0; j < JW; ++j) {
+            const unsigned lo_a = (a2.x ^ (unsigned)((j0 + j) << 5)) + cbx, hi_a = (a2.y ^ (unsigned)((j0 + j) << 5)) + cbx;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+              const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(s_x + p * X_PLANE + lo_a));
+              const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(s_x + p * X_PLANE + hi_a));
+              union { s16x4_t s[2]; bf16x8 b; } u;
+              u.s[0] = lo; u.s[1] = hi;
+              fb[j][p] = u.b;
+            }
+          }
+        };
+        auto mult = [&](int ti, const bf16x8 (&fb)[JW][NPL]) {
+#pragma unroll
+          for (int j = 0; j < JW; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              f32x4 c = acc[ti][i][j];      // smallest terms first
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[i][1]), __builtin_bit_cast(f16x8, fb[j][0]), c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, fb[j][1]), c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, fb[j][0]), c, 0, 0, 0);
+              acc[ti][i][j] = c;
+            }
+        };
+        bf16x8 fb0[JW][NPL], fb1[JW][NPL];
+        read_fb(tap0, fb0);
+#pragma unroll
+        for (int ti = 0; ti < TPW; ti += 2) {
+          if (ti + 1 < TPW) read_fb(tap0 + ti + 1, fb1);
+          mult(ti, fb0);
+          if (ti + 1 < TPW) {
+#pragma unroll
+            for (int q = 0; q < JW * NPL * 2 + 1; ++q) {      // one LDS read behind each of the first MFMAs, the rest back to back
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, JW * 6 - (JW * NPL * 2 + 1), 0);
+            if (ti + 2 < TPW) read_fb(tap0 + ti + 2, fb0);
+            mult(ti + 1, fb1);
+            if (ti + 2 < TPW) {
+#pragma unroll
+              for (int q = 0; q < JW * NPL * 2 + 1; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+              __builtin_amdgcn_sched_group_barrier(0x008, JW * 6 - (JW * NPL * 2 + 1), 0);
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int ti = 0; ti < TPW; ++ti) {
         const int tp = tap0 + ti;

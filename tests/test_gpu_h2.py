@@ -205,3 +205,24 @@ def test_without_the_maxima_the_three_plane_kernels_run(dev):
     ops.set_conv_compute_dtype("fp32x3")
     y3 = ops.conv_fwd(x, ops._pack_weights(w, 64, 0), 64, 3, 3, 1, 1, True)[0]
     assert torch.equal(y, y3)
+
+
+def test_subnormal_second_plane_reaches_the_matrix_pipe(dev):
+    """x = 1 + 2^-20 beside one element 2^14: scaled by 2^1, the second plane of the small elements is 2^-19 - a SUBNORMAL fp16 number.
+    v_mfma_f32_16x16x32_f16 must take it as it is (no flush to zero): with a weight that is 0.5 on the centre tap of the matching
+    channel and 0 elsewhere, y = 0.5 x EXACTLY (one non-zero product per output: nothing for the fp32 accumulator to round)"""
+    g = torch.Generator(device=dev).manual_seed(7)
+    N, H, C = 2, 14, 64
+    x = torch.full((N, H, H, C), 1.0 + 2.0 ** -20, device=dev)
+    x[0, 0, 0, 0] = 2.0 ** 14
+    w = torch.zeros(C, C, 3, 3, device=dev)
+    w[torch.arange(C), torch.arange(C), 1, 1] = 0.5
+    dy = torch.randn(N, H, H, C, device=dev, generator=g)
+    y, dx, dw = _conv3(x, w, dy)
+    assert torch.equal(y, 0.5 * x)
+    # the data gradient is 0.5 dy through the two-plane representation of dy: exact where dy's residual fits the second plane, else within
+    # one fp32 ulp (2^-23 relative) - or, for the elements below 2^-17 of the maximum, within 2^-25 of the scaled tensor
+    import math
+    s = 15 - math.ceil(math.log2(float(dy.abs().max())))
+    assert bool(((dx - 0.5 * dy).abs() <= 0.5 * (2.0 ** -23 * dy.abs() + 2.0 ** (-25 - s))).all())
+    assert float((dx == 0.5 * dy).float().mean()) > 0.45
