@@ -77,17 +77,21 @@ int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound 
    at or below mode 2's on every layer (profiles/r04_h2_error.txt).  A launch whose operand maxima are not named runs mode 2. */
 int lmkd_conv_set_compute_dtype(int mode);
 /* mode 4: the maxima of the operands of the NEXT convolution launch of this host thread (forward: x; data gradient: dy; weight gradient:
-   both), one-shot - consumed and cleared by that launch.  Each points at TWO device words holding the fp32 bits of max |tensor| over
-   frame segment 0 / segment 1 (the *_seg entry points; one segment: word 0) - any upper bound is valid - complete in stream order
-   before the launch; null = unknown.  Ignored in the other modes. */
+   both), one-shot - consumed and cleared by that launch.  Each points at the lmkd_amax_words() device words of a maximum as
+   lmkd_amax_next / lmkd_amax write them (two frame segments x 64 slots, 64 bytes apart; the maximum of a segment is the largest of its
+   slots' fp32 bit patterns; any upper bound is valid), complete in stream order before the launch; null = unknown.  Ignored in the
+   other modes. */
 int lmkd_conv_operand_amax(const void* x_word, const void* dy_word);
 /* the NEXT launch of lmkd_bn_apply(_seg) / lmkd_bn_relu_maxpool_fwd(_seg) / lmkd_bn_backward(_seg) / lmkd_bn_backward_part(_seg) on this
-   host thread also folds max |y| (backward: max |dx|) into word[0] - the elements of frame segment 1 into word[1] - with an atomic max
-   on the fp32 bits; the caller zeroes both words.
+   host thread also folds max |y| (backward: max |dx|) into the lmkd_amax_words() words at `word`: every wave into one of 64 slots of
+   its elements' frame segment (float atomics execute at the memory side: thousands of them on one address cost more than the pass
+   itself), atomic max on the fp32 bits; the caller zeroes the words.
    One-shot.  This is how a trunk tensor gets the word lmkd_conv_operand_amax names, without a pass of its own. */
 int lmkd_amax_next(void* word);
-/* max |x[0 .. n)| -> *word (zeroed here first): a pass of its own, for tensors no kernel of this library wrote */
+/* max |x[0 .. n)| -> the slots of ONE frame segment at `word` (lmkd_amax_words() / 2 words, zeroed here first; segment 1 of a tensor's
+   maximum starts lmkd_amax_words() / 2 words in): a pass of its own, for tensors no kernel of this library wrote */
 int lmkd_amax(const float* x, long n, void* word, void* stream);
+long lmkd_amax_words(void);
 /* 16-bit elements of the plane buffer lmkd_conv2d_split_weights fills for a packed weight [ncols][Kp] in the current mode:
    ncols Kp (mode 1), 12 ncols Kp (2 / 3), 16 ncols Kp + 32 (4: + the two fp16 planes of W and of -W in the 16x16x32 order and, in the
    last 64 bytes, max |w|) */

@@ -10,7 +10,8 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "lmkd.h")
-LIB_PATH = os.path.join(_HERE, "liblmkd_hip.so")
+# LMKD_LIB: another build of the same sources (tools/ab_build.sh: kernel A/B comparisons on one GPU box)
+LIB_PATH = os.environ.get("LMKD_LIB") or os.path.join(_HERE, "liblmkd_hip.so")
 
 _CT = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "char": ctypes.c_char,

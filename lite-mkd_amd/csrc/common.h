@@ -60,10 +60,28 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
 __device__ __forceinline__ float amax4(float m, const float4& v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
+// A maximum is LMKD_AMAX_SLOTS words, 64 bytes apart (one memory-side atomic request each), per frame segment: every wave of the
+// producer folds its own maximum into the slot of its (workgroup, wave) - float atomics execute at the memory side and 4096 of them on
+// ONE address cost a 321 MB elementwise pass as much as the pass itself (85 -> 160 us) - and a consumer takes the maximum over the slots
+// (one load per lane + a wave reduction, amax_read).  Layout of a tensor's words: [segment][slot][16 words, the first one used].
+#define LMKD_AMAX_SLOTS 64
+#define LMKD_AMAX_STRIDE 16
+#define LMKD_AMAX_SEG_WORDS (LMKD_AMAX_SLOTS * LMKD_AMAX_STRIDE)
 __device__ __forceinline__ void amax_commit(unsigned* __restrict__ word, float m) {      // call with the whole wave active
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(word, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0 && m > 0.f)
+    atomicMax(word + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (LMKD_AMAX_SLOTS - 1)) * LMKD_AMAX_STRIDE, __float_as_uint(m));
+}
+// the fp32 bits of the maximum of frame segment `seg` (wave-uniform; call with the whole wave active)
+__device__ __forceinline__ unsigned amax_read(const unsigned* __restrict__ word, int seg) {
+  unsigned v = word[seg * LMKD_AMAX_SEG_WORDS + (threadIdx.x & (LMKD_AMAX_SLOTS - 1)) * LMKD_AMAX_STRIDE];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned u = (unsigned)__shfl_xor((int)v, o, 64);
+    v = u > v ? u : v;
+  }
+  return __builtin_amdgcn_readfirstlane(v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

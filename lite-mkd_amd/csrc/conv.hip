@@ -632,19 +632,22 @@ extern "C" long lmkd_conv2d_plane_elems(int ncols, int Kp) {
   const long n = (long)ncols * Kp;
   return g_conv_bf16 ? n : (g_conv_h2 ? 16 * n + 32 : 12 * n);
 }
-// max |x| of n floats into *word (zeroed here first).  The fallback for a tensor whose producer did not record it.
-extern "C" int lmkd_amax(const float* x, long n, void* word, void* stream) {
+// max |x| of n floats: slots = 0: into the ONE word at `word` (weight packs); slots = 1: into the slot words of one frame segment of an
+// activation maximum (lmkd_amax_next's layout: segment s at word + s * lmkd_amax_words() / 2).  The words are zeroed here first.
+static int amax_impl(const float* x, long n, void* word, int slots, void* stream) {
   LMKD_REQUIRE(x && word && n > 0, "lmkd_amax: bad arguments");
-  if (hipMemsetAsync(word, 0, 4, (hipStream_t)stream) != hipSuccess) {
+  if (hipMemsetAsync(word, 0, slots ? LMKD_AMAX_SEG_WORDS * 4 : 4, (hipStream_t)stream) != hipSuccess) {
     lmkd_set_error("lmkd_amax: hipMemsetAsync failed");
     return LMKD_EHIP;
   }
   int grid = cdiv(n, 256 * 16);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(amax_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, (unsigned*)word);
+  if (slots) hipLaunchKernelGGL(amax_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, (unsigned*)word);
+  else hipLaunchKernelGGL(amax_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, (unsigned*)word);
   LMKD_CHECK_LAUNCH("amax_kernel");
   return LMKD_OK;
 }
+extern "C" int lmkd_amax(const float* x, long n, void* word, void* stream) { return amax_impl(x, n, word, 1, stream); }
 
 extern "C" int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, int Kp, void* stream) {
   LMKD_REQUIRE(wp && wf, "lmkd_conv2d_split_weights: null pointer");
@@ -661,7 +664,7 @@ extern "C" int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, i
   }
   if (g_conv_h2) {         // + the two fp16 planes (16x16x32 order) and max |w| behind them
     unsigned short* wh = (unsigned short*)wf + (long)ncols * Kp * 12;
-    const int rc = lmkd_amax(wp, (long)ncols * Kp, wh + (long)ncols * Kp * 4, stream);
+    const int rc = amax_impl(wp, (long)ncols * Kp, wh + (long)ncols * Kp * 4, 0, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(split_weights16_h2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wp, wh, ncols, Kp);
     LMKD_CHECK_LAUNCH("split_weights16_h2_kernel");

@@ -121,6 +121,18 @@ __device__ __forceinline__ float h2_scale(unsigned amax) {
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void h2_split4(const float4& v, float s, uint2& p0, uint2& p1) {
+#ifdef LMKD_AB_SCALAR_SPLIT      // tools/ab_build.sh: the element-wise form
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+  union { _Float16 h[4]; uint2 u; } d0, d1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    d0.h[j] = (_Float16)x[j];
+    d1.h[j] = (_Float16)(x[j] - (float)d0.h[j]);
+  }
+  p0 = d0.u;
+  p1 = d1.u;
+  return;
+#endif
   // on pairs: v_pk_mul_f32, v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32 - three vector instructions per element
   // (the kernels that call this are bound by vector-instruction issue)
   union { f16x2_t h[2]; uint2 u; } c0, c1;
@@ -160,9 +172,12 @@ __global__ void split_weights16_h2_kernel(const float* __restrict__ wp, unsigned
   }
 }
 // max |x| over n floats folded into *word (the fp32 bits of a non-negative number order like unsigned integers); *word zeroed by the caller
+// SLOTS: into the slots of an activation maximum (amax_commit); else into the one word of a weight pack
+template <bool SLOTS>
 __global__ void amax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ word) {
   float m = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+  if (SLOTS) { amax_commit(word, m); return; }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(word, __float_as_uint(m));
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   float h2_sx = 1.f, h2_ix = 1.f, h2_iw = 1.f;
   bool h2_one = true;
   if constexpr (NPROD == 3) {
-    h2_sx = h2_scale(a.h2_xw[sg.seg]);      // two words: the operand's maximum per frame segment
+    h2_sx = h2_scale(amax_read(a.h2_xw, sg.seg));      // the operand's maximum over this tile's frame segment
     const float sw = h2_scale(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(a.wpk) + (long)a.Co * a.Kp * 16));
     h2_ix = 1.f / h2_sx;      // exact: powers of two within 2^+-126
     h2_iw = 1.f / sw;

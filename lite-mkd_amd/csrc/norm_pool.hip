@@ -162,11 +162,12 @@ extern "C" int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst,
 extern "C" long lmkd_ticket_words(void) { return LMKD_TICKET_WORDS; }
 
 // One-shot, per host thread: the NEXT launch of lmkd_bn_apply(_seg), lmkd_bn_relu_maxpool_fwd(_seg), lmkd_bn_backward(_seg) or
-// lmkd_bn_backward_part(_seg) on this thread also folds max |y| (max |dx| for the backward) into word[0] - frame segment 1's elements
-// into word[1] (two words: the two trunk calls of an episode keep the scales they would have as two launches) - fp32 bits, atomic max:
-// the caller zeroes both.  The two-plane fp16 convolutions scale their operands by a power of two taken from it (lmkd_conv_operand_amax).
+// lmkd_bn_backward_part(_seg) on this thread also folds max |y| (max |dx| for the backward) into the words at `word` - 2 segments x
+// LMKD_AMAX_SLOTS slots x 16 words (common.h: amax_commit; frame segment 1's elements go to the second half: the two trunk calls of an
+// episode keep the scales they would have as two launches) - fp32 bits, atomic max: the caller zeroes all lmkd_amax_words() of them.  The two-plane fp16 convolutions scale their operands by a power of two taken from it (lmkd_conv_operand_amax).
 static thread_local unsigned* g_amax_next = nullptr;
 extern "C" int lmkd_amax_next(void* word) { g_amax_next = (unsigned*)word; return LMKD_OK; }
+extern "C" long lmkd_amax_words(void) { return 2 * LMKD_AMAX_SEG_WORDS; }
 static inline unsigned* take_amax_next() { unsigned* p = g_amax_next; g_amax_next = nullptr; return p; }
 static inline int cs_slices(int T) { return T <= 64 ? 1 : std::min(CS_MAX_SLICES, cdiv(T, 64)); }
 
@@ -465,7 +466,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
   }
   if (amax) {
     amax_commit(amax, am);
-    if (n4_0 < n4) amax_commit(amax + 1, am1);
+    if (n4_0 < n4) amax_commit(amax + LMKD_AMAX_SEG_WORDS, am1);
   }
 }
 
@@ -676,7 +677,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
   }
   if (amax) {
     amax_commit(amax, am);
-    if (n4_0 < n4) amax_commit(amax + 1, am1);
+    if (n4_0 < n4) amax_commit(amax + LMKD_AMAX_SEG_WORDS, am1);
   }
 }
 
@@ -915,7 +916,7 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __r
   }
   if (amax) {
     amax_commit(amax, amx);
-    if (N0 < N) amax_commit(amax + 1, amx1);
+    if (N0 < N) amax_commit(amax + LMKD_AMAX_SEG_WORDS, amx1);
   }
 }
 

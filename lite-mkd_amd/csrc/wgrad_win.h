@@ -282,8 +282,8 @@ __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW), JW == 
   unsigned x_ok = 0;
   float h2_sx = 1.f, h2_sdy = 1.f;
   if constexpr (NPROD == 3) {
-    h2_sx = h2_scale(a.h2_xw[sl.seg]);      // two words each: the maxima per frame segment (a slab lies in one segment)
-    h2_sdy = h2_scale(a.h2_dyw[sl.seg]);
+    h2_sx = h2_scale(amax_read(a.h2_xw, sl.seg));      // the maxima over this slab's frame segment
+    h2_sdy = h2_scale(amax_read(a.h2_dyw, sl.seg));
   }
   float4 psc = float4(), psh = float4();
   if (PRE) {

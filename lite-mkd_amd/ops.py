@@ -467,7 +467,8 @@ def refresh_packs(streams=()):
 # the tensor as the attribute `_lmkd_amax`; a convolution whose operands carry it runs the two-plane form (lmkd_conv_operand_amax), any
 # other launch - a tensor from elsewhere, a view - the three-plane form: both fp32-class, so a lost word costs time, never correctness.
 _AMAX_POOLS = {}
-_AMAX_POOL_WORDS = 4096
+_AMAX_WORDS = [0]
+_AMAX_POOL_TENSORS = 256      # maxima per pool (8 KB each: 2 frame segments x 64 slots x 64 bytes, csrc/common.h amax_commit)
 
 
 def _h2_mode():
@@ -475,14 +476,17 @@ def _h2_mode():
 
 
 def _amax_slot(dev):
-    """two zeroed device words - max |tensor| per frame segment - as a 2-element int32 view of a pool; the pool is zeroed once, on the
-    stream that first needs it (every other stream waits for that), and inside a hipGraph capture it is a pool of the capture, so a
-    replay zeroes it again"""
+    """the zeroed words of one maximum (lmkd_amax_words(): per frame segment, 64 slots that the producer's waves fold their maxima into)
+    as an int32 view of a pool; the pool is zeroed once, on the stream that first needs it (every other stream waits for that), and
+    inside a hipGraph capture it is a pool of the capture, so a replay zeroes it again"""
+    if not _AMAX_WORDS[0]:
+        _AMAX_WORDS[0] = lib().value("lmkd_amax_words")
+    nw = _AMAX_WORDS[0]
     cap = torch.cuda.is_current_stream_capturing()
     cur = torch.cuda.current_stream(dev)
     p = _AMAX_POOLS.get(dev.index)
-    if p is None or p["next"] + 2 > _AMAX_POOL_WORDS or p["cap"] != cap:
-        buf = torch.zeros(_AMAX_POOL_WORDS, dtype=torch.int32, device=dev)
+    if p is None or p["next"] + nw > p["buf"].numel() or p["cap"] != cap:
+        buf = torch.zeros(_AMAX_POOL_TENSORS * nw, dtype=torch.int32, device=dev)
         ev = torch.cuda.Event()
         ev.record(cur)
         p = _AMAX_POOLS[dev.index] = {"buf": buf, "next": 0, "cap": cap, "event": ev, "seen": {cur.cuda_stream}}
@@ -490,8 +494,8 @@ def _amax_slot(dev):
         cur.wait_event(p["event"])
         p["seen"].add(cur.cuda_stream)
     i = p["next"]
-    p["next"] = i + 2
-    return p["buf"][i:i + 2]
+    p["next"] = i + nw
+    return p["buf"][i:i + nw]
 
 
 def amax_pool_reset():
@@ -520,12 +524,13 @@ def _amax_operands(x, dy):
 
 def amax_compute(t, seg=0):
     """max |t| by a reduction pass of its own (tensors that no kernel of this library wrote: tests, tools); seg = F0: per frame segment"""
-    w = torch.zeros(2, dtype=torch.int32, device=t.device)
+    nw = lib().value("lmkd_amax_words")
+    w = torch.zeros(nw, dtype=torch.int32, device=t.device)
     seg = _seg_frames(seg, t.shape[0])
     n0 = (t.numel() // t.shape[0]) * seg if seg else t.numel()
     lib().call("lmkd_amax", _p(t), n0, w.data_ptr(), _stream())
     if seg:
-        lib().call("lmkd_amax", t.data_ptr() + 4 * n0, t.numel() - n0, w.data_ptr() + 4, _stream())
+        lib().call("lmkd_amax", t.data_ptr() + 4 * n0, t.numel() - n0, w.data_ptr() + 2 * nw, _stream())
     t._lmkd_amax = w
     return t
 
