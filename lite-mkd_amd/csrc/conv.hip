@@ -1020,6 +1020,8 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
 #undef LMKD_PATCH
 }
 
+// (round 4: conv_patch16_x3_kernel on 256 x 64 tiles - four waves stacked over the rows, wave tiles 64 x 64, two workgroups per CU - was
+// built as tile id 15 and measured SLOWER than id 11 on every layer, 443 vs 383 us on layer 1 in fp32h2: profiles/r04_tile_ab.txt; removed)
 // one-plane modes only (tile ids 13 / 14: 256-row tiles with four waves)
 template <class Cfg>
 static void launch_conv_patch_1p(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   // s_adp[tap][wave row][lane % 16][pixel block]: byte offset, inside the patch, of the row a (tap, output pixel) reads - the zero row
   // where the tap leaves the image.  A lane's NB = 4 entries of a tap are one 8-byte read per K-step (before: a mask test, an add and a
   // select per pixel block and step - the kernel is bound by vector-instruction issue)
-  static_assert(NB == 4 && PatchRow<NPL>::BYTES * (Cfg::BM + 2 * PATCH_HALO_MAX + 1) < 65536, "four 16-bit patch offsets per lane and tap");
+  static_assert(NB == 4 && PatchRow<NPL>::BYTES % 16 == 0 && PatchRow<NPL>::BYTES / 16 * (Cfg::BM + 2 * PATCH_HALO_MAX + 1) < 65536,
+                "four 16-bit patch offsets (in units of 16 bytes) per lane and tap");
   __shared__ __attribute__((aligned(8))) unsigned short s_adp[LMKD_MAX_TAPS * Cfg::BM];
   __shared__ float s_red[Cfg::WM * Cfg::BN * 2];
   __shared__ int s_src[SRC2 ? Cfg::BM + 2 * PATCH_HALO_MAX : 1];      // SRC2: byte offset of patch row j's pixel in class (0, 0), -1 outside
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     for (int tp = 0; tp < ntap; ++tp) {
       const int y = hh + taps[tp].dh, x = ww + taps[tp].dw;
       const bool in = (unsigned)y < (unsigned)a.Hs && (unsigned)x < (unsigned)a.Ws;
-      dst[tp * Cfg::BM] = (unsigned short)(in ? (r + halo + taps[tp].dh * a.Ws + taps[tp].dw) * ROWB : P * ROWB);
+      dst[tp * Cfg::BM] = (unsigned short)((in ? (r + halo + taps[tp].dh * a.Ws + taps[tp].dw) : P) * (ROWB / 16));
     }
   }
   const unsigned lane_off = (unsigned)(16 * ksl);      // this lane group's k-slot inside a patch row
@@ -379,7 +380,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       }
     }
     const uint2 pk2 = *reinterpret_cast<const uint2*>(adp_lane + k_tp * Cfg::BM);
-    const unsigned ad[NB] = {(pk2.x & 0xffffu) + lane_off, (pk2.x >> 16) + lane_off, (pk2.y & 0xffffu) + lane_off, (pk2.y >> 16) + lane_off};
+    const unsigned ad[NB] = {((pk2.x & 0xffffu) << 4) + lane_off, ((pk2.x >> 16) << 4) + lane_off, ((pk2.y & 0xffffu) << 4) + lane_off,
+                             ((pk2.y >> 16) << 4) + lane_off};
     // the pixel blocks in two halves (conv_patch.h's two k-groups): one register set, the second half's fragments are read after the
     // first half's MFMAs (the set that would hold both halves costs the third workgroup per CU)
     constexpr int HB = NB / 2;
