@@ -276,7 +276,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   const int kq = lane >> 4;                               // lane group: result rows 4 kq .. 4 kq + 3; k-slot patch16_kslot(kq) of a 32-k step
   const int ksl = patch16_kslot(kq);
   const int pxl = patch16_pixel(lane & 15);               // this lane's pixel of each 16-pixel block
-  for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {      // the offset table (s_adp): row r of the tile, every tap
+  auto fill_adp = [&]() {      // the offset table (s_adp): row r of the tile, every tap (called behind the first patch loads: their latency)
+  for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
     const int m = row0 + r;
     const int within = r % (Cfg::TM * 32), px = within & 15;
     const int l16 = (px & 1) ? ((px >> 1) + (px < 8 ? 0 : 8)) : (px >> 1) + 4;      // the lane (mod 16) whose pixel this is: patch16_pixel(l16) == px
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       dst[tp * Cfg::BM] = (unsigned short)((in ? (r + halo + taps[tp].dh * a.Ws + taps[tp].dw) : P) * (ROWB / 16));
     }
   }
+  };
   const unsigned lane_off = (unsigned)(16 * ksl);      // this lane group's k-slot inside a patch row
   const unsigned short* adp_lane = s_adp + (wm * 16 + (lane & 15)) * NB;
   // patch loader (conv_patch.h): LPR lanes x 16 B per pixel row
@@ -439,9 +441,15 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     __builtin_amdgcn_sched_barrier(0);
     if (t + 2 < nk) issue_b(rb);
   };
+  // 128 x 64 tiles: the first chunk's patch rows are in flight while the offset table is written (layer 1, two chunks per tile: 415-437 ->
+  // 399-402 us at 400 frames in fp32h2).  Not on the 128 x 128 tiles: there the loads' registers, live across the table loop, cost more
+  // than the latency they hide (layer 2: 240 -> 290 us).  SRC2 takes its source offsets from an LDS table: after the barrier.
+  constexpr bool EARLY = !SRC2 && Cfg::BN == 64;
+  if (EARLY && nk > 0) issue_patch(0);
+  fill_adp();
   __syncthreads();      // tap tables, s_out, zero row
   if (nk > 0) {
-    issue_patch(0);
+    if (!EARLY) issue_patch(0);
     issue_b(rb0);
     if (nk > 1) issue_b(rb1);
     x3_landed(rp);
