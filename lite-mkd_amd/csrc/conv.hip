@@ -375,6 +375,8 @@ struct WgradArgs {
   const float* pre_stats;             // PRE: x is a raw conv output; the loader applies relu(BatchNorm(x)) (see ConvGemmArgs)
   int seg_pix0, seg_splits0, sps1;    // two frame segments (wgrad_win.h WgradWinArgs): conv_wgrad_x3_kernel only; one segment: Mpix, splits, 0
   FastDiv div_hw, div_w;
+  const unsigned* h2_xw;              // two-plane fp16 form (conv_wgrad_x3_kernel<.., 3, ..>): the maxima of x / dy (lmkd_conv_operand_amax)
+  const unsigned* h2_dyw;
 };
 
 // split z -> first pixel, pixel limit, number of 32-pixel steps, segment
@@ -1547,6 +1549,7 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.x = x; a.slab = workspace; a.pre_stats = pre_stats;
+  a.h2_xw = amax_x; a.h2_dyw = amax_dy;
   a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cs;
   a.Ho = conv_out(H, KH, stride, pad); a.Wo = conv_out(W, KW, stride, pad); a.Co = Cout;
   a.stride = stride; a.pad = pad; a.KH = KH; a.KW = KW; a.KWp = kw_padded(Cs, KW);
@@ -1709,7 +1712,10 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
       else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 9, false>), grid, dim3(256), 0, s, a);                  \
     } else {                                                                                                             \
       if (pre_stats) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 6, true>), grid, dim3(256), 0, s, a);         \
-      else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 6, false>), grid, dim3(256), 0, s, a);                  \
+      else if (g_conv_h2 && a.h2_xw && a.h2_dyw) {                                                                      \
+        hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 3, false>), grid, dim3(256), 0, s, a);                      \
+        ++g_h2_launches;                                                                                                 \
+      } else hipLaunchKernelGGL((conv_wgrad_x3_kernel<CFG, false, 6, false>), grid, dim3(256), 0, s, a);                 \
     }                                                                                                                    \
   } while (0)
     using W128 = WgCfg<128, 128, 2, 2>;

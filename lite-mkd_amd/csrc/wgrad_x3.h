@@ -67,6 +67,16 @@ __device__ __forceinline__ void tr_store4(unsigned char* __restrict__ img, int k
   }
 }
 
+// the same as two fp16 planes of v * s (conv_patch16.h: h2_split4)
+template <int LDB, int PLANE>
+__device__ __forceinline__ void tr_store4_h2(unsigned char* __restrict__ img, int k, int col, const float4& v, float s) {
+  unsigned char* d = img + k * LDB + col * 2;
+  uint2 p0, p1;
+  h2_split4(v, s, p0, p1);
+  *reinterpret_cast<uint2*>(d) = p0;
+  *reinterpret_cast<uint2*>(d + PLANE) = p1;
+}
+
 __device__ __forceinline__ void tr_store8(unsigned char* __restrict__ img, int ldb, int k, int col, const u32x4& v) {
   *reinterpret_cast<u32x4*>(img + k * ldb + col * 2) = v;      // 8 bf16 columns of k row `k`, already in plane format
 }
@@ -141,8 +151,10 @@ struct LoaderWgradGather16 {      // implicit im2col of a bf16 NHWC tensor, K-ou
 // x) are bf16 tensors in HBM (one-plane mode only).
 template <class Cfg, bool SMALLC, int NPROD, bool PRE, bool ACT16 = false>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a) {
-  constexpr int NPL = NPROD == 1 ? 1 : 3;
+  // NPROD == 3: two fp16 planes per operand, three products (conv_patch16.h: h2_split4; lmkd_conv_set_compute_dtype(4))
+  constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
   static_assert(!ACT16 || (NPROD == 1 && !PRE), "bf16 activations: one plane, no store-side arithmetic");
+  static_assert(NPROD != 3 || (!PRE && !SMALLC), "two-plane form: operands whose maxima their producers recorded");
   constexpr bool B16 = ACT16 && !SMALLC;
   using LA = typename std::conditional<ACT16, LoaderMMajorDense16<Cfg::BM, Cfg::THREADS>, LoaderMMajorDense<Cfg::BM, Cfg::THREADS>>::type;
   using LB = typename std::conditional<B16, LoaderWgradGather16<Cfg::BN, Cfg::THREADS>, LoaderWgradGather<Cfg::BN, SMALLC, Cfg::THREADS, PRE>>::type;
@@ -186,6 +198,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
   // the negation of dy at store time cost the rolling-window kernel 25 % - its register allocation - and was not kept.)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float h2_sx = 1.f, h2_sdy = 1.f;
+  if constexpr (NPROD == 3) {
+    h2_sx = h2_scale(amax_read(a.h2_xw, sl.seg));      // the maxima over this slab's frame segment
+    h2_sdy = h2_scale(amax_read(a.h2_dyw, sl.seg));
+  }
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int offA = tr_lane_off(IA::LDB, lane) + wm * (Cfg::TM * 32) * 2;
   const int offB = tr_lane_off(IB::LDB, lane) + wn * (Cfg::TN * 32) * 2;
@@ -201,6 +218,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
 #pragma unroll
     for (int i = 0; i < LA::NI; ++i) {
       if constexpr (ACT16) tr_store8(sa, IA::LDB, tid / LA::CPR + LA::KPP * i, la.r4, la.reg[i]);
+      else if constexpr (NPROD == 3) tr_store4_h2<IA::LDB, IA::PLANE>(sa, tid / LA::CPR + LA::KPP * i, la.r4, la.reg[i], h2_sdy);
       else tr_store4<NPL, IA::LDB, IA::PLANE>(sa, tid / LA::CPR + LA::KPP * i, la.r4, la.reg[i]);
     }
     if constexpr (B16) {
@@ -214,7 +232,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
         v.x = fmaxf(fmaf(v.x, lb.psc.x, lb.psh.x), 0.f); v.y = fmaxf(fmaf(v.y, lb.psc.y, lb.psh.y), 0.f);
         v.z = fmaxf(fmaf(v.z, lb.psc.z, lb.psh.z), 0.f); v.w = fmaxf(fmaf(v.w, lb.psc.w, lb.psh.w), 0.f);
       }
-      tr_store4<NPL, IB::LDB, IB::PLANE>(sb, tid / LB::CPR + LB::KPP * i, lb.r4, v);
+      if constexpr (NPROD == 3) tr_store4_h2<IB::LDB, IB::PLANE>(sb, tid / LB::CPR + LB::KPP * i, lb.r4, v, h2_sx);
+      else tr_store4<NPL, IB::LDB, IB::PLANE>(sb, tid / LB::CPR + LB::KPP * i, lb.r4, v);
     }
     }
   };
@@ -243,15 +262,19 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
           f32x16 c = acc[i][j];
           if constexpr (NPROD == 1) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0][i], fb[g][0][j], c, 0, 0, 0);
+          } else if constexpr (NPROD == 3) {      // two fp16 planes: smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[g][1][i]), __builtin_bit_cast(f16x8, fb[g][0][j]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[g][0][i]), __builtin_bit_cast(f16x8, fb[g][1][j]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[g][0][i]), __builtin_bit_cast(f16x8, fb[g][0][j]), c, 0, 0, 0);
           } else {
             if (NPROD == 9) {
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][2][i], fb[g][2][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][1][i], fb[g][2][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][2][i], fb[g][1][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][NPL - 1][i], fb[g][NPL - 1][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][1][i], fb[g][NPL - 1][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][NPL - 1][i], fb[g][1][j], c, 0, 0, 0);
             }
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][1][i], fb[g][1][j], c, 0, 0, 0);     // smallest terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0][i], fb[g][2][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][2][i], fb[g][0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0][i], fb[g][NPL - 1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][NPL - 1][i], fb[g][0][j], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0][i], fb[g][1][j], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][1][i], fb[g][0][j], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g][0][i], fb[g][0][j], c, 0, 0, 0);
@@ -279,6 +302,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
   }
 
   float* C = a.slab + (long)z * a.Co * a.Kp;
+  const float h2_ix = 1.f / h2_sx, h2_idy = 1.f / h2_sdy;      // exact (powers of two), applied one after the other
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) {
     const int col = j0 + wn * (Cfg::TN * 32) + j * 32 + (lane & 31);
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_x3_kernel(WgradArgs a
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * (Cfg::TM * 32) + i * 32 + acc_row(e, lane);
-        if (row < a.Co) C[(long)row * a.Kp + col] = acc[i][j][e];
+        if (row < a.Co) C[(long)row * a.Kp + col] = NPROD == 3 ? acc[i][j][e] * h2_ix * h2_idy : acc[i][j][e];
       }
   }
 }
