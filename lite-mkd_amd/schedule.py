@@ -17,7 +17,7 @@ _PIPELINE = [False]      # the installed schedule's loop-level choice (Schedule.
 @dataclasses.dataclass
 class Schedule:
     # ---- arithmetic (process-wide in liblmkd_hip.so: lmkd_conv_set_compute_dtype / lmkd_set_activation_dtype)
-    conv_dtype: str = "fp32x3"             # fp32x3 (default: fp32 as 3 x bf16 on the matrix pipe) | fp32 (native MFMA) | bf16 | fp32x3_9
+    conv_dtype: str = "fp32x3"             # fp32x3 (default: fp32 as 3 x bf16 on the matrix pipe) | fp32h2 (bench.py: + the 3x3 kernels on 2 x fp16) | fp32 (native MFMA) | bf16 | fp32x3_9
     act_dtype: str = "fp32"                # storage of the trunk's activations: fp32 | bf16 (BASELINE configs[2], needs conv_dtype bf16)
     # ---- streams
     overlap_trunk_calls: bool = True       # support / query trunk call on two streams (resnet.OVERLAP_TRUNK_CALLS; where the calls are not merged)
