@@ -577,6 +577,10 @@ def stream_inputs_pass(a, cfg, dev, student, teacher, distiller, accuracy_fn, op
                 nxt = stage(i + 1)                         # staged while episode i computes
             main.wait_event(s_["ready"])
             TL.train_task(ep, student, teacher, distiller, accuracy_fn, cfg)
+            # the set is free once EVERY stream that read it has passed: the weight-gradient stream (the stem's weight gradient reads
+            # s_["x"]) and the side / auxiliary streams (query frames, teacher features) run on behind the main stream
+            with torch.cuda.stream(main):
+                ops.join_all_streams()
             s_["free"].record(main)
             if (it + 1) % every == 0:
                 opt.step()

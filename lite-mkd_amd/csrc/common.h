@@ -5,6 +5,13 @@
 #include <stdio.h>
 #include <string.h>
 
+// gfx950 only: the ticketed single-launch reductions (norm_pool.hip colsum_ticket, gemm.hip split-K) hand partial sums from one workgroup
+// to another through relaxed agent-scope atomics behind s_waitcnt vmcnt(0), relying on the write-through completion of sc1 stores on
+// this target; another target needs release / acquire there.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "liblmkd_hip is written for gfx950 (MI355X): see the note above before porting the ticketed reductions"
+#endif
+
 #define LMKD_OK 0
 #define LMKD_EINVAL (-1)
 #define LMKD_EHIP (-2)

@@ -7,6 +7,7 @@ tag=${1:-r03}; out=gpurun_out/final_$tag; mkdir -p $out
 B="python bench.py"
 sleep 6; $B --steps 20 --warmup 5 --stream-inputs --layer-table > $out/bench.json 2> $out/layer_table.txt; echo "bench $?"
 sleep 6; $B --steps 32 --warmup 5 --no-cpu-baseline --no-other-modes --dtype bf16 --layer-table > $out/bench_bf16.json 2> $out/layer_table_bf16.txt; echo "bf16 $?"
+sleep 6; $B --steps 32 --warmup 5 --no-cpu-baseline --no-other-modes --dtype f32x3 --layer-table > $out/bench_f32x3.json 2> $out/layer_table_f32x3.txt; echo "f32x3 $?"
 sleep 6; $B --steps 32 --warmup 5 --no-cpu-baseline --no-other-modes --dtype f32native --layer-table > $out/bench_f32native.json 2> $out/layer_table_f32native.txt; echo "native $?"
 sleep 6; $B --steps 32 --warmup 5 --no-other-modes --shot 1 --cpu-episodes 1 > $out/bench_shot1.json 2>/dev/null; echo "shot1 $?"
 sleep 6; $B --steps 8 --warmup 3 --no-cpu-baseline --no-other-modes --backbone resnet50_2fc --live-mfm > $out/bench_r50_mfm.json 2>/dev/null; echo "r50 $?"
@@ -26,3 +27,6 @@ sleep 6; python tools/stem_wgrad_bench.py 2>/dev/null | tail -2 > $out/stem_wgra
 sleep 6; python tools/gemm_splitk_bench.py 2>/dev/null | tail -7 > $out/gemm_splitk_bench.txt; echo "splitk $?"
 sleep 6; LMKD_DGRAD_BN=0 $B --steps 32 --warmup 5 --no-cpu-baseline --no-other-modes > $out/bench_no_dgrad_bn_sums.json 2>/dev/null; echo "no dgrad bn $?"
 sleep 6; $B --steps 32 --warmup 5 --no-cpu-baseline --no-other-modes > $out/bench_repeat.json 2>/dev/null; echo "repeat $?"
+sleep 6; python tools/h2_error.py 40 2>/dev/null > $out/h2_error.txt; echo "h2 error $?"
+sleep 6; python tools/proto_bench.py 400 2>/dev/null > $out/h2_layers_400.txt; echo "h2 layers $?"
+sleep 6; python tools/h2_episode.py 3 serial 2>/dev/null > $out/h2_episode.txt; echo "h2 episode $?"

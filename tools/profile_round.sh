@@ -12,6 +12,8 @@ cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py --warmup 1 --no-cpu-baseline --no-other-modes --serial"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_f32 -o r -- python3 $B --steps 4 > $out/trace_f32.log 2>&1
 echo "trace f32 done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_f32x3 -o r -- python3 $B --steps 4 --dtype f32x3 > $out/trace_f32x3.log 2>&1
+echo "trace f32x3 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_f32native -o r -- python3 $B --steps 4 --dtype f32native > $out/trace_f32native.log 2>&1
 echo "trace f32native done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_bf16 -o r -- python3 $B --steps 4 --dtype bf16 > $out/trace_bf16.log 2>&1

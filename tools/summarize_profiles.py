@@ -45,7 +45,7 @@ def load_pmc(d, counter):
 
 
 os.makedirs("profiles", exist_ok=True)
-for mode in ("f32", "f32native", "bf16"):
+for mode in ("f32", "f32x3", "f32native", "bf16"):
     f = find("trace_" + mode, "kernel_stats.csv")
     if f is None:
         continue
