@@ -1,6 +1,6 @@
 """Which launches of a training episode are NOT liblmkd_hip.so kernels, and where in the Python code do they come from?
 Runs a few benchmark episodes under torch.profiler with stacks and prints, per (ATen op, innermost repo frame), the number of
-device launches per episode.  usage: python tools/aten_ops.py [f32|bf16] [episodes]"""
+device launches per episode.  usage: python tools/aten_ops.py [f32|f32x3|bf16] [episodes]   (f32 = bench.py's headline arithmetic, fp32h2)"""
 import os
 import sys
 from collections import Counter
@@ -16,7 +16,7 @@ from litemkd_amd.utils import aggregate_accuracy
 mode = sys.argv[1] if len(sys.argv) > 1 else "f32"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 dev = torch.device("cuda:0")
-ops.set_conv_compute_dtype({"f32": "fp32x3", "bf16": "bf16"}[mode])
+ops.set_conv_compute_dtype({"f32": "fp32h2", "f32x3": "fp32x3", "bf16": "bf16"}[mode])
 ops.set_activation_dtype("bf16" if mode == "bf16" else "fp32")
 from litemkd_amd.schedule import Schedule
 Schedule.from_env().apply(arithmetic=False)      # the benchmark's schedule (merged trunk call; the episodes here are not pipelined: one at a time)

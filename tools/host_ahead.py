@@ -12,6 +12,7 @@ from litemkd_amd.options import default_args
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 dev = torch.device("cuda:0")
 ops.SIDE_WGRAD, ops.SYNC_WGRAD_AT_BACKWARD_END, ops.DIRECT_PARAM_GRAD = True, False, True
+ops.set_conv_compute_dtype(os.environ.get("LMKD_CONV", "fp32h2"))      # bench.py's headline arithmetic
 TL.TEACHER_STREAM = os.environ.get("LMKD_TEACHER_STREAM", "1") != "0"
 ops.HEADS_ON_TWO_STREAMS = os.environ.get("LMKD_HEADS2", "1") != "0"
 cfg = default_args(shot=5, device=dev, trans_dropout=0.1, training_iterations=10 ** 9, print_freq=10 ** 9)
