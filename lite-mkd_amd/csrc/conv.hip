@@ -632,7 +632,7 @@ static inline const unsigned* take_amax_dy() { const unsigned* p = g_amax_dy; g_
 // elements (16-bit) of the plane buffer of a packed weight of ncols x Kp in the current mode
 extern "C" long lmkd_conv2d_plane_elems(int ncols, int Kp) {
   const long n = (long)ncols * Kp;
-  return g_conv_bf16 ? n : (g_conv_h2 ? 16 * n + 32 : 12 * n);
+  return g_conv_bf16 ? n : (g_conv_h2 ? 18 * n + 32 : 12 * n);
 }
 // max |x| of n floats: slots = 0: into the ONE word at `word` (weight packs); slots = 1: into the slot words of one frame segment of an
 // activation maximum (lmkd_amax_next's layout: segment s at word + s * lmkd_amax_words() / 2).  The words are zeroed here first.
@@ -670,6 +670,8 @@ extern "C" int lmkd_conv2d_split_weights(const float* wp, void* wf, int ncols, i
     if (rc) return rc;
     hipLaunchKernelGGL(split_weights16_h2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wp, wh, ncols, Kp);
     LMKD_CHECK_LAUNCH("split_weights16_h2_kernel");
+    hipLaunchKernelGGL(split_weights_h2_32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wp, wh, ncols, Kp);
+    LMKD_CHECK_LAUNCH("split_weights_h2_32_kernel");
   }
   return LMKD_OK;
 }
@@ -723,7 +725,8 @@ __global__ void repack_h2_kernel(RepackArgs a, int phase) {
     return;
   }
   const float s = h2_scale(*word);
-  const int G16 = e.Kp >> 5;
+  const int G16 = e.Kp >> 5, G = e.Kp >> 4;
+  unsigned short* wh32 = wh + total * 4 + 32;      // split_weights_h2_32_kernel
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int col = (int)(idx / e.Kp), k = (int)(idx - (long)col * e.Kp);
     const int lane16 = (col & 15) + 16 * patch16_kslot((k >> 3) & 3);
@@ -733,6 +736,8 @@ __global__ void repack_h2_kernel(RepackArgs a, int phase) {
     wh[q] = p0; wh[q + 512] = p1;
     const long q2 = q + total * 2;
     wh[q2] = p0 ^ 0x8000u; wh[q2 + 512] = p1 ^ 0x8000u;
+    const long o = ((((long)(col >> 5) * G + (k >> 4)) * 2) * 64 + (col & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
+    wh32[o] = p0; wh32[o + 512] = p1;
   }
 }
 __global__ void repack_multi_kernel(RepackArgs a) {
@@ -1257,7 +1262,10 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
     if (g_lmkd_act_bf16) hipLaunchKernelGGL((conv_stem_patch_kernel<1, true, OR>), grid, block, lds, s, a);            \
     else if (g_conv_bf16) hipLaunchKernelGGL((conv_stem_patch_kernel<1, false, OR>), grid, block, lds, s, a);          \
     else if (g_conv_x3 == 9) hipLaunchKernelGGL((conv_stem_patch_kernel<9, false, OR>), grid, block, lds, s, a);       \
-    else hipLaunchKernelGGL((conv_stem_patch_kernel<6, false, OR>), grid, block, lds, s, a);                           \
+    else if (g_conv_h2 && a.h2_xw) {                                                                                   \
+      hipLaunchKernelGGL((conv_stem_patch_kernel<3, false, OR>), grid, block, lds, s, a);                              \
+      ++g_h2_launches;                                                                                                 \
+    } else hipLaunchKernelGGL((conv_stem_patch_kernel<6, false, OR>), grid, block, lds, s, a);                         \
   } while (0)
     LMKD_STEM(2);      // two output rows per workgroup (one row, four waves: 557 vs 447 us at 200 frames)
 #undef LMKD_STEM
@@ -1565,6 +1573,7 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
       StemWgradArgs w;
       memset(&w, 0, sizeof(w));
       w.dy = dy; w.x = x; w.slab = workspace;
+      w.h2_xw = amax_x; w.h2_dyw = amax_dy;
       w.N = N; w.H = H; w.W = W; w.Ho = a.Ho; w.Wo = a.Wo;
       w.upi = cdiv(a.Ho, 2); w.units = N * w.upi; w.G = G; w.slabs = slabs;
       w.RL = 16 * a.Wo + 64;
@@ -1583,6 +1592,11 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
         if (deep && w.RL == 1856) LMKD_STEM_WG(9, 6, 1856);      // 224-pixel images
         else if (deep) LMKD_STEM_WG(9, 6, 0);
         else LMKD_STEM_WG(9, 2, 0);
+      } else if (g_conv_h2 && amax_x && amax_dy) {      // two fp16 planes, three products
+        if (deep && w.RL == 1856) LMKD_STEM_WG(3, 6, 1856);
+        else if (deep) LMKD_STEM_WG(3, 6, 0);
+        else LMKD_STEM_WG(3, 2, 0);
+        ++g_h2_launches;
       } else {
         if (deep && w.RL == 1856) LMKD_STEM_WG(6, 6, 1856);
         else if (deep) LMKD_STEM_WG(6, 6, 0);

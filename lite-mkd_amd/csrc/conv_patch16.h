@@ -171,6 +171,23 @@ __global__ void split_weights16_h2_kernel(const float* __restrict__ wp, unsigned
     wh[o2 + 512] = p1 ^ 0x8000u;
   }
 }
+// ... and in conv_x3.h's 32x32x16 fragment order (X3FragB with two planes; W only - the stem's forward, the one two-plane kernel on that
+// MFMA shape, has no -W tiles), behind the maximum's 64 bytes: wh32 = wh + 4 * total + 32
+__global__ void split_weights_h2_32_kernel(const float* __restrict__ wp, unsigned short* __restrict__ wh, int ncols, int Kp) {
+  const long total = (long)ncols * Kp;
+  const int G = Kp >> 4;
+  const float s = h2_scale(*reinterpret_cast<const unsigned*>(wh + total * 4));
+  unsigned short* wh32 = wh + total * 4 + 32;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx / Kp), k = (int)(idx - (long)col * Kp);
+    const int lane = (col & 31) + 32 * ((k >> 3) & 1);
+    const long o = ((((long)(col >> 5) * G + (k >> 4)) * 2) * 64 + lane) * 8 + (k & 7);
+    unsigned short p0, p1;
+    h2_split1(wp[idx] * s, p0, p1);
+    wh32[o] = p0;
+    wh32[o + 512] = p1;
+  }
+}
 // max |x| over n floats folded into *word (the fp32 bits of a non-negative number order like unsigned integers); *word zeroed by the caller
 // SLOTS: into the slots of an activation maximum (amax_commit); else into the one word of a weight pack
 template <bool SLOTS>

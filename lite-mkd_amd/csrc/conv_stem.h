@@ -18,9 +18,11 @@
 #define STEM_MAX_WP 240      // patch row pitch in pixels: W + 3 + 5 <= 240
 
 // OR: output rows per workgroup (2: eight waves, 1: four waves)
+// NPROD == 3: two fp16 planes, three products (conv_patch16.h: h2_split4; lmkd_conv_set_compute_dtype(4)): the weights' fp16 planes in
+// this kernel's 32x32x16 fragment order are the last region of the weight buffer (split_weights_h2_32_kernel)
 template <int NPROD, bool OUT16, int OR>
 __global__ __launch_bounds__(256 * OR) void conv_stem_patch_kernel(ConvGemmArgs a) {
-  constexpr int NPL = NPROD == 1 ? 1 : 3;
+  constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
   constexpr int NTHR = 256 * OR;
   using Cfg = X3Cfg<128 * OR, 64, 4 * OR, 1>;      // 4 OR waves x (32 rows x 64 columns): TM = 1, TN = 2
   using LB = X3FragB<Cfg::TN, NPL>;
@@ -35,6 +37,15 @@ __global__ __launch_bounds__(256 * OR) void conv_stem_patch_kernel(ConvGemmArgs 
   const int WP = a.halo;                           // row pitch of the patch in pixels (host: even, >= 2 (Wo - 1) + 8)
   const int plane_bytes = PR * WP * 8;
   const int ih0 = 2 * oh0 - 3;
+  float h2_sx = 1.f, h2_ix = 1.f, h2_iw = 1.f;
+  const unsigned short* wpk = reinterpret_cast<const unsigned short*>(a.wpk);
+  if constexpr (NPROD == 3) {
+    const long nw = (long)a.Co * a.Kp;
+    h2_sx = h2_scale(amax_read(a.h2_xw, (a.seg_m0 > 0 && (long)n * a.Ho * a.Wo >= a.seg_m0) ? 1 : 0));      // this image's frame segment
+    h2_ix = 1.f / h2_sx;
+    h2_iw = 1.f / h2_scale(*reinterpret_cast<const unsigned*>(wpk + nw * 16));
+    wpk += nw * 16 + 32;
+  }
   // ---- patch: input rows ih0 .. ih0 + PR - 1, columns -3 .. WP - 4, zero outside the image.  Thread -> (column, row parity);
   // every thread's loads are issued before the first one is split (a load -> split -> store loop waits one memory latency per trip)
   {
@@ -57,6 +68,11 @@ __global__ __launch_bounds__(256 * OR) void conv_stem_patch_kernel(ConvGemmArgs 
       unsigned char* d = psm + (pr * WP + pc) * 8;
       if (NPL == 1) {
         *reinterpret_cast<uint2*>(d) = x3_round4(v);
+      } else if constexpr (NPROD == 3) {
+        uint2 q0, q1;
+        h2_split4(v, h2_sx, q0, q1);
+        *reinterpret_cast<uint2*>(d) = q0;
+        *reinterpret_cast<uint2*>(d + plane_bytes) = q1;
       } else {
         uint2 q0, q1, q2;
         x3_split4(v, q0, q1, q2);
@@ -81,7 +97,7 @@ __global__ __launch_bounds__(256 * OR) void conv_stem_patch_kernel(ConvGemmArgs 
     a_off = ((2 * orow) * WP + 2 * ow + 2 * (lane >> 5)) * 8;
   }
   LB lb;
-  lb.init(a.wpk, a.Co, a.Kp, 0, lane);
+  lb.init(wpk, a.Co, a.Kp, 0, lane);
   f32x16 acc[1][Cfg::TN];
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j)
@@ -105,6 +121,11 @@ __global__ __launch_bounds__(256 * OR) void conv_stem_patch_kernel(ConvGemmArgs 
           f32x16 c = acc[0][j];
           if constexpr (NPROD == 1) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[g][0], x3_as_bf16(rb[j * 2 + g]), c, 0, 0, 0);
+          } else if constexpr (NPROD == 3) {      // two fp16 planes: smallest terms first
+            const bf16x8 b0 = x3_as_bf16(rb[j * 4 + g * 2 + 0]), b1 = x3_as_bf16(rb[j * 4 + g * 2 + 1]);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[g][1]), __builtin_bit_cast(f16x8, b0), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[g][0]), __builtin_bit_cast(f16x8, b1), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[g][0]), __builtin_bit_cast(f16x8, b0), c, 0, 0, 0);
           } else {
             const bf16x8 b0 = x3_as_bf16(rb[j * 6 + g * 3 + 0]), b1 = x3_as_bf16(rb[j * 6 + g * 3 + 1]), b2 = x3_as_bf16(rb[j * 6 + g * 3 + 2]);
             if (NPROD == 9) {
@@ -131,5 +152,11 @@ __global__ __launch_bounds__(256 * OR) void conv_stem_patch_kernel(ConvGemmArgs 
     if (s_out[wave * 32 + acc_row(e, lane)] < 0)
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j) acc[0][j][e] = 0.f;
+  if constexpr (NPROD == 3) {      // 2^-sx, 2^-sw: exact, one after the other
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[0][j][e] = acc[0][j][e] * h2_ix * h2_iw;
+  }
   x3_epilogue<Cfg, true, OUT16>(a, acc, s_out, s_red, rt, 0, wave, 0, lane, tid);
 }

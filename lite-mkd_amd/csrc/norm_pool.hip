@@ -22,22 +22,36 @@ static inline int ew_grid(long n_items) {
   return (int)g;
 }
 
+// One-shot, per host thread: the NEXT launch of lmkd_bn_apply(_seg), lmkd_bn_relu_maxpool_fwd(_seg), lmkd_bn_backward(_seg) or
+// lmkd_bn_backward_part(_seg), lmkd_stem_unpool_bn_bwd(_seg) or lmkd_nchw3_to_nhwc4 on this thread also folds max |y| (max |dx| for the backward) into the words at `word` - 2 segments x
+// LMKD_AMAX_SLOTS slots x 16 words (common.h: amax_commit; frame segment 1's elements go to the second half: the two trunk calls of an
+// episode keep the scales they would have as two launches) - fp32 bits, atomic max: the caller zeroes all lmkd_amax_words() of them.  The two-plane fp16 convolutions scale their operands by a power of two taken from it (lmkd_conv_operand_amax).
+static thread_local unsigned* g_amax_next = nullptr;
+extern "C" int lmkd_amax_next(void* word) { g_amax_next = (unsigned*)word; return LMKD_OK; }
+extern "C" long lmkd_amax_words(void) { return 2 * LMKD_AMAX_SEG_WORDS; }
+static inline unsigned* take_amax_next() { unsigned* p = g_amax_next; g_amax_next = nullptr; return p; }
+
 // ---------------------------------------------------------------------------------
 // [N,3,H,W] -> [N,H,W,4] (4th channel zero): the stem conv runs on NHWC4
 // ---------------------------------------------------------------------------------
-__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float4* __restrict__ y, long npix_total, long hw) {
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float4* __restrict__ y, long npix_total, long hw, unsigned* __restrict__ amax) {
+  float am = 0.f;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix_total; p += (long)gridDim.x * blockDim.x) {
     const long n = p / hw, r = p - n * hw;
     const float* b = x + n * 3 * hw + r;
-    y[p] = make_float4(b[0], b[hw], b[2 * hw], 0.f);
+    const float4 v = make_float4(b[0], b[hw], b[2 * hw], 0.f);
+    y[p] = v;
+    am = amax4(am, v);
   }
+  if (amax) amax_commit(amax, am);      // (one frame segment per call: the slots at `amax`)
 }
 
 extern "C" int lmkd_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, void* stream) {
+  unsigned* amax = take_amax_next();
   LMKD_REQUIRE(x && y && N > 0 && H > 0 && W > 0, "lmkd_nchw3_to_nhwc4: bad arguments");
   LMKD_REQUIRE(aligned16(y), "lmkd_nchw3_to_nhwc4: output must be 16-byte aligned");
   const long hw = (long)H * W, total = hw * N;
-  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, (float4*)y, total, hw);
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, (float4*)y, total, hw, amax);
   LMKD_CHECK_LAUNCH("lmkd_nchw3_to_nhwc4");
   return LMKD_OK;
 }
@@ -161,14 +175,6 @@ extern "C" int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst,
 #define LMKD_TICKET_WORDS 512      // two segments (blockIdx.z) x cdiv(2 C, CS_COLS) words: C <= 4096
 extern "C" long lmkd_ticket_words(void) { return LMKD_TICKET_WORDS; }
 
-// One-shot, per host thread: the NEXT launch of lmkd_bn_apply(_seg), lmkd_bn_relu_maxpool_fwd(_seg), lmkd_bn_backward(_seg) or
-// lmkd_bn_backward_part(_seg) on this thread also folds max |y| (max |dx| for the backward) into the words at `word` - 2 segments x
-// LMKD_AMAX_SLOTS slots x 16 words (common.h: amax_commit; frame segment 1's elements go to the second half: the two trunk calls of an
-// episode keep the scales they would have as two launches) - fp32 bits, atomic max: the caller zeroes all lmkd_amax_words() of them.  The two-plane fp16 convolutions scale their operands by a power of two taken from it (lmkd_conv_operand_amax).
-static thread_local unsigned* g_amax_next = nullptr;
-extern "C" int lmkd_amax_next(void* word) { g_amax_next = (unsigned*)word; return LMKD_OK; }
-extern "C" long lmkd_amax_words(void) { return 2 * LMKD_AMAX_SEG_WORDS; }
-static inline unsigned* take_amax_next() { unsigned* p = g_amax_next; g_amax_next = nullptr; return p; }
 static inline int cs_slices(int T) { return T <= 64 ? 1 : std::min(CS_MAX_SLICES, cdiv(T, 64)); }
 
 // -> true in the block that holds the totals of its CS_COLS columns in tot[] (every thread of the block gets the same answer)
@@ -990,10 +996,11 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uchar4* __res
 template <typename T>
 __global__ void stem_unpool_bn_bwd_kernel(const T* __restrict__ dy, const uchar4* __restrict__ idx, const T* __restrict__ c,
                                           const float* __restrict__ stats, const float* __restrict__ coef, T* __restrict__ dc, int N,
-                                          int H, int W, int C, int OH, int OW, int N0, ParamGradSeg pg) {
+                                          int H, int W, int C, int OH, int OW, int N0, ParamGradSeg pg, unsigned* __restrict__ amax) {
   const int C4 = C >> 2;
   const int HB = (H + 1) >> 1, WB = (W + 1) >> 1;
   const long total = (long)N * HB * WB * C4;
+  float amx = 0.f, amx1 = 0.f;      // max |dc| of frame segment 0 / 1 (lmkd_amax_next)
   if (N0 < N) bn_param_grads_seg(coef, C, pg);      // two frame segments: tables [2][5][C], parameter gradients from both (bn_bwd_coef_kernel)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cq = (int)(i % C4);
@@ -1059,8 +1066,13 @@ __global__ void stem_unpool_bn_bwd_kernel(const T* __restrict__ dy, const uchar4
         o.z = A.z * (g.z - mg.z - (xv.z - mean.z) * istd.z * mgx.z);
         o.w = A.w * (g.w - mg.w - (xv.w - mean.w) * istd.w * mgx.w);
         st4<T>(dc, p, o);
+        if (n >= N0) amx1 = amax4(amx1, o); else amx = amax4(amx, o);
       }
     }
+  }
+  if (amax) {
+    amax_commit(amax, amx);
+    if (N0 < N) amax_commit(amax + LMKD_AMAX_SEG_WORDS, amx1);
   }
 }
 
@@ -1078,6 +1090,7 @@ extern "C" int lmkd_stem_unpool_bn_bwd(const float* dy, const unsigned char* idx
 extern "C" int lmkd_stem_unpool_bn_bwd_seg(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef,
                                            float* dc, float* dgamma, float* dbeta, int accumulate_param_grads, int N, int N0, int H, int W, int C,
                                            void* stream) {
+  unsigned* amax = take_amax_next();
   LMKD_REQUIRE(dy && idx && c && stats && coef && dc && C % 4 == 0 && N > 0 && H > 0 && W > 0, "lmkd_stem_unpool_bn_bwd: bad arguments");
   if (N0 <= 0 || N0 > N) N0 = N;
   ParamGradSeg pg;
@@ -1086,10 +1099,10 @@ extern "C" int lmkd_stem_unpool_bn_bwd_seg(const float* dy, const unsigned char*
   const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * C / 4;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(stem_unpool_bn_bwd_kernel<lmkd_bf16_t>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream,
-                       (const lmkd_bf16_t*)dy, (const uchar4*)idx, (const lmkd_bf16_t*)c, stats, coef, (lmkd_bf16_t*)dc, N, H, W, C, OH, OW, N0, pg);
+                       (const lmkd_bf16_t*)dy, (const uchar4*)idx, (const lmkd_bf16_t*)c, stats, coef, (lmkd_bf16_t*)dc, N, H, W, C, OH, OW, N0, pg, amax);
   else
     hipLaunchKernelGGL(stem_unpool_bn_bwd_kernel<float>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, dy, (const uchar4*)idx, c,
-                       stats, coef, dc, N, H, W, C, OH, OW, N0, pg);
+                       stats, coef, dc, N, H, W, C, OH, OW, N0, pg, amax);
   LMKD_CHECK_LAUNCH("stem_unpool_bn_bwd_kernel");
   return LMKD_OK;
 }

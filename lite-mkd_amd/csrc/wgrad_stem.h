@@ -29,6 +29,8 @@ struct StemWgradArgs {
   int upi;              // units (output-row pairs) per image
   int units, G, slabs;  // G units per slab
   int RL;               // bytes of one row image of one plane
+  const unsigned* h2_xw;      // two-plane fp16 form (NPROD == 3): the maxima of x / dy (lmkd_conv_operand_amax).  ONE scale per operand - the
+  const unsigned* h2_dyw;     // larger of the two frame segments' maxima (an upper bound is a valid scale): a slab may sum units of both
 };
 
 #define STEM_WG_LDA 160
@@ -41,8 +43,8 @@ template <int V> struct StemSlot { static constexpr int value = V; };
 // RLC: the row-image size as a compile-time constant (0: a.RL) - with it the (kernel row, plane) offsets of the B reads are immediates
 template <int NPROD, int D, int RLC>
 __global__ __launch_bounds__(512) void stem_wgrad_kernel(StemWgradArgs a) {
-  static_assert(NPROD == 6 || NPROD == 9, "three-plane modes");
-  constexpr int NPL = 3;
+  static_assert(NPROD == 6 || NPROD == 9 || NPROD == 3, "three bf16 planes (6 / 9 products) or two fp16 planes (3 products: conv_patch16.h)");
+  constexpr int NPL = NPROD == 3 ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int RL = RLC ? RLC : a.RL;
   const int XBUF = 10 * NPL * RL;                     // nine row images (+ one image of slack for the reads past a unit), three planes each
@@ -59,6 +61,12 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(StemWgradArgs a) {
   const __amdgpu_buffer_rsrc_t rs_dy = x3_rsrc(a.dy, (long)a.N * a.Ho * Wo * 64 * 4);
   const __amdgpu_buffer_rsrc_t rs_x = x3_rsrc(a.x, (long)a.N * a.H * W * 4 * 4);
 
+  float h2_sx = 1.f, h2_sdy = 1.f;
+  if constexpr (NPROD == 3) {
+    const unsigned mx0 = amax_read(a.h2_xw, 0), mx1 = amax_read(a.h2_xw, 1), md0 = amax_read(a.h2_dyw, 0), md1 = amax_read(a.h2_dyw, 1);
+    h2_sx = h2_scale(mx0 > mx1 ? mx0 : mx1);
+    h2_sdy = h2_scale(md0 > md1 ? md0 : md1);
+  }
   const int d_k = tid >> 4, d_c = (tid & 15) * 4;      // dy loader: pixel of the step, 4 channels
   u32x4 rq[D];
   u32x4 rx[9];
@@ -97,10 +105,10 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(StemWgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
       uint2 p0, p1, p2;
-      x3_split4(as_f4(rx[j]), p0, p1, p2);
+      if constexpr (NPROD == 3) h2_split4(as_f4(rx[j]), h2_sx, p0, p1); else x3_split4(as_f4(rx[j]), p0, p1, p2);
       *reinterpret_cast<uint2*>(d + (j * NPL + 0) * RL) = p0;
       *reinterpret_cast<uint2*>(d + (j * NPL + 1) * RL) = p1;
-      *reinterpret_cast<uint2*>(d + (j * NPL + 2) * RL) = p2;
+      if constexpr (NPL == 3) *reinterpret_cast<uint2*>(d + (j * NPL + 2) * RL) = p2;
     }
   };
 
@@ -137,7 +145,8 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(StemWgradArgs a) {
   int gstep = 0;        // running step count: the dy buffer alternates across unit boundaries too
   auto step = [&](auto slot) {
     constexpr int S = decltype(slot)::value;
-    tr_store4<NPL, STEM_WG_LDA, STEM_WG_APLANE>(s_dy + (gstep & 1) * NPL * STEM_WG_APLANE, d_k, d_c, as_f4(rq[S]));
+    if constexpr (NPROD == 3) tr_store4_h2<STEM_WG_LDA, STEM_WG_APLANE>(s_dy + (gstep & 1) * NPL * STEM_WG_APLANE, d_k, d_c, as_f4(rq[S]), h2_sdy);
+    else tr_store4<NPL, STEM_WG_LDA, STEM_WG_APLANE>(s_dy + (gstep & 1) * NPL * STEM_WG_APLANE, d_k, d_c, as_f4(rq[S]));
     if (x_pending && cp.ks == ksteps - 1) {      // fetched at least D - 1 steps ago; its buffer was last read one unit ago
       store_x(xb ^ 1);
       x_pending = false;
@@ -188,17 +197,23 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(StemWgradArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8(&b)[NPL] = fb[kh & 1];
       f32x4 c = acc[kh];
-      if (NPROD == 9) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], b[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], b[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], b[1], c, 0, 0, 0);
+      if constexpr (NPROD == 3) {      // two fp16 planes: smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[1]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[0]), __builtin_bit_cast(f16x8, b[1]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[0]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+      } else {
+        if (NPROD == 9) {
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[NPL - 1], b[NPL - 1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], b[NPL - 1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[NPL - 1], b[1], c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], b[1], c, 0, 0, 0);      // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], b[NPL - 1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[NPL - 1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], b[0], c, 0, 0, 0);
       }
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], b[1], c, 0, 0, 0);      // smallest terms first
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], b[2], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], b[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], b[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], b[0], c, 0, 0, 0);
       acc[kh] = c;
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -212,7 +227,8 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(StemWgradArgs a) {
 #pragma unroll
       for (int kh = 0; kh < 7; ++kh) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) C[(16 * cb + 4 * q4 + e) * 224 + kh * 32 + 16 * nb + idx] = acc[kh][e];
+        for (int e = 0; e < 4; ++e)
+          C[(16 * cb + 4 * q4 + e) * 224 + kh * 32 + 16 * nb + idx] = NPROD == 3 ? acc[kh][e] * (1.f / h2_sx) * (1.f / h2_sdy) : acc[kh][e];
         acc[kh] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }

@@ -1124,6 +1124,7 @@ class StemFn(torch.autograd.Function):
             if Cin != 3:
                 raise RuntimeError("stem expects 3-channel frames")
             x4 = _empty((F_, H, W, 4), x)
+            _amax_record(x4)
             lib().call("lmkd_nchw3_to_nhwc4", _p(x.contiguous()), _p(x4), F_, H, W, _stream())
         seg = _seg_frames(seg, F_) if training else 0
         c, stats = _conv_bn_train_or_eval(x4, w, 4, 2, 3, gamma, beta, rm, rv, training, seg=seg)
@@ -1141,6 +1142,7 @@ class StemFn(torch.autograd.Function):
         if training:
             ctx.save_for_backward(x4, c, stats, idx, gamma, w, cmax)
             ctx.beta = beta
+            ctx.amax = getattr(x4, "_lmkd_amax", None)
         ctx.training = training
         ctx.seg = seg
         return y
@@ -1150,6 +1152,8 @@ class StemFn(torch.autograd.Function):
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         x4, c, stats, idx, gamma, w, cmax = ctx.saved_tensors
+        if ctx.amax is not None:      # the maximum recorded in the forward (a saved tensor may come back as a new object)
+            x4._lmkd_amax = ctx.amax
         dy = dy.contiguous()
         N, Hc, Wc, C = c.shape
         seg = ctx.seg
@@ -1166,6 +1170,7 @@ class StemFn(torch.autograd.Function):
             lib().call("lmkd_bn_backward_stats_seg", _p(dy), _p(cmax), _p(stats), _p(gamma), _p(coef), _p(ws), _p(_tickets(c)),
                        N * prow, seg * prow, N * crow, seg * crow, C, _stream())
             dc = torch.empty_like(c)
+            _amax_record(dc)
             lib().call("lmkd_stem_unpool_bn_bwd_seg", _p(dy), _p(idx), _p(c), _p(stats), _p(coef), _p(dc), _p(dgamma), _p(dbeta), int(direct),
                        N, seg, Hc, Wc, C, _stream())
             if direct:
@@ -1182,6 +1187,7 @@ class StemFn(torch.autograd.Function):
             lib().call("lmkd_bn_backward_stats", _p(dy), _p(cmax), _p(stats), _p(gamma), _p(dgamma), _p(dbeta), _p(coef), _p(ws),
                        _p(_tickets(c)), dy.numel() // C, c.numel() // C, C, int(direct), _stream())
             dc = torch.empty_like(c)
+            _amax_record(dc)
             lib().call("lmkd_stem_unpool_bn_bwd", _p(dy), _p(idx), _p(c), _p(stats), _p(coef), _p(dc), N, Hc, Wc, C, _stream())
             if direct:
                 dgamma = dbeta = None
@@ -1209,11 +1215,16 @@ def frames_pair_to_nhwc4(a, b):
     if (H, W) != (Hb, Wb):
         raise RuntimeError("support and query frames differ in size")
     out = _empty((Fa + Fb, H, W, 4), a)
-    for t, is4, dst, F_ in ((a, a4, out[:Fa], Fa), (b, b4, out[Fa:], Fb)):
+    words = _amax_slot(out.device) if (_h2_mode() and not (a4 or b4)) else None      # fp32h2: the stem's kernels scale by max |frames|, per segment
+    for seg, (t, is4, dst, F_) in enumerate(((a, a4, out[:Fa], Fa), (b, b4, out[Fa:], Fb))):
         if is4:
             dst.copy_(t)
         else:
+            if words is not None:
+                lib().call("lmkd_amax_next", words.data_ptr() + 2 * words.numel() * seg)      # (bytes: half the words per segment)
             lib().call("lmkd_nchw3_to_nhwc4", _p(t.contiguous()), _p(dst), F_, H, W, _stream())
+    if words is not None:
+        out._lmkd_amax = words
     return out
 
 

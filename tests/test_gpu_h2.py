@@ -97,8 +97,8 @@ def test_weight_planes_repack_equals_split(dev):
     L.call("lmkd_conv2d_repack_multi", wp, wf, dims, m, None)
     torch.cuda.synchronize()
     for e, o in zip(ents, outs):
-        n = (e[3].numel() - 32) // 16
-        assert torch.equal(o[:16 * n + 2], e[3][:16 * n + 2]), tuple(e[0].shape)
+        n = (e[3].numel() - 32) // 18      # 12 n bf16 planes, 4 n fp16 planes (16x16x32 order), the maximum's 64 bytes, 2 n fp16 planes (32x32x16 order)
+        assert torch.equal(o[:16 * n + 2], e[3][:16 * n + 2]) and torch.equal(o[16 * n + 32:], e[3][16 * n + 32:]), tuple(e[0].shape)
         assert float(o[16 * n:16 * n + 2].view(torch.float32)) == float(e[0].abs().max())
 
 

@@ -102,7 +102,7 @@ def test_basic_block_two_segments_equal_two_calls(dev, mode, act, F0, F1, H, cin
         assert _rel(a, b) < 4e-6, (tuple(a.shape), _rel(a, b))
 
 
-@pytest.mark.parametrize("mode,act", [("fp32x3", "fp32"), ("bf16", "bf16")])
+@pytest.mark.parametrize("mode,act", [("fp32x3", "fp32"), ("fp32h2", "fp32"), ("bf16", "bf16")])
 @pytest.mark.parametrize("F0,F1,H", [(3, 5, 32), (2, 1, 64), (1, 4, 50)])
 def test_stem_two_segments_equal_two_calls(dev, mode, act, F0, F1, H):
     import litemkd_amd  # noqa: F401

@@ -106,10 +106,10 @@ def test_bench_schedule_equals_serial_full_size(dev, which, conv):
     n1 = litemkd_amd.lib().value("lmkd_conv_h2_launches")
     tst = _run(dev, _sched(which, conv), 5, 224, 3)
     n2 = litemkd_amd.lib().value("lmkd_conv_h2_launches")
-    if conv == "fp32h2":      # bench.py's headline arithmetic: the two-plane kernels ran - 54 launches per trunk call (16 forward, 16 + 3 data gradient,
-        # 16 + 3 weight gradient) x 2 calls x 3 episodes in the serial run, once per episode in the merged one, + the 16 forward launches per
-        # call of _run's probe - i.e. every maximum reached its consumer
-        assert n1 - n0 == 2 * (n2 - n1) and n2 - n1 == 3 * 54 + 16, (n1 - n0, n2 - n1)
+    if conv == "fp32h2":      # bench.py's headline arithmetic: the two-plane kernels ran - 56 launches per trunk call (1 + 16 forward, 16 + 3 data
+        # gradient, 1 + 16 + 3 weight gradient; the 1s: the stem) x 2 calls x 3 episodes in the serial run, once per episode in the merged
+        # one, + the 17 forward launches per call of _run's probe - i.e. every maximum reached its consumer
+        assert n1 - n0 == 2 * (n2 - n1) and n2 - n1 == 3 * 56 + 17, (n1 - n0, n2 - n1)
     else:
         assert n2 == n0
     _compare(tst, ref, 2e-6, 1e-2)
