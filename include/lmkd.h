@@ -68,8 +68,9 @@ int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound 
    products, 0 = native fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16 MFMA inputs + fp32 accumulation (BASELINE configs[2]).
    In modes 1/2/3 the packed-weight arguments of lmkd_conv2d_fwd / lmkd_conv2d_bwd_data point at the buffer written by
    lmkd_conv2d_split_weights (in that mode).
-   4 (round 4) = mode 2 with the kernels that carry 93 % of the trunk's flops - the 3x3 convolutions' forward and data gradient
-   (conv_patch16_x3_kernel) and the 3x3 / stride-1 weight gradient (conv_wgrad_win16_kernel) - on TWO fp16 planes and THREE
+   4 (round 4) = mode 2 with the trunk's convolution kernels - the 3x3 forward and data gradient (conv_patch16_x3_kernel, also the
+   1x1 / stride-2 data gradient), the weight gradients (conv_wgrad_win16_kernel, conv_wgrad_x3_kernel, stem_wgrad_kernel) and the stem's
+   forward (conv_stem_patch_kernel); not the 1x1 forward and the head GEMMs - on TWO fp16 planes and THREE
    v_mfma_f32_16x16x32_f16 products per fp32 product: x 2^s = h0 + h1 with h0 = fp16(x 2^s), h1 = fp16(x 2^s - h0) (round to nearest)
    represents x to 2^-23 (one fp32 ulp; exactly for at least half of all fp32 values; zero-mean), the dropped h1 h1' term is <= 2^-22
    of the product with zero mean (mode 2 drops <= 2^-23, all of one sign: its planes are truncations), accumulation stays fp32, and 2^s
@@ -82,8 +83,8 @@ int lmkd_conv_set_compute_dtype(int mode);
    slots' fp32 bit patterns; any upper bound is valid), complete in stream order before the launch; null = unknown.  Ignored in the
    other modes. */
 int lmkd_conv_operand_amax(const void* x_word, const void* dy_word);
-/* the NEXT launch of lmkd_bn_apply(_seg) / lmkd_bn_relu_maxpool_fwd(_seg) / lmkd_bn_backward(_seg) / lmkd_bn_backward_part(_seg) on this
-   host thread also folds max |y| (backward: max |dx|) into the lmkd_amax_words() words at `word`: every wave into one of 64 slots of
+/* the NEXT launch of lmkd_bn_apply(_seg) / lmkd_bn_relu_maxpool_fwd(_seg) / lmkd_bn_backward(_seg) / lmkd_bn_backward_part(_seg) /
+   lmkd_stem_unpool_bn_bwd(_seg) / lmkd_nchw3_to_nhwc4 (one frame segment per call: the slots at `word`) on this host thread also folds max |y| (backward: max |dx|) into the lmkd_amax_words() words at `word`: every wave into one of 64 slots of
    its elements' frame segment (float atomics execute at the memory side: thousands of them on one address cost more than the pass
    itself), atomic max on the fp32 bits; the caller zeroes the words.
    One-shot.  This is how a trunk tensor gets the word lmkd_conv_operand_amax names, without a pass of its own. */
@@ -93,8 +94,8 @@ int lmkd_amax_next(void* word);
 int lmkd_amax(const float* x, long n, void* word, void* stream);
 long lmkd_amax_words(void);
 /* 16-bit elements of the plane buffer lmkd_conv2d_split_weights fills for a packed weight [ncols][Kp] in the current mode:
-   ncols Kp (mode 1), 12 ncols Kp (2 / 3), 16 ncols Kp + 32 (4: + the two fp16 planes of W and of -W in the 16x16x32 order and, in the
-   last 64 bytes, max |w|) */
+   ncols Kp (mode 1), 12 ncols Kp (2 / 3), 18 ncols Kp + 32 (4: + the two fp16 planes of W and of -W in the 16x16x32 order, 64 bytes
+   holding max |w|, and the two fp16 planes of W in the 32x32x16 order) */
 long lmkd_conv2d_plane_elems(int ncols, int Kp);
 long lmkd_conv_h2_launches(void); /* launches that took the two-plane form so far (tests) */
 /* re-pack n convolution weights in ONE launch (after an optimizer step; trainwandb.py:142): entry i = OIHW weight ws[i] -> wfs[i], the

@@ -603,9 +603,10 @@ static int g_conv_bf16 = 0;
 static int g_conv_patch = 1;   // same-size convolutions of the bf16-plane modes from an LDS-resident patch (conv_patch.h); 0 = im2col gather
 extern "C" int lmkd_conv_set_patch(int on) { g_conv_patch = on ? 1 : 0; return LMKD_OK; }
 static int g_conv_x3 = 6;   // 0 | 6 | 9 bf16 MFMA products per fp32 product (conv_x3.h); library default: 6
-// mode 4: fp32 as TWO fp16 planes, three products (conv_patch16.h: h2_split4) in the kernels that carry 93 % of the trunk's flops - the 3x3
-// convolutions' forward / data gradient (conv_patch16_x3_kernel) and the window weight gradient (conv_wgrad_win16_kernel) - wherever the
-// caller names the operands' maxima (lmkd_conv_operand_amax); every other launch, and every launch without them, runs mode 2.
+// mode 4: fp32 as TWO fp16 planes, three products (conv_patch16.h: h2_split4) in the trunk's convolution kernels - the 3x3 forward / data
+// gradient (conv_patch16_x3_kernel), the weight gradients (conv_wgrad_win16_kernel, conv_wgrad_x3_kernel, stem_wgrad_kernel), the stem's
+// forward (conv_stem_patch_kernel) - wherever the caller names the operands' maxima (lmkd_conv_operand_amax); every other launch (the
+// 1x1 forward, the inference epilogues, the loader-side BatchNorm), and every launch without them, runs mode 2.
 static int g_conv_h2 = 0;
 static long g_h2_launches = 0;      // launches that took the two-plane form (tests)
 extern "C" long lmkd_conv_h2_launches(void) { return g_h2_launches; }
