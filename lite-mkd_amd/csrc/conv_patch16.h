@@ -200,6 +200,31 @@ __global__ void amax_kernel(const float* __restrict__ x, long n, unsigned* __res
   if ((threadIdx.x & 63) == 0) atomicMax(word, __float_as_uint(m));
 }
 
+// the offset table s_adp of a tile (conv_patch16_x3_kernel): row r of the tile, every tap -> patch offset in units of 16 bytes (the zero row
+// where the tap leaves the image or the row lies past the tile's segment)
+template <class Cfg, int NB, int ROWB>
+__device__ __forceinline__ void patch16_fill_adp(unsigned short* __restrict__ s_adp, const ConvGemmArgs& a, const Tap* __restrict__ taps, int ntap,
+                                                 int tid, int row0, int M, int halo, int P) {
+  for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
+    const int m = row0 + r;
+    const int within = r % (Cfg::TM * 32), px = within & 15;
+    const int l16 = (px & 1) ? ((px >> 1) + (px < 8 ? 0 : 8)) : (px >> 1) + 4;      // the lane (mod 16) whose pixel this is: patch16_pixel(l16) == px
+    unsigned short* dst = s_adp + ((r / (Cfg::TM * 32)) * 16 + l16) * NB + (within >> 4);
+    int hh = -0x40000000, ww = 0;      // rows past the tile's segment: every tap reads the zero row
+    if (m < M) {
+      const int n = fdiv(m, a.div_hw);
+      const int rem = m - n * a.Hs * a.Ws;
+      hh = fdiv(rem, a.div_w);
+      ww = rem - hh * a.Ws;
+    }
+    for (int tp = 0; tp < ntap; ++tp) {
+      const int y = hh + taps[tp].dh, x = ww + taps[tp].dw;
+      const bool in = (unsigned)y < (unsigned)a.Hs && (unsigned)x < (unsigned)a.Ws;
+      dst[tp * Cfg::BM] = (unsigned short)((in ? (r + halo + taps[tp].dh * a.Ws + taps[tp].dw) : P) * (ROWB / 16));
+    }
+  }
+}
+
 // SRC2: a stride-2 FORWARD convolution (3x3 / pad 1 on an even-sized input).  The input's four parity classes x[:, sph::2, spw::2] are
 // images of the OUTPUT's size, and a tap (kh, kw) reads one of them at a shift of -1 or 0 pixels: the convolution is the sum of four
 // same-size convolutions with 4 + 2 + 2 + 1 taps.  The K loop runs (chunk, class, tap of the class); the patch of a (chunk, class) is the
@@ -293,26 +318,31 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   const int kq = lane >> 4;                               // lane group: result rows 4 kq .. 4 kq + 3; k-slot patch16_kslot(kq) of a 32-k step
   const int ksl = patch16_kslot(kq);
   const int pxl = patch16_pixel(lane & 15);               // this lane's pixel of each 16-pixel block
-  auto fill_adp = [&]() {      // the offset table (s_adp): row r of the tile, every tap (called behind the first patch loads: their latency)
-  for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
-    const int m = row0 + r;
-    const int within = r % (Cfg::TM * 32), px = within & 15;
-    const int l16 = (px & 1) ? ((px >> 1) + (px < 8 ? 0 : 8)) : (px >> 1) + 4;      // the lane (mod 16) whose pixel this is: patch16_pixel(l16) == px
-    unsigned short* dst = s_adp + ((r / (Cfg::TM * 32)) * 16 + l16) * NB + (within >> 4);
-    int hh = -0x40000000, ww = 0;      // rows past the tile's segment: every tap reads the zero row
-    if (m < M) {
-      const int n = fdiv(m, a.div_hw);
-      const int rem = m - n * a.Hs * a.Ws;
-      hh = fdiv(rem, a.div_w);
-      ww = rem - hh * a.Ws;
-    }
-    for (int tp = 0; tp < ntap; ++tp) {
-      const int y = hh + taps[tp].dh, x = ww + taps[tp].dw;
-      const bool in = (unsigned)y < (unsigned)a.Hs && (unsigned)x < (unsigned)a.Ws;
-      dst[tp * Cfg::BM] = (unsigned short)((in ? (r + halo + taps[tp].dh * a.Ws + taps[tp].dw) : P) * (ROWB / 16));
+  // 128 x 64 tiles: the table is written behind the first patch loads, below (layer 1, two chunks per tile: 415-437 -> 399-402 us at 400
+  // frames in fp32h2).  The 128 x 128 tiles write it HERE, before the accumulators and the loader's registers are live: written below,
+  // the loop's temporaries push that instance (230 registers) over its budget - layer 2: 240 -> 290 us.  SRC2 takes its source offsets
+  // from an LDS table, so its loads wait for the barrier anyway.
+  constexpr bool EARLY = !SRC2 && Cfg::BN == 64;
+  if constexpr (!EARLY) {      // (written out: as a call of patch16_fill_adp the 128 x 128 two-plane instance spills - 256 registers + 224 bytes of scratch)
+    for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
+      const int m = row0 + r;
+      const int within = r % (Cfg::TM * 32), px = within & 15;
+      const int l16 = (px & 1) ? ((px >> 1) + (px < 8 ? 0 : 8)) : (px >> 1) + 4;
+      unsigned short* dst = s_adp + ((r / (Cfg::TM * 32)) * 16 + l16) * NB + (within >> 4);
+      int hh = -0x40000000, ww = 0;
+      if (m < M) {
+        const int n = fdiv(m, a.div_hw);
+        const int rem = m - n * a.Hs * a.Ws;
+        hh = fdiv(rem, a.div_w);
+        ww = rem - hh * a.Ws;
+      }
+      for (int tp = 0; tp < ntap; ++tp) {
+        const int y = hh + taps[tp].dh, x = ww + taps[tp].dw;
+        const bool in = (unsigned)y < (unsigned)a.Hs && (unsigned)x < (unsigned)a.Ws;
+        dst[tp * Cfg::BM] = (unsigned short)((in ? (r + halo + taps[tp].dh * a.Ws + taps[tp].dw) : P) * (ROWB / 16));
+      }
     }
   }
-  };
   const unsigned lane_off = (unsigned)(16 * ksl);      // this lane group's k-slot inside a patch row
   const unsigned short* adp_lane = s_adp + (wm * 16 + (lane & 15)) * NB;
   // patch loader (conv_patch.h): LPR lanes x 16 B per pixel row
@@ -458,12 +488,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     __builtin_amdgcn_sched_barrier(0);
     if (t + 2 < nk) issue_b(rb);
   };
-  // 128 x 64 tiles: the first chunk's patch rows are in flight while the offset table is written (layer 1, two chunks per tile: 415-437 ->
-  // 399-402 us at 400 frames in fp32h2).  Not on the 128 x 128 tiles: there the loads' registers, live across the table loop, cost more
-  // than the latency they hide (layer 2: 240 -> 290 us).  SRC2 takes its source offsets from an LDS table: after the barrier.
-  constexpr bool EARLY = !SRC2 && Cfg::BN == 64;
-  if (EARLY && nk > 0) issue_patch(0);
-  fill_adp();
+  if constexpr (EARLY) {
+    if (nk > 0) issue_patch(0);
+    patch16_fill_adp<Cfg, NB, ROWB>(s_adp, a, taps, ntap, tid, row0, M, halo, P);
+  }
   __syncthreads();      // tap tables, s_out, zero row
   if (nk > 0) {
     if (!EARLY) issue_patch(0);
