@@ -157,16 +157,6 @@ def main():
     # the reference's make() (trainwandb.py:78-109): models, episode source, distiller, accuracy function, optimizer, scheduler
     student, teacher, src, distiller, aggregate_accuracy, _, opt, sch = TL.make(cfg, base_seed=2024)
     pool = [src.episode(e) for e in range(a.pool)]           # resident in HBM before the timed region
-    # One arena for the activations instead of hundreds of hipMalloc calls: the caching allocator grows by device allocations of a few
-    # hundred MB whenever the live set reaches a new shape - for the first ~200 episodes of a run (tools/soak.py: 409 device mallocs at
-    # episode 100, 410 from episode 200 on), each a host-blocking call of milliseconds that lands at random inside a 20-step timed region
-    # (same process, same box: 45.2 vs 50.1 episodes/s).  288 GB of HBM: reserve once, let the allocator split the block.
-    arena_gb = float(os.environ.get("LMKD_ARENA_GB", "100"))
-    if dev.type == "cuda" and arena_gb > 0:
-        free_b, _ = torch.cuda.mem_get_info(dev)
-        nbytes = int(min(arena_gb * 2 ** 30, 0.6 * free_b))
-        arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        del arena
     mfm = None
     if a.live_mfm:
         import argparse as _ap
@@ -270,11 +260,13 @@ def main():
     ops.CONV_TIMING = None if (use_graph or os.environ.get("LMKD_TIMED_EVENTS", "1") == "0") else []      # per-launch HIP events cannot be recorded into a captured graph (roofline_pass below times them)
     PAR.ALLREDUCE_TIMING = []
     steps0 = opt.steps
+    mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) if dev.type == "cuda" else 0
     t0 = time.perf_counter()
     it = run(a.steps, it)
     t_enq = time.perf_counter() - t0                 # host time to enqueue the timed region (before the fence)
     fence()
     dt = time.perf_counter() - t0
+    mallocs_timed = (torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0) if dev.type == "cuda" else 0
     opt_steps_timed = opt.steps - steps0             # read HERE: the repeat and host-idle passes below step the optimizer too
     timed_events, ops.CONV_TIMING = (ops.CONV_TIMING or []), None
     # the same K steps once more, timed the same way (barrier + synchronize on both sides), WITHOUT the per-launch HIP events of the
@@ -473,6 +465,7 @@ def main():
         # queue whenever the GPU is the bottleneck
         "repeat": {"value": world * a.steps / dt_rep, "unit": "episodes/s", "steps": a.steps,
                    "what": "the timed K steps run a second time right after the timed region, without per-launch timing events"},
+        "device_mallocs_in_timed_region": mallocs_timed,
         "host_enqueue_ms_per_episode": host_idle * 1e3,
         "host_loop_ms_per_episode_in_timed_region": t_enq / a.steps * 1e3,
         "episode_pipelining": bool(use_pipe),
