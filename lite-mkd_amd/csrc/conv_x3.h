@@ -96,13 +96,16 @@ struct X3FragB {
       off[j] = (nt * 32 < ncols) ? (unsigned)(((long)nt * (Kp >> 4) * NPL * 64 + lane) * 16) : X3_OOB;
     }
   }
-  // koff: first k of the K-step (multiple of 32)
+  // koff: first k of the K-step (multiple of 32), the same for every lane: it travels in the SCALAR offset of the buffer load (the range
+  // check looks at the vector offset alone: an out-of-range column block, off = X3_OOB, still reads zeros) - no vector add / select per load
+  // (conv_patch16.h: X3FragB16::load, where the counters showed these kernels bound by vector-instruction issue)
   __device__ __forceinline__ void load(int koff, u32x4 (&reg)[NR]) const {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((koff >> 4) * NPL * 1024));
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int q = 0; q < 2 * NPL; ++q)   // q = group * NPL + plane
-        reg[j * 2 * NPL + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j] == X3_OOB ? X3_OOB : off[j] + (unsigned)(((koff >> 4) * NPL + q) * 1024), 0, 0);
+        reg[j * 2 * NPL + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], so + (unsigned)(q * 1024), 0);
   }
 };
 
