@@ -554,7 +554,9 @@ def _pack_weights(w, Cs, mode, out=None):
     return planes
 
 
-# Library default (also the default of liblmkd_hip.so itself): the arithmetic of the benchmark's headline line
+# Library default (also the default of liblmkd_hip.so itself): exact 3-way bf16 split, six products - a caller of the C ABI needs no
+# protocol for it.  bench.py and the training CLI run "fp32h2" (the trunk's convolutions on two fp16 planes, three products, scales from
+# the tensors' maxima: csrc/conv_patch16.h), which this module's functions support by carrying the maxima with the tensors (_amax_*).
 DEFAULT_CONV_DTYPE = "fp32x3"
 
 

@@ -84,8 +84,9 @@ def build_parser():
     p.add_argument("--learning_rate", "-lr", type=float, default=0.0001, help="Learning rate.")
     p.add_argument("--opt", choices=["adam", "sgd"], default="sgd", help="Optimizer")
     # ---- not in the reference
-    p.add_argument("--dtype", choices=["f32", "f32h2", "f32native", "bf16"], default="f32", help="arithmetic: f32 = fp32 as 3 x bf16 on the matrix pipe (default), "
-                   "f32h2 = the same with the 3x3 convolutions on two fp16 planes + power-of-two scales (what bench.py times; DESIGN 10), "
+    p.add_argument("--dtype", choices=["f32", "f32h2", "f32x3", "f32native", "bf16"], default="f32", help="arithmetic: f32 = f32h2 (default, what bench.py times): "
+                   "fp32 tensors and accumulation, the trunk's convolutions on two fp16 planes + power-of-two scales from the tensors' maxima (DESIGN 10); "
+                   "f32x3 = every fp32 product from an exact 3-way bf16 split, six products (the library's default arithmetic); "
                    "f32native = v_mfma_f32_32x32x2_f32, bf16 = bf16 tensors + bf16 MFMA (the reference's autocast path, trainwandb.py:20,126)")
     p.add_argument("--serial", action="store_true", help="single-stream schedule (Schedule.serial())")
     p.add_argument("--two_call", action="store_true", help="round 3's schedule (two trunk calls on two streams, no cross-episode pipelining) instead of "
@@ -185,7 +186,7 @@ class ClipDirectoryEpisodes:
 
 
 def schedule_from_args(args):
-    conv = {"f32": "fp32x3", "f32h2": "fp32h2", "f32native": "fp32", "bf16": "bf16"}[args.dtype]
+    conv = {"f32": "fp32h2", "f32h2": "fp32h2", "f32x3": "fp32x3", "f32native": "fp32", "bf16": "bf16"}[args.dtype]
     act = "bf16" if args.dtype == "bf16" else "fp32"
     if args.serial:
         return Schedule.serial(conv_dtype=conv, act_dtype=act)
