@@ -498,6 +498,21 @@ def _amax_slot(dev):
     return p["buf"][i:i + nw]
 
 
+_AMAX_UNIT = {}
+
+
+def _amax_unit_words(dev):
+    """the words of a maximum equal to 1.0 in both frame segments (constant; one tensor per device)"""
+    w = _AMAX_UNIT.get(dev.index)
+    if w is None:
+        nw = lib().value("lmkd_amax_words")
+        w = torch.zeros(nw, dtype=torch.int32, device=dev)
+        w[0] = 0x3f800000
+        w[nw // 2] = 0x3f800000
+        _AMAX_UNIT[dev.index] = w
+    return w
+
+
 def amax_pool_reset():
     """the next word comes from a new pool (a hipGraph capture: each graph zeroes the pool its own words live in)"""
     _AMAX_POOLS.clear()
@@ -1247,6 +1262,8 @@ def frames_u8_to_nhwc4(frames_u8, crop_y, crop_x, flip, size, frames_per_video=8
         raise RuntimeError("frames_u8_to_nhwc4: `out` must be a contiguous float32 [%d, %d, %d, 4] tensor" % (F_, size, size))
     lib().call("lmkd_frames_u8_to_nhwc4", _p(frames_u8), _p(out), _p(crop_y), _p(crop_x), _p(flip), F_, Hs, Ws, size, size,
                frames_per_video, _stream())
+    if _h2_mode():      # ToTensor output lies in [0, 1]: 1.0 is a valid maximum (an upper bound costs range, not correctness) for both frame segments
+        out._lmkd_amax = _amax_unit_words(out.device)
     return out
 
 

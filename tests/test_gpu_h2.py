@@ -228,3 +228,26 @@ def test_subnormal_second_plane_reaches_the_matrix_pipe(dev):
     s = 15 - math.ceil(math.log2(float(dy.abs().max())))
     assert bool(((dx - 0.5 * dy).abs() <= 0.5 * (2.0 ** -23 * dy.abs() + 2.0 ** (-25 - s))).all())
     assert float((dx == 0.5 * dy).float().mean()) > 0.45
+
+
+def test_uint8_frames_carry_a_unit_maximum(dev):
+    """frames from the uint8 transform (Resize / crop / flip / ToTensor, values in [0, 1]) carry the constant maximum 1.0 - an upper bound is
+    a valid scale - so the stem runs its two-plane kernels on them too; result equal to the three-plane arithmetic to fp32 rounding"""
+    import litemkd_amd
+    from litemkd_amd import ops
+    g = torch.Generator().manual_seed(8)
+    F_, S = 8, 64
+    u8 = torch.randint(0, 256, (F_, 72, 80, 3), dtype=torch.uint8, generator=g).to(dev)
+    cy = torch.tensor([3], dtype=torch.int32, device=dev)
+    cx = torch.tensor([5], dtype=torch.int32, device=dev)
+    fl = torch.tensor([1], dtype=torch.int32, device=dev)
+    w = torch.nn.Parameter((torch.randn(64, 3, 7, 7, generator=g) * 0.05).to(dev))
+    gam, bet = (1 + 0.1 * torch.randn(64, generator=g)).to(dev), (0.1 * torch.randn(64, generator=g)).to(dev)
+    outs = {}
+    for mode in ("fp32h2", "fp32x3"):
+        ops.set_conv_compute_dtype(mode)
+        x4 = ops.frames_u8_to_nhwc4(u8, cy, cx, fl, S)
+        n0 = _launches()
+        outs[mode] = ops.StemFn.apply(x4, w, gam, bet, torch.zeros(64, device=dev), torch.ones(64, device=dev), True).detach()
+        assert _launches() - n0 == (1 if mode == "fp32h2" else 0)
+    assert float((outs["fp32h2"] - outs["fp32x3"]).abs().max()) <= 2e-6 * float(outs["fp32x3"].abs().max())
