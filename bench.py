@@ -469,6 +469,8 @@ def main():
         "host_enqueue_ms_per_episode": host_idle * 1e3,
         "host_loop_ms_per_episode_in_timed_region": t_enq / a.steps * 1e3,
         "episode_pipelining": bool(use_pipe),
+        # after every timed / repeated / probe episode and optimizer step of this process (ReLU(NaN) = 0 keeps a loss finite on NaN weights)
+        "weights_finite": bool(torch.isfinite(opt.bucket.flat).all()),
         "hipgraph": {"enabled": bool(use_graph), "replays": runners[a.dtype].replays if use_graph else 0,
                      "eager_episodes": runners[a.dtype].eager if use_graph else None, "graphs": len(runners[a.dtype].graphs) if use_graph else 0},
     }

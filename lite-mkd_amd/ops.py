@@ -4,6 +4,7 @@ graph); all arithmetic of the hot path happens in liblmkd_hip.so.
 
 Activations are NHWC fp32.  Every wrapper checks device/dtype/contiguity and raises on misuse."""
 import ctypes
+import os
 import math
 
 import torch
@@ -492,6 +493,7 @@ def _amax_slot(dev):
         p = _AMAX_POOLS[dev.index] = {"buf": buf, "next": 0, "cap": cap, "event": ev, "seen": {cur.cuda_stream}}
     if cur.cuda_stream not in p["seen"]:
         cur.wait_event(p["event"])
+        p["buf"].record_stream(cur)      # the pool's block must not be recycled under kernels of this stream (it is freed when its last word dies)
         p["seen"].add(cur.cuda_stream)
     i = p["next"]
     p["next"] = i + nw
@@ -518,8 +520,13 @@ def amax_pool_reset():
     _AMAX_POOLS.clear()
 
 
-def _amax_record(t):
+_H2_DEBUG_OFF = set(filter(None, os.environ.get("LMKD_H2_OFF", "").split(",")))      # diagnosis: "stem_x", "stem_dc" -> those tensors carry no maximum
+
+
+def _amax_record(t, what=None):
     """call immediately before the launch that writes t (lmkd_amax_next is one-shot): that launch also folds max |t| into a fresh word"""
+    if what is not None and what in _H2_DEBUG_OFF:
+        return
     if t.dtype is torch.float32 and _h2_mode():
         w = _amax_slot(t.device)
         lib().call("lmkd_amax_next", w.data_ptr())
@@ -864,6 +871,10 @@ def weight_grad(w, x, dy, stride, pad, pre_stats=None, seg=0):
                 w.grad.add_(dw)
     x.record_stream(sw)
     dy.record_stream(sw)
+    for t in (x, dy):      # ... and the words holding their maxima (fp32h2): the side-stream kernel reads them when it starts
+        wm = getattr(t, "_lmkd_amax", None)
+        if wm is not None:
+            wm.record_stream(sw)
     if pre_stats is not None:      # read by the side-stream kernel too: its block must not be recycled under it
         pre_stats.record_stream(sw)
     _join_at_backward_end()
@@ -1141,7 +1152,7 @@ class StemFn(torch.autograd.Function):
             if Cin != 3:
                 raise RuntimeError("stem expects 3-channel frames")
             x4 = _empty((F_, H, W, 4), x)
-            _amax_record(x4)
+            _amax_record(x4, "stem_x")
             lib().call("lmkd_nchw3_to_nhwc4", _p(x.contiguous()), _p(x4), F_, H, W, _stream())
         seg = _seg_frames(seg, F_) if training else 0
         c, stats = _conv_bn_train_or_eval(x4, w, 4, 2, 3, gamma, beta, rm, rv, training, seg=seg)
@@ -1187,7 +1198,7 @@ class StemFn(torch.autograd.Function):
             lib().call("lmkd_bn_backward_stats_seg", _p(dy), _p(cmax), _p(stats), _p(gamma), _p(coef), _p(ws), _p(_tickets(c)),
                        N * prow, seg * prow, N * crow, seg * crow, C, _stream())
             dc = torch.empty_like(c)
-            _amax_record(dc)
+            _amax_record(dc, "stem_dc")
             lib().call("lmkd_stem_unpool_bn_bwd_seg", _p(dy), _p(idx), _p(c), _p(stats), _p(coef), _p(dc), _p(dgamma), _p(dbeta), int(direct),
                        N, seg, Hc, Wc, C, _stream())
             if direct:
@@ -1204,7 +1215,7 @@ class StemFn(torch.autograd.Function):
             lib().call("lmkd_bn_backward_stats", _p(dy), _p(cmax), _p(stats), _p(gamma), _p(dgamma), _p(dbeta), _p(coef), _p(ws),
                        _p(_tickets(c)), dy.numel() // C, c.numel() // C, C, int(direct), _stream())
             dc = torch.empty_like(c)
-            _amax_record(dc)
+            _amax_record(dc, "stem_dc")
             lib().call("lmkd_stem_unpool_bn_bwd", _p(dy), _p(idx), _p(c), _p(stats), _p(coef), _p(dc), N, Hc, Wc, C, _stream())
             if direct:
                 dgamma = dbeta = None
@@ -1232,7 +1243,7 @@ def frames_pair_to_nhwc4(a, b):
     if (H, W) != (Hb, Wb):
         raise RuntimeError("support and query frames differ in size")
     out = _empty((Fa + Fb, H, W, 4), a)
-    words = _amax_slot(out.device) if (_h2_mode() and not (a4 or b4)) else None      # fp32h2: the stem's kernels scale by max |frames|, per segment
+    words = _amax_slot(out.device) if (_h2_mode() and not (a4 or b4) and "stem_x" not in _H2_DEBUG_OFF) else None      # fp32h2: the stem's kernels scale by max |frames|, per segment
     for seg, (t, is4, dst, F_) in enumerate(((a, a4, out[:Fa], Fa), (b, b4, out[Fa:], Fb))):
         if is4:
             dst.copy_(t)

@@ -251,3 +251,90 @@ def test_uint8_frames_carry_a_unit_maximum(dev):
         outs[mode] = ops.StemFn.apply(x4, w, gam, bet, torch.zeros(64, device=dev), torch.ones(64, device=dev), True).detach()
         assert _launches() - n0 == (1 if mode == "fp32h2" else 0)
     assert float((outs["fp32h2"] - outs["fp32x3"]).abs().max()) <= 2e-6 * float(outs["fp32x3"].abs().max())
+
+
+def test_training_across_optimizer_steps_tracks_the_three_plane_arithmetic(dev):
+    """50 full-size episodes with three optimizer steps under bench.py's schedule in fp32h2 and in fp32x3, same seeds: every weight stays
+    finite and the losses after the steps agree to 2 %.  (A regression test: the words that hold a tensor's maximum were once recycled
+    by the allocator while the weight-gradient stream's last kernel - the stem's - had not started; it then read a maximum of zero,
+    its fp16 planes overflowed and the stem's weights were NaN after the first optimizer step - with finite losses, ReLU(NaN) being 0.
+    The race needs the pool of words to be recycled inside the weight-gradient stream's 2.5 ms tail: this loop hit it in about half of
+    its runs; test_words_are_protected_on_every_stream_that_reads_them checks the protection itself.)"""
+    from litemkd_amd import ops, trainloop as TL
+    from litemkd_amd.options import default_args
+    from litemkd_amd.schedule import Schedule
+    out = {}
+    pool_tensors, ops._AMAX_POOL_TENSORS = ops._AMAX_POOL_TENSORS, 4      # a new pool of words every four tensors: the recycling happens many times per episode
+    ops.amax_pool_reset()
+    for mode in ("fp32h2", "fp32x3"):
+        with Schedule.bench(conv_dtype=mode).applied():
+            cfg = default_args(shot=5, device=dev, trans_dropout=0.1, training_iterations=10 ** 9, print_freq=10 ** 9)
+            torch.manual_seed(1234)
+            student, teacher, src, distiller, acc_fn, _, opt, sch = TL.make(cfg, base_seed=2024)
+            pool = [src.episode(e) for e in range(2)]
+            losses = []
+            for i in range(50):
+                loss, _, _ = TL.train_task(pool[i % 2], student, teacher, distiller, acc_fn, cfg)
+                losses.append(loss.detach().clone())      # no host synchronisation, no reference to the episode's tensors: the next forward is
+                del loss                                  # enqueued - and allocates - while the weight-gradient stream still runs
+                if (i + 1) % 16 == 0:
+                    opt.step()
+                    opt.zero_grad()
+                sch.step()
+            torch.cuda.synchronize()
+            assert all(bool(torch.isfinite(p).all()) for p in student.parameters()), mode
+            out[mode] = torch.stack([l.float() for l in losses]).cpu()
+            ops.join_all_streams()
+    ops._AMAX_POOL_TENSORS = pool_tensors
+    ops.amax_pool_reset()
+    a, b = out["fp32h2"], out["fp32x3"]
+    assert torch.isfinite(a).all() and float(((a - b).abs() / b.abs()).max()) < 0.02, (a[-4:], b[-4:])
+
+
+def test_words_are_protected_on_every_stream_that_reads_them(dev, monkeypatch):
+    """the words of a maximum live in a pool tensor that is freed when its last word dies; every stream whose kernels touch them must be
+    recorded on that tensor (torch.Tensor.record_stream), or the allocator recycles the block under a kernel that has not started:
+    (1) the weight-gradient stream for the words of both operands of ops.weight_grad, (2) any stream that takes a word from a pool
+    created on another stream"""
+    from litemkd_amd import ops
+    calls = []
+    orig = torch.Tensor.record_stream
+
+    def spy(self, s):
+        calls.append((self.data_ptr(), self.dtype, s.cuda_stream))
+        return orig(self, s)
+    monkeypatch.setattr(torch.Tensor, "record_stream", spy)
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = ops.amax_compute(torch.relu(torch.randn(4, 14, 14, 64, device=dev, generator=g)))
+    dy = ops.amax_compute(torch.randn(4, 14, 14, 64, device=dev, generator=g))
+    w = torch.nn.Parameter(torch.randn(64, 64, 3, 3, device=dev, generator=g) * 0.05)
+    w.grad = torch.zeros_like(w)
+    prev = ops.SIDE_WGRAD
+    ops.SIDE_WGRAD = True
+
+    class _InBackward(torch.autograd.Function):      # ops.weight_grad joins its stream at the end of the backward pass: it has to run inside one
+        @staticmethod
+        def forward(ctx, t):
+            return t * 1.0
+
+        @staticmethod
+        def backward(ctx, gr):
+            assert ops.weight_grad(w, x, dy, 1, 1) is None      # accumulated into w.grad on the weight-gradient stream
+            return gr
+    try:
+        _InBackward.apply(torch.ones(1, device=dev, requires_grad=True)).sum().backward()
+        ops.wait_weight_grads()
+    finally:
+        ops.SIDE_WGRAD = prev
+    sw = ops._wgrad_stream(dev).cuda_stream
+    for t in (x, dy):
+        assert (t._lmkd_amax.data_ptr(), torch.int32, sw) in calls, "the words of an operand were not recorded on the weight-gradient stream"
+    ops.amax_pool_reset()
+    first = ops._amax_slot(dev)                              # a new pool, created on the current stream
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        second = ops._amax_slot(dev)                         # the same pool, from another stream
+    pool_ptr = ops._AMAX_POOLS[dev.index]["buf"].data_ptr()
+    assert second.data_ptr() == first.data_ptr() + 4 * first.numel()
+    assert (pool_ptr, torch.int32, side.cuda_stream) in calls, "the pool was not recorded on the second stream"
+    torch.cuda.synchronize()
