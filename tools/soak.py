@@ -9,7 +9,7 @@ from litemkd_amd.options import default_args
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 dev = torch.device("cuda:0")
 from litemkd_amd.schedule import Schedule
-Schedule.bench(conv_dtype=os.environ.get("LMKD_CONV", "fp32h2")).apply()      # bench.py's schedule and arithmetic (the loop below is the unpipelined one)
+getattr(Schedule, os.environ.get("LMKD_SCHED", "bench"))(conv_dtype=os.environ.get("LMKD_CONV", "fp32h2")).apply()      # bench.py's schedule and arithmetic by default (the loop below is the unpipelined one); LMKD_SCHED = two_call | serial
 cfg = default_args(shot=5, device=dev, trans_dropout=0.1, training_iterations=10 ** 9, print_freq=10 ** 9)
 torch.manual_seed(1234)
 student, teacher, src, distiller, acc_fn, _, opt, sch = TL.make(cfg, base_seed=2024)
