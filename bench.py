@@ -67,8 +67,8 @@ def main():
                     "mode under rocprofv3 so per-kernel durations are not inflated by concurrent kernels")
     ap.add_argument("--roofline-episodes", type=int, default=2)
     ap.add_argument("--dtype", choices=["f32", "f32native", "bf16", "bf16conv", "f32x3"], default="f32", help="f32 (headline, BASELINE "
-                    "configs[1]): fp32 tensors, fp32 accumulation; f32x3's arithmetic with the 3x3 convolutions (forward, data gradient, "
-                    "window weight gradient: 93 %% of the trunk's flops) on TWO fp16 planes + power-of-two scales, three products per fp32 "
+                    "configs[1]): fp32 tensors, fp32 accumulation; f32x3's arithmetic with the trunk's convolution kernels (3x3 forward and data "
+                    "gradient, every weight gradient, the stem: 97 %% of the trunk's flops) on TWO fp16 planes + power-of-two scales, three products per fp32 "
                     "product ('fp32h2', csrc/conv_patch16.h) - error vs fp64 at or below f32x3's on every layer (tests/test_gpu_h2.py, "
                     "profiles/r04_h2_error.txt); f32x3 (rounds 2-3's headline, the library default): the convolution products on the bf16 "
                     "matrix pipe from an EXACT 3-way bf16 split of both operands, 6 products per fp32 product (csrc/conv_x3.h, wgrad_x3.h; "
@@ -421,12 +421,12 @@ def main():
         "config": {"workload": "HMDB-shape 5-way %d-shot %s + TRX_2fcsup + D2M fc_2_sup_dist training episode%s, %s"
                                % (a.shot, a.backbone, " + live MFM fusion" if a.live_mfm else "",
                                   {"f32": "fp32", "f32x3": "fp32", "f32native": "fp32", "bf16": "bf16 tensors / fp32 accumulate", "bf16conv": "bf16 conv operands / fp32 tensors"}[a.dtype]),
-                   "conv_arithmetic": {"f32": "fp32 tensors and accumulation.  The 3x3 convolutions - forward, data gradient, stride-1 weight gradient: 93 % of "
-                                              "the trunk's flops - split each fp32 operand x into TWO fp16 planes, h0 = fp16(x 2^s), h1 = fp16(x 2^s - h0) "
+                   "conv_arithmetic": {"f32": "fp32 tensors and accumulation.  The trunk's convolution kernels - 3x3 forward and data gradient, every weight "
+                                              "gradient, the stem: 97 % of the trunk's flops - split each fp32 operand x into TWO fp16 planes, h0 = fp16(x 2^s), h1 = fp16(x 2^s - h0) "
                                               "(round to nearest: |x 2^s - h0 - h1| <= 2^-23 |x 2^s|, one fp32 ulp, zero for at least half of all fp32 values; 2^s a power of two from max |tensor|, which the kernel "
                                               "that writes the tensor records, so the scaling is exact) and form h0 w0 + h0 w1 + h1 w0 on "
                                               "v_mfma_f32_16x16x32_f16 with fp32 accumulation (the dropped h1 w1 <= 2^-22 of the product, zero-mean; the three-plane "
-                                              "bf16 form drops <= 2^-23, all of one sign).  Everything else (stem, 1x1 / stride-2 weight gradients, heads) runs f32x3's "
+                                              "bf16 form drops <= 2^-23, all of one sign).  Everything else (the 1x1 forward of the downsample branches, the heads) runs f32x3's "
                                               "arithmetic.  Relative-L2 error vs fp64 on the trunk's four 3x3 shapes: forward 2.7e-7 .. 7.0e-7, data gradient "
                                               "2.7e-7 .. 7.1e-7, weight gradient 2.3e-7 .. 5.5e-7 - BELOW f32x3's (3.5e-7 .. 9.6e-7 | 3.6e-7 .. 1.0e-6 | 2.9e-7 .. "
                                               "8.2e-7) and at torch's fp32 convolution's on every one (profiles/r04_h2_error.txt; tests/test_gpu_h2.py holds "
