@@ -249,6 +249,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # the first all-reduce of a kind sets the backend up for it (gloo: staging buffers - a stall of seconds; RCCL: channels and
+        # proxies for the stream): both collectives of an optimizer step - the bucket's tail on the early all-reduce's stream, the head
+        # on the main stream - run once on the zeroed gradient buffers before the warm-up, so that a W too short to contain an
+        # optimizer step (world 2: a step every 8 local episodes) does not move that one-time cost into the timed region
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        opt.early.arm(1)
+        opt.early.launch()
+        opt.bucket.allreduce_grads(opt.early.finish())
+        torch.cuda.synchronize()
+        opt.zero_grad()
+        PAR.ALLREDUCE_TIMING = None
     # warm-up: with graphs every resident episode has to be seen twice before it replays (first eager, then captured)
     interval_mode = use_graph and a.graph_interval and mfm is None
     if interval_mode:      # whole optimizer intervals only: the interval that repeats is seen (eager), captured and replayed before the timed region
