@@ -22,6 +22,8 @@ def main():
     from litemkd_amd.options import default_args
     from litemkd_amd.utils import aggregate_accuracy
     rank, world, dev = init_distributed()
+    if os.environ.get("LMKD_CONV"):      # the arithmetic under test (default: the library's)
+        ops.set_conv_compute_dtype(os.environ["LMKD_CONV"])
     cfg = default_args(shot=1, query_per_class=1, img_size=64, trans_dropout=0.0, device=dev, learning_rate=1e-2, save_dir=out_dir,
                        mode="w%d_" % world)
     torch.manual_seed(33)

@@ -207,7 +207,8 @@ def test_trx_dropout_forward_and_backward_use_the_same_mask(dev):
     assert float((l3 - l1).abs().max()) > 0
 
 
-def test_data_parallel_world2_equals_world1(dev, tmp_path):
+@pytest.mark.parametrize("conv", ["fp32x3", "fp32h2"])
+def test_data_parallel_world2_equals_world1(dev, tmp_path, conv):
     """Episode parallelism (parallel.py): 16 global episodes dealt to 2 ranks (two processes on this one GPU, gloo
     — the bucket / all-reduce / optimizer code is the one RCCL runs), one all-reduce of the flat gradient bucket, one SGD
     step: the updated weights equal the 1-process run over the same 16 episodes to fp32 rounding (different summation
@@ -226,7 +227,7 @@ def test_data_parallel_world2_equals_world1(dev, tmp_path):
         procs = []
         for r in range(world):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                       LMKD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+                       LMKD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", LMKD_CONV=conv)
             procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path), "16"], env=env))
         for p in procs:
             assert p.wait(timeout=600) == 0
