@@ -89,6 +89,13 @@ int lmkd_conv_operand_amax(const void* x_word, const void* dy_word);
    itself), atomic max on the fp32 bits; the caller zeroes the words.
    One-shot.  This is how a trunk tensor gets the word lmkd_conv_operand_amax names, without a pass of its own. */
 int lmkd_amax_next(void* word);
+/* mode 4, for a consumer that applies relu(BatchNorm(x)) in its loader (lmkd_conv2d_fwd_pre, lmkd_conv2d_bwd_weight_pre): (1) the NEXT
+   forward convolution launch of this thread records max |y| in `words` (only the launches that run conv_patch16_x3_kernel do: any other
+   leaves them zero = unknown); (2) the NEXT lmkd_bn_finalize(_seg) launch turns max |x| (`x_words`) and its scale / shift tables into
+   an upper bound of max |relu(BatchNorm(x))| per frame segment in `bound_words` (zeroed by the caller) - the words to name in
+   lmkd_conv_operand_amax for that consumer.  Both one-shot. */
+int lmkd_conv_output_amax(void* words);
+int lmkd_bn_finalize_bound(const void* x_words, void* bound_words);
 /* max |x[0 .. n)| -> the slots of ONE frame segment at `word` (lmkd_amax_words() / 2 words, zeroed here first; segment 1 of a tensor's
    maximum starts lmkd_amax_words() / 2 words in): a pass of its own, for tensors no kernel of this library wrote */
 int lmkd_amax(const float* x, long n, void* word, void* stream);

@@ -55,6 +55,7 @@ struct ConvGemmArgs {
   // Unsegmented launch: seg_m0 = rows_per_class, seg_t0 = tiles_per_class (conv_set_tiles).
   int seg_m0, seg_t0;
   const unsigned* h2_xw;      // two-plane fp16 arithmetic (compute dtype 4): the word holding max |operand| (lmkd_conv_operand_amax); null: three bf16 planes
+  unsigned* amax_out;         // conv_patch16_x3_kernel: fold max |out| into these words (lmkd_conv_output_amax); null: not recorded
   FastDiv div_hw, div_w;
   int ntap[LMKD_MAX_CLASSES];
   Tap taps[LMKD_MAX_CLASSES][LMKD_MAX_TAPS];
@@ -628,6 +629,13 @@ extern "C" int lmkd_conv_operand_amax(const void* x_word, const void* dy_word) {
   g_amax_dy = (const unsigned*)dy_word;
   return LMKD_OK;
 }
+// the NEXT forward launch of this host thread also folds max |y| into the words at `words` (lmkd_amax_next's layout; one-shot; only the
+// launches that run conv_patch16_x3_kernel do it - any other kernel leaves the words at zero, and a maximum of zero is "unknown").  With it
+// lmkd_bn_finalize_bound can bound relu(BatchNorm(y)) for a consumer that applies the BatchNorm in its loader.
+static thread_local unsigned* g_amax_out = nullptr;
+extern "C" int lmkd_conv_output_amax(void* words) { g_amax_out = (unsigned*)words; return LMKD_OK; }
+static inline unsigned* take_amax_out() { unsigned* p = g_amax_out; g_amax_out = nullptr; return p; }
+static thread_local bool t_amax_recorded = false;      // set by the launches whose kernel folds ConvGemmArgs::amax_out (conv_patch16_x3_kernel)
 static inline const unsigned* take_amax_x() { const unsigned* p = g_amax_x; g_amax_x = nullptr; return p; }
 static inline const unsigned* take_amax_dy() { const unsigned* p = g_amax_dy; g_amax_dy = nullptr; return p; }
 // elements (16-bit) of the plane buffer of a packed weight of ncols x Kp in the current mode
@@ -637,9 +645,9 @@ extern "C" long lmkd_conv2d_plane_elems(int ncols, int Kp) {
 }
 // max |x| of n floats: slots = 0: into the ONE word at `word` (weight packs); slots = 1: into the slot words of one frame segment of an
 // activation maximum (lmkd_amax_next's layout: segment s at word + s * lmkd_amax_words() / 2).  The words are zeroed here first.
-static int amax_impl(const float* x, long n, void* word, int slots, void* stream) {
+static int amax_impl(const float* x, long n, void* word, int slots, void* stream, bool zero = true) {
   LMKD_REQUIRE(x && word && n > 0, "lmkd_amax: bad arguments");
-  if (hipMemsetAsync(word, 0, slots ? LMKD_AMAX_SEG_WORDS * 4 : 4, (hipStream_t)stream) != hipSuccess) {
+  if (zero && hipMemsetAsync(word, 0, slots ? LMKD_AMAX_SEG_WORDS * 4 : 4, (hipStream_t)stream) != hipSuccess) {
     lmkd_set_error("lmkd_amax: hipMemsetAsync failed");
     return LMKD_EHIP;
   }
@@ -984,6 +992,7 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
     if (g_patch16 && g_conv_x3 && !g_lmkd_act_bf16) {
 #define LMKD_PATCH16(NPROD, PRE, EP)                                                                                           \
   do {                                                                                                                         \
+    t_amax_recorded = true;                                                                                                    \
     static std::atomic<unsigned long long> attr_done{0};                                                                       \
     lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch16_x3_kernel<Cfg, NPROD, PRE, EP>),                 \
                        (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));                                                      \
@@ -992,6 +1001,7 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
       if (a.src2) {
 #define LMKD_PATCH16S(NPROD, EP)                                                                                               \
   do {                                                                                                                         \
+    t_amax_recorded = true;                                                                                                    \
     static std::atomic<unsigned long long> attr_done{0};                                                                       \
     lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch16_x3_kernel<Cfg, NPROD, false, EP, true>),         \
                        (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));                                                      \
@@ -1004,7 +1014,11 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
         return;
       }
       if (a.ep_stats) { if (g_conv_x3 == 9) LMKD_PATCH16(9, false, true); else LMKD_PATCH16(6, false, true); }
-      else if (a.pre_stats) { if (g_conv_x3 == 9) LMKD_PATCH16(9, true, false); else LMKD_PATCH16(6, true, false); }
+      else if (a.pre_stats) {
+        if (g_conv_x3 == 9) LMKD_PATCH16(9, true, false);
+        else if (g_conv_h2 && a.h2_xw) { LMKD_PATCH16(3, true, false); ++g_h2_launches; }      // h2_xw: a bound of relu(BatchNorm(x)) (lmkd_bn_finalize_bound)
+        else LMKD_PATCH16(6, true, false);
+      }
       else if (g_conv_h2 && a.h2_xw) { LMKD_PATCH16(3, false, false); ++g_h2_launches; }
       else { if (g_conv_x3 == 9) LMKD_PATCH16(9, false, false); else LMKD_PATCH16(6, false, false); }
 #undef LMKD_PATCH16
@@ -1198,6 +1212,7 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
   memset(&a, 0, sizeof(a));
   a.src = x; a.wpk = wp; a.out = y; a.stat_partial = stat_partial;
   a.h2_xw = take_amax_x(); (void)take_amax_dy();
+  a.amax_out = take_amax_out();
   a.ep_stats = ep_stats; a.ep_res = ep_res; a.ep_relu = ep_relu;
   a.pre_stats = pre_stats;
   LMKD_REQUIRE(!pre_stats || (stat_partial && !smallc && !g_lmkd_act_bf16),
@@ -1273,9 +1288,19 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
     LMKD_CHECK_LAUNCH("conv_stem_patch_kernel");
     return LMKD_OK;
   }
-  if (ep_stats) return smallc ? launch_conv_gemm<true, 2>(a, Cout, s) : launch_conv_gemm<false, 2>(a, Cout, s);
-  if (smallc) return stat_partial ? launch_conv_gemm<true, 1>(a, Cout, s) : launch_conv_gemm<true, 0>(a, Cout, s);
-  return stat_partial ? launch_conv_gemm<false, 1>(a, Cout, s) : launch_conv_gemm<false, 0>(a, Cout, s);
+  t_amax_recorded = false;
+  int rc;
+  if (ep_stats) rc = smallc ? launch_conv_gemm<true, 2>(a, Cout, s) : launch_conv_gemm<false, 2>(a, Cout, s);
+  else if (smallc) rc = stat_partial ? launch_conv_gemm<true, 1>(a, Cout, s) : launch_conv_gemm<true, 0>(a, Cout, s);
+  else rc = stat_partial ? launch_conv_gemm<false, 1>(a, Cout, s) : launch_conv_gemm<false, 0>(a, Cout, s);
+  if (rc == LMKD_OK && a.amax_out && !t_amax_recorded && !g_lmkd_act_bf16) {
+    // lmkd_conv_output_amax on a launch whose kernel does not fold the maximum in its epilogue: a reduction pass of its own per frame
+    // segment (rare shapes; the trunk's 3x3 convolutions all run conv_patch16_x3_kernel) - the words are never left at "unknown"
+    const long per = (long)a.Ho * a.Wo * Cout, n0 = seg_n0 ? seg_n0 * per : (long)N * per;
+    rc = amax_impl(y, n0, a.amax_out, 1, stream, false);
+    if (rc == LMKD_OK && seg_n0) rc = amax_impl(y + n0, (long)N * per - n0, a.amax_out + LMKD_AMAX_SEG_WORDS, 1, stream, false);
+  }
+  return rc;
 }
 
 extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float* stat_partial, int N, int H, int W, int Cs,
@@ -1658,7 +1683,10 @@ static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const 
   do {                                                                                                                  \
     if (g_wgrad_win16 && g_conv_x3 && !g_lmkd_act_bf16) {      /* three-plane modes, fp32 tensors: the 16x16x32 MFMA form */ \
       if (g_conv_x3 == 9) { if (pre_stats) LMKD_WIN16(COB, 9, true); else LMKD_WIN16(COB, 9, false); }                  \
-      else if (g_conv_h2 && !pre_stats && w.h2_xw && w.h2_dyw) { LMKD_WIN16(COB, 3, false); ++g_h2_launches; }          \
+      else if (g_conv_h2 && w.h2_xw && w.h2_dyw) {                                                                      \
+        if (pre_stats) LMKD_WIN16(COB, 3, true); else LMKD_WIN16(COB, 3, false);                                        \
+        ++g_h2_launches;                                                                                                \
+      }                                                                                                                 \
       else { if (pre_stats) LMKD_WIN16(COB, 6, true); else LMKD_WIN16(COB, 6, false); }                                 \
       break;                                                                                                            \
     }                                                                                                                   \

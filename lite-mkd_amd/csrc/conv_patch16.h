@@ -234,7 +234,6 @@ __device__ __forceinline__ void patch16_fill_adp(unsigned short* __restrict__ s_
 template <class Cfg, int NPROD, bool PRE, bool EP, bool SRC2 = false>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kernel(ConvGemmArgs a) {
   static_assert(NPROD == 6 || NPROD == 9 || NPROD == 3, "three bf16 planes (6 / 9 products) or two fp16 planes (3 products)");
-  static_assert(NPROD != 3 || !PRE, "two-plane form: the operand's maximum comes from its producer, a BatchNorm applied in the loader has none");
   static_assert(!SRC2 || !PRE, "the stride-2 source form has no BatchNorm loader");
   constexpr int NPL = 3;
   constexpr int NPU = NPROD == 3 ? 2 : 3;      // planes stored / read / multiplied (the LDS rows keep their three-plane pitch)
@@ -512,6 +511,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   // ---- epilogue: lane = (pixel patch16_pixel(lane % 16) of each 16-pixel block, channels 4 kq .. 4 kq + 3 of each 16-channel block)
   const int ch0 = n0 + wn * (Cfg::TN * 32) + 4 * kq;      // + 16 c
   float4 s1[NC], s2[NC];
+  float amo = 0.f;      // max |out| of this lane (ConvGemmArgs::amax_out)
   float4 esc[NC], esh[NC];
   float4 bmean[NC], bistd[NC];      // bnb_x: the BatchNorm table of this lane's channels, once per tile (esc / esh hold scale / shift)
   const bool bnb = !EP && a.bnb_x != nullptr;
@@ -561,7 +561,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       } else if (a.accum) {
         v.x += prev[c].x; v.y += prev[c].y; v.z += prev[c].z; v.w += prev[c].w;
       }
-      if (ok) *reinterpret_cast<float4*>(a.out + (long)ob + col) = v;
+      if (ok) {
+        *reinterpret_cast<float4*>(a.out + (long)ob + col) = v;
+        amo = amax4(amo, v);
+      }
       if (!EP) {
         if (bnb) {      // sums of the BatchNorm backward this gradient feeds (ConvGemmArgs::bnb_x): bn_bwd_reduce_kernel's terms, mask mode 2
           if (ok) {
@@ -580,6 +583,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       }
     }
   }
+  if (a.amax_out) amax_commit(a.amax_out + sg.seg * LMKD_AMAX_SEG_WORDS, amo);      // (every wave of the workgroup reaches this point)
   if (!EP && a.stat_partial) {
     // sum over the 16 pixel lanes of each 16-lane row, then over the WM row groups of the workgroup through LDS
 #pragma unroll

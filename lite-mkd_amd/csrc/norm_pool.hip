@@ -262,14 +262,17 @@ __device__ __forceinline__ bool colsum_ticket(const float* __restrict__ in, int 
 __global__ void bn_finalize_kernel(const float* __restrict__ part, int T, int C, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, float* __restrict__ stats, double* __restrict__ scratch,
-                                   unsigned* __restrict__ tickets, int T0 = 0, double count1 = 0.0, int S0 = 0, int S1 = 0) {
+                                   unsigned* __restrict__ tickets, int T0 = 0, double count1 = 0.0, int S0 = 0, int S1 = 0,
+                                   const unsigned* __restrict__ c_words = nullptr, unsigned* __restrict__ bound_words = nullptr) {
   __shared__ double sm[CS_LANES][CS_COLS];
   __shared__ double tot[CS_COLS];
   __shared__ int s_last;
   int S = 0;
   if (gridDim.z > 1) {
-    if (blockIdx.z) { part += (long)T0 * 2 * C; T -= T0; count = count1; stats += 5 * C; scratch += (long)CS_MAX_SLICES * 2 * C; tickets += LMKD_TICKET_WORDS / 2; S = S1; }
-    else { T = T0; S = S0; }
+    if (blockIdx.z) {
+      part += (long)T0 * 2 * C; T -= T0; count = count1; stats += 5 * C; scratch += (long)CS_MAX_SLICES * 2 * C; tickets += LMKD_TICKET_WORDS / 2; S = S1;
+      if (c_words) { c_words += LMKD_AMAX_SEG_WORDS; bound_words += LMKD_AMAX_SEG_WORDS; }
+    } else { T = T0; S = S0; }
   }
   if (!colsum_ticket(part, T, 2 * C, scratch, tickets, sm, tot, &s_last, nullptr, S)) return;
   const int c = blockIdx.x * (CS_COLS / 2) + threadIdx.x;
@@ -286,6 +289,21 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int T, int C,
   stats[3 * C + c] = b - (float)mean * g * invstd;
   const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
   stats[4 * C + c] = (float)unb;
+  if (c_words) {
+    // lmkd_bn_finalize_bound: max over the elements of channel c of relu(x scale + shift) <= |scale| max |x| + |shift|, with max |x| over
+    // the whole tensor (the convolution's epilogue recorded it: lmkd_conv_output_amax) - an upper bound of max |relu(BatchNorm(x))|, which
+    // is all the two-plane kernels need from a maximum (a bound that is 2^k too large costs k of the 17 binades of full precision).
+    // A recorded maximum of zero means "not recorded" (the convolution ran another kernel): the bound stays zero = unknown.
+    unsigned gm = 0u;
+    for (int s = 0; s < LMKD_AMAX_SLOTS; ++s) {
+      const unsigned u = c_words[s * LMKD_AMAX_STRIDE];
+      gm = u > gm ? u : gm;
+    }
+    if (gm) {
+      const float bnd = fabsf(g * invstd) * __uint_as_float(gm) + fabsf(b - (float)mean * g * invstd);
+      atomicMax(bound_words + (c & (LMKD_AMAX_SLOTS - 1)) * LMKD_AMAX_STRIDE, __float_as_uint(bnd));
+    }
+  }
   if (running_mean) {
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
@@ -383,14 +401,29 @@ __global__ void bn_eval_stats_kernel(int C, const float* __restrict__ gamma, con
   stats[4 * C + c] = running_var[c];
 }
 
+// One-shot, per host thread: the NEXT lmkd_bn_finalize(_seg) launch also writes, into `bound_words` (lmkd_amax_next's layout, zeroed by
+// the caller), an upper bound of max |relu(BatchNorm(x))| per frame segment, from its scale / shift tables and max |x| in `x_words` (the
+// words the convolution that wrote x recorded: lmkd_conv_output_amax).  This is the maximum lmkd_conv_operand_amax names for a
+// convolution that applies the BatchNorm + ReLU in its loader (lmkd_conv2d_fwd_pre, lmkd_conv2d_bwd_weight_pre) in mode 4.
+static thread_local const unsigned* g_bound_in = nullptr;
+static thread_local unsigned* g_bound_out = nullptr;
+extern "C" int lmkd_bn_finalize_bound(const void* x_words, void* bound_words) {
+  g_bound_in = (const unsigned*)x_words;
+  g_bound_out = (unsigned*)bound_words;
+  return LMKD_OK;
+}
 // partial: [T][C][2] (sum, sumsq) from the conv epilogue; scratch: >= 64*2*C doubles; tickets: lmkd_ticket_words() zeroed words
 extern "C" int lmkd_bn_finalize(const float* partial, int T, int C, long count, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* stats,
                                 double* scratch, unsigned* tickets, void* stream) {
+  const unsigned* bin = g_bound_in;
+  unsigned* bout = g_bound_out;
+  g_bound_in = nullptr; g_bound_out = nullptr;
+  if (!bin || !bout) { bin = nullptr; bout = nullptr; }
   LMKD_REQUIRE(partial && stats && scratch && tickets && T > 0 && C > 0 && count > 0, "lmkd_bn_finalize: bad arguments");
   LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS, "lmkd_bn_finalize: C=%d exceeds the ticket buffer", C);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(2 * C, CS_COLS), cs_slices(T)), dim3(CS_COLS, CS_LANES), 0, (hipStream_t)stream, partial, T,
-                     C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, stats, scratch, tickets);
+                     C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, stats, scratch, tickets, 0, 0.0, 0, 0, bin, bout);
   LMKD_CHECK_LAUNCH("bn_finalize_kernel");
   return LMKD_OK;
 }
@@ -400,11 +433,15 @@ extern "C" int lmkd_bn_finalize(const float* partial, int T, int C, long count, 
 // (two segments = two sequential updates: lmkd_bn_running_update_multi applies them in order).  scratch: >= 2 * 64 * 2 * C doubles.
 extern "C" int lmkd_bn_finalize_seg(const float* partial, int T, int T0, int C, long count0, long count1, const float* gamma, const float* beta,
                                     float eps, float* stats, double* scratch, unsigned* tickets, void* stream) {
+  const unsigned* bin = g_bound_in;
+  unsigned* bout = g_bound_out;
+  g_bound_in = nullptr; g_bound_out = nullptr;
+  if (!bin || !bout) { bin = nullptr; bout = nullptr; }
   LMKD_REQUIRE(partial && stats && scratch && tickets && T0 > 0 && T > T0 && C > 0 && count0 > 0 && count1 > 0, "lmkd_bn_finalize_seg: bad arguments");
   LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS / 2, "lmkd_bn_finalize_seg: C=%d exceeds the ticket buffer", C);
   const int S0 = cs_slices(T0), S1 = cs_slices(T - T0);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(2 * C, CS_COLS), std::max(S0, S1), 2), dim3(CS_COLS, CS_LANES), 0, (hipStream_t)stream, partial, T,
-                     C, (double)count0, gamma, beta, (float*)nullptr, (float*)nullptr, 0.f, eps, stats, scratch, tickets, T0, (double)count1, S0, S1);
+                     C, (double)count0, gamma, beta, (float*)nullptr, (float*)nullptr, 0.f, eps, stats, scratch, tickets, T0, (double)count1, S0, S1, bin, bout);
   LMKD_CHECK_LAUNCH("bn_finalize_kernel");
   return LMKD_OK;
 }

@@ -251,7 +251,6 @@ template <int COB, int NPROD, int R, bool PRE = false, int TPW = 9, int JW = 2>
 __global__ __launch_bounds__(64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW), JW == 2 ? 2 : 3) void conv_wgrad_win16_kernel(WgradWinArgs a) {
   static_assert(JW == 2 || (JW == 1 && TPW == 9), "the channel-block split exists for nine taps per wave");
   static_assert(NPROD == 6 || NPROD == 9 || NPROD == 3, "three bf16 planes (6 / 9 products) or two fp16 planes (3 products: conv_patch16.h)");
-  static_assert(NPROD != 3 || !PRE, "two-plane form: no BatchNorm in the loader (the operand's maximum comes from its producer)");
   constexpr int NPL = NPROD == 3 ? 2 : 3;
   constexpr int THREADS = 64 * COB * ((9 + TPW - 1) / TPW) * (2 / JW), BM = 32 * COB;
   constexpr int LDA = BM * 2 + 32, A_PLANE = LMKD_BK * LDA;      // dy image [k][co], bytes

@@ -533,15 +533,17 @@ def _amax_record(t, what=None):
         t._lmkd_amax = w
 
 
-def _amax_ptr(t):
-    w = getattr(t, "_lmkd_amax", None) if t is not None else None
+def _amax_ptr(t, pre=False):
+    """pre: t is a raw convolution output that the consumer normalises + rectifies in its loader: the words are the BOUND of
+    max |relu(BatchNorm(t))| that lmkd_bn_finalize_bound wrote (_conv_bn_train_or_eval(bound=True))"""
+    w = getattr(t, "_lmkd_pre_amax" if pre else "_lmkd_amax", None) if t is not None else None
     return w.data_ptr() if w is not None else None
 
 
-def _amax_operands(x, dy):
+def _amax_operands(x, dy, pre=False):
     """call immediately before a convolution launch (one-shot): the words of its operands, where they are known"""
     if _h2_mode():
-        lib().call("lmkd_conv_operand_amax", _amax_ptr(x), _amax_ptr(dy))
+        lib().call("lmkd_conv_operand_amax", _amax_ptr(x, pre), _amax_ptr(dy))
 
 
 def amax_compute(t, seg=0):
@@ -684,7 +686,7 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None, seg=0
     cin = 3 if Cs == 4 else Cs
     with _timed(_conv_family(0, N, H, W, Cs, cin, Cout, KH, KW, stride, pad), 2.0 * N * Ho * Wo * Cout * cin * KH * KW,
                 x.element_size() * x.numel() + y.element_size() * y.numel() + 4 * wp.numel()):
-        _amax_operands(x if pre_stats is None else None, None)
+        _amax_operands(x, None, pre=pre_stats is not None)
         if seg:
             lib().call("lmkd_conv2d_fwd_seg", _p(x), _p(pre_stats), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, seg, _stream())
         elif pre_stats is not None:
@@ -749,7 +751,7 @@ def conv_bwd_weight(x, dy, w_shape, stride, pad, pre_stats=None, acc_into=None, 
     dw = acc_into if acc_into is not None else _empty(w_shape, x)
     with _timed("conv_wgrad_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
                 x.element_size() * x.numel() + dy.element_size() * dy.numel() + 4 * dw.numel()):
-        _amax_operands(x if pre_stats is None else None, dy)
+        _amax_operands(x, dy, pre=pre_stats is not None)
         if seg:
             lib().call("lmkd_conv2d_bwd_weight_seg", _p(x), _p(pre_stats), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW,
                        stride, pad, int(acc_into is not None), seg, _stream())
@@ -872,9 +874,10 @@ def weight_grad(w, x, dy, stride, pad, pre_stats=None, seg=0):
     x.record_stream(sw)
     dy.record_stream(sw)
     for t in (x, dy):      # ... and the words holding their maxima (fp32h2): the side-stream kernel reads them when it starts
-        wm = getattr(t, "_lmkd_amax", None)
-        if wm is not None:
-            wm.record_stream(sw)
+        for attr in ("_lmkd_amax", "_lmkd_pre_amax"):
+            wm = getattr(t, attr, None)
+            if wm is not None:
+                wm.record_stream(sw)
     if pre_stats is not None:      # read by the side-stream kernel too: its block must not be recycled under it
         pre_stats.record_stream(sw)
     _join_at_backward_end()
@@ -885,10 +888,16 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
+_PENDING_BOUND = [None]      # (words of max |y|, words for the bound): set by _conv_bn_train_or_eval(bound=True), consumed by the next bn_stats_train
+
+
 def bn_stats_train(part, count, gamma, beta, running_mean, running_var, seg=None):
     """seg = (T0, count0): two frame segments - partial rows [0, T0) / [T0, T), count0 / count - count0 elements per channel ->
     stats [2, 5, C]; the running statistics are not touched (the caller defers both updates: apply_deferred)"""
     T, C, _ = part.shape
+    pb, _PENDING_BOUND[0] = _PENDING_BOUND[0], None
+    if pb is not None:
+        lib().call("lmkd_bn_finalize_bound", pb[0].data_ptr(), pb[1].data_ptr())      # one-shot: the finalize launch below
     if seg is not None:
         T0, count0 = seg
         if running_mean is not None or running_var is not None:
@@ -1103,13 +1112,21 @@ def _train_pre():
     the activation memory go away; the one-plane bf16 mode keeps the materialised activation (56.0 vs 59.7)."""
     cd = lib().value("lmkd_conv_get_compute_dtype")
     return (FUSE_TRAIN_BN and _ACT_DTYPE[0] is torch.float32
-            and (FUSE_PRE_ALL_MODES or cd == 0 or (cd in (2, 3) and PRE_IN_PLANE_MODES)))
+            and (FUSE_PRE_ALL_MODES or cd == 0 or (cd in (2, 3, 4) and PRE_IN_PLANE_MODES)))
 
 
-def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training, pre_stats=None, seg=0):
+def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training, pre_stats=None, seg=0, bound=False):
+    """bound (fp32h2, training): the output y feeds a consumer that applies relu(BatchNorm(y)) in its loader - the convolution records
+    max |y| (lmkd_conv_output_amax) and the statistics launch turns it into a bound of max |relu(BatchNorm(y))| per frame segment
+    (lmkd_bn_finalize_bound), which travels with y as `_lmkd_pre_amax`"""
     Cout, _, KH, KW = w.shape
     wp = pack_weights(w, Cs, 0)
     seg = _seg_frames(seg, x.shape[0]) if training else 0      # eval: one table (the running statistics) for every frame
+    bw = None
+    if bound and training and x.dtype is torch.float32 and _h2_mode():
+        cw, bw = _amax_slot(x.device), _amax_slot(x.device)
+        lib().call("lmkd_conv_output_amax", cw.data_ptr())      # one-shot: the conv_fwd launch below
+        _PENDING_BOUND[0] = (cw, bw)
     if seg:
         # both trunk calls of the episode in this launch: per-segment batch statistics -> [2, 5, C]; the two running-statistics updates are
         # deferred and applied in the reference's order (support call, then query call) by apply_deferred
@@ -1120,8 +1137,12 @@ def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training,
         stats = bn_stats_train(part, count, gamma, beta, None, None, seg=(T0, seg * (count // y.shape[0])))
         _DEFER.append((rm, rv, stats[0]))
         _DEFER.append((rm, rv, stats[1]))
+        if bw is not None:
+            y._lmkd_pre_amax = bw
         return y, stats
     y, part = conv_fwd(x, wp, Cout, KH, KW, stride, pad, training, pre_stats)
+    if bw is not None:
+        y._lmkd_pre_amax = bw
     if training:
         if _DEFER is not None:
             stats = bn_stats_train(part, y.numel() // Cout, gamma, beta, None, None)
@@ -1370,7 +1391,7 @@ class BasicBlockFn(torch.autograd.Function):
         fused = training and _train_fused()
         pre = training and _train_pre()
         seg = _seg_frames(seg, x.shape[0]) if training else 0
-        c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, stride, 1, g1, b1, rm1, rv1, training, seg=seg)
+        c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, stride, 1, g1, b1, rm1, rv1, training, seg=seg, bound=pre)
         if pre:         # conv2 normalises + rectifies c1 in its loader: a1 = relu(bn1(c1)) is never stored
             a1 = None
             c2, st2 = _conv_bn_train_or_eval(c1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training, pre_stats=st1, seg=seg)
@@ -1399,6 +1420,7 @@ class BasicBlockFn(torch.autograd.Function):
             # fused: the backward needs neither a1 (recomputed from c1 in the weight-gradient loader) nor y (its mask travels as bits)
             ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, ybits if fused else y, wd, gd, cd, std)
             ctx.amax = (getattr(x, "_lmkd_amax", None), getattr(a1, "_lmkd_amax", None) if a1 is not None else None)
+            ctx.pre_amax = getattr(c1, "_lmkd_pre_amax", None)
         return y
 
     @staticmethod
@@ -1409,6 +1431,8 @@ class BasicBlockFn(torch.autograd.Function):
         for t, wm in zip((x, a1), ctx.amax):      # the maxima recorded in the forward (saved tensors may come back as new objects)
             if t is not None and wm is not None:
                 t._lmkd_amax = wm
+        if ctx.pre_amax is not None:
+            c1._lmkd_pre_amax = ctx.pre_amax
         dy = dy.contiguous()
         stride = ctx.stride
         seg = ctx.seg
@@ -1460,7 +1484,7 @@ class BottleneckFn(torch.autograd.Function):
         fused = training and _train_fused()
         pre = training and _train_pre()
         seg = _seg_frames(seg, x.shape[0]) if training else 0      # two frame segments (BasicBlockFn)
-        c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, 1, 0, g1, b1, rm1, rv1, training, seg=seg)
+        c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, 1, 0, g1, b1, rm1, rv1, training, seg=seg, bound=pre)      # (c1 feeds the 3x3 convolution's loader)
         if pre:         # conv2 / conv3 normalise + rectify their raw inputs in the loader (BasicBlockFn)
             a1 = a2 = None
             c2, st2 = _conv_bn_train_or_eval(c1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training, pre_stats=st1, seg=seg)

@@ -338,3 +338,40 @@ def test_words_are_protected_on_every_stream_that_reads_them(dev, monkeypatch):
     assert second.data_ptr() == first.data_ptr() + 4 * first.numel()
     assert (pool_ptr, torch.int32, side.cuda_stream) in calls, "the pool was not recorded on the second stream"
     torch.cuda.synchronize()
+
+
+def test_bound_of_the_loader_side_batchnorm(dev):
+    """a consumer that applies relu(BatchNorm(c)) in its loader scales by a BOUND of the activation's maximum: the convolution records
+    max |c| (lmkd_conv_output_amax: in its epilogue, or - a launch on another kernel - by a pass of its own), the statistics launch folds
+    |scale| max |c| + |shift| over the channels (lmkd_bn_finalize_bound).  The bound is never below the true maximum (an overflow of
+    the fp16 planes otherwise) and, on unit-variance data, within 2^4 of it; the consumers then agree with the three-plane form to fp32
+    rounding"""
+    import litemkd_amd
+    from litemkd_amd import ops
+    g = torch.Generator(device=dev).manual_seed(10)
+    for (N, seg, H, Cin, C, stride) in ((6, 0, 14, 64, 64, 1), (6, 2, 28, 64, 128, 2), (4, 0, 14, 96, 64, 1)):      # the last: 96 channels -> not the patch kernel's tiles
+        x = ops.amax_compute(torch.relu(torch.randn(N, H, H, Cin, device=dev, generator=g)), seg)
+        w1 = torch.randn(C, Cin, 3, 3, device=dev, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+        w2 = torch.randn(C, C, 3, 3, device=dev, generator=g) * (2.0 / (9 * C)) ** 0.5
+        gam, bet = 1 + 0.3 * torch.randn(C, device=dev, generator=g), 0.3 * torch.randn(C, device=dev, generator=g)
+        upd = []
+        ops.set_defer(upd)
+        try:
+            c1, st1 = ops._conv_bn_train_or_eval(x, w1, Cin, stride, 1, gam, bet, torch.zeros(C, device=dev), torch.ones(C, device=dev), True, seg=seg, bound=True)
+            a1 = ops.bn_apply(c1, st1, True, seg=seg)
+            words = c1._lmkd_pre_amax.view(torch.float32)
+            half = words.numel() // 2
+            parts = [a1] if not seg else [a1[:seg], a1[seg:]]
+            for i, p in enumerate(parts):
+                bound, true = float(words[i * half:(i + 1) * half].max()), float(p.max())
+                assert true <= bound <= 16 * true, (N, seg, C, i, bound, true)
+            # the consumer: conv2 with the BatchNorm in its loader, two-plane against three-plane
+            n0 = _launches()
+            y_h2 = ops.conv_fwd(c1, ops._pack_weights(w2, C, 0), C, 3, 3, 1, 1, True, pre_stats=st1, seg=seg)[0]
+            assert _launches() - n0 == 1
+            ops.set_conv_compute_dtype("fp32x3")
+            y_x3 = ops.conv_fwd(c1, ops._pack_weights(w2, C, 0), C, 3, 3, 1, 1, True, pre_stats=st1, seg=seg)[0]
+            ops.set_conv_compute_dtype("fp32h2")
+            assert float((y_h2 - y_x3).norm() / y_x3.norm()) < 2e-6
+        finally:
+            ops.set_defer(None)
