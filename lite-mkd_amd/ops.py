@@ -1482,7 +1482,10 @@ class BottleneckFn(torch.autograd.Function):
             r = x if wd is None else conv_bn_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, False)
             return conv_bn_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, True, r)
         fused = training and _train_fused()
-        pre = training and _train_pre()
+        # fp32h2: the 3x3 convolution's raw input c1 comes from a 1x1 convolution (a gather kernel: no maximum in its epilogue, a reduction
+        # pass instead); materialising relu(bn1(c1)) - whose BatchNorm-apply records the maximum for free - is faster here (ResNet-50 + MFM:
+        # 12.4 against 11.9 episodes/s), so the Bottleneck keeps the loader-side BatchNorm for the other arithmetics only
+        pre = training and _train_pre() and not (os.environ.get("LMKD_R50_PRE_H2", "0") != "1" and _h2_mode())
         seg = _seg_frames(seg, x.shape[0]) if training else 0      # two frame segments (BasicBlockFn)
         c1, st1 = _conv_bn_train_or_eval(x, w1, Cs, 1, 0, g1, b1, rm1, rv1, training, seg=seg, bound=pre)      # (c1 feeds the 3x3 convolution's loader)
         if pre:         # conv2 / conv3 normalise + rectify their raw inputs in the loader (BasicBlockFn)
