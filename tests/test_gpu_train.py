@@ -493,3 +493,21 @@ def test_train_cli_synthetic_and_clip_directory(dev, tmp_path):
     losses, accs = T.main(["--shot", "1", "--query_per_class", "1", "--img_size", "84", "--tasks_per_batch", "2", "--training_iterations", "4",
                            "--no_save", "--data_dir", str(root), "--dtype", "bf16", "--test_iters", "100", "--seed", "3"])
     assert len(losses) == 4 and all(np.isfinite(losses))
+
+
+def test_rccl_one_rank_rehearsal(dev):
+    """every RCCL call of the multi-GPU path on the real backend (process group "nccl", ONE rank - the test box has one GPU, and two ranks
+    of one communicator cannot share it): the early all-reduce of the bucket's tail from its communication stream, the head's all-reduce,
+    broadcast, the float64 MAX reductions, all_gather_object, barrier, the BatchNorm pooling - tools/rccl_rehearsal.py in a process of its
+    own (a process group is per process).  The two-rank arithmetic is covered over gloo (test_data_parallel_world2_equals_world1)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_rehearsal.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL one-rank rehearsal ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
