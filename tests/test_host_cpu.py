@@ -306,6 +306,12 @@ def test_train_cli_parses_the_reference_command_line():
     for k, v in ref_defaults.items():
         assert getattr(d, k) == v, k
     assert d.cfg["temperature"] == 4 and d.cfg["soft_loss_weight"] == 2
+    # the default arithmetic and schedule are the ones bench.py times; the reference's fp32 semantics under other arithmetics stay selectable
+    s = T.schedule_from_args(d)
+    assert (s.conv_dtype, s.act_dtype, s.merge_trunk_calls, s.pipeline_episodes) == ("fp32h2", "fp32", True, True)
+    assert T.schedule_from_args(p.parse_args(["--dtype", "f32x3"])).conv_dtype == "fp32x3"
+    assert T.schedule_from_args(p.parse_args(["--dtype", "bf16"])).act_dtype == "bf16"
+    assert not T.schedule_from_args(p.parse_args(["--dtype", "f32native"])).merge_trunk_calls
     # when the reference tree is at hand (the build container), every `--flag` its parser and its script name is known here
     ref = "/root/reference"
     if os.path.isdir(ref):
