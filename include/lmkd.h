@@ -74,28 +74,48 @@ int lmkd_set_elementwise_wg_per_cu(int n); /* tuning: grid cap of the HBM-bound 
    v_mfma_f32_16x16x32_f16 products per fp32 product: x 2^s = h0 + h1 with h0 = fp16(x 2^s), h1 = fp16(x 2^s - h0) (round to nearest)
    represents x to 2^-23 (one fp32 ulp; exactly for at least half of all fp32 values; zero-mean), the dropped h1 h1' term is <= 2^-22
    of the product with zero mean (mode 2 drops <= 2^-23, all of one sign: its planes are truncations), accumulation stays fp32, and 2^s
-   is a power of two taken from the tensor's maximum (lmkd_conv_operand_amax), so the scaling is exact.  Measured error against fp64
+   is a power of two taken from the tensor's maximum (lmkd_amax_desc::x_words / dy_words), so the scaling is exact.  Measured error against fp64
    at or below mode 2's on every layer (profiles/r04_h2_error.txt).  A launch whose operand maxima are not named runs mode 2. */
 int lmkd_conv_set_compute_dtype(int mode);
-/* mode 4: the maxima of the operands of the NEXT convolution launch of this host thread (forward: x; data gradient: dy; weight gradient:
-   both), one-shot - consumed and cleared by that launch.  Each points at the lmkd_amax_words() device words of a maximum as
-   lmkd_amax_next / lmkd_amax write them (two frame segments x 64 slots, 64 bytes apart; the maximum of a segment is the largest of its
-   slots' fp32 bit patterns; any upper bound is valid), complete in stream order before the launch; null = unknown.  Ignored in the
-   other modes. */
-int lmkd_conv_operand_amax(const void* x_word, const void* dy_word);
-/* the NEXT launch of lmkd_bn_apply(_seg) / lmkd_bn_relu_maxpool_fwd(_seg) / lmkd_bn_backward(_seg) / lmkd_bn_backward_part(_seg) /
-   lmkd_stem_unpool_bn_bwd(_seg) / lmkd_nchw3_to_nhwc4 (one frame segment per call: the slots at `word`) on this host thread also folds max |y| (backward: max |dx|) into the lmkd_amax_words() words at `word`: every wave into one of 64 slots of
-   its elements' frame segment (float atomics execute at the memory side: thousands of them on one address cost more than the pass
-   itself), atomic max on the fp32 bits; the caller zeroes the words.
-   One-shot.  This is how a trunk tensor gets the word lmkd_conv_operand_amax names, without a pass of its own. */
-int lmkd_amax_next(void* word);
-/* mode 4, for a consumer that applies relu(BatchNorm(x)) in its loader (lmkd_conv2d_fwd_pre, lmkd_conv2d_bwd_weight_pre): (1) the NEXT
-   forward convolution launch of this thread records max |y| in `words` (only the launches that run conv_patch16_x3_kernel do: any other
-   leaves them zero = unknown); (2) the NEXT lmkd_bn_finalize(_seg) launch turns max |x| (`x_words`) and its scale / shift tables into
-   an upper bound of max |relu(BatchNorm(x))| per frame segment in `bound_words` (zeroed by the caller) - the words to name in
-   lmkd_conv_operand_amax for that consumer.  Both one-shot. */
-int lmkd_conv_output_amax(void* words);
-int lmkd_bn_finalize_bound(const void* x_words, void* bound_words);
+/* mode 4: the range bookkeeping of ONE launch, an explicit argument of the *_seg entry points, lmkd_bn_finalize and
+   lmkd_stem_unpool_bn_bwd (round 5; before: four one-shot "the next launch of this host thread" channels).  Every member is nullable and a
+   null struct pointer means "none"; the other modes ignore it.  A "maximum" is lmkd_amax_words() device words: two frame segments x 64
+   slots, 64 bytes apart (float atomics execute at the memory side: thousands of them on one address cost more than the pass itself);
+   word 0 of a slot holds fp32 bits folded with an atomic max - the maximum of a segment is the largest of its slots, and any upper bound
+   is a valid maximum - word 1 and words 2-3 the range statistics described under ref_words.  The caller zeroes the words before the
+   launch that writes them; they must be complete in stream order before a launch that reads them.
+     x_words / dy_words  convolutions: the maxima of the gathered operand (forward: x; data gradient: dy; weight gradient: both).  A launch
+                         whose operand maxima are not named runs mode 2.  With pre_stats: the BOUND written by lmkd_bn_finalize(_seg).
+                         lmkd_bn_finalize(_seg): x_words = max |x| recorded by the convolution that wrote the BatchNorm's input.
+     out_words           producers (lmkd_bn_apply_seg, lmkd_bn_relu_maxpool_fwd_seg, lmkd_bn_backward_seg, lmkd_bn_backward_part_seg,
+                         lmkd_stem_unpool_bn_bwd(_seg)): also fold max |result| into these words - this is how a trunk tensor gets its
+                         maximum without a pass of its own.  lmkd_conv2d_fwd_seg: also fold max |y| (in the epilogue of
+                         conv_patch16_x3_kernel, or by a reduction pass behind any other kernel).  lmkd_bn_finalize(_seg): turn x_words and
+                         the scale / shift tables into an upper bound of max |relu(BatchNorm(x))| per segment - the x_words of a consumer
+                         that applies the BatchNorm + ReLU in its loader (lmkd_conv2d_fwd_seg / lmkd_conv2d_bwd_weight_seg with pre_stats).
+     ref_words           producers, with out_words: words holding the maximum the same tensor had the last time it was written (previous
+                         episode; lmkd_h2_fence_eval maintains them).  The
+                         launch then also counts, per segment, n_small = nonzero elements below 2^-17 of that maximum (the two-plane split
+                         resolves those to an absolute 2^-40 of the maximum instead of a relative 2^-23) and Q = sum of min(|x| 2^17 /
+                         maximum, 1024) - integers, independent of the order of the waves.  lmkd_h2_fence_eval judges them (the range fence).
+     flags               LMKD_AMAX_FENCED: the caller withheld a maximum from this convolution because the fence had flagged its tensor
+                         (counted by lmkd_conv_h2_fallbacks). */
+typedef struct lmkd_amax_desc {
+  const void* x_words;
+  const void* dy_words;
+  void* out_words;
+  const void* ref_words;
+  int flags;
+} lmkd_amax_desc;
+#define LMKD_AMAX_FENCED 1
+/* the range fence: entry e of the HOST arrays words / refs = the words a producer has just written and the ref_words it was given - the
+   PERSISTENT reference words of that tensor's site (caller-owned, lmkd_amax_words() words, zero before the first episode).  flags[e]
+   (device ints) bit s is set when segment s has more than a quarter as much rounding-error mass in under-resolved elements (4 n_small > Q)
+   as in resolved ones - judged only where the reference was adequate (current maximum >= reference / 4).  Then refs[e] is overwritten
+   with this launch's maxima: the reference of the next episode.  The caller stops naming a flagged tensor's maximum: its convolutions
+   run the three-plane form (mode 2), which has no range to speak of. */
+int lmkd_h2_fence_eval(const void* const* words, void* const* refs, int n, int* flags, void* stream);
+long lmkd_conv_h2_fallbacks(void); /* mode-4 launches that carried LMKD_AMAX_FENCED so far */
 /* max |x[0 .. n)| -> the slots of ONE frame segment at `word` (lmkd_amax_words() / 2 words, zeroed here first; segment 1 of a tensor's
    maximum starts lmkd_amax_words() / 2 words in): a pass of its own, for tensors no kernel of this library wrote */
 int lmkd_amax(const float* x, long n, void* word, void* stream);
@@ -123,7 +143,6 @@ int lmkd_conv_set_wgrad_win16(int on); /* tuning (modes 2-3, fp32 tensors): 1 = 
 int lmkd_conv_set_wgrad_stem(int on); /* tuning (modes 2-3, fp32 tensors): 1 = the stem's weight gradient on stem_wgrad_kernel (input rows resident in LDS, no im2col copy; default), 0 = im2col-gather kernel */
 int lmkd_conv_set_wgrad_window(int on); /* tuning (modes 1-3): 1 = 3x3 / stride-1 weight gradients read a rolling LDS window of x, all nine taps per workgroup (default), 0 = im2col-gather kernel */
 int lmkd_conv_set_patch16(int on); /* tuning (modes 2/3, fp32 tensors): 1 = the 4-wave patch tiles run on v_mfma_f32_16x16x32_bf16 (conv_patch16_x3_kernel, default), 0 = on 32x32x16 (conv_patch_x3_kernel) */
-int lmkd_conv_set_patch_debug(int mask); /* measurement only: timing ablations of the patch kernel (results are garbage): 1 no weight-fragment loads, 2 no A-fragment LDS reads, 4 no patch split / store, 8 no output stores; 0 = off */
 int lmkd_conv_set_xcd_mode(int mode); /* tuning: -1 auto (XCD-aware tile order + XCD-grouped weight-gradient splits), 0 plain orders, 1 auto without the weight-gradient grouping */
 int lmkd_conv_set_tile(int id); /* tuning: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 64x128 */
 /* stat_partial (nullable): [row_tiles][Cout][2] per-tile (sum, sum of squares) for train-mode BatchNorm */
@@ -179,7 +198,8 @@ int lmkd_frames_u8_to_nhwc4(const unsigned char* src, float* dst, const int* cro
 int lmkd_resize_plan(int in_size, int out_size, int* bounds_host, int* coeffs_host);
 int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst, const int* bounds_dev, const int* coeffs_dev, int ksize, long outer,
                         int n_in, int n_out, long inner, void* stream);
-int lmkd_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int N, int H, int W, void* stream);
+/* amax_words (nullable; mode 4): also fold max |y| into the slots of ONE frame segment at this address (lmkd_amax_words() / 2 words) */
+int lmkd_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int N, int H, int W, void* stream, void* amax_words);
 /* Ticket words: the single-launch column reductions (lmkd_bn_finalize, lmkd_bn_backward, lmkd_colsum) elect their finishing workgroup
  * through counters in a caller-owned buffer of lmkd_ticket_words() 32-bit words that must be ZERO on entry and is zero again when
  * the launch has finished; launches that may run concurrently (different streams) need different buffers. */
@@ -187,7 +207,8 @@ long lmkd_ticket_words(void);
 /* stats: [5][C] = mean, invstd, scale, shift, unbiased batch variance.  scratch: >= 64*2*C doubles.
  * running_mean/var may be NULL (update deferred to lmkd_bn_running_update) */
 int lmkd_bn_finalize(const float* partial, int T, int C, long count, const float* gamma, const float* beta, float* running_mean,
-                     float* running_var, float momentum, float eps, float* stats, double* scratch, unsigned* tickets, void* stream);
+                     float* running_var, float momentum, float eps, float* stats, double* scratch, unsigned* tickets, void* stream,
+                     const lmkd_amax_desc* amax /*nullable*/);
 int lmkd_bn_running_update(float* running_mean, float* running_var, const float* stats, int C, float momentum, void* stream);
 /* n BatchNorm layers in one launch: HOST arrays of n device pointers / channel counts; layer i applies stats_first[i], then (if not
    null) stats_second[i] - the two trunk calls of an episode in the reference's order */
@@ -227,7 +248,7 @@ int lmkd_bn_backward_stats(const float* dy, const float* cmax, const float* stat
                            float* coef, void* workspace, unsigned* tickets, long pooled_rows, long count, int C, int accumulate_param_grads,
                            void* stream);
 int lmkd_stem_unpool_bn_bwd(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef, float* dc,
-                            int N, int H, int W, int C, void* stream);
+                            int N, int H, int W, int C, void* stream, const lmkd_amax_desc* amax /*nullable*/);
 /* AdaptiveMaxPool2d((4,4)) + mean over the 16 patches: resnet18_2fc.py:44-54 */
 int lmkd_adaptive_maxpool_mean_fwd(const float* x, float* y, int F, int H, int W, int C, void* stream);
 int lmkd_adaptive_maxpool_mean_bwd(const float* x, const float* dy, float* dx, int F, int H, int W, int C, void* stream);
@@ -301,35 +322,37 @@ int lmkd_fill(float* p, float v, long n, void* stream);
  * seg_n0 = 0 or N (rows0 = rows, T0 = T) = one segment = the plain entry point.  Modes 1-3 of lmkd_conv_set_compute_dtype. */
 int lmkd_conv2d_fwd_row_tiles_seg(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0, int* tiles0 /*host, nullable*/);
 int lmkd_conv2d_fwd_seg(const float* x, const float* pre_stats /*nullable: [2][5][Cs], lmkd_conv2d_fwd_pre*/, const float* wp, float* y,
-                        float* stat_partial, int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0, void* stream);
+                        float* stat_partial, int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0, void* stream,
+                        const lmkd_amax_desc* amax /*nullable*/);
 int lmkd_conv2d_bwd_data_bn_tiles_seg(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int seg_n0, int* tiles0 /*host, nullable*/);
 int lmkd_conv2d_bwd_data_seg(const float* dy, const float* wd, float* dx, const float* bn_x /*nullable with bn_stats, part: lmkd_conv2d_bwd_data_bn*/,
                              const float* bn_stats, float* part, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                             int accumulate, int seg_n0, void* stream);
+                             int accumulate, int seg_n0, void* stream, const lmkd_amax_desc* amax /*nullable*/);
 long lmkd_conv2d_bwd_weight_workspace_seg(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0);
 int lmkd_conv2d_bwd_weight_seg(const float* x, const float* pre_stats /*nullable: [2][5][Cs]*/, const float* dy, float* dw_oihw, float* workspace,
                                long ws_bytes, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,
-                               int seg_n0, void* stream);
+                               int seg_n0, void* stream, const lmkd_amax_desc* amax /*nullable*/);
 /* BatchNorm family.  lmkd_bn_finalize_seg does not touch the running statistics (lmkd_bn_running_update_multi applies both segments'
    updates in the reference's order); scratch: 2 * 64 * 2 * C doubles.  The backward forms take coef = [2][5][C] floats of scratch and a
    workspace of 2 * lmkd_bn_bwd_workspace(C) bytes; dgamma / dbeta (+)= (segment 0's sums + segment 1's), written by the apply pass. */
 int lmkd_bn_finalize_seg(const float* partial, int T, int T0, int C, long count0, long count1, const float* gamma, const float* beta, float eps,
-                         float* stats /*[2][5][C]*/, double* scratch, unsigned* tickets, void* stream);
+                         float* stats /*[2][5][C]*/, double* scratch, unsigned* tickets, void* stream, const lmkd_amax_desc* amax /*nullable*/);
 int lmkd_bn_apply_seg(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows, long rows0, int C, int relu,
-                      int res_mode, unsigned* mask_bits, void* stream);
+                      int res_mode, unsigned* mask_bits, void* stream, const lmkd_amax_desc* amax /*nullable*/);
 int lmkd_bn_backward_seg(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dx, float* g_out,
                          float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, long rows0, int C, int mask_mode,
-                         int accumulate_param_grads, void* stream);
+                         int accumulate_param_grads, void* stream, const lmkd_amax_desc* amax /*nullable*/);
 int lmkd_bn_backward_part_seg(const float* part, int T, int T0, const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
                               float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, long rows0, int C,
-                              int accumulate_param_grads, void* stream);
+                              int accumulate_param_grads, void* stream, const lmkd_amax_desc* amax /*nullable*/);
 /* the stem (resnet children 0-3): BatchNorm + ReLU + max-pool forward, and its backward from the pooled side */
 int lmkd_bn_relu_maxpool_fwd_seg(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int N0, int H, int W, int C,
-                                 void* stream);
+                                 void* stream, const lmkd_amax_desc* amax /*nullable*/);
 int lmkd_bn_backward_stats_seg(const float* dy, const float* cmax, const float* stats, const float* gamma, float* coef, void* workspace,
                                unsigned* tickets, long pooled_rows, long pooled_rows0, long count, long count0, int C, void* stream);
 int lmkd_stem_unpool_bn_bwd_seg(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef, float* dc,
-                                float* dgamma, float* dbeta, int accumulate_param_grads, int N, int N0, int H, int W, int C, void* stream);
+                                float* dgamma, float* dbeta, int accumulate_param_grads, int N, int N0, int H, int W, int C, void* stream,
+                                const lmkd_amax_desc* amax /*nullable*/);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,16 @@ extern "C" void lmkd_set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
+// include/lmkd.h: the range bookkeeping of one launch in compute mode 4 (every member nullable; a null struct = none)
+struct lmkd_amax_desc {
+  const void* x_words;
+  const void* dy_words;
+  void* out_words;
+  const void* ref_words;
+  int flags;
+};
+#define LMKD_AMAX_FENCED 1      // lmkd_amax_desc::flags: the caller withheld an operand's maximum because the range fence flagged its tensor
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -79,6 +89,48 @@ __device__ __forceinline__ void amax_commit(unsigned* __restrict__ word, float m
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0 && m > 0.f)
     atomicMax(word + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (LMKD_AMAX_SLOTS - 1)) * LMKD_AMAX_STRIDE, __float_as_uint(m));
+}
+// Range statistics beside a maximum (the range fence of compute mode 4, include/lmkd.h lmkd_amax_desc::ref_words): a producer that is
+// given the maximum its result had LAST time (the reference) also counts, per frame segment, the nonzero elements that the two-plane
+// split cannot resolve fully against that reference - |x| < thr = 2^-17 reference: each of them carries an absolute error of up to
+// 2^-23 thr - and Q = sum of min(|x| / thr, 1024): the fully resolved elements carry up to 2^-23 |x| each, so 2^-23 thr Q bounds their
+// share.  n_small / Q is therefore the ratio of the two error masses; lmkd_h2_fence_eval flags a tensor where the under-resolved
+// elements would add more than a quarter.  Integers (the wave's float sum is rounded once, then added atomically): the result does
+// not depend on the order of the waves.  Slot layout: word 0 maximum, word 1 n_small (u32), words 2-3 Q (u64).
+struct AmaxRef { float thr, inv_thr; };      // thr = 0: no reference, nothing is counted
+__device__ __forceinline__ AmaxRef amax_ref(unsigned ref_bits) {
+  AmaxRef r;
+  const float m = __uint_as_float(ref_bits);
+  const bool ok = ref_bits != 0u && m * 7.62939453125e-06f > 0.f && m < 3.0e38f;      // 2^-17 m a normal-range number
+  r.thr = ok ? m * 7.62939453125e-06f : 0.f;
+  r.inv_thr = ok ? 1.f / r.thr : 0.f;
+  return r;
+}
+struct AmaxStat { float m, q; unsigned ns; };
+__device__ __forceinline__ void amax_stat4(AmaxStat& s, const float4& v, const AmaxRef& r) {
+  s.m = amax4(s.m, v);
+  const float a[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s.q += fminf(a[j] * r.inv_thr, 1024.f);
+    s.ns += (a[j] < r.thr && a[j] > 0.f) ? 1u : 0u;
+  }
+}
+__device__ __forceinline__ void amax_commit_stat(unsigned* __restrict__ word, const AmaxStat& s, bool counted) {      // whole wave active
+  amax_commit(word, s.m);
+  if (!counted) return;
+  float q = s.q;
+  unsigned ns = s.ns;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    q += __shfl_xor(q, o, 64);
+    ns += (unsigned)__shfl_xor((int)ns, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && (ns | (q > 0.f ? 1u : 0u))) {
+    unsigned* slot = word + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (LMKD_AMAX_SLOTS - 1)) * LMKD_AMAX_STRIDE;
+    if (ns) atomicAdd(slot + 1, ns);
+    atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)(q + 0.5f));
+  }
 }
 // the fp32 bits of the maximum of frame segment `seg` (wave-uniform; call with the whole wave active)
 __device__ __forceinline__ unsigned amax_read(const unsigned* __restrict__ word, int seg) {

@@ -14,6 +14,7 @@
 // Train-mode BatchNorm statistics (sum, sum of squares per channel) are reduced from the
 // accumulators in the forward epilogue into per-row-tile partials (deterministic).
 #include "gemm_core.h"
+#include <atomic>
 
 struct ConvGemmArgs {
   const float* src;
@@ -609,8 +610,11 @@ static int g_conv_x3 = 6;   // 0 | 6 | 9 bf16 MFMA products per fp32 product (co
 // forward (conv_stem_patch_kernel) - wherever the caller names the operands' maxima (lmkd_conv_operand_amax); every other launch (the
 // 1x1 forward, the inference epilogues, the loader-side BatchNorm), and every launch without them, runs mode 2.
 static int g_conv_h2 = 0;
-static long g_h2_launches = 0;      // launches that took the two-plane form (tests)
-extern "C" long lmkd_conv_h2_launches(void) { return g_h2_launches; }
+static std::atomic<long> g_h2_launches{0};       // launches that took the two-plane form (tests; the forward's thread and the autograd engine's both launch)
+static std::atomic<long> g_h2_fallbacks{0};      // mode-4 launches whose caller withheld a maximum because the range fence flagged the tensor (LMKD_AMAX_FENCED)
+extern "C" long lmkd_conv_h2_launches(void) { return g_h2_launches.load(); }
+extern "C" long lmkd_conv_h2_fallbacks(void) { return g_h2_fallbacks.load(); }
+static inline void note_fenced(const lmkd_amax_desc* am) { if (g_conv_h2 && am && (am->flags & LMKD_AMAX_FENCED)) ++g_h2_fallbacks; }
 extern "C" int lmkd_conv_set_compute_dtype(int mode) {
   LMKD_REQUIRE(mode >= 0 && mode <= 4, "lmkd_conv_set_compute_dtype: 0 fp32 MFMA, 1 bf16, 2 fp32 as 3xbf16 (6 products), 3 (9 products), 4 fp32 as 2xfp16 (3 products) over mode 2");
   g_conv_bf16 = mode == 1;
@@ -619,25 +623,13 @@ extern "C" int lmkd_conv_set_compute_dtype(int mode) {
   return LMKD_OK;
 }
 extern "C" int lmkd_conv_get_compute_dtype(void) { return g_conv_bf16 ? 1 : (g_conv_h2 ? 4 : (g_conv_x3 == 6 ? 2 : (g_conv_x3 == 9 ? 3 : 0))); }
-// the maxima of the NEXT convolution launch's operands on this host thread (one-shot: consumed - and cleared - by that launch):
-// x_word / dy_word: device words holding the fp32 bits of max |x| / max |dy| over the whole tensor (upper bounds are valid: a larger word
-// costs range, not correctness), complete in stream order before the launch.  Either may be null.  Only mode 4 reads them.
-static thread_local const unsigned* g_amax_x = nullptr;
-static thread_local const unsigned* g_amax_dy = nullptr;
-extern "C" int lmkd_conv_operand_amax(const void* x_word, const void* dy_word) {
-  g_amax_x = (const unsigned*)x_word;
-  g_amax_dy = (const unsigned*)dy_word;
-  return LMKD_OK;
-}
-// the NEXT forward launch of this host thread also folds max |y| into the words at `words` (lmkd_amax_next's layout; one-shot; only the
-// launches that run conv_patch16_x3_kernel do it - any other kernel leaves the words at zero, and a maximum of zero is "unknown").  With it
-// lmkd_bn_finalize_bound can bound relu(BatchNorm(y)) for a consumer that applies the BatchNorm in its loader.
-static thread_local unsigned* g_amax_out = nullptr;
-extern "C" int lmkd_conv_output_amax(void* words) { g_amax_out = (unsigned*)words; return LMKD_OK; }
-static inline unsigned* take_amax_out() { unsigned* p = g_amax_out; g_amax_out = nullptr; return p; }
-static thread_local bool t_amax_recorded = false;      // set by the launches whose kernel folds ConvGemmArgs::amax_out (conv_patch16_x3_kernel)
-static inline const unsigned* take_amax_x() { const unsigned* p = g_amax_x; g_amax_x = nullptr; return p; }
-static inline const unsigned* take_amax_dy() { const unsigned* p = g_amax_dy; g_amax_dy = nullptr; return p; }
+// The maxima of a launch's operands travel as explicit arguments (lmkd_amax_desc on the *_seg entry points; round 5 - before: one-shot
+// thread-local channels).  x_words / dy_words: device words holding the fp32 bits of max |x| / max |dy| per frame segment (upper bounds are
+// valid: a larger word costs range, not correctness), complete in stream order before the launch; either may be null; only mode 4 reads
+// them.  out_words (forward): the launch also folds max |y| into these words - in the epilogue of conv_patch16_x3_kernel, or by a
+// reduction pass of its own behind any other kernel - so that lmkd_bn_finalize_seg can bound relu(BatchNorm(y)) for a consumer that
+// applies the BatchNorm in its loader.
+static thread_local bool t_amax_recorded = false;      // (inside one call) set by the launch macros whose kernel folds ConvGemmArgs::amax_out
 // elements (16-bit) of the plane buffer of a packed weight of ncols x Kp in the current mode
 extern "C" long lmkd_conv2d_plane_elems(int ncols, int Kp) {
   const long n = (long)ncols * Kp;
@@ -905,7 +897,6 @@ static void launch_conv_cfg(ConvGemmArgs a, int ncols, hipStream_t s) {
 
 // hipFuncAttributeMaxDynamicSharedMemorySize of a kernel instance, once per (instance, device), from whichever host thread launches
 // first (the forward's thread and the autograd engine's both launch): `mask` is the instance's static bit set of devices done.
-#include <atomic>
 static inline void lmkd_lds_attr_once(std::atomic<unsigned long long>& mask, const void* fn, int bytes) {
   int d = 0;
   if (hipGetDevice(&d) != hipSuccess) d = 0;
@@ -943,8 +934,6 @@ static int g_conv_s2_patch = 1;      // stride-2 3x3 forward on conv_patch16_x3_
 extern "C" int lmkd_conv_set_s2_patch(int on) { g_conv_s2_patch = on ? 1 : 0; return LMKD_OK; }
 static int g_patch16 = 1;      // three-plane modes, fp32 tensors, the 4-wave tiles: conv_patch16_x3_kernel (v_mfma_f32_16x16x32_bf16); 0 = conv_patch_x3_kernel (32x32x16)
 extern "C" int lmkd_conv_set_patch16(int on) { g_patch16 = on ? 1 : 0; return LMKD_OK; }
-static int g_patch_debug = 0;      // timing ablations of conv_patch_x3_kernel (DBG template argument; tools/patch_ablate.py); 0 = the product kernel
-extern "C" int lmkd_conv_set_patch_debug(int mask) { g_patch_debug = mask & 63; return LMKD_OK; }
 
 template <class Cfg>
 static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
@@ -963,31 +952,6 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
                        (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, NPROD == 1 ? 1 : 3));                                     \
     hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>), grid, dim3(Cfg::THREADS), lds, s, a);                      \
   } while (0)
-  if constexpr (Cfg::BM == 128 && Cfg::BN == 64 && Cfg::THREADS == 256) {      // ablation instances exist for the benchmark's main tile only
-    if (g_patch_debug && g_conv_x3 == 6 && !g_lmkd_act_bf16 && !a.pre_stats && !a.ep_stats) {
-#define LMKD_PATCH_DBG(D)                                                                                                      \
-  do {                                                                                                                         \
-    static std::atomic<unsigned long long> attr_done{0};                                                                       \
-    lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, 6, false, 0, D>),                   \
-                       (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));                                                      \
-    hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, 6, false, 0, D>), grid, dim3(Cfg::THREADS), lds, s, a);                      \
-  } while (0)
-      switch (g_patch_debug) {
-        case 1: LMKD_PATCH_DBG(1); return;
-        case 2: LMKD_PATCH_DBG(2); return;
-        case 3: LMKD_PATCH_DBG(3); return;
-        case 4: LMKD_PATCH_DBG(4); return;
-        case 7: LMKD_PATCH_DBG(7); return;
-        case 8: LMKD_PATCH_DBG(8); return;
-        case 15: LMKD_PATCH_DBG(15); return;
-        case 16: LMKD_PATCH_DBG(16); return;
-        case 32: LMKD_PATCH_DBG(32); return;
-        case 47: LMKD_PATCH_DBG(47); return;
-        default: break;
-      }
-#undef LMKD_PATCH_DBG
-    }
-  }
   if constexpr (Cfg::THREADS == 256 && Cfg::BM == 128) {      // the benchmark's tiles (ids 11 / 12) on the 16x16x32 MFMA (conv_patch16.h)
     if (g_patch16 && g_conv_x3 && !g_lmkd_act_bf16) {
 #define LMKD_PATCH16(NPROD, PRE, EP)                                                                                           \
@@ -1154,7 +1118,7 @@ static int launch_conv_gemm(const ConvGemmArgs& a, int ncols, hipStream_t s) {
 // one workgroup per pair of output rows.  Returns the patch row pitch in pixels, or 0 when the launch is not of that kind.
 // stride-2 3x3 forward convolution as four same-size convolutions over the input's parity classes (conv_patch16.h, SRC2)?
 static bool fwd_s2_patch_ok(int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad) {
-  if (!(g_conv_s2_patch && g_patch16 && g_conv_patch && g_conv_x3 && !g_lmkd_act_bf16 && !g_patch_debug) || Cs % 32 != 0 || stride != 2 || KH != 3 ||
+  if (!(g_conv_s2_patch && g_patch16 && g_conv_patch && g_conv_x3 && !g_lmkd_act_bf16) || Cs % 32 != 0 || stride != 2 || KH != 3 ||
       KW != 3 || pad != 1 || H % 2 != 0 || W % 2 != 0 || W / 2 + 1 > PATCH_HALO_MAX)
     return false;
   const int id = pick_conv_cfg((long)N * (H / 2) * (W / 2), 1, Cout, true);
@@ -1196,7 +1160,7 @@ extern "C" int lmkd_conv2d_fwd_row_tiles(int N, int H, int W, int Cout, int KH, 
 
 static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* stat_partial, const float* ep_stats,
                            const float* ep_res, int ep_relu, int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride,
-                           int pad, void* stream, const float* pre_stats = nullptr, int seg_n0 = 0) {
+                           int pad, void* stream, const float* pre_stats = nullptr, int seg_n0 = 0, const lmkd_amax_desc* am = nullptr) {
   LMKD_REQUIRE(x && wp && y, "lmkd_conv2d_fwd: null pointer");
   if (seg_n0 <= 0 || seg_n0 >= N) seg_n0 = 0;
   LMKD_REQUIRE(!seg_n0 || ((g_conv_x3 || g_conv_bf16) && !ep_stats), "lmkd_conv2d_fwd_seg: two frame segments exist in the bf16-plane modes (training / plain forward)");
@@ -1211,8 +1175,9 @@ static int conv2d_fwd_impl(const float* x, const float* wp, float* y, float* sta
   ConvGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.src = x; a.wpk = wp; a.out = y; a.stat_partial = stat_partial;
-  a.h2_xw = take_amax_x(); (void)take_amax_dy();
-  a.amax_out = take_amax_out();
+  a.h2_xw = am ? (const unsigned*)am->x_words : nullptr;
+  a.amax_out = am ? (unsigned*)am->out_words : nullptr;
+  note_fenced(am);
   a.ep_stats = ep_stats; a.ep_res = ep_res; a.ep_relu = ep_relu;
   a.pre_stats = pre_stats;
   LMKD_REQUIRE(!pre_stats || (stat_partial && !smallc && !g_lmkd_act_bf16),
@@ -1316,8 +1281,8 @@ extern "C" int lmkd_conv2d_fwd(const float* x, const float* wp, float* y, float*
 // segment), stat_partial has lmkd_conv2d_fwd_row_tiles_seg rows of which the first *tiles0 belong to segment 0.  Results are bit-identical
 // to two launches on the two halves.  bf16-plane modes (lmkd_conv_set_compute_dtype 1-3).
 extern "C" int lmkd_conv2d_fwd_seg(const float* x, const float* pre_stats, const float* wp, float* y, float* stat_partial, int N, int H, int W,
-                                   int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0, void* stream) {
-  return conv2d_fwd_impl(x, wp, y, stat_partial, nullptr, nullptr, 0, N, H, W, Cs, Cout, KH, KW, stride, pad, stream, pre_stats, seg_n0);
+                                   int Cs, int Cout, int KH, int KW, int stride, int pad, int seg_n0, void* stream, const lmkd_amax_desc* amax) {
+  return conv2d_fwd_impl(x, wp, y, stat_partial, nullptr, nullptr, 0, N, H, W, Cs, Cout, KH, KW, stride, pad, stream, pre_stats, seg_n0, amax);
 }
 
 extern "C" int lmkd_conv2d_fwd_pre(const float* x_raw, const float* pre_stats, const float* wp, float* y, float* stat_partial, int N,
@@ -1338,7 +1303,7 @@ extern "C" int lmkd_conv2d_fwd_bn(const float* x, const float* wp, float* y, con
 
 // dx[N,H,W,Cin] (+= when accumulate) from dy[N,Ho,Wo,Cout]; wd = weights packed with mode 1
 static int bwd_data_args(ConvGemmArgs& a, const float* dy, const float* wd, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                         int stride, int pad, int accumulate, int seg_n0 = 0) {
+                         int stride, int pad, int accumulate, int seg_n0 = 0, const lmkd_amax_desc* am = nullptr) {
   if (seg_n0 <= 0 || seg_n0 >= N) seg_n0 = 0;
   LMKD_REQUIRE(!seg_n0 || g_conv_x3 || g_conv_bf16, "lmkd_conv2d_bwd_data_seg: two frame segments exist in the bf16-plane modes");
   LMKD_REQUIRE(Cout % 32 == 0, "lmkd_conv2d_bwd_data: Cout=%d must be a multiple of 32", Cout);
@@ -1352,7 +1317,7 @@ static int bwd_data_args(ConvGemmArgs& a, const float* dy, const float* wd, floa
                "lmkd_conv2d_bwd_data: dy exceeds the 4 GiB buffer range of the bf16-plane kernels");
   memset(&a, 0, sizeof(a));
   a.src = dy; a.wpk = wd; a.out = dx; a.stat_partial = nullptr; a.accum = accumulate;
-  a.h2_xw = take_amax_dy(); (void)take_amax_x();
+  a.h2_xw = am ? (const unsigned*)am->dy_words : nullptr;
   a.N = N; a.Hs = Ho; a.Ws = Wo; a.Cs = Cout;
   a.Ho = H; a.Wo = W; a.Co = Cin;
   a.Kp = KH * KW * Cout; a.cps = Cout / 32;
@@ -1404,7 +1369,7 @@ extern "C" int lmkd_conv2d_bwd_data(const float* dy, const float* wd, float* dx,
 // over (dx, bn_x).  Exists for the launches conv_patch16_x3_kernel serves (stride 1, three-plane arithmetic, fp32 tensors, 128-row
 // tiles); lmkd_conv2d_bwd_data_bn_tiles returns the row count of `part` ([tiles][Cin][2] floats) or 0 when the launch has no such form.
 static bool bwd_data_bn_ok(const ConvGemmArgs& a, int Cin) {
-  if (!(g_patch16 && g_conv_x3 && !g_lmkd_act_bf16 && !g_patch_debug) || a.nclass != 1 || Cin % 4 != 0) return false;
+  if (!(g_patch16 && g_conv_x3 && !g_lmkd_act_bf16) || a.nclass != 1 || Cin % 4 != 0) return false;
   if (patch_halo(a) < 0) return false;
   const int id = pick_conv_cfg(a.rows_per_class, a.nclass, Cin, a.same != 0);
   return id == 11 || id == 12;
@@ -1424,12 +1389,14 @@ extern "C" int lmkd_conv2d_bwd_data_bn_tiles(int N, int H, int W, int Cin, int C
 // lmkd_conv2d_bwd_data / lmkd_conv2d_bwd_data_bn (bn_x / bn_stats / part nullable together) over two frame segments (lmkd_conv2d_fwd_seg):
 // bn_stats is a [2][5][Cin] table, part has lmkd_conv2d_bwd_data_bn_tiles_seg rows.  Bit-identical to two launches on the halves.
 extern "C" int lmkd_conv2d_bwd_data_seg(const float* dy, const float* wd, float* dx, const float* bn_x, const float* bn_stats, float* part, int N,
-                                        int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate, int seg_n0, void* stream) {
+                                        int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate, int seg_n0, void* stream,
+                                        const lmkd_amax_desc* amax) {
   LMKD_REQUIRE(dy && wd && dx, "lmkd_conv2d_bwd_data_seg: null pointer");
   LMKD_REQUIRE(aligned16(dy) && aligned16(wd), "lmkd_conv2d_bwd_data_seg: operands must be 16-byte aligned");
   LMKD_REQUIRE((bn_x != nullptr) == (bn_stats != nullptr) && (bn_x != nullptr) == (part != nullptr), "lmkd_conv2d_bwd_data_seg: bn_x, bn_stats and part go together");
   ConvGemmArgs a;
-  if (const int rc = bwd_data_args(a, dy, wd, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, accumulate, seg_n0)) return rc;
+  if (const int rc = bwd_data_args(a, dy, wd, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, accumulate, seg_n0, amax)) return rc;
+  note_fenced(amax);
   if (bn_x) {
     LMKD_REQUIRE(!accumulate && aligned16(bn_x) && aligned16(bn_stats), "lmkd_conv2d_bwd_data_seg: the fused BatchNorm sums need a plain (non-accumulating) launch and aligned operands");
     LMKD_REQUIRE(bwd_data_bn_ok(a, Cin), "lmkd_conv2d_bwd_data_seg: this launch has no fused form (lmkd_conv2d_bwd_data_bn_tiles_seg returned 0)");
@@ -1566,9 +1533,10 @@ extern "C" long lmkd_conv2d_bwd_weight_workspace(int N, int H, int W, int Cs, in
 // dw_oihw[Cout,Cin,KH,KW] from x[N,H,W,Cs] (Cs >= Cin channel-padded) and dy[N,Ho,Wo,Cout]
 static int conv2d_bwd_weight_impl(const float* x, const float* pre_stats, const float* dy, float* dw_oihw, float* workspace,
                                   long ws_bytes, int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                  void* stream, int accumulate = 0, int seg_n0 = 0) {
-  const unsigned* amax_x = take_amax_x();
-  const unsigned* amax_dy = take_amax_dy();
+                                  void* stream, int accumulate = 0, int seg_n0 = 0, const lmkd_amax_desc* am = nullptr) {
+  const unsigned* amax_x = am ? (const unsigned*)am->x_words : nullptr;
+  const unsigned* amax_dy = am ? (const unsigned*)am->dy_words : nullptr;
+  note_fenced(am);
   LMKD_REQUIRE(x && dy && dw_oihw && workspace, "lmkd_conv2d_bwd_weight: null pointer");
   // two frame segments: each is split into the slabs a launch of its own would use (same partial sums, same accumulation error), the
   // PRE loader takes the segment's BatchNorm table, ONE slab reduce sums everything
@@ -1827,8 +1795,8 @@ extern "C" int lmkd_conv2d_bwd_weight_acc(const float* x, const float* pre_stats
 // lmkd_conv2d_bwd_weight_workspace_seg bytes.  The split-K slabs are those of two separate launches; they are summed in one pass.
 extern "C" int lmkd_conv2d_bwd_weight_seg(const float* x, const float* pre_stats, const float* dy, float* dw_oihw, float* workspace, long ws_bytes,
                                           int N, int H, int W, int Cs, int Cin, int Cout, int KH, int KW, int stride, int pad, int accumulate,
-                                          int seg_n0, void* stream) {
-  return conv2d_bwd_weight_impl(x, pre_stats, dy, dw_oihw, workspace, ws_bytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, stream, accumulate, seg_n0);
+                                          int seg_n0, void* stream, const lmkd_amax_desc* amax) {
+  return conv2d_bwd_weight_impl(x, pre_stats, dy, dw_oihw, workspace, ws_bytes, N, H, W, Cs, Cin, Cout, KH, KW, stride, pad, stream, accumulate, seg_n0, amax);
 }
 
 // stride-2 data gradient: does the LDS-patch kernel run its four parity classes (patch_halo() of the launch's arguments >= 0)?

@@ -23,8 +23,8 @@ template <int NPL> struct PatchRow { static constexpr int BYTES = NPL == 1 ? 80 
 // dynamic LDS bytes of a launch
 static inline size_t patch_lds_bytes(int bm, int halo, int npl) { return (size_t)(bm + 2 * halo + 1) * (npl == 1 ? 80 : 208); }
 
-// DBG (tools/patch_ablate.py, never in the product path): timing ablations that leave a part of the work out - results are garbage -
-// to see what the kernel waits for: 1 = no weight-fragment loads after the first two steps, 2 = no A-fragment LDS reads after the
+// DBG (never instantiated in the library; a measurement build passes it by hand): timing ablations that leave a part of the work out -
+// results are garbage - to see what the kernel waits for: 1 = no weight-fragment loads after the first two steps, 2 = no A-fragment LDS reads after the
 // first step, 4 = no patch split / LDS store (the loads are still issued), 8 = no output stores
 template <class Cfg, int NPROD, bool PRE, int IO, int DBG = 0>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(ConvGemmArgs a) {

@@ -22,6 +22,9 @@
 // 32 bytes apart; the weight fragments are written in the same order), and the columns {4..11} carry the EVEN pixels of the 16-block,
 // the columns {0..3, 12..15} the ODD ones (patch16_pixel): 13 x + 2 = 13 y has no solution with x odd, y even - no conflicts left.
 #pragma once
+#ifndef LMKD_ABL
+#define LMKD_ABL 0
+#endif
 
 __device__ __host__ __forceinline__ constexpr int patch16_kslot(int q) { return ((q & 1) << 1) | (q >> 1); }      // self-inverse
 __device__ __forceinline__ int patch16_pixel(int j) { return (j >= 4 && j < 12) ? 2 * (j - 4) : (j < 4 ? 2 * j + 1 : 2 * (j - 8) + 1); }
@@ -121,18 +124,6 @@ __device__ __forceinline__ float h2_scale(unsigned amax) {
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void h2_split4(const float4& v, float s, uint2& p0, uint2& p1) {
-#ifdef LMKD_AB_SCALAR_SPLIT      // tools/ab_build.sh: the element-wise form
-  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
-  union { _Float16 h[4]; uint2 u; } d0, d1;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    d0.h[j] = (_Float16)x[j];
-    d1.h[j] = (_Float16)(x[j] - (float)d0.h[j]);
-  }
-  p0 = d0.u;
-  p1 = d1.u;
-  return;
-#endif
   // on pairs: v_pk_mul_f32, v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32 - three vector instructions per element
   // (the kernels that call this are bound by vector-instruction issue)
   union { f16x2_t h[2]; uint2 u; } c0, c1;
@@ -356,9 +347,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     if (tid / LPR + RPP * i < P && pix >= 0 && pix < (long)a.N * a.Hs * a.Ws) p_ok |= 1u << i;
   }
   u32x4 rp[NI];
+  int k_cc_abl = 0;
   float4 psc = float4(), psh = float4();
   const float* pre_tab = PRE ? a.pre_stats + (long)sg.seg * 5 * a.Cs : nullptr;      // the [5][Cs] BatchNorm table of this tile's segment
   auto issue_patch = [&](int cc, int sc = 0) {
+    if ((LMKD_ABL & 32) && cc > 0) return;
     if constexpr (SRC2) {      // patch row j = pixel s_src[j] of class (0, 0), moved to class sc's origin
       const unsigned rel = (unsigned)((a.s2_off[sc] + cc * 32 + pk) * 4);
 #pragma unroll
@@ -379,6 +372,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     }
   };
   auto store_patch = [&]() {
+    if ((LMKD_ABL & 64) && k_cc_abl > 0) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int j = tid / LPR + RPP * i;
@@ -390,7 +384,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
         v.z = fmaxf(fmaf(v.z, psc.z, psh.z), 0.f); v.w = fmaxf(fmaf(v.w, psc.w, psh.w), 0.f);
       }
       uint2 q0, q1, q2;
-      if constexpr (NPROD == 3) h2_split4(v, h2_sx, q0, q1); else x3_split4(v, q0, q1, q2);
+      if constexpr (NPROD == 3) {
+        if (LMKD_ABL & 4) { q0 = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); q1 = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); }
+        else h2_split4(v, h2_sx, q0, q1);
+      } else x3_split4(v, q0, q1, q2);
       *reinterpret_cast<uint2*>(d) = q0;
       *reinterpret_cast<uint2*>(d + 64) = q1;
       if (NPU == 3) *reinterpret_cast<uint2*>(d + 128) = q2;
@@ -414,6 +411,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   };
   int k_tp = 0, k_cc = 0;      // (tap, chunk) of the current K-step
   int k_sc = 0;                // SRC2: source class of the current K-step (taps are ordered by class: class c = taps s2_t0[c] .. s2_t0[c + 1] - 1)
+  bf16x8 av[NPL][NB / 2];
   // K-step t (one tap of one 32-channel chunk = ONE 16x16x32 MFMA deep): see conv_patch.h for the prefetch / landing discipline
   auto step = [&](int t, u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR]) {
     if (SRC2 ? k_tp == a.s2_t0[k_sc] : k_tp == 0) {
@@ -433,8 +431,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     // the pixel blocks in two halves (conv_patch.h's two k-groups): one register set, the second half's fragments are read after the
     // first half's MFMAs (the set that would hold both halves costs the third workgroup per CU)
     constexpr int HB = NB / 2;
-    bf16x8 av[NPL][HB];
     auto read_a = [&](int hf) {
+      if ((LMKD_ABL & 2) && t > 0) return;
 #pragma unroll
       for (int p = 0; p < NPU; ++p)
 #pragma unroll
@@ -480,12 +478,12 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     }
     ++k_tp;
     if (SRC2 && k_sc + 1 < a.s2_ncls && k_tp == a.s2_t0[k_sc + 1]) ++k_sc;
-    if (k_tp == ntap) { k_tp = 0; ++k_cc; k_sc = 0; }
+    if (k_tp == ntap) { k_tp = 0; ++k_cc; k_sc = 0; k_cc_abl = 1; }
     __builtin_amdgcn_sched_barrier(0);
     x3_landed(rbn);
     x3_landed(rp);
     __builtin_amdgcn_sched_barrier(0);
-    if (t + 2 < nk) issue_b(rb);
+    if (t + 2 < nk && !(LMKD_ABL & 1)) issue_b(rb);
   };
   if constexpr (EARLY) {
     if (nk > 0) issue_patch(0);
@@ -561,11 +559,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       } else if (a.accum) {
         v.x += prev[c].x; v.y += prev[c].y; v.z += prev[c].z; v.w += prev[c].w;
       }
-      if (ok) {
+      if (ok && (!(LMKD_ABL & 8) || v.x == 123456.789f)) {
         *reinterpret_cast<float4*>(a.out + (long)ob + col) = v;
-        amo = amax4(amo, v);
+        if (!(LMKD_ABL & 256)) amo = amax4(amo, v);
       }
-      if (!EP) {
+      if (!EP && !(LMKD_ABL & 16)) {
         if (bnb) {      // sums of the BatchNorm backward this gradient feeds (ConvGemmArgs::bnb_x): bn_bwd_reduce_kernel's terms, mask mode 2
           if (ok) {
             const float4 xv = *reinterpret_cast<const float4*>(a.bnb_x + (long)ob + col);
@@ -584,7 +582,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     }
   }
   if (a.amax_out) amax_commit(a.amax_out + sg.seg * LMKD_AMAX_SEG_WORDS, amo);      // (every wave of the workgroup reaches this point)
-  if (!EP && a.stat_partial) {
+  if (!EP && a.stat_partial && !(LMKD_ABL & 16)) {
     // sum over the 16 pixel lanes of each 16-lane row, then over the WM row groups of the workgroup through LDS
 #pragma unroll
     for (int c = 0; c < NC; ++c) {

@@ -22,14 +22,64 @@ static inline int ew_grid(long n_items) {
   return (int)g;
 }
 
-// One-shot, per host thread: the NEXT launch of lmkd_bn_apply(_seg), lmkd_bn_relu_maxpool_fwd(_seg), lmkd_bn_backward(_seg) or
-// lmkd_bn_backward_part(_seg), lmkd_stem_unpool_bn_bwd(_seg) or lmkd_nchw3_to_nhwc4 on this thread also folds max |y| (max |dx| for the backward) into the words at `word` - 2 segments x
-// LMKD_AMAX_SLOTS slots x 16 words (common.h: amax_commit; frame segment 1's elements go to the second half: the two trunk calls of an
-// episode keep the scales they would have as two launches) - fp32 bits, atomic max: the caller zeroes all lmkd_amax_words() of them.  The two-plane fp16 convolutions scale their operands by a power of two taken from it (lmkd_conv_operand_amax).
-static thread_local unsigned* g_amax_next = nullptr;
-extern "C" int lmkd_amax_next(void* word) { g_amax_next = (unsigned*)word; return LMKD_OK; }
+// Compute mode 4 (two fp16 planes): the kernels that WRITE a trunk tensor - lmkd_bn_apply_seg, lmkd_bn_relu_maxpool_fwd_seg,
+// lmkd_bn_backward_seg, lmkd_bn_backward_part_seg, lmkd_stem_unpool_bn_bwd(_seg), lmkd_nchw3_to_nhwc4 - also fold max |result| into the
+// words lmkd_amax_desc::out_words names: 2 frame segments x LMKD_AMAX_SLOTS slots x 16 words (common.h: amax_commit; segment 1's elements
+// go to the second half: the two trunk calls of an episode keep the scales they would have as two launches), fp32 bits, atomic max; the
+// caller zeroes all lmkd_amax_words() of them.  The two-plane convolutions scale their operands by a power of two taken from it
+// (lmkd_amax_desc::x_words / dy_words).  With lmkd_amax_desc::ref_words (the words the same tensor had in the previous episode) they also
+// leave the range statistics of common.h (amax_commit_stat) beside the maximum: the range fence, lmkd_h2_fence_eval.
 extern "C" long lmkd_amax_words(void) { return 2 * LMKD_AMAX_SEG_WORDS; }
-static inline unsigned* take_amax_next() { unsigned* p = g_amax_next; g_amax_next = nullptr; return p; }
+static inline unsigned* amd_out(const lmkd_amax_desc* d) { return d ? (unsigned*)d->out_words : nullptr; }
+static inline const unsigned* amd_ref(const lmkd_amax_desc* d) { return (d && d->out_words) ? (const unsigned*)d->ref_words : nullptr; }
+
+// The range fence of compute mode 4.  entry e: words[e] = the words a tensor's producer has just written with lmkd_amax_desc::ref_words =
+// refs[e] (its maximum + range statistics, common.h amax_commit_stat); refs[e] = the PERSISTENT reference words of that tensor's site (one
+// set per BatchNorm output / gradient of the network, owned by the caller, zero before the first episode).  flags[e] bit s is set when
+// frame segment s of the tensor has too much of its magnitude in elements the two-plane split does not resolve fully: 4 n_small > Q, i.e.
+// the under-resolved elements would add more than a quarter to the rounding error of the resolved ones - judged only where the reference
+// was adequate (current maximum >= reference / 4: against a stale, much larger reference everything looks small; such a launch is simply
+// not judged).  Then the reference becomes this episode's maximum (slot 0 of each segment; the other slots stay zero), for the next
+// episode's producer.  The caller stops naming a flagged tensor's maximum to the convolutions (LMKD_AMAX_FENCED): they run the three-plane
+// form, which has no range to speak of.  One wave per entry.
+#define LMKD_FENCE_MAX 128
+struct FenceArgs { const unsigned* w[LMKD_FENCE_MAX]; unsigned* r[LMKD_FENCE_MAX]; };
+__global__ void h2_fence_eval_kernel(FenceArgs a, int* __restrict__ flags) {
+  const unsigned* w = a.w[blockIdx.x];
+  unsigned* r = a.r[blockIdx.x];
+  int f = 0;
+  for (int seg = 0; seg < 2; ++seg) {
+    const unsigned* slot = w + seg * LMKD_AMAX_SEG_WORDS + (threadIdx.x & (LMKD_AMAX_SLOTS - 1)) * LMKD_AMAX_STRIDE;
+    unsigned long long ns = slot[1], q = *reinterpret_cast<const unsigned long long*>(slot + 2);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      ns += (unsigned long long)__shfl_xor((long long)ns, o, 64);
+      q += (unsigned long long)__shfl_xor((long long)q, o, 64);
+    }
+    const unsigned cb = amax_read(w, seg), rb = amax_read(r, seg);
+    const float cur = __uint_as_float(cb), ref = __uint_as_float(rb);
+    if (ref > 0.f && cur >= 0.25f * ref && ns > 0 && 4 * ns > q) f |= 1 << seg;
+    if (threadIdx.x == 0) r[seg * LMKD_AMAX_SEG_WORDS] = cb;
+  }
+  if (threadIdx.x == 0) flags[blockIdx.x] = f;
+}
+// words / refs: HOST arrays of n device pointers (lmkd_amax_words() words each); flags: n device ints
+extern "C" int lmkd_h2_fence_eval(const void* const* words, void* const* refs, int n, int* flags, void* stream) {
+  LMKD_REQUIRE(words && refs && flags && n > 0, "lmkd_h2_fence_eval: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += LMKD_FENCE_MAX) {
+    FenceArgs a;
+    const int m = std::min(LMKD_FENCE_MAX, n - i0);
+    for (int j = 0; j < m; ++j) {
+      LMKD_REQUIRE(words[i0 + j] && refs[i0 + j], "lmkd_h2_fence_eval: null entry %d", i0 + j);
+      a.w[j] = (const unsigned*)words[i0 + j];
+      a.r[j] = (unsigned*)refs[i0 + j];
+    }
+    for (int j = m; j < LMKD_FENCE_MAX; ++j) { a.w[j] = nullptr; a.r[j] = nullptr; }
+    hipLaunchKernelGGL(h2_fence_eval_kernel, dim3(m), dim3(64), 0, (hipStream_t)stream, a, flags + i0);
+    LMKD_CHECK_LAUNCH("h2_fence_eval_kernel");
+  }
+  return LMKD_OK;
+}
 
 // ---------------------------------------------------------------------------------
 // [N,3,H,W] -> [N,H,W,4] (4th channel zero): the stem conv runs on NHWC4
@@ -46,8 +96,8 @@ __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float4* __res
   if (amax) amax_commit(amax, am);      // (one frame segment per call: the slots at `amax`)
 }
 
-extern "C" int lmkd_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, void* stream) {
-  unsigned* amax = take_amax_next();
+extern "C" int lmkd_nchw3_to_nhwc4(const float* x, float* y, int N, int H, int W, void* stream, void* amax_words) {
+  unsigned* amax = (unsigned*)amax_words;      // nullable: fold max |y| into the slots of ONE frame segment at this address
   LMKD_REQUIRE(x && y && N > 0 && H > 0 && W > 0, "lmkd_nchw3_to_nhwc4: bad arguments");
   LMKD_REQUIRE(aligned16(y), "lmkd_nchw3_to_nhwc4: output must be 16-byte aligned");
   const long hw = (long)H * W, total = hw * N;
@@ -263,7 +313,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int T, int C,
                                    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, float* __restrict__ stats, double* __restrict__ scratch,
                                    unsigned* __restrict__ tickets, int T0 = 0, double count1 = 0.0, int S0 = 0, int S1 = 0,
-                                   const unsigned* __restrict__ c_words = nullptr, unsigned* __restrict__ bound_words = nullptr) {
+                                   const unsigned* __restrict__ c_words = nullptr, unsigned* __restrict__ bound_words = nullptr,
+                                   const unsigned* __restrict__ ref_words = nullptr) {
   __shared__ double sm[CS_LANES][CS_COLS];
   __shared__ double tot[CS_COLS];
   __shared__ int s_last;
@@ -272,6 +323,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int T, int C,
     if (blockIdx.z) {
       part += (long)T0 * 2 * C; T -= T0; count = count1; stats += 5 * C; scratch += (long)CS_MAX_SLICES * 2 * C; tickets += LMKD_TICKET_WORDS / 2; S = S1;
       if (c_words) { c_words += LMKD_AMAX_SEG_WORDS; bound_words += LMKD_AMAX_SEG_WORDS; }
+      if (ref_words) ref_words += LMKD_AMAX_SEG_WORDS;
     } else { T = T0; S = S0; }
   }
   if (!colsum_ticket(part, T, 2 * C, scratch, tickets, sm, tot, &s_last, nullptr, S)) return;
@@ -290,8 +342,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int T, int C,
   const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
   stats[4 * C + c] = (float)unb;
   if (c_words) {
-    // lmkd_bn_finalize_bound: max over the elements of channel c of relu(x scale + shift) <= |scale| max |x| + |shift|, with max |x| over
-    // the whole tensor (the convolution's epilogue recorded it: lmkd_conv_output_amax) - an upper bound of max |relu(BatchNorm(x))|, which
+    // lmkd_amax_desc (x_words -> out_words): max over the elements of channel c of relu(x scale + shift) <= |scale| max |x| + |shift|, with max |x| over
+    // the whole tensor (the convolution's epilogue recorded it: lmkd_amax_desc::out_words of its launch) - an upper bound of max |relu(BatchNorm(x))|, which
     // is all the two-plane kernels need from a maximum (a bound that is 2^k too large costs k of the 17 binades of full precision).
     // A recorded maximum of zero means "not recorded" (the convolution ran another kernel): the bound stays zero = unknown.
     unsigned gm = 0u;
@@ -301,7 +353,24 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int T, int C,
     }
     if (gm) {
       const float bnd = fabsf(g * invstd) * __uint_as_float(gm) + fabsf(b - (float)mean * g * invstd);
-      atomicMax(bound_words + (c & (LMKD_AMAX_SLOTS - 1)) * LMKD_AMAX_STRIDE, __float_as_uint(bnd));
+      unsigned* slot = bound_words + (c & (LMKD_AMAX_SLOTS - 1)) * LMKD_AMAX_STRIDE;
+      atomicMax(slot, __float_as_uint(bnd));
+      if (ref_words) {
+        // the range statistics of a tensor that is never written (common.h amax_commit_stat), per CHANNEL: the normalised activation of
+        // channel c has unit variance times gamma around beta, so sqrt(gamma^2 + beta^2) is its typical magnitude; a channel whose typical
+        // magnitude lies below 2^-17 of the (previous) bound is under-resolved as a whole
+        unsigned rm = 0u;
+        for (int q = 0; q < LMKD_AMAX_SLOTS; ++q) {
+          const unsigned u = ref_words[q * LMKD_AMAX_STRIDE];
+          rm = u > rm ? u : rm;
+        }
+        const AmaxRef rf = amax_ref(rm);
+        const float typ = sqrtf(g * g + b * b);
+        if (rf.thr > 0.f && typ > 0.f) {
+          if (typ < rf.thr) atomicAdd(slot + 1, 1u);
+          atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)(fminf(typ * rf.inv_thr, 1024.f) + 0.5f));
+        }
+      }
     }
   }
   if (running_mean) {
@@ -401,29 +470,22 @@ __global__ void bn_eval_stats_kernel(int C, const float* __restrict__ gamma, con
   stats[4 * C + c] = running_var[c];
 }
 
-// One-shot, per host thread: the NEXT lmkd_bn_finalize(_seg) launch also writes, into `bound_words` (lmkd_amax_next's layout, zeroed by
-// the caller), an upper bound of max |relu(BatchNorm(x))| per frame segment, from its scale / shift tables and max |x| in `x_words` (the
-// words the convolution that wrote x recorded: lmkd_conv_output_amax).  This is the maximum lmkd_conv_operand_amax names for a
-// convolution that applies the BatchNorm + ReLU in its loader (lmkd_conv2d_fwd_pre, lmkd_conv2d_bwd_weight_pre) in mode 4.
-static thread_local const unsigned* g_bound_in = nullptr;
-static thread_local unsigned* g_bound_out = nullptr;
-extern "C" int lmkd_bn_finalize_bound(const void* x_words, void* bound_words) {
-  g_bound_in = (const unsigned*)x_words;
-  g_bound_out = (unsigned*)bound_words;
-  return LMKD_OK;
-}
+// lmkd_amax_desc on lmkd_bn_finalize(_seg) (mode 4): the launch also writes, into out_words (lmkd_amax_words() zeroed words), an upper
+// bound of max |relu(BatchNorm(x))| per frame segment, from its scale / shift tables and max |x| in x_words (the words the convolution
+// that wrote x recorded: lmkd_amax_desc::out_words of lmkd_conv2d_fwd_seg).  This is the maximum to name as x_words for a convolution
+// that applies the BatchNorm + ReLU in its loader (pre_stats given).
 // partial: [T][C][2] (sum, sumsq) from the conv epilogue; scratch: >= 64*2*C doubles; tickets: lmkd_ticket_words() zeroed words
 extern "C" int lmkd_bn_finalize(const float* partial, int T, int C, long count, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* stats,
-                                double* scratch, unsigned* tickets, void* stream) {
-  const unsigned* bin = g_bound_in;
-  unsigned* bout = g_bound_out;
-  g_bound_in = nullptr; g_bound_out = nullptr;
+                                double* scratch, unsigned* tickets, void* stream, const lmkd_amax_desc* amd) {
+  const unsigned* bin = amd ? (const unsigned*)amd->x_words : nullptr;
+  unsigned* bout = amd ? (unsigned*)amd->out_words : nullptr;
   if (!bin || !bout) { bin = nullptr; bout = nullptr; }
   LMKD_REQUIRE(partial && stats && scratch && tickets && T > 0 && C > 0 && count > 0, "lmkd_bn_finalize: bad arguments");
   LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS, "lmkd_bn_finalize: C=%d exceeds the ticket buffer", C);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(2 * C, CS_COLS), cs_slices(T)), dim3(CS_COLS, CS_LANES), 0, (hipStream_t)stream, partial, T,
-                     C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, stats, scratch, tickets, 0, 0.0, 0, 0, bin, bout);
+                     C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, stats, scratch, tickets, 0, 0.0, 0, 0, bin, bout,
+                     bout && amd ? (const unsigned*)amd->ref_words : nullptr);
   LMKD_CHECK_LAUNCH("bn_finalize_kernel");
   return LMKD_OK;
 }
@@ -432,16 +494,16 @@ extern "C" int lmkd_bn_finalize(const float* partial, int T, int C, long count, 
 // count0 / count1 elements per channel; bit-identical to two lmkd_bn_finalize launches.  The running statistics are NOT updated here
 // (two segments = two sequential updates: lmkd_bn_running_update_multi applies them in order).  scratch: >= 2 * 64 * 2 * C doubles.
 extern "C" int lmkd_bn_finalize_seg(const float* partial, int T, int T0, int C, long count0, long count1, const float* gamma, const float* beta,
-                                    float eps, float* stats, double* scratch, unsigned* tickets, void* stream) {
-  const unsigned* bin = g_bound_in;
-  unsigned* bout = g_bound_out;
-  g_bound_in = nullptr; g_bound_out = nullptr;
+                                    float eps, float* stats, double* scratch, unsigned* tickets, void* stream, const lmkd_amax_desc* amd) {
+  const unsigned* bin = amd ? (const unsigned*)amd->x_words : nullptr;
+  unsigned* bout = amd ? (unsigned*)amd->out_words : nullptr;
   if (!bin || !bout) { bin = nullptr; bout = nullptr; }
   LMKD_REQUIRE(partial && stats && scratch && tickets && T0 > 0 && T > T0 && C > 0 && count0 > 0 && count1 > 0, "lmkd_bn_finalize_seg: bad arguments");
   LMKD_REQUIRE(cdiv(2 * C, CS_COLS) <= LMKD_TICKET_WORDS / 2, "lmkd_bn_finalize_seg: C=%d exceeds the ticket buffer", C);
   const int S0 = cs_slices(T0), S1 = cs_slices(T - T0);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(2 * C, CS_COLS), std::max(S0, S1), 2), dim3(CS_COLS, CS_LANES), 0, (hipStream_t)stream, partial, T,
-                     C, (double)count0, gamma, beta, (float*)nullptr, (float*)nullptr, 0.f, eps, stats, scratch, tickets, T0, (double)count1, S0, S1, bin, bout);
+                     C, (double)count0, gamma, beta, (float*)nullptr, (float*)nullptr, 0.f, eps, stats, scratch, tickets, T0, (double)count1, S0, S1, bin, bout,
+                     bout && amd ? (const unsigned*)amd->ref_words : nullptr);
   LMKD_CHECK_LAUNCH("bn_finalize_kernel");
   return LMKD_OK;
 }
@@ -466,12 +528,13 @@ extern "C" int lmkd_bn_eval_stats(int C, const float* gamma, const float* beta, 
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const T* __restrict__ res,
                                 const float* __restrict__ rstats, T* __restrict__ y, long n4, int C, int relu, int res_mode,
-                                unsigned* __restrict__ mask_bits, long n4_0, unsigned* __restrict__ amax) {
+                                unsigned* __restrict__ mask_bits, long n4_0, unsigned* __restrict__ amax, const unsigned* __restrict__ aref) {
   // n4_0: groups of 4 elements in frame segment 0 (rows0 * C / 4; = n4 for one segment): elements past it use the second [5][C] table
   constexpr int U = ActU<T>::U;
   const int C4 = C >> 2;
   const long nu = n4 / U;
-  float am = 0.f, am1 = 0.f;      // max |y| of segment 0 / segment 1
+  AmaxStat am = {0.f, 0.f, 0u}, am1 = {0.f, 0.f, 0u};      // max |y| (+ range statistics) of segment 0 / segment 1
+  const AmaxRef rf0 = amax_ref(aref ? amax_read(aref, 0) : 0u), rf1 = amax_ref(aref ? amax_read(aref, 1) : 0u);
   for (long iu = (long)blockIdx.x * blockDim.x + threadIdx.x; iu < nu; iu += (long)gridDim.x * blockDim.x) {
     float4 v[U], r[U];
     ldv<T, U>(x, iu, v);
@@ -495,7 +558,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
       }
       if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
       nibs |= ((w.x > 0.f ? 1u : 0u) | (w.y > 0.f ? 2u : 0u) | (w.z > 0.f ? 4u : 0u) | (w.w > 0.f ? 8u : 0u)) << (4 * u);
-      if (so) am1 = amax4(am1, w); else am = amax4(am, w);
+      if (so) amax_stat4(am1, w, rf1); else amax_stat4(am, w, rf0);
     }
     stv<T, U>(y, iu, v);      // bf16 storage: a positive value never rounds to zero, so the mask equals (stored y > 0)
     if (mask_bits) {
@@ -508,21 +571,22 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
     }
   }
   if (amax) {
-    amax_commit(amax, am);
-    if (n4_0 < n4) amax_commit(amax + LMKD_AMAX_SEG_WORDS, am1);
+    amax_commit_stat(amax, am, aref != nullptr);
+    if (n4_0 < n4) amax_commit_stat(amax + LMKD_AMAX_SEG_WORDS, am1, aref != nullptr);
   }
 }
 
 extern "C" int lmkd_bn_apply_seg(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows, long rows0,
-                                 int C, int relu, int res_mode, unsigned* mask_bits, void* stream);
+                                 int C, int relu, int res_mode, unsigned* mask_bits, void* stream, const lmkd_amax_desc* amd);
 extern "C" int lmkd_bn_apply(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows,
                              int C, int relu, int res_mode, unsigned* mask_bits, void* stream) {
-  return lmkd_bn_apply_seg(x, stats, res, rstats, y, rows, rows, C, relu, res_mode, mask_bits, stream);
+  return lmkd_bn_apply_seg(x, stats, res, rstats, y, rows, rows, C, relu, res_mode, mask_bits, stream, nullptr);
 }
 // two frame segments: rows [0, rows0) use stats[0] (and rstats[0]), rows [rows0, rows) stats[1] / rstats[1] ([2][5][C] tables)
 extern "C" int lmkd_bn_apply_seg(const float* x, const float* stats, const float* res, const float* rstats, float* y, long rows, long rows0,
-                                 int C, int relu, int res_mode, unsigned* mask_bits, void* stream) {
-  unsigned* amax = take_amax_next();
+                                 int C, int relu, int res_mode, unsigned* mask_bits, void* stream, const lmkd_amax_desc* amd) {
+  unsigned* amax = amd_out(amd);
+  const unsigned* aref = amd_ref(amd);
   LMKD_REQUIRE(x && stats && y && rows > 0 && C > 0 && C % 4 == 0, "lmkd_bn_apply: bad arguments (C=%d)", C);
   if (rows0 <= 0 || rows0 > rows) rows0 = rows;
   LMKD_REQUIRE(res_mode == 0 || res, "lmkd_bn_apply: residual pointer missing");
@@ -532,10 +596,10 @@ extern "C" int lmkd_bn_apply_seg(const float* x, const float* stats, const float
   const long n4 = rows * C / 4;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_apply_kernel<lmkd_bf16_t>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)x, stats,
-                       (const lmkd_bf16_t*)res, rstats, (lmkd_bf16_t*)y, n4, C, relu, res_mode, mask_bits, rows0 * C / 4, amax);
+                       (const lmkd_bf16_t*)res, rstats, (lmkd_bf16_t*)y, n4, C, relu, res_mode, mask_bits, rows0 * C / 4, amax, aref);
   else
     hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, stats, res, rstats, y, n4, C,
-                       relu, res_mode, mask_bits, rows0 * C / 4, amax);
+                       relu, res_mode, mask_bits, rows0 * C / 4, amax, aref);
   LMKD_CHECK_LAUNCH("bn_apply_kernel");
   return LMKD_OK;
 }
@@ -684,13 +748,14 @@ template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ yact,
                                     const float* __restrict__ stats, const float* __restrict__ coef, T* __restrict__ dx,
                                     T* __restrict__ g_out, long n4, int C, int mask_mode, long n4_0, ParamGradSeg pg,
-                                    unsigned* __restrict__ amax) {
+                                    unsigned* __restrict__ amax, const unsigned* __restrict__ aref) {
   // n4_0 < n4: two frame segments - elements from n4_0 on use stats[1] / coef[1] ([2][5][C] tables), and pg carries the parameter gradients
   constexpr int U = ActU<T>::U;
   const int C4 = C >> 2;
   const long nu = n4 / U;
   if (n4_0 < n4) bn_param_grads_seg(coef, C, pg);
-  float am = 0.f, am1 = 0.f;
+  AmaxStat am = {0.f, 0.f, 0u}, am1 = {0.f, 0.f, 0u};
+  const AmaxRef rf0 = amax_ref(aref ? amax_read(aref, 0) : 0u), rf1 = amax_ref(aref ? amax_read(aref, 1) : 0u);
   for (long iu = (long)blockIdx.x * blockDim.x + threadIdx.x; iu < nu; iu += (long)gridDim.x * blockDim.x) {
     float4 xv[U], dv[U], o[U], gq[U];
     ldv<T, U>(x, iu, xv);
@@ -713,14 +778,14 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
       o[u].z = A.z * (g.z - mg.z - (xv[u].z - mean.z) * istd.z * mgx.z);
       o[u].w = A.w * (g.w - mg.w - (xv[u].w - mean.w) * istd.w * mgx.w);
       gq[u] = g;
-      if (so) am1 = amax4(am1, o[u]); else am = amax4(am, o[u]);
+      if (so) amax_stat4(am1, o[u], rf1); else amax_stat4(am, o[u], rf0);
     }
     stv<T, U>(dx, iu, o);
     if (g_out) stv<T, U>(g_out, iu, gq);
   }
   if (amax) {
-    amax_commit(amax, am);
-    if (n4_0 < n4) amax_commit(amax + LMKD_AMAX_SEG_WORDS, am1);
+    amax_commit_stat(amax, am, aref != nullptr);
+    if (n4_0 < n4) amax_commit_stat(amax + LMKD_AMAX_SEG_WORDS, am1, aref != nullptr);
   }
 }
 
@@ -781,12 +846,12 @@ static int bn_bwd_stats_impl(const float* dy, const float* x, const float* yact,
 // return; one buffer per stream that may run this concurrently);  accumulate_param_grads: dgamma / dbeta += (see bn_bwd_coef_kernel)
 extern "C" int lmkd_bn_backward_seg(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dx,
                                     float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows,
-                                    long rows0, int C, int mask_mode, int accumulate_param_grads, void* stream);
+                                    long rows0, int C, int mask_mode, int accumulate_param_grads, void* stream, const lmkd_amax_desc* amd);
 extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma,
                                 float* dx, float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets,
                                 long rows, int C, int mask_mode, int accumulate_param_grads, void* stream) {
   return lmkd_bn_backward_seg(dy, x, yact, stats, gamma, dx, g_out, dgamma, dbeta, coef, workspace, tickets, rows, rows, C, mask_mode,
-                              accumulate_param_grads, stream);
+                              accumulate_param_grads, stream, nullptr);
 }
 // lmkd_bn_backward over two frame segments [0, rows0) | [rows0, rows) of one tensor (both trunk calls of an episode, resnet18_2fc.py:41-42,
 // each with its own batch statistics): stats = [2][5][C], coef = [2][5][C] floats of scratch, workspace = 2 * lmkd_bn_bwd_workspace(C)
@@ -794,8 +859,9 @@ extern "C" int lmkd_bn_backward(const float* dy, const float* x, const float* ya
 // rows0 = rows (or 0): one segment, coef [3][C], the plain lmkd_bn_backward.
 extern "C" int lmkd_bn_backward_seg(const float* dy, const float* x, const float* yact, const float* stats, const float* gamma, float* dx,
                                     float* g_out, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows,
-                                    long rows0, int C, int mask_mode, int accumulate_param_grads, void* stream) {
-  unsigned* amax = take_amax_next();
+                                    long rows0, int C, int mask_mode, int accumulate_param_grads, void* stream, const lmkd_amax_desc* amd) {
+  unsigned* amax = amd_out(amd);
+  const unsigned* aref = amd_ref(amd);
   LMKD_REQUIRE(dx, "lmkd_bn_backward: null pointer");
   hipStream_t s = (hipStream_t)stream;
   if (rows0 <= 0 || rows0 >= rows) rows0 = rows;
@@ -807,10 +873,10 @@ extern "C" int lmkd_bn_backward_seg(const float* dy, const float* x, const float
   pg.dgamma = dgamma; pg.dbeta = dbeta; pg.accumulate = accumulate_param_grads;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<lmkd_bf16_t>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, (const lmkd_bf16_t*)dy, (const lmkd_bf16_t*)x,
-                       (const lmkd_bf16_t*)yact, stats, (const float*)coef, (lmkd_bf16_t*)dx, (lmkd_bf16_t*)g_out, n4, C, mask_mode, n4_0, pg, amax);
+                       (const lmkd_bf16_t*)yact, stats, (const float*)coef, (lmkd_bf16_t*)dx, (lmkd_bf16_t*)g_out, n4, C, mask_mode, n4_0, pg, amax, aref);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, dy, x, yact, stats, (const float*)coef, dx, g_out,
-                       n4, C, mask_mode, n4_0, pg, amax);
+                       n4, C, mask_mode, n4_0, pg, amax, aref);
   LMKD_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return LMKD_OK;
 }
@@ -819,19 +885,20 @@ extern "C" int lmkd_bn_backward_seg(const float* dy, const float* x, const float
 // (lmkd_conv2d_bwd_data_bn): part = [T][C][2] per-row-tile sums (sum g, sum g * xhat) of mask mode 2.  Coefficient kernel + apply pass.
 extern "C" int lmkd_bn_backward_part_seg(const float* part, int T, int T0, const float* dy, const float* x, const float* stats, const float* gamma,
                                          float* dx, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows,
-                                         long rows0, int C, int accumulate_param_grads, void* stream);
+                                         long rows0, int C, int accumulate_param_grads, void* stream, const lmkd_amax_desc* amd);
 extern "C" int lmkd_bn_backward_part(const float* part, int T, const float* dy, const float* x, const float* stats, const float* gamma,
                                      float* dx, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows, int C,
                                      int accumulate_param_grads, void* stream) {
   return lmkd_bn_backward_part_seg(part, T, T, dy, x, stats, gamma, dx, dgamma, dbeta, coef, workspace, tickets, rows, rows, C,
-                                   accumulate_param_grads, stream);
+                                   accumulate_param_grads, stream, nullptr);
 }
 // two frame segments: partial rows [0, T0) | [T0, T) of lmkd_conv2d_bwd_data_seg, tensor rows [0, rows0) | [rows0, rows); tables as
 // lmkd_bn_backward_seg.  T0 = T (rows0 = rows): one segment.
 extern "C" int lmkd_bn_backward_part_seg(const float* part, int T, int T0, const float* dy, const float* x, const float* stats, const float* gamma,
                                          float* dx, float* dgamma, float* dbeta, float* coef, void* workspace, unsigned* tickets, long rows,
-                                         long rows0, int C, int accumulate_param_grads, void* stream) {
-  unsigned* amax = take_amax_next();
+                                         long rows0, int C, int accumulate_param_grads, void* stream, const lmkd_amax_desc* amd) {
+  unsigned* amax = amd_out(amd);
+  const unsigned* aref = amd_ref(amd);
   LMKD_REQUIRE(part && T > 0 && dy && x && stats && dx && coef && workspace && tickets, "lmkd_bn_backward_part: null pointer");
   LMKD_REQUIRE(!g_lmkd_act_bf16 && C % 4 == 0, "lmkd_bn_backward_part: fp32 tensors, C %% 4 == 0");
   const bool seg = T0 > 0 && T0 < T && rows0 > 0 && rows0 < rows;
@@ -848,7 +915,7 @@ extern "C" int lmkd_bn_backward_part_seg(const float* part, int T, int T0, const
   ParamGradSeg pg;
   pg.dgamma = dgamma; pg.dbeta = dbeta; pg.accumulate = accumulate_param_grads;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(n4)), dim3(NP_THREADS), 0, s, dy, x, (const float*)nullptr, stats, (const float*)coef,
-                     dx, (float*)nullptr, n4, C, 2, rows0 * C / 4, pg, amax);
+                     dx, (float*)nullptr, n4, C, 2, rows0 * C / 4, pg, amax, aref);
   LMKD_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return LMKD_OK;
 }
@@ -901,13 +968,14 @@ extern "C" int lmkd_relu_backward(const float* dy, const float* y, float* g, lon
 template <typename T>
 __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ stats, T* __restrict__ y,
                                        uchar4* __restrict__ idx, T* __restrict__ cmax, int N, int H, int W, int C, int OH, int OW, int N0,
-                                       unsigned* __restrict__ amax) {
+                                       unsigned* __restrict__ amax, const unsigned* __restrict__ aref) {
   // a thread owns U groups of 4 consecutive channels of one output pixel (U = 2 with bf16 tensors: every access 16 bytes; with 8-byte
   // accesses the bf16 instance took as long as the fp32 one on half the bytes - 260 vs 280 us at 200 frames)
   constexpr int U = ActU<T>::U;
   const int CU = C / (4 * U);
   const long total = (long)N * OH * OW * CU;
-  float amx = 0.f, amx1 = 0.f;
+  AmaxStat amx = {0.f, 0.f, 0u}, amx1 = {0.f, 0.f, 0u};
+  const AmaxRef rf0 = amax_ref(aref ? amax_read(aref, 0) : 0u), rf1 = amax_ref(aref ? amax_read(aref, 1) : 0u);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cq = (int)(i % CU);
     long r = i / CU;
@@ -953,36 +1021,37 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __r
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       idx[i * U + u] = am[u];
-      if (n >= N0) amx1 = amax4(amx1, m[u]); else amx = amax4(amx, m[u]);
+      if (n >= N0) amax_stat4(amx1, m[u], rf1); else amax_stat4(amx, m[u], rf0);
     }
     if (cmax) stv<T, U>(cmax, i, cm);
   }
   if (amax) {
-    amax_commit(amax, amx);
-    if (N0 < N) amax_commit(amax + LMKD_AMAX_SEG_WORDS, amx1);
+    amax_commit_stat(amax, amx, aref != nullptr);
+    if (N0 < N) amax_commit_stat(amax + LMKD_AMAX_SEG_WORDS, amx1, aref != nullptr);
   }
 }
 
 extern "C" int lmkd_bn_relu_maxpool_fwd_seg(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int N0, int H,
-                                            int W, int C, void* stream);
+                                            int W, int C, void* stream, const lmkd_amax_desc* amd);
 extern "C" int lmkd_bn_relu_maxpool_fwd(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int H, int W,
                                         int C, void* stream) {
-  return lmkd_bn_relu_maxpool_fwd_seg(x, stats, y, idx, cmax, N, N, H, W, C, stream);
+  return lmkd_bn_relu_maxpool_fwd_seg(x, stats, y, idx, cmax, N, N, H, W, C, stream, nullptr);
 }
 // two frame segments: frames [0, N0) use stats[0], frames [N0, N) stats[1] ([2][5][C])
 extern "C" int lmkd_bn_relu_maxpool_fwd_seg(const float* x, const float* stats, float* y, unsigned char* idx, float* cmax, int N, int N0, int H,
-                                            int W, int C, void* stream) {
-  unsigned* amax = take_amax_next();
+                                            int W, int C, void* stream, const lmkd_amax_desc* amd) {
+  unsigned* amax = amd_out(amd);
+  const unsigned* aref = amd_ref(amd);
   LMKD_REQUIRE(x && stats && y && idx && C % (g_lmkd_act_bf16 ? 8 : 4) == 0, "lmkd_bn_relu_maxpool_fwd: bad arguments");
   if (N0 <= 0 || N0 > N) N0 = N;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long total = (long)N * OH * OW * C / (g_lmkd_act_bf16 ? 8 : 4);
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<lmkd_bf16_t>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, (const lmkd_bf16_t*)x,
-                       stats, (lmkd_bf16_t*)y, (uchar4*)idx, (lmkd_bf16_t*)cmax, N, H, W, C, OH, OW, N0, amax);
+                       stats, (lmkd_bf16_t*)y, (uchar4*)idx, (lmkd_bf16_t*)cmax, N, H, W, C, OH, OW, N0, amax, aref);
   else
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, x, stats, y, (uchar4*)idx,
-                       cmax, N, H, W, C, OH, OW, N0, amax);
+                       cmax, N, H, W, C, OH, OW, N0, amax, aref);
   LMKD_CHECK_LAUNCH("bn_relu_maxpool_kernel");
   return LMKD_OK;
 }
@@ -1033,11 +1102,13 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uchar4* __res
 template <typename T>
 __global__ void stem_unpool_bn_bwd_kernel(const T* __restrict__ dy, const uchar4* __restrict__ idx, const T* __restrict__ c,
                                           const float* __restrict__ stats, const float* __restrict__ coef, T* __restrict__ dc, int N,
-                                          int H, int W, int C, int OH, int OW, int N0, ParamGradSeg pg, unsigned* __restrict__ amax) {
+                                          int H, int W, int C, int OH, int OW, int N0, ParamGradSeg pg, unsigned* __restrict__ amax,
+                                          const unsigned* __restrict__ aref) {
   const int C4 = C >> 2;
   const int HB = (H + 1) >> 1, WB = (W + 1) >> 1;
   const long total = (long)N * HB * WB * C4;
-  float amx = 0.f, amx1 = 0.f;      // max |dc| of frame segment 0 / 1 (lmkd_amax_next)
+  AmaxStat amx = {0.f, 0.f, 0u}, amx1 = {0.f, 0.f, 0u};      // max |dc| (+ range statistics) of frame segment 0 / 1
+  const AmaxRef rf0 = amax_ref(aref ? amax_read(aref, 0) : 0u), rf1 = amax_ref(aref ? amax_read(aref, 1) : 0u);
   if (N0 < N) bn_param_grads_seg(coef, C, pg);      // two frame segments: tables [2][5][C], parameter gradients from both (bn_bwd_coef_kernel)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cq = (int)(i % C4);
@@ -1103,13 +1174,13 @@ __global__ void stem_unpool_bn_bwd_kernel(const T* __restrict__ dy, const uchar4
         o.z = A.z * (g.z - mg.z - (xv.z - mean.z) * istd.z * mgx.z);
         o.w = A.w * (g.w - mg.w - (xv.w - mean.w) * istd.w * mgx.w);
         st4<T>(dc, p, o);
-        if (n >= N0) amx1 = amax4(amx1, o); else amx = amax4(amx, o);
+        if (n >= N0) amax_stat4(amx1, o, rf1); else amax_stat4(amx, o, rf0);
       }
     }
   }
   if (amax) {
-    amax_commit(amax, amx);
-    if (N0 < N) amax_commit(amax + LMKD_AMAX_SEG_WORDS, amx1);
+    amax_commit_stat(amax, amx, aref != nullptr);
+    if (N0 < N) amax_commit_stat(amax + LMKD_AMAX_SEG_WORDS, amx1, aref != nullptr);
   }
 }
 
@@ -1117,17 +1188,18 @@ __global__ void stem_unpool_bn_bwd_kernel(const T* __restrict__ dy, const uchar4
 // stats: its [5][C] table; coef: [3][C] from lmkd_bn_backward_stats; dc: [N, H, W, C] gradient w.r.t. the convolution output
 extern "C" int lmkd_stem_unpool_bn_bwd_seg(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef,
                                            float* dc, float* dgamma, float* dbeta, int accumulate_param_grads, int N, int N0, int H, int W, int C,
-                                           void* stream);
+                                           void* stream, const lmkd_amax_desc* amd);
 extern "C" int lmkd_stem_unpool_bn_bwd(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef,
-                                       float* dc, int N, int H, int W, int C, void* stream) {
-  return lmkd_stem_unpool_bn_bwd_seg(dy, idx, c, stats, coef, dc, nullptr, nullptr, 0, N, N, H, W, C, stream);
+                                       float* dc, int N, int H, int W, int C, void* stream, const lmkd_amax_desc* amd) {
+  return lmkd_stem_unpool_bn_bwd_seg(dy, idx, c, stats, coef, dc, nullptr, nullptr, 0, N, N, H, W, C, stream, amd);
 }
 // two frame segments [0, N0) | [N0, N): stats / coef = the [2][5][C] tables of lmkd_bn_backward_stats_seg; dgamma / dbeta (nullable) (+)= the
 // sums of both segments (rows 3 / 4 of coef).  N0 = N: one segment, the plain form (coef [3][C], dgamma / dbeta ignored).
 extern "C" int lmkd_stem_unpool_bn_bwd_seg(const float* dy, const unsigned char* idx, const float* c, const float* stats, const float* coef,
                                            float* dc, float* dgamma, float* dbeta, int accumulate_param_grads, int N, int N0, int H, int W, int C,
-                                           void* stream) {
-  unsigned* amax = take_amax_next();
+                                           void* stream, const lmkd_amax_desc* amd) {
+  unsigned* amax = amd_out(amd);
+  const unsigned* aref = amd_ref(amd);
   LMKD_REQUIRE(dy && idx && c && stats && coef && dc && C % 4 == 0 && N > 0 && H > 0 && W > 0, "lmkd_stem_unpool_bn_bwd: bad arguments");
   if (N0 <= 0 || N0 > N) N0 = N;
   ParamGradSeg pg;
@@ -1136,10 +1208,10 @@ extern "C" int lmkd_stem_unpool_bn_bwd_seg(const float* dy, const unsigned char*
   const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * C / 4;
   if (g_lmkd_act_bf16)
     hipLaunchKernelGGL(stem_unpool_bn_bwd_kernel<lmkd_bf16_t>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream,
-                       (const lmkd_bf16_t*)dy, (const uchar4*)idx, (const lmkd_bf16_t*)c, stats, coef, (lmkd_bf16_t*)dc, N, H, W, C, OH, OW, N0, pg, amax);
+                       (const lmkd_bf16_t*)dy, (const uchar4*)idx, (const lmkd_bf16_t*)c, stats, coef, (lmkd_bf16_t*)dc, N, H, W, C, OH, OW, N0, pg, amax, aref);
   else
     hipLaunchKernelGGL(stem_unpool_bn_bwd_kernel<float>, dim3(ew_grid(total)), dim3(NP_THREADS), 0, (hipStream_t)stream, dy, (const uchar4*)idx, c,
-                       stats, coef, dc, N, H, W, C, OH, OW, N0, pg, amax);
+                       stats, coef, dc, N, H, W, C, OH, OW, N0, pg, amax, aref);
   LMKD_CHECK_LAUNCH("stem_unpool_bn_bwd_kernel");
   return LMKD_OK;
 }

@@ -157,8 +157,12 @@ _BN_UPDATE_EVENT = {}
 def _grad_ready(y):
     """the input of the last stage: when its gradient arrives, the backward pass has finished the last stage, the heads and the matcher
     (ops.GRAD_READY_HOOK = parallel.EarlyAllReduce.hook while an optimizer step is due)"""
-    if ops.GRAD_READY_HOOK is not None and torch.is_grad_enabled() and y.requires_grad:
-        y.register_hook(ops.GRAD_READY_HOOK)
+    h = ops.GRAD_READY_HOOK
+    if h is not None and torch.is_grad_enabled() and y.requires_grad:
+        y.register_hook(h)
+        owner = getattr(h, "__self__", None)
+        if hasattr(owner, "registered"):
+            owner.registered()
     return y
 
 # Round 4: both trunk calls as ONE launch per layer.  The support and the query frames travel through the trunk as one NHWC tensor

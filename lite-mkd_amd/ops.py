@@ -464,9 +464,10 @@ def refresh_packs(streams=()):
 
 # ---- fp32 as two fp16 planes ('fp32h2', lmkd_conv_set_compute_dtype(4); csrc/conv_patch16.h) ----
 # The kernels scale an operand by a power of two taken from max |operand|.  The maximum of a trunk tensor is folded into a device word
-# by the kernel that WRITES the tensor (BatchNorm apply, BatchNorm backward apply, the stem's pooling: lmkd_amax_next) and travels with
-# the tensor as the attribute `_lmkd_amax`; a convolution whose operands carry it runs the two-plane form (lmkd_conv_operand_amax), any
-# other launch - a tensor from elsewhere, a view - the three-plane form: both fp32-class, so a lost word costs time, never correctness.
+# by the kernel that WRITES the tensor (BatchNorm apply, BatchNorm backward apply, the stem's pooling: lmkd_amax_desc::out_words) and travels
+# with the tensor as the attribute `_lmkd_amax`; a convolution whose operands carry it runs the two-plane form (lmkd_amax_desc::x_words /
+# dy_words), any other launch - a tensor from elsewhere, a view - the three-plane form: both fp32-class, so a lost word costs time, never
+# correctness.
 _AMAX_POOLS = {}
 _AMAX_WORDS = [0]
 _AMAX_POOL_TENSORS = 256      # maxima per pool (8 KB each: 2 frame segments x 64 slots x 64 bytes, csrc/common.h amax_commit)
@@ -520,30 +521,152 @@ def amax_pool_reset():
     _AMAX_POOLS.clear()
 
 
-_H2_DEBUG_OFF = set(filter(None, os.environ.get("LMKD_H2_OFF", "").split(",")))      # diagnosis: "stem_x", "stem_dc" -> those tensors carry no maximum
+class AmaxDesc(ctypes.Structure):
+    """include/lmkd.h lmkd_amax_desc: the range bookkeeping of one launch (explicit argument of the *_seg entry points)"""
+    _fields_ = [("x_words", ctypes.c_void_p), ("dy_words", ctypes.c_void_p), ("out_words", ctypes.c_void_p), ("ref_words", ctypes.c_void_p),
+                ("flags", ctypes.c_int)]
 
 
-def _amax_record(t, what=None):
-    """call immediately before the launch that writes t (lmkd_amax_next is one-shot): that launch also folds max |t| into a fresh word"""
-    if what is not None and what in _H2_DEBUG_OFF:
+AMAX_FENCED = 1
+
+
+def _desc_arg(d):
+    return ctypes.byref(d) if d is not None else None
+
+
+# The range fence of the two-plane arithmetic.  Every tensor a producer writes belongs to a SITE - ("y" | "a" | "d" | "p", data_ptr of the
+# BatchNorm weight whose output / gradient / loader-side bound it is).  A site owns persistent reference words (the maximum its tensor had
+# in the previous episode); the producer counts, against that reference, how much of the tensor the two fp16 planes do not resolve fully
+# (csrc/common.h amax_commit_stat) and h2_fence_step() - once per episode, no host synchronisation: the verdict is read an episode or two
+# later - lets lmkd_h2_fence_eval judge the counts.  A flagged site stays flagged (h2_fence_reset() clears): its tensor's maximum is
+# withheld from the convolutions, which then run the three-plane form, and lmkd_conv_h2_fallbacks() counts those launches.
+H2_FENCE = True
+_FENCE_SITES = {}        # site -> {"ref": persistent words, "bad": bool}
+_FENCE_PENDING = []      # (site, words) written since the last h2_fence_step()
+_FENCE_INFLIGHT = []     # (event, pinned host flags, [sites], keep-alive)
+
+
+def _fence_site(site, dev):
+    e = _FENCE_SITES.get(site)
+    if e is None:
+        e = _FENCE_SITES[site] = {"ref": torch.zeros(lib().value("lmkd_amax_words"), dtype=torch.int32, device=dev), "bad": False}
+    return e
+
+
+def h2_fence_reset():
+    """forget every verdict and reference (a new model, another data distribution)"""
+    _FENCE_SITES.clear()
+    del _FENCE_PENDING[:]
+    del _FENCE_INFLIGHT[:]
+
+
+def h2_fence_flagged():
+    """the sites the fence has flagged so far"""
+    return sorted(k for k, e in _FENCE_SITES.items() if e["bad"])
+
+
+def _fence_poll(wait=False):
+    keep = []
+    for ev, host, sites, alive in _FENCE_INFLIGHT:
+        if wait:
+            ev.synchronize()
+        if not ev.query():
+            keep.append((ev, host, sites, alive))
+            continue
+        for site, f in zip(sites, host.tolist()):
+            if f:
+                _FENCE_SITES[site]["bad"] = True
+    _FENCE_INFLIGHT[:] = keep
+
+
+def h2_fence_step(wait=False):
+    """judge the tensors written since the last call (one small launch + one 4-bytes-per-tensor copy to pinned memory, both asynchronous)
+    and take in the verdicts that have arrived.  Call once per episode, on a stream that is ordered behind the episode's producers (after
+    backward()).  wait=True (tests): also wait for this call's verdicts."""
+    if not _FENCE_PENDING and not _FENCE_INFLIGHT:
         return
-    if t.dtype is torch.float32 and _h2_mode():
-        w = _amax_slot(t.device)
-        lib().call("lmkd_amax_next", w.data_ptr())
-        t._lmkd_amax = w
+    if torch.cuda.is_current_stream_capturing():
+        return
+    _fence_poll()
+    if _FENCE_PENDING:
+        pend = list(_FENCE_PENDING)
+        del _FENCE_PENDING[:]
+        n = len(pend)
+        dev = pend[0][1].device
+        P = ctypes.c_void_p * n
+        words = P(*[w.data_ptr() for _, w in pend])
+        refs = P(*[_FENCE_SITES[site]["ref"].data_ptr() for site, _ in pend])
+        flags = torch.empty(n, dtype=torch.int32, device=dev)
+        lib().call("lmkd_h2_fence_eval", words, refs, n, _p(flags), _stream())
+        host = torch.empty(n, dtype=torch.int32).pin_memory()
+        host.copy_(flags, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _FENCE_INFLIGHT.append((ev, host, [site for site, _ in pend], (pend, flags)))
+    if wait:
+        _fence_poll(wait=True)
+
+
+def _amax_out(t, site=None):
+    """call for the launch that writes t: -> AmaxDesc whose out_words are fresh zeroed words that the launch folds max |t| into (and, with a
+    site, ref_words = the site's reference: the launch also leaves the range statistics); the words travel with t.  None outside fp32h2."""
+    if t.dtype is not torch.float32 or not _h2_mode():
+        return None
+    w = _amax_slot(t.device)
+    t._lmkd_amax = w
+    d = AmaxDesc(None, None, w.data_ptr(), None, 0)
+    if site is not None and H2_FENCE and not torch.cuda.is_current_stream_capturing():
+        e = _fence_site(site, t.device)
+        d.ref_words = e["ref"].data_ptr()
+        t._lmkd_site = site
+        _FENCE_PENDING.append((site, w))
+    elif site is not None:
+        t._lmkd_site = site
+    return d
+
+
+_AMAX_ATTRS = ("_lmkd_amax", "_lmkd_site", "_lmkd_pre_amax", "_lmkd_pre_site")
+
+
+def _amax_tag(t):
+    """what travels with a tensor in fp32h2 (its maximum's words, its fence site; the same for the loader-side bound) - to carry across
+    save_for_backward, which may hand back a new tensor object"""
+    return None if t is None else tuple(getattr(t, a, None) for a in _AMAX_ATTRS)
+
+
+def _amax_retag(t, tag):
+    if t is not None and tag is not None:
+        for a, v in zip(_AMAX_ATTRS, tag):
+            if v is not None:
+                setattr(t, a, v)
 
 
 def _amax_ptr(t, pre=False):
-    """pre: t is a raw convolution output that the consumer normalises + rectifies in its loader: the words are the BOUND of
-    max |relu(BatchNorm(t))| that lmkd_bn_finalize_bound wrote (_conv_bn_train_or_eval(bound=True))"""
-    w = getattr(t, "_lmkd_pre_amax" if pre else "_lmkd_amax", None) if t is not None else None
-    return w.data_ptr() if w is not None else None
+    """-> (words pointer | None, fenced): pre: t is a raw convolution output that the consumer normalises + rectifies in its loader: the
+    words are the BOUND of max |relu(BatchNorm(t))| that lmkd_bn_finalize(_seg) wrote (_conv_bn_train_or_eval(bound=True)).  A tensor whose
+    site the range fence has flagged yields no words: the launch runs the three-plane form."""
+    if t is None:
+        return None, False
+    w = getattr(t, "_lmkd_pre_amax" if pre else "_lmkd_amax", None)
+    if w is None:
+        return None, False
+    site = getattr(t, "_lmkd_pre_site" if pre else "_lmkd_site", None)
+    if site is not None and H2_FENCE:
+        e = _FENCE_SITES.get(site)
+        if e is not None and e["bad"]:
+            return None, True
+    return w.data_ptr(), False
 
 
 def _amax_operands(x, dy, pre=False):
-    """call immediately before a convolution launch (one-shot): the words of its operands, where they are known"""
-    if _h2_mode():
-        lib().call("lmkd_conv_operand_amax", _amax_ptr(x, pre), _amax_ptr(dy))
+    """-> AmaxDesc naming the maxima of a convolution's operands where they are known (None outside fp32h2)"""
+    if not _h2_mode():
+        return None
+    px, fx = _amax_ptr(x, pre)
+    pd, fd = _amax_ptr(dy)
+    if px is None and pd is None and not (fx or fd):
+        return None
+    return AmaxDesc(px, pd, None, None, AMAX_FENCED if (fx or fd) else 0)
 
 
 def amax_compute(t, seg=0):
@@ -668,11 +791,12 @@ def _seg_frames(seg, N):
     return seg if 0 < seg < N else 0
 
 
-def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None, seg=0):
+def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None, seg=0, amax_out=None):
     """x NHWC [N,H,W,Cs] -> (y [N,Ho,Wo,Cout], stat partial [T,Cout,2] | None).  pre_stats: x is the RAW output of the previous
     convolution and the loader applies relu(BatchNorm(x)) with that layer's [5][Cs] table (lmkd_conv2d_fwd_pre).
     seg = F0 > 0: frames [0, F0) and [F0, N) are two BatchNorm batches (lmkd_conv2d_fwd_seg): pre_stats is [2, 5, Cs] and the result is
-    (y, part, T0) - the first T0 rows of part belong to segment 0."""
+    (y, part, T0) - the first T0 rows of part belong to segment 0.
+    amax_out (fp32h2): zeroed words that the launch folds max |y| into (lmkd_amax_desc::out_words)"""
     _chk(x, wp, pre_stats)
     N, H, W, Cs = x.shape
     seg = _seg_frames(seg, N)
@@ -686,9 +810,13 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None, seg=0
     cin = 3 if Cs == 4 else Cs
     with _timed(_conv_family(0, N, H, W, Cs, cin, Cout, KH, KW, stride, pad), 2.0 * N * Ho * Wo * Cout * cin * KH * KW,
                 x.element_size() * x.numel() + y.element_size() * y.numel() + 4 * wp.numel()):
-        _amax_operands(x, None, pre=pre_stats is not None)
-        if seg:
-            lib().call("lmkd_conv2d_fwd_seg", _p(x), _p(pre_stats), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, seg, _stream())
+        d = _amax_operands(x, None, pre=pre_stats is not None)
+        if amax_out is not None and _h2_mode():
+            d = d if d is not None else AmaxDesc(None, None, None, None, 0)
+            d.out_words = amax_out.data_ptr()
+        if seg or d is not None:
+            lib().call("lmkd_conv2d_fwd_seg", _p(x), _p(pre_stats), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, seg, _stream(),
+                       _desc_arg(d))
         elif pre_stats is not None:
             lib().call("lmkd_conv2d_fwd_pre", _p(x), _p(pre_stats), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, _stream())
         else:
@@ -724,11 +852,12 @@ def conv_bwd_data(dy, wd, x_shape, Cout, KH, KW, stride, pad, out=None, accumula
     with _timed(_conv_family(1, N, H, W, Cin, Cin, Cout, KH, KW, stride, pad), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
                 dy.element_size() * dy.numel() + dx.element_size() * dx.numel() * (2 if accumulate else 1) + 4 * wd.numel()
                 + (bn[0].element_size() * bn[0].numel() if part is not None else 0)):      # the fused form also reads the BatchNorm input
-        _amax_operands(None, dy)
-        if seg:
+        d = _amax_operands(None, dy)
+        if seg or d is not None:
             lib().call("lmkd_conv2d_bwd_data_seg", _p(dy), _p(wd), _p(dx), _p(bn[0]) if part is not None else None,
-                       _p(bn[1]) if part is not None else None, _p(part), N, H, W, Cin, Cout, KH, KW, stride, pad, int(accumulate), seg, _stream())
-            if part is not None:
+                       _p(bn[1]) if part is not None else None, _p(part), N, H, W, Cin, Cout, KH, KW, stride, pad, int(accumulate), seg, _stream(),
+                       _desc_arg(d))
+            if part is not None and seg:
                 part = (part, int(t0[0]))
         elif part is not None:
             lib().call("lmkd_conv2d_bwd_data_bn", _p(dy), _p(wd), _p(dx), _p(bn[0]), _p(bn[1]), _p(part), N, H, W, Cin, Cout, KH, KW, stride,
@@ -751,10 +880,10 @@ def conv_bwd_weight(x, dy, w_shape, stride, pad, pre_stats=None, acc_into=None, 
     dw = acc_into if acc_into is not None else _empty(w_shape, x)
     with _timed("conv_wgrad_kernel", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * Cout * Cin * KH * KW,
                 x.element_size() * x.numel() + dy.element_size() * dy.numel() + 4 * dw.numel()):
-        _amax_operands(x, dy, pre=pre_stats is not None)
-        if seg:
+        d = _amax_operands(x, dy, pre=pre_stats is not None)
+        if seg or d is not None:
             lib().call("lmkd_conv2d_bwd_weight_seg", _p(x), _p(pre_stats), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW,
-                       stride, pad, int(acc_into is not None), seg, _stream())
+                       stride, pad, int(acc_into is not None), seg, _stream(), _desc_arg(d))
         elif acc_into is not None:
             lib().call("lmkd_conv2d_bwd_weight_acc", _p(x), _p(pre_stats), _p(dy), _p(dw), _p(ws), nbytes, N, H, W, Cs, Cin, Cout, KH, KW,
                        stride, pad, _stream())
@@ -818,7 +947,7 @@ def _has_hooks(w):
 
 
 def _wgrad_stream(device):
-    dev = device.index
+    dev = device_index(device)
     if dev not in _WG_STREAM:
         _WG_STREAM[dev] = _new_stream(device, "wgrad")
     return _WG_STREAM[dev]
@@ -888,16 +1017,17 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
-_PENDING_BOUND = [None]      # (words of max |y|, words for the bound): set by _conv_bn_train_or_eval(bound=True), consumed by the next bn_stats_train
-
-
-def bn_stats_train(part, count, gamma, beta, running_mean, running_var, seg=None):
+def bn_stats_train(part, count, gamma, beta, running_mean, running_var, seg=None, bound=None):
     """seg = (T0, count0): two frame segments - partial rows [0, T0) / [T0, T), count0 / count - count0 elements per channel ->
-    stats [2, 5, C]; the running statistics are not touched (the caller defers both updates: apply_deferred)"""
+    stats [2, 5, C]; the running statistics are not touched (the caller defers both updates: apply_deferred).
+    bound = (words of max |x|, zeroed words for the bound, site | None) (fp32h2): the launch also writes a bound of max |relu(BatchNorm(x))|"""
     T, C, _ = part.shape
-    pb, _PENDING_BOUND[0] = _PENDING_BOUND[0], None
-    if pb is not None:
-        lib().call("lmkd_bn_finalize_bound", pb[0].data_ptr(), pb[1].data_ptr())      # one-shot: the finalize launch below
+    d = None
+    if bound is not None:
+        d = AmaxDesc(bound[0].data_ptr(), None, bound[1].data_ptr(), None, 0)
+        if bound[2] is not None and H2_FENCE and not torch.cuda.is_current_stream_capturing():
+            d.ref_words = _fence_site(bound[2], part.device)["ref"].data_ptr()
+            _FENCE_PENDING.append((bound[2], bound[1]))
     if seg is not None:
         T0, count0 = seg
         if running_mean is not None or running_var is not None:
@@ -905,12 +1035,12 @@ def bn_stats_train(part, count, gamma, beta, running_mean, running_var, seg=None
         stats = _empty((2, 5, C), part)
         scratch = torch.empty(2 * 64 * 2 * C, dtype=torch.float64, device=part.device)
         lib().call("lmkd_bn_finalize_seg", _p(part), T, T0, C, count0, count - count0, _p(gamma), _p(beta), _f32(BN_EPS), _p(stats), _p(scratch),
-                   _p(_tickets(part)), _stream())
+                   _p(_tickets(part)), _stream(), _desc_arg(d))
         return stats
     stats = _empty((5, C), part)
     scratch = torch.empty(64 * 2 * C, dtype=torch.float64, device=part.device)
     lib().call("lmkd_bn_finalize", _p(part), T, C, count, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-               _f32(BN_MOMENTUM), _f32(BN_EPS), _p(stats), _p(scratch), _p(_tickets(part)), _stream())
+               _f32(BN_MOMENTUM), _f32(BN_EPS), _p(stats), _p(scratch), _p(_tickets(part)), _stream(), _desc_arg(d))
     return stats
 
 
@@ -928,17 +1058,17 @@ def _rows0(t, seg):
     return seg * (rows // t.shape[0]) if seg else rows
 
 
-def bn_apply(x, stats, relu, res=None, rstats=None, want_bits=False, seg=0):
+def bn_apply(x, stats, relu, res=None, rstats=None, want_bits=False, seg=0, site=None):
     """-> y, or (y, bits) with want_bits: the packed ReLU mask (y > 0), one bit per element, for bn_backward(mask_mode 3).
-    seg = F0 > 0: stats (and rstats) are [2, 5, C], one table per frame segment"""
+    seg = F0 > 0: stats (and rstats) are [2, 5, C], one table per frame segment.  site: the range fence's name for y (h2_fence_step)"""
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty_like(x)
     mode = 0 if res is None else (2 if rstats is not None else 1)
     _chk(x, stats, res, rstats)
     bits = torch.empty(x.numel() // 32, dtype=torch.int32, device=x.device) if want_bits else None
-    _amax_record(y)
-    lib().call("lmkd_bn_apply_seg", _p(x), _p(stats), _p(res), _p(rstats), _p(y), rows, _rows0(x, seg), C, int(relu), mode, _p(bits), _stream())
+    lib().call("lmkd_bn_apply_seg", _p(x), _p(stats), _p(res), _p(rstats), _p(y), rows, _rows0(x, seg), C, int(relu), mode, _p(bits), _stream(),
+               _desc_arg(_amax_out(y, site)))
     return (y, bits) if want_bits else y
 
 
@@ -965,13 +1095,11 @@ def bn_backward(dy, x, yact, stats, gamma, mask_mode, want_g=False, dx_out=None,
             raise ValueError("partial sums of the data gradient: mask_mode 2 without g")
         part, T0 = part if isinstance(part, tuple) else (part, part.shape[0])
         _chk(part)
-        _amax_record(dx)
         lib().call("lmkd_bn_backward_part_seg", _p(part), part.shape[0], T0, _p(dy), _p(x), _p(stats), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
-                   _p(coef), _p(ws), _p(_tickets(x)), rows, rows0, C, int(direct), _stream())
+                   _p(coef), _p(ws), _p(_tickets(x)), rows, rows0, C, int(direct), _stream(), _desc_arg(_amax_out(dx, ("d", gamma.data_ptr()))))
     else:
-        _amax_record(dx)
         lib().call("lmkd_bn_backward_seg", _p(dy), _p(x), _p(yact), _p(stats), _p(gamma), _p(dx), _p(g), _p(dgamma), _p(dbeta),
-                   _p(coef), _p(ws), _p(_tickets(x)), rows, rows0, C, mask_mode, int(direct), _stream())
+                   _p(coef), _p(ws), _p(_tickets(x)), rows, rows0, C, mask_mode, int(direct), _stream(), _desc_arg(_amax_out(dx, ("d", gamma.data_ptr()))))
     return (dx, g, None, None) if direct else (dx, g, dgamma, dbeta)
 
 
@@ -1033,19 +1161,28 @@ def _new_stream(device, key):
     return torch.cuda.Stream(device=device, priority=int(STREAM_PRIORITY.get(key, 0)))
 
 
+def device_index(device):
+    """the index the stream tables are keyed with: torch.device('cuda') (index None - the training CLI's default before init_distributed
+    fills it in) means the current device"""
+    device = torch.device(device)
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
 def set_lane(k):
     LANE[0] = int(k)
 
 
 def side_stream(device):
-    key = (device.type, device.index, LANE[0])
+    device = torch.device(device)
+    key = (device.type, device_index(device), LANE[0])
     if key not in _side_streams:
         _side_streams[key] = _new_stream(device, LANE[0])
     return _side_streams[key]
 
 
 def lane_main(device):
-    key = (device.type, device.index, LANE[0])
+    device = torch.device(device)
+    key = (device.type, device_index(device), LANE[0])
     if key not in _lane_mains:
         _lane_mains[key] = _new_stream(device, LANE[0])
     return _lane_mains[key]
@@ -1057,7 +1194,8 @@ _aux_streams = {}
 
 def aux_stream(device):
     """a third forward stream: the frozen teacher head of an episode runs there beside the student's trunk (trainloop.train_task)"""
-    key = (device.type, device.index, LANE[0])
+    device = torch.device(device)
+    key = (device.type, device_index(device), LANE[0])
     if key not in _aux_streams:
         _aux_streams[key] = _new_stream(device, LANE[0])
     return _aux_streams[key]
@@ -1117,38 +1255,37 @@ def _train_pre():
 
 def _conv_bn_train_or_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, training, pre_stats=None, seg=0, bound=False):
     """bound (fp32h2, training): the output y feeds a consumer that applies relu(BatchNorm(y)) in its loader - the convolution records
-    max |y| (lmkd_conv_output_amax) and the statistics launch turns it into a bound of max |relu(BatchNorm(y))| per frame segment
-    (lmkd_bn_finalize_bound), which travels with y as `_lmkd_pre_amax`"""
+    max |y| (lmkd_amax_desc::out_words) and the statistics launch turns it into a bound of max |relu(BatchNorm(y))| per frame segment,
+    which travels with y as `_lmkd_pre_amax` (its site for the range fence: ("p", gamma))"""
     Cout, _, KH, KW = w.shape
     wp = pack_weights(w, Cs, 0)
     seg = _seg_frames(seg, x.shape[0]) if training else 0      # eval: one table (the running statistics) for every frame
-    bw = None
+    bw = cw = bnd = None
     if bound and training and x.dtype is torch.float32 and _h2_mode():
         cw, bw = _amax_slot(x.device), _amax_slot(x.device)
-        lib().call("lmkd_conv_output_amax", cw.data_ptr())      # one-shot: the conv_fwd launch below
-        _PENDING_BOUND[0] = (cw, bw)
+        bnd = (cw, bw, ("p", gamma.data_ptr()))
     if seg:
         # both trunk calls of the episode in this launch: per-segment batch statistics -> [2, 5, C]; the two running-statistics updates are
         # deferred and applied in the reference's order (support call, then query call) by apply_deferred
         if _DEFER is None:
             raise RuntimeError("two frame segments need deferred running-statistics updates (ops.set_defer)")
-        y, part, T0 = conv_fwd(x, wp, Cout, KH, KW, stride, pad, True, pre_stats, seg=seg)
+        y, part, T0 = conv_fwd(x, wp, Cout, KH, KW, stride, pad, True, pre_stats, seg=seg, amax_out=cw)
         count = y.numel() // Cout
-        stats = bn_stats_train(part, count, gamma, beta, None, None, seg=(T0, seg * (count // y.shape[0])))
+        stats = bn_stats_train(part, count, gamma, beta, None, None, seg=(T0, seg * (count // y.shape[0])), bound=bnd)
         _DEFER.append((rm, rv, stats[0]))
         _DEFER.append((rm, rv, stats[1]))
         if bw is not None:
-            y._lmkd_pre_amax = bw
+            y._lmkd_pre_amax, y._lmkd_pre_site = bw, bnd[2]
         return y, stats
-    y, part = conv_fwd(x, wp, Cout, KH, KW, stride, pad, training, pre_stats)
+    y, part = conv_fwd(x, wp, Cout, KH, KW, stride, pad, training, pre_stats, amax_out=cw)
     if bw is not None:
-        y._lmkd_pre_amax = bw
+        y._lmkd_pre_amax, y._lmkd_pre_site = bw, bnd[2]
     if training:
         if _DEFER is not None:
-            stats = bn_stats_train(part, y.numel() // Cout, gamma, beta, None, None)
+            stats = bn_stats_train(part, y.numel() // Cout, gamma, beta, None, None, bound=bnd)
             _DEFER.append((rm, rv, stats))
         else:
-            stats = bn_stats_train(part, y.numel() // Cout, gamma, beta, rm, rv)
+            stats = bn_stats_train(part, y.numel() // Cout, gamma, beta, rm, rv, bound=bnd)
     else:
         stats = bn_stats_eval(gamma, beta, rm, rv)
     return y, stats
@@ -1173,8 +1310,8 @@ class StemFn(torch.autograd.Function):
             if Cin != 3:
                 raise RuntimeError("stem expects 3-channel frames")
             x4 = _empty((F_, H, W, 4), x)
-            _amax_record(x4, "stem_x")
-            lib().call("lmkd_nchw3_to_nhwc4", _p(x.contiguous()), _p(x4), F_, H, W, _stream())
+            xd = _amax_out(x4)      # (frames: no site - ToTensor output lies in [0, 1])
+            lib().call("lmkd_nchw3_to_nhwc4", _p(x.contiguous()), _p(x4), F_, H, W, _stream(), xd.out_words if xd is not None else None)
         seg = _seg_frames(seg, F_) if training else 0
         c, stats = _conv_bn_train_or_eval(x4, w, 4, 2, 3, gamma, beta, rm, rv, training, seg=seg)
         N, Hc, Wc, C = c.shape
@@ -1184,14 +1321,14 @@ class StemFn(torch.autograd.Function):
         # training: also the raw convolution output at each window's arg-max - the BatchNorm backward then takes its sums from the
         # pooled tensors (lmkd_bn_backward_stats) instead of the 4x larger pre-pooling ones
         cmax = torch.empty_like(y) if (training and (STEM_POOLED_BWD or seg)) else None
-        _amax_record(y)
-        lib().call("lmkd_bn_relu_maxpool_fwd_seg", _p(c), _p(stats), _p(y), _p(idx), _p(cmax), N, seg if seg else N, Hc, Wc, C, _stream())
+        lib().call("lmkd_bn_relu_maxpool_fwd_seg", _p(c), _p(stats), _p(y), _p(idx), _p(cmax), N, seg if seg else N, Hc, Wc, C, _stream(),
+                   _desc_arg(_amax_out(y, ("y", gamma.data_ptr()))))
         if BLOCK_TAPS is not None:
             BLOCK_TAPS.append({"stem_c": c, "stem_st": stats, "stem_idx": idx, "seg": seg})
         if training:
             ctx.save_for_backward(x4, c, stats, idx, gamma, w, cmax)
             ctx.beta = beta
-            ctx.amax = getattr(x4, "_lmkd_amax", None)
+            ctx.amax = _amax_tag(x4)
         ctx.training = training
         ctx.seg = seg
         return y
@@ -1201,8 +1338,7 @@ class StemFn(torch.autograd.Function):
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         x4, c, stats, idx, gamma, w, cmax = ctx.saved_tensors
-        if ctx.amax is not None:      # the maximum recorded in the forward (a saved tensor may come back as a new object)
-            x4._lmkd_amax = ctx.amax
+        _amax_retag(x4, ctx.amax)      # the maximum recorded in the forward (a saved tensor may come back as a new object)
         dy = dy.contiguous()
         N, Hc, Wc, C = c.shape
         seg = ctx.seg
@@ -1219,9 +1355,8 @@ class StemFn(torch.autograd.Function):
             lib().call("lmkd_bn_backward_stats_seg", _p(dy), _p(cmax), _p(stats), _p(gamma), _p(coef), _p(ws), _p(_tickets(c)),
                        N * prow, seg * prow, N * crow, seg * crow, C, _stream())
             dc = torch.empty_like(c)
-            _amax_record(dc, "stem_dc")
             lib().call("lmkd_stem_unpool_bn_bwd_seg", _p(dy), _p(idx), _p(c), _p(stats), _p(coef), _p(dc), _p(dgamma), _p(dbeta), int(direct),
-                       N, seg, Hc, Wc, C, _stream())
+                       N, seg, Hc, Wc, C, _stream(), _desc_arg(_amax_out(dc, ("d", gamma.data_ptr()))))
             if direct:
                 dgamma = dbeta = None
         elif cmax is not None:
@@ -1236,8 +1371,8 @@ class StemFn(torch.autograd.Function):
             lib().call("lmkd_bn_backward_stats", _p(dy), _p(cmax), _p(stats), _p(gamma), _p(dgamma), _p(dbeta), _p(coef), _p(ws),
                        _p(_tickets(c)), dy.numel() // C, c.numel() // C, C, int(direct), _stream())
             dc = torch.empty_like(c)
-            _amax_record(dc, "stem_dc")
-            lib().call("lmkd_stem_unpool_bn_bwd", _p(dy), _p(idx), _p(c), _p(stats), _p(coef), _p(dc), N, Hc, Wc, C, _stream())
+            lib().call("lmkd_stem_unpool_bn_bwd", _p(dy), _p(idx), _p(c), _p(stats), _p(coef), _p(dc), N, Hc, Wc, C, _stream(),
+                       _desc_arg(_amax_out(dc, ("d", gamma.data_ptr()))))
             if direct:
                 dgamma = dbeta = None
         else:
@@ -1264,14 +1399,13 @@ def frames_pair_to_nhwc4(a, b):
     if (H, W) != (Hb, Wb):
         raise RuntimeError("support and query frames differ in size")
     out = _empty((Fa + Fb, H, W, 4), a)
-    words = _amax_slot(out.device) if (_h2_mode() and not (a4 or b4) and "stem_x" not in _H2_DEBUG_OFF) else None      # fp32h2: the stem's kernels scale by max |frames|, per segment
+    words = _amax_slot(out.device) if (_h2_mode() and not (a4 or b4)) else None      # fp32h2: the stem's kernels scale by max |frames|, per segment
     for seg, (t, is4, dst, F_) in enumerate(((a, a4, out[:Fa], Fa), (b, b4, out[Fa:], Fb))):
         if is4:
             dst.copy_(t)
         else:
-            if words is not None:
-                lib().call("lmkd_amax_next", words.data_ptr() + 2 * words.numel() * seg)      # (bytes: half the words per segment)
-            lib().call("lmkd_nchw3_to_nhwc4", _p(t.contiguous()), _p(dst), F_, H, W, _stream())
+            lib().call("lmkd_nchw3_to_nhwc4", _p(t.contiguous()), _p(dst), F_, H, W, _stream(),
+                       words.data_ptr() + 2 * words.numel() * seg if words is not None else None)      # (bytes: half the words per segment)
     if words is not None:
         out._lmkd_amax = words
     return out
@@ -1396,7 +1530,7 @@ class BasicBlockFn(torch.autograd.Function):
             a1 = None
             c2, st2 = _conv_bn_train_or_eval(c1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training, pre_stats=st1, seg=seg)
         else:
-            a1 = bn_apply(c1, st1, True, seg=seg)
+            a1 = bn_apply(c1, st1, True, seg=seg, site=("a", g1.data_ptr()))
             c2, st2 = _conv_bn_train_or_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, training, seg=seg)
         if wd is not None:
             cd, std = _conv_bn_train_or_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, training, seg=seg)
@@ -1405,9 +1539,9 @@ class BasicBlockFn(torch.autograd.Function):
             cd = std = None
             res, rst = x, None
         if fused:
-            y, ybits = bn_apply(c2, st2, True, res, rst, want_bits=True, seg=seg)
+            y, ybits = bn_apply(c2, st2, True, res, rst, want_bits=True, seg=seg, site=("y", g2.data_ptr()))
         else:
-            y, ybits = bn_apply(c2, st2, True, res, rst, seg=seg), None
+            y, ybits = bn_apply(c2, st2, True, res, rst, seg=seg, site=("y", g2.data_ptr())), None
         ctx.training = training
         ctx.seg = seg
         ctx.stride = stride
@@ -1419,8 +1553,7 @@ class BasicBlockFn(torch.autograd.Function):
         if training:
             # fused: the backward needs neither a1 (recomputed from c1 in the weight-gradient loader) nor y (its mask travels as bits)
             ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, ybits if fused else y, wd, gd, cd, std)
-            ctx.amax = (getattr(x, "_lmkd_amax", None), getattr(a1, "_lmkd_amax", None) if a1 is not None else None)
-            ctx.pre_amax = getattr(c1, "_lmkd_pre_amax", None)
+            ctx.amax = (_amax_tag(x), _amax_tag(a1), _amax_tag(c1))
         return y
 
     @staticmethod
@@ -1428,11 +1561,8 @@ class BasicBlockFn(torch.autograd.Function):
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         x, w1, g1, c1, st1, a1, w2, g2, c2, st2, y, wd, gd, cd, std = ctx.saved_tensors
-        for t, wm in zip((x, a1), ctx.amax):      # the maxima recorded in the forward (saved tensors may come back as new objects)
-            if t is not None and wm is not None:
-                t._lmkd_amax = wm
-        if ctx.pre_amax is not None:
-            c1._lmkd_pre_amax = ctx.pre_amax
+        for t, tag in zip((x, a1, c1), ctx.amax):      # the maxima recorded in the forward (saved tensors may come back as new objects)
+            _amax_retag(t, tag)
         dy = dy.contiguous()
         stride = ctx.stride
         seg = ctx.seg
@@ -1493,9 +1623,9 @@ class BottleneckFn(torch.autograd.Function):
             c2, st2 = _conv_bn_train_or_eval(c1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training, pre_stats=st1, seg=seg)
             c3, st3 = _conv_bn_train_or_eval(c2, w3, Cm, 1, 0, g3, b3, rm3, rv3, training, pre_stats=st2, seg=seg)
         else:
-            a1 = bn_apply(c1, st1, True, seg=seg)
+            a1 = bn_apply(c1, st1, True, seg=seg, site=("a", g1.data_ptr()))
             c2, st2 = _conv_bn_train_or_eval(a1, w2, Cm, stride, 1, g2, b2, rm2, rv2, training, seg=seg)
-            a2 = bn_apply(c2, st2, True, seg=seg)
+            a2 = bn_apply(c2, st2, True, seg=seg, site=("a", g2.data_ptr()))
             c3, st3 = _conv_bn_train_or_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, training, seg=seg)
         if wd is not None:
             cd, std = _conv_bn_train_or_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, training, seg=seg)
@@ -1504,14 +1634,15 @@ class BottleneckFn(torch.autograd.Function):
             cd = std = None
             res, rst = x, None
         if fused:
-            y, ybits = bn_apply(c3, st3, True, res, rst, want_bits=True, seg=seg)
+            y, ybits = bn_apply(c3, st3, True, res, rst, want_bits=True, seg=seg, site=("y", g3.data_ptr()))
         else:
-            y, ybits = bn_apply(c3, st3, True, res, rst, seg=seg), None
+            y, ybits = bn_apply(c3, st3, True, res, rst, seg=seg, site=("y", g3.data_ptr())), None
         ctx.training, ctx.stride, ctx.has_ds, ctx.fused = training, stride, wd is not None, fused
         ctx.seg = seg
         ctx.betas = (b1, b2, b3, bd)
         if training:
             ctx.save_for_backward(x, w1, g1, c1, st1, a1, w2, g2, c2, st2, a2, w3, g3, c3, st3, ybits if fused else y, wd, gd, cd, std)
+            ctx.amax = tuple(_amax_tag(t) for t in (x, a1, a2, c1, c2))
         return y
 
     @staticmethod
@@ -1519,6 +1650,8 @@ class BottleneckFn(torch.autograd.Function):
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         x, w1, g1, c1, st1, a1, w2, g2, c2, st2, a2, w3, g3, c3, st3, y, wd, gd, cd, std = ctx.saved_tensors
+        for t, tag in zip((x, a1, a2, c1, c2), ctx.amax):
+            _amax_retag(t, tag)
         dy = dy.contiguous()
         stride = ctx.stride
         fused = ctx.fused

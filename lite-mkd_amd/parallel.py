@@ -165,18 +165,23 @@ class EarlyAllReduce:
         self.stream = None
         self.events = None
 
-    def arm(self, trunk_calls):
-        """the next backward pass completes the gradients of an optimizer interval; trunk_calls: hook firings to wait for (2 trunk calls
-        of the episode, 1 when they are merged)"""
+    def arm(self):
+        """the next backward pass completes the gradients of an optimizer interval.  The hook firings to wait for are COUNTED while the
+        armed forward registers them (registered(): two trunk calls of an episode, one when they run merged - which the trunk decides
+        per call, so a global flag cannot tell)"""
         self.armed = world_size() > 1 and self.split < self.bucket.numel and self.bucket.grad.is_cuda
-        self.count, self.expected, self.work = 0, int(trunk_calls), None
+        self.count, self.expected, self.work = 0, 0, None
+
+    def registered(self):
+        """the trunk's forward has put `hook` on one more tensor"""
+        self.expected += 1
 
     def hook(self, grad):
         """tensor hook on the last stage's input (returns None: the gradient passes unchanged)"""
         if not self.armed:
             return None
         self.count += 1
-        if self.count == self.expected:
+        if self.count >= self.expected:      # every hook the armed forward registered has fired: the tail is final
             self.launch()
         return None
 

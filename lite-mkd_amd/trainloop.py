@@ -37,8 +37,7 @@ class FusedOptimizer:
         parallelism the all-reduce of the bucket's tail - last trunk stage, heads, matcher - is then issued as soon as the backward pass
         has left the last stage, and runs beside the rest of it (parallel.EarlyAllReduce).  Harmless on one process."""
         if EARLY_ALLREDUCE and world_size() > 1:
-            from .model.backbone import resnet as R
-            self.early.arm(1 if R.MERGE_TRUNK_CALLS else 2)
+            self.early.arm()
             ops.GRAD_READY_HOOK = self.early.hook
         else:
             ops.GRAD_READY_HOOK = None
@@ -178,6 +177,7 @@ def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
 def _train_task_prepared(prepared, student, teacher, distiller, accuracy_fn, config):
     task_loss, task_accuracy = _episode_forward(prepared, student, teacher, distiller, accuracy_fn, config)
     task_loss.backward(retain_graph=False)
+    ops.h2_fence_step()      # fp32h2: the range fence judges this episode's tensors (asynchronous; a no-op in the other arithmetics)
     return task_loss.detach(), task_accuracy, {"accuracy": task_accuracy}
 
 
@@ -267,11 +267,12 @@ class PipelinedEpisodes:
                 if self.bwd_done is not None:
                     main.wait_event(self.bwd_done)       # gradients accumulate in episode order
                 loss.backward(retain_graph=False)
+                ops.h2_fence_step()      # fp32h2: the range fence judges this episode's tensors (asynchronous)
                 # the lane's side / auxiliary streams wrote parameter gradients directly (autograd got None and joined nothing): the
                 # event that orders the NEXT backward's accumulations must cover them
                 d = torch.device(dev)
                 for table in (ops._side_streams, ops._aux_streams):
-                    s = table.get((d.type, d.index if d.index is not None else torch.cuda.current_device(), lane))
+                    s = table.get((d.type, ops.device_index(d), lane))
                     if s is not None:
                         main.wait_stream(s)
                 ev = torch.cuda.Event()
@@ -281,14 +282,20 @@ class PipelinedEpisodes:
             ops.set_lane(0)
         return loss.detach(), acc
 
+    def join(self):
+        """make the caller's current stream wait for every backward pass run so far - and with it for the loss / accuracy tensors push() and
+        flush() have returned (they are written on the lane streams: a caller that reads them, float(loss), must join first; the host runs
+        several episodes ahead of the device)"""
+        if self.bwd_done is not None:
+            torch.cuda.current_stream(self.config.device).wait_event(self.bwd_done)
+
     def flush(self):
         """run the pending backward passes (oldest first); afterwards the caller's current stream waits for every episode pushed so far.
         -> (loss, accuracy) of the last episode, or a list of them when more than one was pending, or None"""
         outs = []
         while self.queue:
             outs.append(self._backward(self.queue.pop(0)))
-        if self.bwd_done is not None:
-            torch.cuda.current_stream(self.config.device).wait_event(self.bwd_done)
+        self.join()
         if not outs:
             return None
         return outs[0] if len(outs) == 1 else outs
@@ -637,10 +644,14 @@ def _train_loop(student, teacher, video_loader, distiller, optimizer, scheduler,
         # the reference's (iteration + 1) % period == 0 tests, on the global episode count g = (iteration + 1) * world
         g0, g1 = iteration * world, (iteration + 1) * world
         last = (iteration + 1) == total_iterations
-        if log is not None and _crossed(g0, g1, config.print_freq):
+        if log is not None and _crossed(g0, g1, config.print_freq) and losses:      # (pipelined: results arrive one episode late)
             n = max(1, config.print_freq // world)
+            if pipe is not None:
+                pipe.join()                  # the logged tensors were written on the lane streams
             log(iteration, float(torch.stack(losses[-n:]).mean()), float(torch.stack(accuracies[-n:]).mean()))
         if _crossed(g0, g1, config.save_freq) and not last:
+            if pipe is not None:
+                took(pipe.flush())           # the BatchNorm running statistics of the last forward are written on a lane stream
             checkpoint_all_ranks(student, iteration, config)
         if any(g0 < t <= g1 for t in getattr(config, "test_iters", ())) and not last:
             if pipe is not None:

@@ -32,6 +32,8 @@ def _rel(a, b):
                                                              (1, 1, 64, "TRX_2fcsup", "fc_2_sup_dist", "resnet50_2fc", "fp32x3"),
                                                              (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32h2"),
                                                              (2, 1, 64, "e_dist_fc2_sup", "fc_2_sup_dist", "resnet18_2fc", "fp32h2"),
+                                                             # BASELINE configs[4]'s student in the arithmetic its benchmark line runs
+                                                             (1, 1, 64, "TRX_2fcsup", "fc_2_sup_dist", "resnet50_2fc", "fp32h2"),
                                                              (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "bf16"),
                                                              (1, 1, 96, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "bf16act"),
                                                              # BASELINE configs[1] at FULL SIZE in the benchmark's arithmetic: 400 frames of
@@ -57,7 +59,17 @@ def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode):
     try:
         _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode in ("bf16", "bf16act"))
         if mode == "fp32h2":      # 16 forward + 16 data-gradient + 13 weight-gradient launches per trunk call (one merged call here)
-            assert litemkd_amd.lib().value("lmkd_conv_h2_launches") - h2_before >= (45 if img == 224 else 20), "the two-plane kernels did not run"
+            n_h2 = litemkd_amd.lib().value("lmkd_conv_h2_launches") - h2_before
+            import os
+            if os.environ.get("LMKD_PARITY_LOG"):
+                with open(os.environ["LMKD_PARITY_LOG"], "a") as f:
+                    f.write("two-plane launches %s %dpx: %d\n" % (bb, img, n_h2))
+            # ResNet-18: 16 forward + 16 data-gradient + 13 weight-gradient launches per trunk call (one merged call at 224 px).  ResNet-50 (two
+            # trunk calls; its Bottlenecks keep the materialised activations in this mode, so every operand carries a maximum): per call the
+            # stem's forward + weight gradient, the 3x3 and the same-size 1x1 convolutions' forward / data gradient on the patch kernel and
+            # every weight gradient
+            need = 45 if img == 224 else (150 if bb == "resnet50_2fc" else 20)
+            assert n_h2 >= need, "the two-plane kernels did not run: %d launches" % n_h2
     finally:
         O.ACT_BF16 = False
         ops.set_activation_dtype("fp32")

@@ -34,8 +34,12 @@ def h2_mode():
 
 def _word(t, i=0):
     """the recorded maximum of frame segment i: the largest of the segment's slots (csrc/common.h amax_commit)"""
-    w = t._lmkd_amax.view(torch.float32)
-    return float(w[i * (w.numel() // 2):(i + 1) * (w.numel() // 2)].max())
+    return _seg_max(t._lmkd_amax, i)
+
+
+def _seg_max(words, i=0):
+    """word 0 of each of the 64 slots (16 words apart) of segment i; words 1-3 of a slot hold the range fence's counts"""
+    return float(words.view(torch.float32).view(2, 64, 16)[i, :, 0].max())
 
 
 def _launches():
@@ -179,8 +183,8 @@ def test_one_outlier_dominating_the_maximum(dev):
 
 
 def test_two_segments_scale_independently(dev):
-    """two frame segments with maxima 1e6 apart in one launch: each segment is scaled by its own power of two (lmkd_conv_operand_amax
-    takes two words per operand), so the result equals two launches bit for bit"""
+    """two frame segments with maxima 1e6 apart in one launch: each segment is scaled by its own power of two (a maximum holds the
+    words of two segments), so the result equals two launches bit for bit"""
     g = torch.Generator(device=dev).manual_seed(5)
     N, F0, H, C = 7, 3, 14, 64
     x = torch.relu(torch.randn(N, H, H, C, device=dev, generator=g))
@@ -263,9 +267,13 @@ def test_training_across_optimizer_steps_tracks_the_three_plane_arithmetic(dev):
     from litemkd_amd import ops, trainloop as TL
     from litemkd_amd.options import default_args
     from litemkd_amd.schedule import Schedule
+    import litemkd_amd
+    L = litemkd_amd.lib()
     out = {}
     pool_tensors, ops._AMAX_POOL_TENSORS = ops._AMAX_POOL_TENSORS, 4      # a new pool of words every four tensors: the recycling happens many times per episode
     ops.amax_pool_reset()
+    ops.h2_fence_reset()
+    fb0 = L.value("lmkd_conv_h2_fallbacks")
     for mode in ("fp32h2", "fp32x3"):
         with Schedule.bench(conv_dtype=mode).applied():
             cfg = default_args(shot=5, device=dev, trans_dropout=0.1, training_iterations=10 ** 9, print_freq=10 ** 9)
@@ -285,6 +293,9 @@ def test_training_across_optimizer_steps_tracks_the_three_plane_arithmetic(dev):
             assert all(bool(torch.isfinite(p).all()) for p in student.parameters()), mode
             out[mode] = torch.stack([l.float() for l in losses]).cpu()
             ops.join_all_streams()
+            if mode == "fp32h2":      # the range fence judged every episode's tensors and flagged none: no launch fell back to three planes
+                ops.h2_fence_step(wait=True)
+                assert ops.h2_fence_flagged() == [] and L.value("lmkd_conv_h2_fallbacks") == fb0
     ops._AMAX_POOL_TENSORS = pool_tensors
     ops.amax_pool_reset()
     a, b = out["fp32h2"], out["fp32x3"]
@@ -342,8 +353,8 @@ def test_words_are_protected_on_every_stream_that_reads_them(dev, monkeypatch):
 
 def test_bound_of_the_loader_side_batchnorm(dev):
     """a consumer that applies relu(BatchNorm(c)) in its loader scales by a BOUND of the activation's maximum: the convolution records
-    max |c| (lmkd_conv_output_amax: in its epilogue, or - a launch on another kernel - by a pass of its own), the statistics launch folds
-    |scale| max |c| + |shift| over the channels (lmkd_bn_finalize_bound).  The bound is never below the true maximum (an overflow of
+    max |c| (lmkd_amax_desc::out_words: in its epilogue, or - a launch on another kernel - by a pass of its own), the statistics launch folds
+    |scale| max |c| + |shift| over the channels (lmkd_amax_desc on lmkd_bn_finalize(_seg)).  The bound is never below the true maximum (an overflow of
     the fp16 planes otherwise) and, on unit-variance data, within 2^4 of it; the consumers then agree with the three-plane form to fp32
     rounding"""
     import litemkd_amd
@@ -359,11 +370,9 @@ def test_bound_of_the_loader_side_batchnorm(dev):
         try:
             c1, st1 = ops._conv_bn_train_or_eval(x, w1, Cin, stride, 1, gam, bet, torch.zeros(C, device=dev), torch.ones(C, device=dev), True, seg=seg, bound=True)
             a1 = ops.bn_apply(c1, st1, True, seg=seg)
-            words = c1._lmkd_pre_amax.view(torch.float32)
-            half = words.numel() // 2
             parts = [a1] if not seg else [a1[:seg], a1[seg:]]
             for i, p in enumerate(parts):
-                bound, true = float(words[i * half:(i + 1) * half].max()), float(p.max())
+                bound, true = _seg_max(c1._lmkd_pre_amax, i), float(p.max())
                 assert true <= bound <= 16 * true, (N, seg, C, i, bound, true)
             # the consumer: conv2 with the BatchNorm in its loader, two-plane against three-plane
             n0 = _launches()
@@ -375,3 +384,51 @@ def test_bound_of_the_loader_side_batchnorm(dev):
             assert float((y_h2 - y_x3).norm() / y_x3.norm()) < 2e-6
         finally:
             ops.set_defer(None)
+
+
+def _identity_table(C, dev):
+    st = torch.zeros(5, C, device=dev)
+    st[2] = 1.0      # scale 1, shift 0: lmkd_bn_apply_seg copies its input - a producer that touches every element
+    return st
+
+
+def test_range_fence_takes_the_three_plane_form(dev):
+    """the run-time fence of the two-plane arithmetic.  A producer that is given its tensor's previous maximum counts the elements the two
+    fp16 planes do not resolve fully against it (csrc/common.h amax_commit_stat); lmkd_h2_fence_eval judges the counts once per episode
+    (ops.h2_fence_step) and a flagged site's maximum is withheld from the convolutions, which then run the three-plane form:
+    (1) the tensor of test_one_outlier_dominating_the_maximum - one element 2^20 above the rest - is flagged in its second episode, its
+        convolution falls back (lmkd_conv_h2_fallbacks counts it) and the frames the outlier misses come out at fp32 level, not 2e-3;
+    (2) a log-normal tensor (sigma = 2: 18 % of its elements below 2^-17 of the maximum, but none of its mass) and a half-normal one (the
+        benchmark's kind) are NOT flagged and keep the two-plane kernels."""
+    import litemkd_amd
+    from litemkd_amd import ops
+    L = litemkd_amd.lib()
+    ops.h2_fence_reset()
+    g = torch.Generator(device=dev).manual_seed(11)
+    N, H, C = 4, 14, 64
+    w = torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.05
+    wp = ops._pack_weights(w, C, 0)
+    st = _identity_table(C, dev)
+    outlier = torch.relu(torch.randn(N, H, H, C, device=dev, generator=g))
+    outlier[0, 7, 7, 0] = 2.0 ** 20
+    lognormal = torch.exp(2.0 * torch.randn(N, H, H, C, device=dev, generator=g))
+    halfnormal = torch.relu(torch.randn(N, H, H, C, device=dev, generator=g))
+    tensors = {("y", 1): outlier, ("y", 2): lognormal, ("y", 3): halfnormal}
+    for ep in range(3):
+        for site, x in tensors.items():
+            ops.bn_apply(x, st, False, site=site)
+        ops.h2_fence_step(wait=True)
+        assert ops.h2_fence_flagged() == ([] if ep == 0 else [("y", 1)]), ep      # judged from the second episode on (the first has no reference)
+    for site, x in tensors.items():
+        y = ops.bn_apply(x, st, False, site=site)
+        assert torch.equal(y, x)
+        n0, f0 = _launches(), L.value("lmkd_conv_h2_fallbacks")
+        out = ops.conv_fwd(y, wp, C, 3, 3, 1, 1, True)[0]
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+        fell_back = site == ("y", 1)
+        assert _launches() - n0 == (0 if fell_back else 1) and L.value("lmkd_conv_h2_fallbacks") - f0 == (1 if fell_back else 0), site
+        assert _rel(out, ref) < 1.5e-6, (site, _rel(out, ref))
+        if fell_back:
+            assert _rel(out[1:], ref[1:]) < 1.5e-6, _rel(out[1:], ref[1:])      # the frames the outlier does not touch
+    ops.h2_fence_step(wait=True)
+    ops.h2_fence_reset()

@@ -144,6 +144,9 @@ def test_stem_two_segments_equal_two_calls(dev, mode, act, F0, F1, H):
         assert _rel(a, b) < 4e-6, (tuple(a.shape), _rel(a, b))
 
 
+R50_H2_LAUNCHES = 155      # 53 weight gradients + 52 data gradients + 50 forwards (the stem, 16 3x3, 33 same-size 1x1; the three stride-2 1x1 downsample forwards run the gather kernel on three planes)
+
+
 def _trunk_pair(dev, bb, Fs, Fq, img, mode, act, seed=0):
     """(features, parameter gradients, running statistics) of one forward + backward of the backbone's trunk + pooled head over the two
     frame sets, merged and as two calls on one stream"""
@@ -166,6 +169,7 @@ def _trunk_pair(dev, bb, Fs, Fq, img, mode, act, seed=0):
         for p in trunk.parameters():
             p.grad = None
         R.MERGE_TRUNK_CALLS, R.OVERLAP_TRUNK_CALLS = merged, False
+        h2_0 = litemkd_amd.lib().value("lmkd_conv_h2_launches")
         try:
             X, n0 = R.trunk_features(trunk, ops.PoolHeadFn.apply, cf, tf)
             assert n0 == Fs
@@ -175,16 +179,25 @@ def _trunk_pair(dev, bb, Fs, Fq, img, mode, act, seed=0):
         torch.cuda.synchronize()
         out[merged] = (X.detach().clone(), {n: p.grad.clone() for n, p in trunk.named_parameters()},
                        {n: b.clone() for n, b in trunk.named_buffers()})
+        out[("h2", merged)] = litemkd_amd.lib().value("lmkd_conv_h2_launches") - h2_0
     return out
 
 
 @pytest.mark.parametrize("bb,Fs,Fq,img,mode,act", [("r18", 8, 40, 64, "fp32x3", "fp32"), ("r18", 40, 40, 96, "fp32x3", "fp32"),
                                                      ("r18", 8, 40, 64, "fp32h2", "fp32"), ("r18", 40, 40, 96, "fp32h2", "fp32"),
                                                      ("r18", 8, 40, 64, "bf16", "bf16"), ("r18", 24, 8, 64, "bf16", "fp32"),
-                                                     ("r50", 8, 16, 64, "fp32x3", "fp32"), ("r50", 8, 16, 64, "bf16", "bf16")])
+                                                     ("r50", 8, 16, 64, "fp32x3", "fp32"), ("r50", 8, 16, 64, "fp32h2", "fp32"),
+                                                     ("r50", 8, 16, 64, "bf16", "bf16")])
 def test_merged_trunk_equals_two_calls(dev, bb, Fs, Fq, img, mode, act):
     out = _trunk_pair(dev, bb, Fs, Fq, img, mode, act)
     (X2, g2, b2), (X1, g1, b1) = out[False], out[True]
+    if mode == "fp32h2":
+        # the two-plane launches of ONE merged trunk call, forward + backward: ResNet-18 = 17 forward (stem + 16 3x3) + 19 data gradient
+        # (16 3x3 + 3 downsample 1x1) + 20 weight gradient = 56 (the two-call form runs each twice).  ResNet-50 (its
+        # Bottlenecks keep the materialised activations in this mode, so every operand carries a maximum): the stem, every convolution's
+        # weight gradient (53), the data gradients (52) and the forwards that run the patch kernel (3x3, same-size 1x1)
+        want = 56 if bb == "r18" else R50_H2_LAUNCHES
+        assert out[("h2", True)] == want and out[("h2", False)] == 2 * want, (out[("h2", True)], out[("h2", False)])
     assert torch.equal(X1, X2), _rel(X1, X2)
     for n in b2:
         assert torch.equal(b1[n], b2[n]), n      # running statistics: both updates, in the reference's order; num_batches_tracked += 2
