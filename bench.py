@@ -427,6 +427,7 @@ def main():
             print("bench.py: " + traffic_note, file=sys.stderr)
     frames = 8 * 5 * (a.shot + cfg.query_per_class)
     step_tflop = 3 * FWD_GFLOP_PER_FRAME * frames / 1e3
+    ops.h2_fence_step(wait=True)      # fp32h2: take in the range fence's last verdicts before they are reported
     out = {
         "metric": "episodes/sec (5-way %d-shot, 8x224^2 frames)" % a.shot, "value": world * a.steps / dt, "unit": "episodes/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -441,10 +442,14 @@ def main():
                                               "v_mfma_f32_16x16x32_f16 with fp32 accumulation (the dropped h1 w1 <= 2^-22 of the product, zero-mean; the three-plane "
                                               "bf16 form drops <= 2^-23, all of one sign).  Everything else (the 1x1 forward of the downsample branches, the heads) runs f32x3's "
                                               "arithmetic.  Relative-L2 error vs fp64 on the trunk's four 3x3 shapes: forward 2.7e-7 .. 7.0e-7, data gradient "
-                                              "2.7e-7 .. 7.1e-7, weight gradient 2.3e-7 .. 5.5e-7 - BELOW f32x3's (3.5e-7 .. 9.6e-7 | 3.6e-7 .. 1.0e-6 | 2.9e-7 .. "
-                                              "8.2e-7) and at torch's fp32 convolution's on every one (profiles/r04_h2_error.txt; tests/test_gpu_h2.py holds "
-                                              "it to the fp64-anchored criterion of the f32x3 tests).  The same job in f32x3 (rounds 2-3's headline): "
-                                              "other_modes.f32x3",
+                                              "2.7e-7 .. 7.1e-7, weight gradient 2.3e-7 .. 5.5e-7 - below f32x3's (3.5e-7 .. 9.6e-7 | 3.6e-7 .. 1.0e-6 | 2.9e-7 .. "
+                                              "8.2e-7; profiles/r04_h2_error.txt, 40 frames, where torch's GPU fp32 convolution reads 3.0e-7 .. 8.0e-7).  Against the CPU "
+                                              "ORACLE - the stated baseline - at the benchmark's 200 frames the pairs (HIP | torch-CPU fp32, both vs fp64) are in "
+                                              "profiles/r05_parity_errors.txt: layers 1-2 level with it, layers 3-4 2-3x above (forward 7.0e-7 vs 2.3e-7 on layer 4): fp32-class - "
+                                              "inside the fp64-anchored criterion 3 x CPU + 1e-6 of tests/test_gpu_fullsize.py, which also holds with trained-like "
+                                              "statistics (log-normal activations, |gamma| in [0.2, 3], 2^6 weight-scale spread) - not 'at the oracle's level'.  A run-time "
+                                              "range fence (DESIGN 11.2) counts what the two planes do not resolve and moves a tensor's convolutions to the three-plane "
+                                              "form: h2_fallbacks below, 0 on this benchmark.  The same job in f32x3 (rounds 2-3's headline): other_modes.f32x3",
                                        "f32x3": "the library default: fp32 tensors and accumulation; every convolution (forward, data and weight "
                                               "gradient, stem included) forms its products on the bf16 matrix pipe from an exact 3-way bf16 split of "
                                               "both operands, 6 of 9 cross products; half the row tiles of a launch accumulate -y so that the MFMA's "
@@ -484,6 +489,10 @@ def main():
         "episode_pipelining": bool(use_pipe),
         # after every timed / repeated / probe episode and optimizer step of this process (ReLU(NaN) = 0 keeps a loss finite on NaN weights)
         "weights_finite": bool(torch.isfinite(opt.bucket.flat).all()),
+        # the range fence of the two-plane arithmetic (ops.h2_fence_step after every backward pass): launches that fell back to the three-plane
+        # form because their tensor was flagged, and the flagged tensors ("y" | "a" | "d" | "p", BatchNorm) - expected 0 / none on this benchmark
+        "h2_fallbacks": int(litemkd_amd.lib().value("lmkd_conv_h2_fallbacks")),
+        "h2_fence_flagged_sites": len(ops.h2_fence_flagged()),
         "hipgraph": {"enabled": bool(use_graph), "replays": runners[a.dtype].replays if use_graph else 0,
                      "eager_episodes": runners[a.dtype].eager if use_graph else None, "graphs": len(runners[a.dtype].graphs) if use_graph else 0},
     }

@@ -359,6 +359,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_gemm_kernel(ConvGemmArgs a)
 }
 
 #include "conv_x3.h"
+#include "h2.h"
 #include "conv_patch.h"
 #include "conv_patch16.h"
 #include "conv_stem.h"
@@ -932,8 +933,16 @@ static inline bool conv_same_size(int H, int W, int KH, int KW, int stride, int 
 
 static int g_conv_s2_patch = 1;      // stride-2 3x3 forward on conv_patch16_x3_kernel's SRC2 form; 0 = im2col-gather kernel
 extern "C" int lmkd_conv_set_s2_patch(int on) { g_conv_s2_patch = on ? 1 : 0; return LMKD_OK; }
-static int g_patch16 = 1;      // three-plane modes, fp32 tensors, the 4-wave tiles: conv_patch16_x3_kernel (v_mfma_f32_16x16x32_bf16); 0 = conv_patch_x3_kernel (32x32x16)
-extern "C" int lmkd_conv_set_patch16(int on) { g_patch16 = on ? 1 : 0; return LMKD_OK; }
+// three-plane modes, fp32 tensors, the 4-wave tiles: conv_patch16_x3_kernel (v_mfma_f32_16x16x32_*); 0 = conv_patch_x3_kernel (32x32x16).
+// 1 (default) = automatic: the 16x16x32 kernel, except the TWO-PLANE launches with Cout <= 64 (layer 1; NOT the 64-column tile of a wider layer: the
+// two-call and the merged form of an episode pick different tiles there and must stay bit-identical), which run
+// conv_patch_x3_kernel<.., 3, ..> on v_mfma_f32_32x32x16_f16 - with half the MFMAs of the three-plane form these launches are bound by
+// vector-instruction issue (5.6 vector instructions per 16x16x32 MFMA, which holds the SIMD's vector issue for 8 of its 16 cycles; a
+// 32x32x16 MFMA does the work of two and holds it for 8 of 32), and a lane of the 32x32 result owns ONE channel, so the BatchNorm sums
+// need one shuffle instead of a 16-lane reduction per channel: 431 -> 350 us forward + sums, 378 -> 347 us data gradient at 400 frames
+// (profiles/r05_patch32_vs_16.txt; the 128-column tiles of layers 2-4 stay 5-10 % faster on 16x16x32).  2 = 16x16x32 everywhere.
+static int g_patch16 = 1;
+extern "C" int lmkd_conv_set_patch16(int on) { g_patch16 = on < 0 ? 0 : (on > 2 ? 2 : on); return LMKD_OK; }
 
 template <class Cfg>
 static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
@@ -953,7 +962,8 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
     hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>), grid, dim3(Cfg::THREADS), lds, s, a);                      \
   } while (0)
   if constexpr (Cfg::THREADS == 256 && Cfg::BM == 128) {      // the benchmark's tiles (ids 11 / 12) on the 16x16x32 MFMA (conv_patch16.h)
-    if (g_patch16 && g_conv_x3 && !g_lmkd_act_bf16) {
+    const bool h2_on_32 = g_patch16 == 1 && Cfg::BN == 64 && a.Co <= 64 && g_conv_h2 && a.h2_xw && !a.src2 && !a.ep_stats;      // (lmkd_conv_set_patch16)
+    if (g_patch16 && g_conv_x3 && !g_lmkd_act_bf16 && !h2_on_32) {
 #define LMKD_PATCH16(NPROD, PRE, EP)                                                                                           \
   do {                                                                                                                         \
     t_amax_recorded = true;                                                                                                    \
@@ -988,6 +998,12 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
 #undef LMKD_PATCH16
       return;
     }
+  }
+  if (g_conv_h2 && a.h2_xw && !a.ep_stats && !g_lmkd_act_bf16) {      // two fp16 planes on v_mfma_f32_32x32x16_f16: the 64-column tile (lmkd_conv_set_patch16), or a tile conv_patch16_x3_kernel does not have
+    t_amax_recorded = true;      // (x3_epilogue<.., H2> folds ConvGemmArgs::amax_out)
+    if (a.pre_stats) LMKD_PATCH(3, true, 0); else LMKD_PATCH(3, false, 0);
+    ++g_h2_launches;
+    return;
   }
   if (a.ep_stats) {      // inference: BatchNorm affine (+ residual, ReLU) in the epilogue, fp32 tensors
     if (g_conv_bf16) LMKD_PATCH(1, false, 4);

@@ -30,12 +30,13 @@ template <class Cfg, int NPROD, bool PRE, int IO, int DBG = 0>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(ConvGemmArgs a) {
   constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0, EP = (IO & 4) != 0;      // IO bits: conv_gemm_x3_kernel
   constexpr int NPL = NPROD == 1 ? 1 : 3;
+  constexpr int NPU = NPROD == 3 ? 2 : NPL;      // NPROD == 3: two fp16 planes (h2.h) in the three-plane row pitch
   static_assert(((IO & 3) == 0 || NPROD == 1) && !(IN16 && PRE), "bf16 tensors: one-plane mode, no load-side arithmetic");
   constexpr int ROWB = PatchRow<NPL>::BYTES;
   constexpr int LPR = IN16 ? 4 : 8;                       // lanes per patch row (16 bytes each)
   constexpr int RPP = Cfg::THREADS / LPR;                 // patch rows per pass
   constexpr int NI = (Cfg::BM + 2 * PATCH_HALO_MAX + RPP - 1) / RPP;
-  using LB = X3FragB<Cfg::TN, NPL>;
+  using LB = X3FragB<Cfg::TN, NPU>;
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   __shared__ int s_out[Cfg::BM];
   __shared__ int s_tap_shift[LMKD_MAX_TAPS], s_tap_kofs[LMKD_MAX_TAPS];
@@ -115,6 +116,12 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     if (tid / LPR + RPP * i < P && pix >= 0 && pix < (long)a.N * a.Hs * a.Ws) p_ok |= 1u << i;
   }
   u32x4 rp[NI];
+  float h2_sx = 1.f, h2_ix = 1.f, h2_iw = 1.f;
+  if constexpr (NPROD == 3) {
+    h2_sx = h2_scale(amax_read(a.h2_xw, sg.seg));
+    h2_ix = 1.f / h2_sx;
+    h2_iw = 1.f / h2_scale(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(a.wpk) + (long)a.Co * a.Kp * 16));
+  }
   float4 psc = float4(), psh = float4();
   const float* pre_tab = PRE ? a.pre_stats + (long)sg.seg * 5 * a.Cs : nullptr;      // the [5][Cs] BatchNorm table of this tile's segment
   auto issue_patch = [&](int cc) {
@@ -142,6 +149,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
         }
         if (NPL == 1) {
           *reinterpret_cast<uint2*>(d) = x3_round4(v);
+        } else if constexpr (NPROD == 3) {
+          uint2 q0, q1;
+          h2_split4(v, h2_sx, q0, q1);
+          *reinterpret_cast<uint2*>(d) = q0;
+          *reinterpret_cast<uint2*>(d + 64) = q1;
         } else {
           uint2 q0, q1, q2;
           x3_split4(v, q0, q1, q2);
@@ -153,8 +165,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     }
   };
   LB lb;
-  const bool neg = NPL == 3 && x3_neg_tile(sg.ltile, sg.ltiles);      // half the row tiles (of the segment) accumulate -y: X3FragB::init
-  lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, neg);
+  const bool neg = NPL == 3 && NPROD != 3 && x3_neg_tile(sg.ltile, sg.ltiles);      // half the row tiles (of the segment) accumulate -y: X3FragB::init
+  if constexpr (NPROD == 3)      // the fp16 planes of W in the 32x32x16 order: behind the bf16 planes, the 16x16x32 fp16 planes and the maximum's 64 bytes
+    lb.init(reinterpret_cast<const unsigned short*>(a.wpk) + (long)a.Co * a.Kp * 16 + 32, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, false);
+  else
+    lb.init(a.wpk, a.Co, a.Kp, n0 + wn * (Cfg::TN * 32), lane, neg);
   f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     auto read_a = [&](int g) {
       if ((DBG & 2) && (t > 0 || (!AHEAD && g == 1))) return;
 #pragma unroll
-      for (int p = 0; p < NPL; ++p)
+      for (int p = 0; p < NPU; ++p)
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i) av[AHEAD ? g : 0][p][i] = *reinterpret_cast<const bf16x8*>(psm + ad[i] + p * 64 + g * 32);
     };
@@ -251,6 +266,16 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
           const bf16x8 b0 = x3_as_bf16(rb[j * 2 + g]);
 #pragma unroll
           for (int i = 0; i < Cfg::TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ga][0][i], b0, acc[i][j], 0, 0, 0);
+        } else if constexpr (NPROD == 3) {      // two fp16 planes, three products, smallest terms first
+          const f16x8 b0 = __builtin_bit_cast(f16x8, rb[j * 4 + g * 2 + 0]), b1 = __builtin_bit_cast(f16x8, rb[j * 4 + g * 2 + 1]);
+#pragma unroll
+          for (int i = 0; i < Cfg::TM; ++i) {
+            f32x16 c = acc[i][j];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[ga][0][i]), b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[ga][1][i]), b0, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[ga][0][i]), b0, c, 0, 0, 0);
+            acc[i][j] = c;
+          }
         } else {
           const bf16x8 b0 = x3_as_bf16(rb[j * 6 + g * 3 + 0]), b1 = x3_as_bf16(rb[j * 6 + g * 3 + 1]), b2 = x3_as_bf16(rb[j * 6 + g * 3 + 2]);
           if constexpr ((DBG & 32) != 0) {      // power / clock probe: the same FLOPs as v_mfma_f32_16x16x32_bf16 (two per 32x32x16), garbage results
@@ -346,6 +371,16 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
     if (sacc == 1.2345e-30f) a.out[0] = sacc;
+    return;
+  }
+  if constexpr (NPROD == 3) {      // 2^-sx, 2^-sw: two exact multiplications (no product of scales is formed)
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] * h2_ix * h2_iw;
+    x3_epilogue<Cfg, true, OUT16, EP, true>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid, false, sg.seg);
     return;
   }
   x3_epilogue<Cfg, true, OUT16, EP>(a, acc, s_out, s_red, rt, n0, wm, wn, lane, tid, neg);

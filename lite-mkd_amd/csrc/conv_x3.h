@@ -296,10 +296,16 @@ __device__ __forceinline__ void x3_kstep(const unsigned char* __restrict__ As, i
 // EP (inference, lmkd_conv2d_fwd_bn): out = relu?( acc * scale[c] + shift[c] (+ res) ) with scale / shift = rows 2 / 3 of the [5][C]
 // BatchNorm table a.ep_stats - the operations of bn_apply_kernel in its order, so the fused forward is bit-identical to the
 // two-pass form (conv_gemm_kernel's STATS == 2 epilogue does the same for the native fp32 mode).
-template <class Cfg, bool STATS, bool OUT16, bool EP = false>
+// H2 (the two-plane instances of conv_patch_x3_kernel, compute mode 4): also fold max |out| of the tile's frame segment `seg` into
+// a.amax_out, and - a.bnb_x given: the data gradient that feeds relu + train-mode BatchNorm backward, lmkd_conv2d_bwd_data_seg - leave the
+// sums of that backward (sum g, sum g xhat; g = out where fma(x, scale, shift) > 0: bn_bwd_reduce_kernel's terms) in a.stat_partial
+// instead of the forward's (sum, sum of squares).  A lane owns ONE channel per 32-column block here, so either pair of sums is local
+// to the lane over its 16 TM rows and meets its partner lane (+ 32) in one shuffle.
+template <class Cfg, bool STATS, bool OUT16, bool EP = false, bool H2 = false>
 __device__ __forceinline__ void x3_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], const int* s_out, float* s_red, int rt,
-                                            int n0, int wm, int wn, int lane, int tid, bool neg = false) {
+                                            int n0, int wm, int wn, int lane, int tid, bool neg = false, int seg = 0) {
   static_assert(!(EP && OUT16), "the BatchNorm epilogue writes fp32 tensors");
+  static_assert(!H2 || (!EP && !OUT16), "two-plane instances: fp32 tensors, training / plain epilogue");
   if (neg) {      // this workgroup accumulated -y (X3FragB::init)
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i)
@@ -361,6 +367,21 @@ __device__ __forceinline__ void x3_epilogue(const ConvGemmArgs& a, f32x16 (&acc)
   float s1[Cfg::TN], s2[Cfg::TN];
 #pragma unroll
   for (int j = 0; j < Cfg::TN; ++j) s1[j] = s2[j] = 0.f;
+  float amo = 0.f;
+  const bool bnb = H2 && a.bnb_x != nullptr;      // (uniform)
+  float bsc[Cfg::TN], bsh[Cfg::TN], bmean[Cfg::TN], bistd[Cfg::TN];
+  if (H2 && bnb) {
+    const float* tab = a.bnb_stats + (long)seg * 5 * a.Co;
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = n0 + cl0 + j * 32;
+      const bool in = col < a.Co;
+      bmean[j] = in ? tab[col] : 0.f;
+      bistd[j] = in ? tab[a.Co + col] : 0.f;
+      bsc[j] = in ? tab[2 * a.Co + col] : 0.f;
+      bsh[j] = in ? tab[3 * a.Co + col] : 0.f;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i) {
 #pragma unroll
@@ -371,6 +392,20 @@ __device__ __forceinline__ void x3_epilogue(const ConvGemmArgs& a, f32x16 (&acc)
       for (int j = 0; j < Cfg::TN; ++j) {
         const int col = n0 + cl0 + j * 32;
         float v = acc[i][j][e];
+        if constexpr (H2) {
+          if (ob >= 0 && col < a.Co) {
+            a.out[(long)ob + col] = v;
+            amo = fmaxf(amo, fabsf(v));
+            if (bnb) {
+              const float xv = a.bnb_x[(long)ob + col];
+              const float g = fmaf(xv, bsc[j], bsh[j]) > 0.f ? v : 0.f;
+              s1[j] += g;
+              s2[j] = fmaf(g, (xv - bmean[j]) * bistd[j], s2[j]);
+            }
+          }
+          if (!bnb) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }      // (rows outside the tensor hold exact zeros)
+          continue;
+        }
         if (OUT16) {      // the tensor in HBM is bf16: the BatchNorm statistics are those of the stored (rounded) values
           const lmkd_bf16_t b = f32_to_bf16(v);
           if (ob >= 0 && col < a.Co) out16[(long)ob + col] = b;
@@ -383,6 +418,7 @@ __device__ __forceinline__ void x3_epilogue(const ConvGemmArgs& a, f32x16 (&acc)
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (H2 && a.amax_out) amax_commit(a.amax_out + seg * LMKD_AMAX_SEG_WORDS, amo);      // (every wave of the workgroup reaches this point)
   if (STATS) {
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {

@@ -540,7 +540,7 @@ def _desc_arg(d):
 # (csrc/common.h amax_commit_stat) and h2_fence_step() - once per episode, no host synchronisation: the verdict is read an episode or two
 # later - lets lmkd_h2_fence_eval judge the counts.  A flagged site stays flagged (h2_fence_reset() clears): its tensor's maximum is
 # withheld from the convolutions, which then run the three-plane form, and lmkd_conv_h2_fallbacks() counts those launches.
-H2_FENCE = True
+H2_FENCE = os.environ.get("LMKD_H2_FENCE", "1") != "0"      # (bench.py A/B: LMKD_H2_FENCE=0 runs the two-plane arithmetic unfenced)
 _FENCE_SITES = {}        # site -> {"ref": persistent words, "bad": bool}
 _FENCE_PENDING = []      # (site, words) written since the last h2_fence_step()
 _FENCE_INFLIGHT = []     # (event, pinned host flags, [sites], keep-alive)

@@ -85,7 +85,10 @@ def build_parser():
     p.add_argument("--opt", choices=["adam", "sgd"], default="sgd", help="Optimizer")
     # ---- not in the reference
     p.add_argument("--dtype", choices=["f32", "f32h2", "f32x3", "f32native", "bf16"], default="f32", help="arithmetic: f32 = f32h2 (default, what bench.py times): "
-                   "fp32 tensors and accumulation, the trunk's convolutions on two fp16 planes + power-of-two scales from the tensors' maxima (DESIGN 10); "
+                   "fp32 tensors and accumulation, the trunk's convolutions on two fp16 planes + power-of-two scales from the tensors' maxima (DESIGN 10): "
+                   "full precision for elements within 2^17 of their tensor's maximum, an absolute 2^-40 of the maximum below; a run-time range fence "
+                   "(ops.h2_fence_step, once per episode) counts what that leaves under-resolved and moves a tensor whose under-resolved elements would add more "
+                   "than a quarter to its rounding error to f32x3's kernels from the next episode on (INTEGRATION.md, 'range fence'); "
                    "f32x3 = every fp32 product from an exact 3-way bf16 split, six products (the library's default arithmetic); "
                    "f32native = v_mfma_f32_32x32x2_f32, bf16 = bf16 tensors + bf16 MFMA (the reference's autocast path, trainwandb.py:20,126)")
     p.add_argument("--serial", action="store_true", help="single-stream schedule (Schedule.serial())")

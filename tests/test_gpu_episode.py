@@ -40,7 +40,11 @@ def _rel(a, b):
                                                              # 224^2, forward, loss and every parameter gradient (three oracle runs, ~2 min)
                                                              (5, 5, 224, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32x3"),
                                                              # ... and in bench.py's headline arithmetic (two fp16 planes in the 3x3 kernels)
-                                                             (5, 5, 224, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32h2")])
+                                                             (5, 5, 224, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32h2"),
+                                                             # ... with the statistics of a TRAINED network: BatchNorm
+                                                             # |gamma| ~ U(0.2, 3) of either sign, beta ~ N(0, 1), convolution weights with a 2^6
+                                                             # spread of per-output-channel scales
+                                                             (5, 5, 224, "TRX_2fcsup", "fc_2_sup_dist", "resnet18_2fc", "fp32h2+trained")])
 def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode):
     """mode fp32h2 (bench.py's headline arithmetic): fp32x3 with the 3x3 convolutions on two fp16 planes (csrc/conv_patch16.h); the test
     asserts that those kernels ran.
@@ -50,6 +54,8 @@ def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode):
     arithmetic on the CPU, not the GPU's own fp32 run."""
     from litemkd_amd import ops
     from oracle import ref_cpu as O
+    trained = mode.endswith("+trained")
+    mode = mode.split("+")[0]
     ops.set_conv_compute_dtype("bf16" if mode == "bf16act" else mode)
     if mode == "bf16act":      # + every stored activation / activation gradient of the trunk as bf16: oracle.ACT_BF16 rounds at the same places
         ops.set_activation_dtype("bf16")
@@ -57,7 +63,7 @@ def test_episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode):
     import litemkd_amd
     h2_before = litemkd_amd.lib().value("lmkd_conv_h2_launches")
     try:
-        _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode in ("bf16", "bf16act"))
+        _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, mode in ("bf16", "bf16act"), trained=trained)
         if mode == "fp32h2":      # 16 forward + 16 data-gradient + 13 weight-gradient launches per trunk call (one merged call here)
             n_h2 = litemkd_amd.lib().value("lmkd_conv_h2_launches") - h2_before
             import os
@@ -127,7 +133,24 @@ def _hip_pool_choices(taps):
     return calls
 
 
-def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
+def _trained_like_(student, seed=77):
+    """in place: the trunk's BatchNorm tables and convolution weights as a trained network has them (the reference starts from ImageNet
+    weights, resnet18_2fc.py:30) - |gamma| ~ U(0.2, 3) of either sign, beta ~ N(0, 1), a 2^6 spread of per-output-channel weight scales"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in student.named_parameters():
+            if not n.startswith("backbone.resnet."):
+                continue
+            if p.dim() == 4:
+                p.mul_(torch.exp2(6.0 * torch.rand(p.shape[0], 1, 1, 1, generator=g) - 3.0).to(p.device))
+            elif n.endswith(".weight"):
+                sg = torch.where(torch.randn(p.shape, generator=g) < 0, -1.0, 1.0)
+                p.copy_(((0.2 + 2.8 * torch.rand(p.shape, generator=g)) * sg).to(p.device))
+            elif n.endswith(".bias"):
+                p.copy_(torch.randn(p.shape, generator=g).to(p.device))
+
+
+def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False, trained=False):
     from litemkd_amd.model.model_select import Student, Teacher
     from litemkd_amd.distillers import Distiller
     from litemkd_amd.options import default_args
@@ -139,6 +162,8 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
                         model_backbone=bb)
     torch.manual_seed(1)
     student, teacher = Student(args).to(dev), Teacher(args).to(dev)
+    if trained:
+        _trained_like_(student)
     ep = O.make_episode(900 + shot, 5, shot, query, img=img)
     sp = {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
     tp = {k[len("classifier.transformers."):]: v.detach().cpu().clone() for k, v in teacher.state_dict().items()
@@ -240,7 +265,8 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
                 anchored("teacher logits " + k, tl[k], ot[k], ot64[k], 3.0, 1e-5)
         assert abs(loss.item() - ol64.item()) <= 3 * abs(ol.item() - ol64.item()) + 1e-5 * abs(ol64.item()), (loss.item(), ol.item(), ol64.item())
         from _anchor import record as _rec
-        _rec("episode forward %d-shot %d-query %dpx %s %s [%s]" % (shot, query, img, clf, bb, ops.get_conv_compute_dtype()), fwd)
+        _rec("episode forward %d-shot %d-query %dpx %s %s [%s%s]" % (shot, query, img, clf, bb, ops.get_conv_compute_dtype(),
+                                                                    ", trained-like statistics" if trained else ""), fwd)
     # argmax bit-exact wherever the oracle's top-2 margin exceeds the logit tolerance
     lg = o["logits"]["kl"].detach() + o["logits"]["ce"].detach()
     srt = torch.sort(lg, -1).values
@@ -279,8 +305,9 @@ def _episode_matches_oracle(dev, shot, query, img, clf, dist, bb, bf16=False):
     print("worst HIP/CPU gradient error ratio vs fp64:", worst, "loss", loss.item(), ol.item(), ol64.item(), "mask flips vs fp64:", flips,
           "pooling selections that differ from fp64's:", pflips)
     from _anchor import record
-    record("episode %d-shot %d-query %dpx %s %s [%s%s]" % (shot, query, img, clf, bb, ops.get_conv_compute_dtype(),
-                                                          ", bf16 tensors" if ops.get_activation_dtype() == "bf16" else ""),
+    record("episode %d-shot %d-query %dpx %s %s [%s%s%s]" % (shot, query, img, clf, bb, ops.get_conv_compute_dtype(),
+                                                            ", bf16 tensors" if ops.get_activation_dtype() == "bf16" else "",
+                                                            ", trained-like statistics" if trained else ""),
            {"worst parameter gradient (%s)" % worst[1]: worst[2:], "loss (hip, oracle fp32) vs fp64 abs": (abs(loss.item() - ol64.item()), abs(ol.item() - ol64.item()))})
 
 

@@ -82,7 +82,7 @@ def _ulp_close(name, hip16, ref64):
     return frac
 
 
-def _run_shape(dev, name, H, Cs, Cin, Cout, K, s, p, N=FRAMES, check_wgrad=True, act16=False):
+def _run_shape(dev, name, H, Cs, Cin, Cout, K, s, p, N=FRAMES, check_wgrad=True, act16=False, trained=False):
     """act16 (BASELINE configs[2]: ops.set_conv_compute_dtype('bf16') + set_activation_dtype('bf16') by the caller): x / dy / y / dx
     are bf16 tensors (the stem's NHWC4 input stays fp32), the kernels round the weights to one bf16 plane; the references are
     fp64 convolutions of the SAME bf16-rounded operands, so what is judged is the accumulation and the output rounding."""
@@ -95,6 +95,19 @@ def _run_shape(dev, name, H, Cs, Cin, Cout, K, s, p, N=FRAMES, check_wgrad=True,
     w = torch.randn(Cout, Cin, K, K, device=dev, generator=g) * (2.0 / (Cout * K * K)) ** 0.5
     Ho = (H + 2 * p - K) // s + 1
     dy = torch.randn(N, Ho, Ho, Cout, device=dev, generator=g)
+    if trained:
+        # statistics of a TRAINED network instead of the benchmark's fresh one (the reference starts from ImageNet weights,
+        # resnet18_2fc.py:30): heavy-tailed pre-activations (log-normal magnitudes, sigma = 2), BatchNorm tables with |gamma| ~ U(0.2, 3),
+        # either sign, beta ~ N(0, 1); weights whose output channels differ in scale by up to 2^6; gradients with log-normal magnitudes
+        # and a 1e3 imbalance between the two halves of the frames (support / query) - inside ONE segment, i.e. under one scale
+        sgn = lambda t: torch.where(t < 0, -torch.ones_like(t), torch.ones_like(t))      # noqa: E731
+        gam = (0.2 + 2.8 * torch.rand(Cs, device=dev, generator=g)) * sgn(torch.randn(Cs, device=dev, generator=g))
+        bet = torch.randn(Cs, device=dev, generator=g)
+        t = torch.exp(2.0 * torch.randn(N, H, H, Cs, device=dev, generator=g)) * sgn(x)
+        x = torch.relu(t * gam + bet)
+        w = w * torch.exp2(6.0 * torch.rand(Cout, 1, 1, 1, device=dev, generator=g) - 3.0)
+        dy = dy * torch.exp(torch.randn(N, Ho, Ho, Cout, device=dev, generator=g))
+        dy[:N // 2] *= 1e3
     if act16:
         x = _r16(x)      # the values a bf16 tensor holds (the stem input, fp32 in HBM, is rounded by the kernel: same thing)
         dy = _r16(dy)
@@ -159,7 +172,7 @@ def _run_shape(dev, name, H, Cs, Cin, Cout, K, s, p, N=FRAMES, check_wgrad=True,
         SEEN["wgrad"].add(plan(2, N, H, Cs, Cin, Cout, K, s, p)[:2])
         SEEN["x3w"].add(plan(2, N, H, Cs, Cin, Cout, K, s, p)[::4])      # (tile id, rolling-window kernel?)
     print(name, {k: "hip %.2e cpu %.2e" % v for k, v in res.items()})
-    record("conv %s [%s%s]" % (name, ops.get_conv_compute_dtype(), ", bf16 tensors" if act16 else ""), res)
+    record("conv %s [%s%s%s]" % (name, ops.get_conv_compute_dtype(), ", bf16 tensors" if act16 else "", ", trained-like statistics" if trained else ""), res)
     return res
 
 
@@ -221,6 +234,24 @@ def test_conv_benchmark_shapes_h2_mode_vs_fp64(dev, shape):
         # gradient on kernels of their own (conv_stem.h, wgrad_stem.h)
         want = (3 if (K == 1 and Cs % 32 == 0) else (2 if K == 7 else 0)) if K != 3 else 4
         assert ran == want, (name, ran, want)
+    finally:
+        ops.reset_compute_dtypes()
+
+
+@pytest.mark.parametrize("shape", [s for s in SHAPES if s[5] == 3], ids=[s[0] for s in SHAPES if s[5] == 3])
+def test_conv_h2_trained_like_statistics_vs_fp64(dev, shape):
+    """the headline arithmetic OUTSIDE the synthetic envelope: every 3x3 convolution of the trunk at 200 frames
+    with trained-like tensors - log-normal activations (sigma = 2) through BatchNorm tables with |gamma| in [0.2, 3] of either sign and
+    beta ~ N(0, 1), weights with a 2^6 spread of per-channel scales, log-normal gradients with a 1e3 support / query imbalance under ONE
+    scale - under the same fp64-anchored criterion as the benchmark's tensors (3 x torch-CPU-fp32's own error + 1e-6 / 2e-6), with the
+    two-plane launches asserted.  The pairs go to $LMKD_PARITY_LOG."""
+    import litemkd_amd
+    from litemkd_amd import ops
+    ops.set_conv_compute_dtype("fp32h2")
+    n0 = litemkd_amd.lib().value("lmkd_conv_h2_launches")
+    try:
+        _run_shape(dev, *shape, trained=True)
+        assert litemkd_amd.lib().value("lmkd_conv_h2_launches") - n0 == 4, shape[0]
     finally:
         ops.reset_compute_dtypes()
 

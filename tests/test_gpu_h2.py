@@ -351,7 +351,8 @@ def test_words_are_protected_on_every_stream_that_reads_them(dev, monkeypatch):
     torch.cuda.synchronize()
 
 
-def test_bound_of_the_loader_side_batchnorm(dev):
+@pytest.mark.parametrize("trained", [False, True], ids=["fresh", "trained-like"])
+def test_bound_of_the_loader_side_batchnorm(dev, trained):
     """a consumer that applies relu(BatchNorm(c)) in its loader scales by a BOUND of the activation's maximum: the convolution records
     max |c| (lmkd_amax_desc::out_words: in its epilogue, or - a launch on another kernel - by a pass of its own), the statistics launch folds
     |scale| max |c| + |shift| over the channels (lmkd_amax_desc on lmkd_bn_finalize(_seg)).  The bound is never below the true maximum (an overflow of
@@ -365,6 +366,11 @@ def test_bound_of_the_loader_side_batchnorm(dev):
         w1 = torch.randn(C, Cin, 3, 3, device=dev, generator=g) * (2.0 / (9 * Cin)) ** 0.5
         w2 = torch.randn(C, C, 3, 3, device=dev, generator=g) * (2.0 / (9 * C)) ** 0.5
         gam, bet = 1 + 0.3 * torch.randn(C, device=dev, generator=g), 0.3 * torch.randn(C, device=dev, generator=g)
+        if trained:      # a trained network's tables and inputs: |gamma| ~ U(0.2, 3) of either sign, beta ~ N(0, 1), log-normal activations, weights with a 2^6 channel spread
+            sg = torch.where(torch.randn(C, device=dev, generator=g) < 0, -1.0, 1.0)
+            gam, bet = (0.2 + 2.8 * torch.rand(C, device=dev, generator=g)) * sg, torch.randn(C, device=dev, generator=g)
+            x = ops.amax_compute(x * torch.exp(2.0 * torch.randn(N, H, H, Cin, device=dev, generator=g)), seg)
+            w1 = w1 * torch.exp2(6.0 * torch.rand(C, 1, 1, 1, device=dev, generator=g) - 3.0)
         upd = []
         ops.set_defer(upd)
         try:
@@ -373,7 +379,14 @@ def test_bound_of_the_loader_side_batchnorm(dev):
             parts = [a1] if not seg else [a1[:seg], a1[seg:]]
             for i, p in enumerate(parts):
                 bound, true = _seg_max(c1._lmkd_pre_amax, i), float(p.max())
-                assert true <= bound <= 16 * true, (N, seg, C, i, bound, true)
+                # the bound takes max |c1| over ALL channels for every channel: with a spread of |gamma| it is looser (each factor of two
+                # costs one of the 17 binades of full precision); measured 2^0.5 .. 2^1.3 on fresh tables, recorded for the trained-like ones
+                assert true <= bound <= (256 if trained else 16) * true, (N, seg, C, i, bound, true)
+                import os
+                if os.environ.get("LMKD_PARITY_LOG"):
+                    with open(os.environ["LMKD_PARITY_LOG"], "a") as f:
+                        f.write("bound / true maximum of relu(BatchNorm(c1)) [%s tables, %d frames, C %d, segment %d]: 2^%.2f\n" % (
+                            "trained-like" if trained else "fresh", N, C, i, __import__("math").log2(bound / true)))
             # the consumer: conv2 with the BatchNorm in its loader, two-plane against three-plane
             n0 = _launches()
             y_h2 = ops.conv_fwd(c1, ops._pack_weights(w2, C, 0), C, 3, 3, 1, 1, True, pre_stats=st1, seg=seg)[0]
@@ -382,6 +395,9 @@ def test_bound_of_the_loader_side_batchnorm(dev):
             y_x3 = ops.conv_fwd(c1, ops._pack_weights(w2, C, 0), C, 3, 3, 1, 1, True, pre_stats=st1, seg=seg)[0]
             ops.set_conv_compute_dtype("fp32h2")
             assert float((y_h2 - y_x3).norm() / y_x3.norm()) < 2e-6
+            # ... and with an fp64 evaluation of the same convolution (the loader's BatchNorm + ReLU in fp32, as the kernels compute it)
+            ref = F.conv2d(a1.permute(0, 3, 1, 2).double(), w2.double(), padding=1).permute(0, 2, 3, 1)
+            assert _rel(y_h2, ref) < 1.5e-6, _rel(y_h2, ref)
         finally:
             ops.set_defer(None)
 

@@ -24,7 +24,8 @@ b.grad.normal_()
 b.shadow.normal_()
 ref = (b.grad + b.shadow).clone()
 PAR.ALLREDUCE_TIMING = []
-opt.early.arm(1)
+opt.early.arm()
+opt.early.registered()          # (the trunk's forward does this for every tensor it puts the hook on)
 assert opt.early.armed
 opt.early.hook(None)                # fires launch(): tail += shadow tail, async all-reduce on the communication stream
 assert opt.early.work is not None
