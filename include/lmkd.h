@@ -157,7 +157,8 @@ int lmkd_conv2d_fwd_pre(const float* x_raw, const float* pre_stats, const float*
    BatchNorm (bn_stats = the [5][C] table of lmkd_bn_eval_stats), the residual add and the ReLU of torchvision's BasicBlock /
    Bottleneck run in the convolution's epilogue.  Bit-identical to lmkd_conv2d_fwd followed by lmkd_bn_apply. */
 int lmkd_conv2d_fwd_bn(const float* x, const float* wp_fwd, float* y, const float* bn_stats, const float* res /*nullable*/, int relu,
-                       int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, void* stream);
+                       int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, void* stream,
+                       const lmkd_amax_desc* amax /*nullable; mode 4: x_words -> two planes, out_words <- max |y| after the epilogue*/);
 /* accumulate != 0: dx += ... (the block's residual-branch gradient is already in dx) */
 int lmkd_conv2d_bwd_data(const float* dy, const float* wp_dgrad, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int accumulate, void* stream);

@@ -7,6 +7,8 @@ import ctypes
 import os
 import re
 
+from . import _audit
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "lmkd.h")
@@ -63,6 +65,8 @@ class _Lib:
 
     def call(self, name, *args):
         """Call an int-returning entry point; non-zero -> RuntimeError with the library's message."""
+        if _audit.ON:      # LMKD_STREAM_AUDIT: the tensors named to this call (ops._p) against the stream it launches on
+            _audit.check(name)
         rc = getattr(self.cdll, name)(*args)
         if rc != 0:
             raise RuntimeError("%s failed (%d): %s" % (name, rc, self.last_error()))

@@ -962,7 +962,8 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
     hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>), grid, dim3(Cfg::THREADS), lds, s, a);                      \
   } while (0)
   if constexpr (Cfg::THREADS == 256 && Cfg::BM == 128) {      // the benchmark's tiles (ids 11 / 12) on the 16x16x32 MFMA (conv_patch16.h)
-    const bool h2_on_32 = g_patch16 == 1 && Cfg::BN == 64 && a.Co <= 64 && g_conv_h2 && a.h2_xw && !a.src2 && !a.ep_stats;      // (lmkd_conv_set_patch16)
+    // (lmkd_conv_set_patch16; the inference epilogue - residual loads, no sums - stays on the 16x16x32 kernel and its 16-byte accesses: 168.7 vs 160.6 inference episodes/s)
+    const bool h2_on_32 = g_patch16 == 1 && Cfg::BN == 64 && a.Co <= 64 && g_conv_h2 && a.h2_xw && !a.src2 && !a.ep_stats;
     if (g_patch16 && g_conv_x3 && !g_lmkd_act_bf16 && !h2_on_32) {
 #define LMKD_PATCH16(NPROD, PRE, EP)                                                                                           \
   do {                                                                                                                         \
@@ -981,13 +982,21 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
                        (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));                                                      \
     hipLaunchKernelGGL((conv_patch16_x3_kernel<Cfg, NPROD, false, EP, true>), grid, dim3(Cfg::THREADS), lds, s, a);            \
   } while (0)
-        if (a.ep_stats) { if (g_conv_x3 == 9) LMKD_PATCH16S(9, true); else LMKD_PATCH16S(6, true); }
+        if (a.ep_stats) {
+          if (g_conv_x3 == 9) LMKD_PATCH16S(9, true);
+          else if (g_conv_h2 && a.h2_xw) { LMKD_PATCH16S(3, true); ++g_h2_launches; }      // inference in the two-plane arithmetic (round 5)
+          else LMKD_PATCH16S(6, true);
+        }
         else if (g_conv_h2 && a.h2_xw) { LMKD_PATCH16S(3, false); ++g_h2_launches; }
         else { if (g_conv_x3 == 9) LMKD_PATCH16S(9, false); else LMKD_PATCH16S(6, false); }
 #undef LMKD_PATCH16S
         return;
       }
-      if (a.ep_stats) { if (g_conv_x3 == 9) LMKD_PATCH16(9, false, true); else LMKD_PATCH16(6, false, true); }
+      if (a.ep_stats) {
+        if (g_conv_x3 == 9) LMKD_PATCH16(9, false, true);
+        else if (g_conv_h2 && a.h2_xw) { LMKD_PATCH16(3, false, true); ++g_h2_launches; }      // inference: BatchNorm affine (+ residual, ReLU) on the scaled accumulators; max |y| recorded in the same epilogue
+        else LMKD_PATCH16(6, false, true);
+      }
       else if (a.pre_stats) {
         if (g_conv_x3 == 9) LMKD_PATCH16(9, true, false);
         else if (g_conv_h2 && a.h2_xw) { LMKD_PATCH16(3, true, false); ++g_h2_launches; }      // h2_xw: a bound of relu(BatchNorm(x)) (lmkd_bn_finalize_bound)
@@ -1001,6 +1010,15 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
   }
   if (g_conv_h2 && a.h2_xw && !a.ep_stats && !g_lmkd_act_bf16) {      // two fp16 planes on v_mfma_f32_32x32x16_f16: the 64-column tile (lmkd_conv_set_patch16), or a tile conv_patch16_x3_kernel does not have
     t_amax_recorded = true;      // (x3_epilogue<.., H2> folds ConvGemmArgs::amax_out)
+#ifdef LMKD_ABL32      // measurement builds (tools/ab_build.sh): a timing ablation of the two-plane instance
+    if (!a.pre_stats) {
+      static std::atomic<unsigned long long> attr_done{0};
+      lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, 3, false, 0, LMKD_ABL32>), (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));
+      hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, 3, false, 0, LMKD_ABL32>), grid, dim3(Cfg::THREADS), lds, s, a);
+      ++g_h2_launches;
+      return;
+    }
+#endif
     if (a.pre_stats) LMKD_PATCH(3, true, 0); else LMKD_PATCH(3, false, 0);
     ++g_h2_launches;
     return;
@@ -1310,11 +1328,11 @@ extern "C" int lmkd_conv2d_fwd_pre(const float* x_raw, const float* pre_stats, c
 // Inference form: y = relu?( conv(x) * scale[c] + shift[c] (+ res) ) in the convolution's epilogue (scale/shift = rows 2/3 of
 // the [5][C] table of lmkd_bn_eval_stats); the same operations in the same order as lmkd_conv2d_fwd + lmkd_bn_apply.
 extern "C" int lmkd_conv2d_fwd_bn(const float* x, const float* wp, float* y, const float* bn_stats, const float* res, int relu,
-                                  int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+                                  int N, int H, int W, int Cs, int Cout, int KH, int KW, int stride, int pad, void* stream, const lmkd_amax_desc* amax) {
   LMKD_REQUIRE(bn_stats, "lmkd_conv2d_fwd_bn: BatchNorm table missing");
   LMKD_REQUIRE(!g_lmkd_act_bf16, "lmkd_conv2d_fwd_bn: fp32 tensors only (with bf16 tensors run lmkd_conv2d_fwd + lmkd_bn_apply)");
   LMKD_REQUIRE(!(g_conv_x3 || g_conv_bf16) || Cs % 32 == 0, "lmkd_conv2d_fwd_bn: the bf16-plane modes need Cs %% 32 == 0 (Cs=%d)", Cs);
-  return conv2d_fwd_impl(x, wp, y, nullptr, bn_stats, res, relu, N, H, W, Cs, Cout, KH, KW, stride, pad, stream);
+  return conv2d_fwd_impl(x, wp, y, nullptr, bn_stats, res, relu, N, H, W, Cs, Cout, KH, KW, stride, pad, stream, nullptr, 0, amax);
 }
 
 // dx[N,H,W,Cin] (+= when accumulate) from dy[N,Ho,Wo,Cout]; wd = weights packed with mode 1

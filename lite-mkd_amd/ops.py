@@ -10,6 +10,7 @@ import math
 import torch
 
 from ._lib import lib
+from . import _audit
 
 
 # ------------------------------------------------------------------------------------------
@@ -29,7 +30,18 @@ def _stream():
 def _p(t):
     if t is None:
         return None
+    if _audit.ON:
+        _audit.note(t)
     return ctypes.c_void_p(t.data_ptr())
+
+
+def _pw(t):
+    """address of a tensor as a plain integer (the members of AmaxDesc, pointer arrays), noted for the stream-lifetime audit like _p"""
+    if t is None:
+        return None
+    if _audit.ON:
+        _audit.note(t)
+    return t.data_ptr()
 
 
 def _chk(*tensors):
@@ -88,6 +100,9 @@ def gemm(layA, layB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, beta=0.0, bias=
     split_k: True / False forces lmkd_gemm_f32_splitk / lmkd_gemm_f32 for this call (None: the module default GEMM_SPLIT_K)"""
     _chk(A, B, C, bias)
     es = 4
+    if _audit.ON:
+        for t in (A, B, C):
+            _audit.note(t)
     if GEMM_SPLIT_K if split_k is None else split_k:
         ws, tk = _gemm_workspace(C)
         lib().call("lmkd_gemm_f32_splitk", layA.encode(), layB.encode(), M, N, K, _f32(alpha),
@@ -226,7 +241,7 @@ def linear_infer(x, w, b=None, relu=False):
             _AFFINE_CACHE.clear()
         _AFFINE_CACHE[key] = (weakref.ref(b) if b is not None else None, b._version if b is not None else 0, st)
     y = _empty((M, N), x)
-    lib().call("lmkd_conv2d_fwd_bn", _p(x), _p(wp), _p(y), _p(st), None, int(relu), M, 1, 1, K, N, 1, 1, 1, 0, _stream())
+    lib().call("lmkd_conv2d_fwd_bn", _p(x), _p(wp), _p(y), _p(st), None, int(relu), M, 1, 1, K, N, 1, 1, 1, 0, _stream(), None)
     return y
 
 
@@ -550,6 +565,7 @@ def _fence_site(site, dev):
     e = _FENCE_SITES.get(site)
     if e is None:
         e = _FENCE_SITES[site] = {"ref": torch.zeros(lib().value("lmkd_amax_words"), dtype=torch.int32, device=dev), "bad": False}
+        _audit.audit_ok(e["ref"], "persistent: a site's reference words are never freed")
     return e
 
 
@@ -614,8 +630,10 @@ def _amax_out(t, site=None):
         return None
     w = _amax_slot(t.device)
     t._lmkd_amax = w
-    d = AmaxDesc(None, None, w.data_ptr(), None, 0)
-    if site is not None and H2_FENCE and not torch.cuda.is_current_stream_capturing():
+    d = AmaxDesc(None, None, _pw(w), None, 0)
+    if site is not None and H2_FENCE and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():      # (training: the loops call h2_fence_step once per episode)
+        if len(_FENCE_PENDING) > 4096:      # nobody calls h2_fence_step(): keep the newest
+            del _FENCE_PENDING[:2048]
         e = _fence_site(site, t.device)
         d.ref_words = e["ref"].data_ptr()
         t._lmkd_site = site
@@ -655,7 +673,7 @@ def _amax_ptr(t, pre=False):
         e = _FENCE_SITES.get(site)
         if e is not None and e["bad"]:
             return None, True
-    return w.data_ptr(), False
+    return _pw(w), False
 
 
 def _amax_operands(x, dy, pre=False):
@@ -813,7 +831,7 @@ def conv_fwd(x, wp, Cout, KH, KW, stride, pad, want_stats, pre_stats=None, seg=0
         d = _amax_operands(x, None, pre=pre_stats is not None)
         if amax_out is not None and _h2_mode():
             d = d if d is not None else AmaxDesc(None, None, None, None, 0)
-            d.out_words = amax_out.data_ptr()
+            d.out_words = _pw(amax_out)
         if seg or d is not None:
             lib().call("lmkd_conv2d_fwd_seg", _p(x), _p(pre_stats), _p(wp), _p(y), _p(part), N, H, W, Cs, Cout, KH, KW, stride, pad, seg, _stream(),
                        _desc_arg(d))
@@ -1024,8 +1042,8 @@ def bn_stats_train(part, count, gamma, beta, running_mean, running_var, seg=None
     T, C, _ = part.shape
     d = None
     if bound is not None:
-        d = AmaxDesc(bound[0].data_ptr(), None, bound[1].data_ptr(), None, 0)
-        if bound[2] is not None and H2_FENCE and not torch.cuda.is_current_stream_capturing():
+        d = AmaxDesc(_pw(bound[0]), None, _pw(bound[1]), None, 0)
+        if bound[2] is not None and H2_FENCE and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
             d.ref_words = _fence_site(bound[2], part.device)["ref"].data_ptr()
             _FENCE_PENDING.append((bound[2], bound[1]))
     if seg is not None:
@@ -1210,8 +1228,10 @@ def _eval_fused():
     return FUSE_EVAL_BN and not torch.is_grad_enabled() and _ACT_DTYPE[0] is torch.float32
 
 
-def conv_bn_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, relu, res=None):
-    """inference: relu?(BN_eval(conv(x)) (+ res)) in one kernel; bit-identical to conv_fwd + bn_stats_eval + bn_apply"""
+def conv_bn_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, relu, res=None, feeds_conv=True):
+    """inference: relu?(BN_eval(conv(x)) (+ res)) in one kernel; bit-identical to conv_fwd + bn_stats_eval + bn_apply.
+    fp32h2: x's maximum (recorded by the launch that wrote x) puts the launch on two planes, and - feeds_conv: y is a convolution's
+    operand - the epilogue records max |y| for the next one (the BatchNorm + ReLU are applied there: no bound is needed)"""
     Cout, _, KH, KW = w.shape
     wp = pack_weights(w, Cs, 0)
     stats = bn_stats_eval(gamma, beta, rm, rv)
@@ -1222,8 +1242,14 @@ def conv_bn_eval(x, w, Cs, stride, pad, gamma, beta, rm, rv, relu, res=None):
     cin = 3 if Cs == 4 else Cs
     with _timed(_conv_family(0, N, H, W, Cs, cin, Cout, KH, KW, stride, pad), 2.0 * N * Ho * Wo * Cout * cin * KH * KW,
                 x.element_size() * x.numel() + y.element_size() * y.numel() + 4 * wp.numel()):
+        d = _amax_operands(x, None)
+        if feeds_conv and _h2_mode():
+            d = d if d is not None else AmaxDesc(None, None, None, None, 0)
+            wds = _amax_slot(x.device)
+            d.out_words = _pw(wds)
+            y._lmkd_amax = wds
         lib().call("lmkd_conv2d_fwd_bn", _p(x), _p(wp), _p(y), _p(stats), _p(res), int(relu), N, H, W, Cs, Cout, KH, KW, stride, pad,
-                   _stream())
+                   _stream(), _desc_arg(d))
     return y
 
 
@@ -1520,7 +1546,7 @@ class BasicBlockFn(torch.autograd.Function):
         if not training and _eval_fused():
             ctx.training = False
             a1 = conv_bn_eval(x, w1, Cs, stride, 1, g1, b1, rm1, rv1, True)
-            r = x if wd is None else conv_bn_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, False)
+            r = x if wd is None else conv_bn_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, False, feeds_conv=False)
             return conv_bn_eval(a1, w2, w1.shape[0], 1, 1, g2, b2, rm2, rv2, True, r)
         fused = training and _train_fused()
         pre = training and _train_pre()
@@ -1609,7 +1635,7 @@ class BottleneckFn(torch.autograd.Function):
             ctx.training = False
             a1 = conv_bn_eval(x, w1, Cs, 1, 0, g1, b1, rm1, rv1, True)
             a2 = conv_bn_eval(a1, w2, Cm, stride, 1, g2, b2, rm2, rv2, True)
-            r = x if wd is None else conv_bn_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, False)
+            r = x if wd is None else conv_bn_eval(x, wd, Cs, stride, 0, gd, bd, rmd, rvd, False, feeds_conv=False)
             return conv_bn_eval(a2, w3, Cm, 1, 0, g3, b3, rm3, rv3, True, r)
         fused = training and _train_fused()
         # fp32h2: the 3x3 convolution's raw input c1 comes from a 1x1 convolution (a gather kernel: no maximum in its epilogue, a reduction

@@ -91,6 +91,9 @@ def build_parser():
                    "than a quarter to its rounding error to f32x3's kernels from the next episode on (INTEGRATION.md, 'range fence'); "
                    "f32x3 = every fp32 product from an exact 3-way bf16 split, six products (the library's default arithmetic); "
                    "f32native = v_mfma_f32_32x32x2_f32, bf16 = bf16 tensors + bf16 MFMA (the reference's autocast path, trainwandb.py:20,126)")
+    p.add_argument("--no_stream_inputs", dest="stream_inputs", action="store_false", help="with --data_dir: read, upload and transform every episode on "
+                   "the training thread (default: a prefetch thread + copy stream + three static input sets, trainloop.StreamedEpisodes; needs one "
+                   "frame resolution per episode)")
     p.add_argument("--serial", action="store_true", help="single-stream schedule (Schedule.serial())")
     p.add_argument("--two_call", action="store_true", help="round 3's schedule (two trunk calls on two streams, no cross-episode pipelining) instead of "
                    "the default merged + pipelined one (Schedule.bench())")
@@ -161,6 +164,33 @@ class ClipDirectoryEpisodes:
         path = (os.path.join(self.froot, cname, vid + ".npy") if self.froot else os.path.join(self.root, cname, vid + ".feature.npy"))
         return torch.from_numpy(np.load(path)).float()
 
+    def host_episode(self):
+        """the HOST half of episode() for trainloop.StreamedEpisodes (a prefetch thread calls it): the same draws in the same order - classes,
+        videos, frames, the two shuffles, then per video flip / crop (support videos first) - but no device work: the decoded frames of all
+        videos as ONE uint8 tensor (they must share a resolution: one H2D copy, one resize launch), the crop parameters, the features"""
+        c = self.c
+        nq = c.query_per_class if self.train else c.query_per_class_test
+        batch_classes = random.sample(list(self.classes), c.way)
+        sup, tgt = [], []
+        for bl, bc in enumerate(batch_classes):
+            vids = self.classes[bc]
+            if len(vids) < c.shot + nq:
+                raise ValueError("class %s has %d videos, an episode needs %d" % (bc, len(vids), c.shot + nq))
+            idxs = random.sample(range(len(vids)), c.shot + nq)
+            for j, i in enumerate(idxs):
+                clip = torch.from_numpy(self._frames(np.load(os.path.join(self.root, bc, vids[i] + ".npy"), mmap_mode="r")).copy())
+                (sup if j < c.shot else tgt).append((clip, self._feature(bc, vids[i]), bl))
+        random.shuffle(sup)
+        random.shuffle(tgt)
+        vids = [v[0] for v in sup + tgt]
+        if len({tuple(v.shape[1:3]) for v in vids}) != 1:
+            raise ValueError("StreamedEpisodes needs one frame resolution per episode (got %s): use the loader without --stream_inputs"
+                             % sorted({tuple(v.shape[1:3]) for v in vids}))
+        params = [self.tf.draw(v.shape[1], v.shape[2], self.train) for v in vids]
+        return {"frames": torch.cat(vids, 0), "params": params, "features": torch.stack([v[1] for v in sup + tgt]), "ns": len(sup),
+                "support_labels": torch.FloatTensor([v[2] for v in sup]), "target_labels": torch.FloatTensor([v[2] for v in tgt]),
+                "real_target_labels": torch.FloatTensor([v[2] for v in tgt]), "batch_class_list": torch.arange(c.way).float()}
+
     def episode(self):
         c = self.c
         nq = c.query_per_class if self.train else c.query_per_class_test
@@ -210,6 +240,10 @@ def main(argv=None):
     loader = None
     if args.data_dir:
         loader = ClipDirectoryEpisodes(args, args.data_dir, args.feature_dir, device=dev)
+        if args.stream_inputs and torch.device(dev).type == "cuda":
+            # the loader beside the compute (trainwandb.py:87-88: a DataLoader worker): a prefetch thread reads and pins the next episodes,
+            # a copy stream uploads the uint8 frames and runs the frame transform into one of three static input sets
+            loader = TL.StreamedEpisodes(loader, args, dev)
     student, teacher, loader, distiller, accuracy_fn, _, optimizer, scheduler = TL.make(args, video_loader=loader, base_seed=args.seed, schedule=sched)
     if args.teacher_checkpoint:
         from .model.model_select import load_teacher

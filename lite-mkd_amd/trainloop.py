@@ -171,7 +171,9 @@ def _labels_to_device(t, dev, dtype):
 
 def train_task(task_dict, student, teacher, distiller, accuracy_fn, config):
     """trainwandb.py:190-287 for the logits-based distillers."""
-    return _train_task_prepared(prepare_task(task_dict, config.device), student, teacher, distiller, accuracy_fn, config)
+    out = _train_task_prepared(prepare_task(task_dict, config.device), student, teacher, distiller, accuracy_fn, config)
+    release_inputs(task_dict)
+    return out
 
 
 def _train_task_prepared(prepared, student, teacher, distiller, accuracy_fn, config):
@@ -252,13 +254,13 @@ class PipelinedEpisodes:
             with torch.cuda.stream(main):
                 prepared = prepare_task(task_dict, dev)
                 loss, acc = _episode_forward(prepared, self.student, self.teacher, self.distiller, self.accuracy_fn, self.config)
-            self.queue.append((loss, acc, lane))
+            self.queue.append((loss, acc, lane, task_dict))
             return self._backward(self.queue.pop(0)) if len(self.queue) > self.depth else None
         finally:
             ops.set_lane(0)
 
     def _backward(self, item):
-        loss, acc, lane = item
+        loss, acc, lane, task_dict = item
         dev = self.config.device
         ops.set_lane(lane)
         try:
@@ -278,6 +280,7 @@ class PipelinedEpisodes:
                 ev = torch.cuda.Event()
                 ev.record(main)
                 self.bwd_done = ev
+                release_inputs(task_dict)      # a StreamedEpisodes loader may now re-stage the episode's input set (behind every stream that read it)
         finally:
             ops.set_lane(0)
         return loss.detach(), acc
@@ -299,6 +302,141 @@ class PipelinedEpisodes:
         if not outs:
             return None
         return outs[0] if len(outs) == 1 else outs
+
+
+class StreamedEpisodes:
+    """The loader side of the loop (trainwandb.py:87-88: a DataLoader worker; :419-443 prepare_task; video_reader.py:474-485 the
+    loader's output), overlapped with the compute that is timed: wraps a HOST-side episode source and yields task_dicts whose frames and
+    teacher features already sit in device memory.
+
+    source.host_episode() -> {"frames": uint8 [F, H, W, 3] (decoded frames of every video of the episode, support videos first, one
+    resolution), "params": [(flip, x1, y1)] per video (GpuFrameTransform.draw), "features": float [N, L, 2048], "support_labels",
+    "target_labels" (+ optional "real_target_labels", "batch_class_list"), "ns": number of support videos}.  A prefetch THREAD runs it
+    one or two episodes ahead (np.load, frame picking and pinning happen off the training thread); the training thread only enqueues:
+    one H2D copy of the uint8 frames (a quarter of the fp32 tensors' bytes) + one of the features on a COPY stream, the frame transform
+    (Resize -> crop / flip -> ToTensor, video_transform.GpuFrameTransform.batch) there too, into one of `sets` static input sets.  The
+    compute stream waits for the set's `ready` event; the copy stream, before it overwrites a set, for the events the loop recorded on
+    every stream that read it (release(): the lane's streams and the weight-gradient stream after the episode's backward pass was
+    queued - nothing on the compute side ever waits for the loader).  With cross-episode pipelining three episodes are in flight
+    (backward i, forward i + 1, staging i + 2): hence sets >= 3."""
+
+    def __init__(self, source, config, device, sets=3, prefetch=2):
+        import queue
+        import threading
+        from .video_transform import GpuFrameTransform
+        self.source, self.c, self.device = source, config, torch.device(device)
+        self.tf = GpuFrameTransform(config.img_size, self.device)
+        self.copy = torch.cuda.Stream(device=self.device)
+        self.nsets = max(2, int(sets))
+        self.sets = [None] * self.nsets
+        self.dataset = getattr(source, "dataset", source)
+        self._q = queue.Queue(maxsize=max(1, int(prefetch)))
+        self._stop = threading.Event()
+        self._thread = None
+        self._threading = threading
+        self.length = getattr(source, "length", 10 ** 9)
+        self.staged = 0
+
+    # ---- host side (prefetch thread)
+    def _produce(self):
+        try:
+            n = 0
+            while not self._stop.is_set() and n < self.length:
+                h = self.source.host_episode()
+                h = dict(h)
+                h["frames"] = h["frames"].contiguous().pin_memory()
+                h["features"] = h["features"].contiguous().float().pin_memory()
+                n += 1
+                while not self._stop.is_set():
+                    try:
+                        self._q.put(h, timeout=0.1)
+                        break
+                    except Exception:      # queue.Full
+                        continue
+        except BaseException as e:      # surfaces in the training thread
+            self._q.put(e)
+        finally:
+            self._q.put(None)
+
+    def _set(self, k, h):
+        s = self.sets[k]
+        F_, H, W, _ = h["frames"].shape
+        N, L, D = h["features"].shape
+        S = self.c.img_size
+        if s is None or s["u8"].shape != h["frames"].shape or s["feat"].shape != h["features"].shape:
+            s = self.sets[k] = {"u8": torch.empty((F_, H, W, 3), dtype=torch.uint8, device=self.device),
+                                "x": torch.empty((F_, S, S, 4), dtype=torch.float32, device=self.device),
+                                "feat": torch.empty((N, L, D), dtype=torch.float32, device=self.device),
+                                "ready": torch.cuda.Event(), "free": []}
+            for t in (s["u8"], s["x"], s["feat"]):
+                ops._audit.audit_ok(t, "static input set: released to the copy stream through the events of release()")
+        return s
+
+    def _stage(self, h):
+        k = self.staged % self.nsets
+        self.staged += 1
+        s = self._set(k, h)
+        L = h["features"].shape[1]
+        with torch.cuda.stream(self.copy):
+            for ev in s["free"]:
+                self.copy.wait_event(ev)                   # every stream that read this set last time has passed
+            s["free"] = []
+            s["u8"].copy_(h["frames"], non_blocking=True)
+            s["feat"].copy_(h["features"], non_blocking=True)
+            self.tf.batch(s["u8"], h["params"], L, out=s["x"])
+            s["ready"].record(self.copy)
+            s["host"] = h                                  # the pinned buffers stay referenced until the set is staged again
+        ns = int(h["ns"])
+        td = {"support_set": s["x"][:ns * L], "target_set": s["x"][ns * L:],
+              "support_set_feature_teacher": s["feat"][:ns], "target_set_feature_teacher": s["feat"][ns:],
+              "support_labels": h["support_labels"], "target_labels": h["target_labels"],
+              "real_target_labels": h.get("real_target_labels", h["target_labels"]),
+              "batch_class_list": h.get("batch_class_list", torch.arange(self.c.way).float())}
+        td = {key: v.unsqueeze(0) for key, v in td.items()}
+        td["_input_set"] = (self, k)
+        return td
+
+    def release(self, k):
+        """the episode that read set k has been queued completely (forward and backward): record where every stream that may still read
+        the set stands - the copy stream waits for these before it overwrites the set"""
+        s = self.sets[k]
+        if s is None:
+            return
+        streams = [torch.cuda.current_stream(self.device)] + list(ops._WG_STREAM.values())
+        for table in (ops._side_streams, ops._aux_streams, ops._lane_mains):
+            streams += list(table.values())
+        seen = set()
+        for st in streams:
+            if st.cuda_stream in seen:
+                continue
+            seen.add(st.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            s["free"].append(ev)
+
+    def __iter__(self):
+        if self._thread is None:
+            self._thread = self._threading.Thread(target=self._produce, daemon=True)
+            self._thread.start()
+        while True:
+            h = self._q.get()
+            if h is None:
+                return
+            if isinstance(h, BaseException):
+                raise h
+            td = self._stage(h)
+            torch.cuda.current_stream(self.device).wait_event(self.sets[td["_input_set"][1]]["ready"])
+            yield td
+
+    def close(self):
+        self._stop.set()
+
+
+def release_inputs(task_dict):
+    """tell a StreamedEpisodes loader that the episode of this task_dict has been queued completely (a no-op for any other loader)"""
+    tag = task_dict.get("_input_set") if isinstance(task_dict, dict) else None
+    if tag is not None:
+        tag[0].release(tag[1])
 
 
 def init_model(config):

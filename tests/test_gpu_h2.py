@@ -302,6 +302,70 @@ def test_training_across_optimizer_steps_tracks_the_three_plane_arithmetic(dev):
     assert torch.isfinite(a).all() and float(((a - b).abs() / b.abs()).max()) < 0.02, (a[-4:], b[-4:])
 
 
+def _parked_weight_grad(dev, protect):
+    """ops.weight_grad queued on the weight-gradient stream BEHIND a one-second sleep kernel; then every reference to its operands (and
+    to the words of their maxima) is dropped and same-sized tensors full of garbage are allocated and written on the caller's stream - the
+    allocator hands the blocks out again unless the side stream was recorded on them.  -> (dW the side stream computed, reference dW)"""
+    from litemkd_amd import ops
+    g = torch.Generator(device=dev).manual_seed(12)
+    C, N, H = 64, 8, 28
+    st = _identity_table(C, dev)
+    w = torch.nn.Parameter(torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.05)
+    x0 = torch.relu(torch.randn(N, H, H, C, device=dev, generator=g))
+    dy0 = torch.randn(N, H, H, C, device=dev, generator=g) * 1e-3
+    ref = ops.conv_bwd_weight(ops.amax_compute(x0.clone()), ops.amax_compute(dy0.clone()), tuple(w.shape), 1, 1).clone()
+    w.grad = torch.zeros_like(w)
+    pool_tensors, ops._AMAX_POOL_TENSORS = ops._AMAX_POOL_TENSORS, 1      # every maximum in a pool of its own: freed with its tensor
+    ops.amax_pool_reset()
+    box = {"x": ops.bn_apply(x0, st, False), "dy": ops.bn_apply(dy0, st, False)}      # producers: the words come from the pools
+    nw = box["x"]._lmkd_amax.numel()
+    orig = torch.Tensor.record_stream
+    if not protect:      # the round-4 state: operands recorded on the side stream, their words not
+        torch.Tensor.record_stream = lambda self, s: None if self.dtype is torch.int32 else orig(self, s)
+    prev = ops.SIDE_WGRAD
+    ops.SIDE_WGRAD = True
+    junk = []
+
+    class _InBackward(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t * 1.0
+
+        @staticmethod
+        def backward(ctx, gr):
+            sw = ops._wgrad_stream(dev)
+            with torch.cuda.stream(sw):
+                torch.cuda._sleep(2_000_000_000)      # parks the side stream: the weight gradient below has not started when the blocks are reused
+            assert ops.weight_grad(w, box["x"], box["dy"], 1, 1) is None
+            box.clear()                               # the operands and their words die here
+            ops.amax_pool_reset()
+            for _ in range(4):                        # ... and the caller's stream takes blocks of the same sizes and overwrites them
+                junk.append(torch.full((nw,), 0x7f000000, dtype=torch.int32, device=dev))
+                junk.append(torch.full((N, H, H, C), 3.0e30, device=dev))
+            return gr
+    try:
+        _InBackward.apply(torch.ones(1, device=dev, requires_grad=True)).sum().backward()
+        ops.wait_weight_grads()
+        torch.cuda.synchronize()
+    finally:
+        ops.SIDE_WGRAD = prev
+        torch.Tensor.record_stream = orig
+        ops._AMAX_POOL_TENSORS = pool_tensors
+        ops.amax_pool_reset()
+    return w.grad.clone(), ref
+
+
+def test_operands_and_words_survive_until_the_side_stream_has_read_them(dev):
+    """the constructed, one-run form of the round-4 lifetime bug (before: a 50-episode loop that hit the race in about half
+    of its runs).  With the protection - record_stream on the operands AND on the words of their maxima, ops.weight_grad - the parked
+    kernel still finds its operands: its result equals the one computed in stream order, bit for bit.  With the words' protection switched
+    off (the state of round 4's first version) the same construction corrupts the result: the test bites."""
+    got, ref = _parked_weight_grad(dev, protect=True)
+    assert torch.equal(got, ref)
+    got, ref = _parked_weight_grad(dev, protect=False)
+    assert not torch.equal(got, ref), "the construction no longer reproduces the hazard it guards against"
+
+
 def test_words_are_protected_on_every_stream_that_reads_them(dev, monkeypatch):
     """the words of a maximum live in a pool tensor that is freed when its last word dies; every stream whose kernels touch them must be
     recorded on that tensor (torch.Tensor.record_stream), or the allocator recycles the block under a kernel that has not started:

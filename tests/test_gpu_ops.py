@@ -1139,7 +1139,7 @@ def test_episode_x3_matches_fp32(dev, x3_convs):
     assert math.sqrt(num / den) < 2e-2
 
 
-@pytest.mark.parametrize("mode", ["fp32x3", "fp32", "fp32x3_9", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32x3", "fp32", "fp32x3_9", "bf16", "fp32h2"])
 @pytest.mark.parametrize("arch,frames,img", [("resnet18", 6, 64), ("resnet50", 6, 64), ("resnet18", 40, 224)])
 def test_eval_bn_fused_in_conv_epilogue(dev, arch, frames, img, mode):
     """inference path (model.eval(), trainwandb.py:366): BatchNorm + residual + ReLU run in the convolution epilogue
@@ -1160,21 +1160,34 @@ def test_eval_bn_fused_in_conv_epilogue(dev, arch, frames, img, mode):
                 b.copy_(torch.rand_like(b) + 0.5)
     trunk.eval()
     x = torch.rand(frames, 3, img, img)
+    import litemkd_amd
+    h2_0 = litemkd_amd.lib().value("lmkd_conv_h2_launches")
     with torch.no_grad():
         assert ops._eval_fused()
         y_fused = trunk(x.to(dev))
+        if mode == "fp32h2":
+            # round 5: inference in the headline arithmetic - the fused epilogue records max |y| itself (the BatchNorm + ReLU are applied
+            # there), so every same-size / stride-2 3x3 and same-size 1x1 launch of the eval forward runs two planes: ResNet-18 the stem + 16,
+            # ResNet-50 the stem + 16 3x3 + 33 1x1 (the stride-2 1x1 downsample convolutions stay on the gather kernel's three planes)
+            assert litemkd_amd.lib().value("lmkd_conv_h2_launches") - h2_0 == (17 if arch == "resnet18" else 50)
         ops.FUSE_EVAL_BN = False
         try:
             y_two = trunk(x.to(dev))
         finally:
             ops.FUSE_EVAL_BN = True
-    assert torch.equal(y_fused, y_two)
+    if mode == "fp32h2":
+        # the fused launches of the 64-channel layers run the 16x16x32 kernel, the two-pass form's convolutions the 32x32x16 one
+        # (lmkd_conv_set_patch16: each the faster for its epilogue): the same arithmetic in another summation order - equal to fp32 rounding
+        assert float((y_fused - y_two).abs().max()) <= 1e-5 * float(y_two.abs().max())
+    else:
+        assert torch.equal(y_fused, y_two)
     sd = {k: v.detach().cpu() for k, v in trunk.state_dict().items()}
     O.CONV_BF16 = mode == "bf16"
     try:
         ref = (O.resnet18_trunk if arch == "resnet18" else O.resnet50_trunk)(x, sd, training=False)
     finally:
         O.CONV_BF16 = False
+        ops.reset_compute_dtypes()
     # bf16: the same operand rounding on both sides, but an activation within accumulation noise of a bf16 rounding boundary rounds
     # the other way (0.4 % of that operand) and the difference travels through the remaining layers: percent-level on single elements
     tol = 2e-2 if mode == "bf16" else 1e-4
