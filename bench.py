@@ -219,14 +219,14 @@ def main():
         it = it0
         for i in range(n):
             it += 1
-            ep = pool[i % len(pool)]
+            ep = next(state["episodes"]) if state.get("episodes") is not None else pool[i % len(pool)]      # (--stream-inputs: from a StreamedEpisodes loader)
             if mfm is not None:      # live fusion: the teacher features of this episode come out of the MFM transformer
                 fused = mfm.extract_feature(mods[i % len(pool)])
                 ns = cfg.way * cfg.shot
                 ep = dict(ep, support_set_feature_teacher=fused[:ns].unsqueeze(0), target_set_feature_teacher=fused[ns:].unsqueeze(0))
             graphed = graph_runner()
-            if (it + 1) % every == 0 and graphed is None and pipe is None:
-                opt.expect_step()                      # world > 1: the bucket's tail is all-reduced under this episode's backward pass
+            if (it + 1) % every == 0 and graphed is None:
+                opt.expect_step()                      # world > 1: the bucket's tail is all-reduced under this episode's backward pass (pipelined: it runs in the flush below)
             if pipe is not None and state.get("pipe", True):
                 pipe.push(ep)
             elif graphed is not None:
@@ -256,7 +256,7 @@ def main():
         # optimizer step (world 2: a step every 8 local episodes) does not move that one-time cost into the timed region
         opt.zero_grad()
         torch.cuda.synchronize()
-        opt.early.arm(1)
+        opt.early.arm()
         opt.early.launch()
         opt.bucket.allreduce_grads(opt.early.finish())
         torch.cuda.synchronize()
@@ -501,7 +501,7 @@ def main():
                                  "note": "per-rank cadence of a %d-rank run rehearsed on ONE GPU (optimizer step + weight re-pack every %d episodes, "
                                          "no collective): value x %d would be the job's rate at perfect scaling" % (a.emulate_world, every, a.emulate_world)}
     if a.stream_inputs:
-        out["stream_inputs"] = stream_inputs_pass(a, cfg, dev, student, teacher, distiller, aggregate_accuracy, opt, sch, every, fence, TL, ops)
+        out["stream_inputs"] = stream_inputs_pass(a, cfg, dev, run, state, fence, TL)
     if world == 1 and a.dtype == "f32" and not a.no_other_modes:
         # the same job in the two other arithmetic modes of the convolutions, for the record (never part of `value`):
         # short timed regions right here, same process, same resident episodes, each with its own per-kernel roofline pass
@@ -549,83 +549,61 @@ def main():
         dist.destroy_process_group()
 
 
-def stream_inputs_pass(a, cfg, dev, student, teacher, distiller, accuracy_fn, opt, sch, every, fence, TL, ops, episodes=None):
-    """The input side inside the loop (trainwandb.py:419-443 prepare_task + video_reader.py:474-485 the loader's output): per episode
-    92 MB of decoded uint8 frames (50 videos x 8 frames of 320x240x3, HMDB's resolution) and 3.3 MB of teacher features leave
-    PINNED host memory on a copy stream; Resize(256) -> crop 224 / flip -> ToTensor run on that stream as HIP kernels
-    (GpuFrameTransform.batch) into one of two static NHWC4 input sets; the compute stream waits for the set's event and the copy
-    stream, before overwriting a set, for the episode that last read it.  Episode i + 1 is staged while episode i computes."""
-    import random
-    from litemkd_amd.video_transform import GpuFrameTransform
+class HostEpisodes:
+    """what a loader's worker processes hand over (video_reader.py:474-485 before ToTensor): decoded uint8 frames of an episode's 50 videos
+    (8 frames of 320x240x3 each, HMDB's resolution: 92 MB), the crop / flip draws, 3.3 MB of teacher features, shuffled labels - two
+    seeded episodes in host memory, cycled"""
+
+    def __init__(self, cfg, n=2, seed=4321):
+        import random
+        from litemkd_amd.video_transform import GpuFrameTransform
+        way, L = cfg.way, cfg.seq_len
+        ns, nq = way * cfg.shot, way * cfg.query_per_class
+        g = torch.Generator().manual_seed(seed)
+        tf = GpuFrameTransform(cfg.img_size, "cpu")
+        state = random.getstate()
+        random.seed(99)
+        self.eps = [{"frames": torch.randint(0, 256, ((ns + nq) * L, 240, 320, 3), dtype=torch.uint8, generator=g).pin_memory(),      # (a worker that decodes into pinned memory)
+                     "params": [tf.draw(240, 320, True) for _ in range(ns + nq)],
+                     "features": torch.randn(ns + nq, L, 2048, generator=g).pin_memory(), "ns": ns,
+                     "support_labels": torch.arange(way).repeat_interleave(cfg.shot)[torch.randperm(ns, generator=g)].float(),
+                     "target_labels": torch.arange(way).repeat_interleave(cfg.query_per_class)[torch.randperm(nq, generator=g)].float()}
+                    for _ in range(n)]
+        random.setstate(state)
+        self.i = 0
+
+    def host_episode(self):
+        e = self.eps[self.i % len(self.eps)]
+        self.i += 1
+        return e
+
+
+def stream_inputs_pass(a, cfg, dev, run, state, fence, TL, episodes=None):
+    """The input side inside the PRODUCT loop, under the schedule that is timed (trainwandb.py:87-88 the DataLoader worker, :419-443
+    prepare_task, video_reader.py:474-485 the loader's output): trainloop.StreamedEpisodes - a prefetch thread pins the next host episodes,
+    a copy stream uploads 92 MB of uint8 frames + 3.3 MB of teacher features per episode and runs Resize(256) -> crop 224 / flip ->
+    ToTensor as HIP kernels into one of three static input sets, the compute streams wait for a set's `ready` event and hand it back
+    through events of their own - feeding the same loop (`run`: cross-episode pipelining, optimizer cadence) as the headline line."""
     n = episodes or a.steps
-    way, L = cfg.way, cfg.seq_len
-    ns, nq = way * cfg.shot, way * cfg.query_per_class
-    nv = ns + nq
-    g = torch.Generator().manual_seed(4321)
-    host = []
-    for e in range(2):      # two decoded episodes in pinned memory, cycled (what a loader's worker processes would hand over)
-        host.append({"frames": torch.randint(0, 256, (nv * L, 240, 320, 3), dtype=torch.uint8, generator=g).pin_memory(),
-                     "feat": torch.randn(nv, L, 2048, generator=g).pin_memory(),
-                     "sl": torch.arange(way).repeat_interleave(cfg.shot)[torch.randperm(ns, generator=g)].float(),
-                     "tl": torch.arange(way).repeat_interleave(cfg.query_per_class)[torch.randperm(nq, generator=g)].float()})
-    tf = GpuFrameTransform(cfg.img_size, dev)
-    copy = torch.cuda.Stream(device=dev)
-    main = torch.cuda.current_stream(dev)
-    sets = [{"u8": torch.empty((nv * L, 240, 320, 3), dtype=torch.uint8, device=dev),
-             "x": torch.empty((nv * L, cfg.img_size, cfg.img_size, 4), dtype=torch.float32, device=dev),
-             "feat": torch.empty((nv, L, 2048), dtype=torch.float32, device=dev),
-             "ready": torch.cuda.Event(), "free": torch.cuda.Event(), "h2d": (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))}
-            for _ in range(2)]
-    for s_ in sets:
-        s_["free"].record(main)
-    random.seed(99)
-
-    def stage(i):
-        h, s_ = host[i % 2], sets[i % 2]
-        params = [tf.draw(240, 320, True) for _ in range(nv)]
-        with torch.cuda.stream(copy):
-            copy.wait_event(s_["free"])                    # the episode that last read this set has finished
-            s_["h2d"][0].record(copy)
-            s_["u8"].copy_(h["frames"], non_blocking=True)
-            s_["feat"].copy_(h["feat"], non_blocking=True)
-            s_["h2d"][1].record(copy)
-            tf.batch(s_["u8"], params, L, out=s_["x"])
-            s_["ready"].record(copy)
-        return {"support_set": s_["x"][:ns * L].unsqueeze(0), "target_set": s_["x"][ns * L:].unsqueeze(0),
-                "support_set_feature_teacher": s_["feat"][:ns].unsqueeze(0), "target_set_feature_teacher": s_["feat"][ns:].unsqueeze(0),
-                "support_labels": h["sl"].unsqueeze(0), "target_labels": h["tl"].unsqueeze(0)}
-
-    def loop(k, it):
-        nxt = stage(0)
-        for i in range(k):
-            it += 1
-            ep, s_ = nxt, sets[i % 2]
-            if i + 1 < k:
-                nxt = stage(i + 1)                         # staged while episode i computes
-            main.wait_event(s_["ready"])
-            TL.train_task(ep, student, teacher, distiller, accuracy_fn, cfg)
-            # the set is free once EVERY stream that read it has passed: the weight-gradient stream (the stem's weight gradient reads
-            # s_["x"]) and the side / auxiliary streams (query frames, teacher features) run on behind the main stream
-            with torch.cuda.stream(main):
-                ops.join_all_streams()
-            s_["free"].record(main)
-            if (it + 1) % every == 0:
-                opt.step()
-                opt.zero_grad()
-            sch.step()
-        return it
-    it = loop(3, 0)
-    fence()
-    t0 = time.perf_counter()
-    loop(n, it)
-    fence()
-    dt = time.perf_counter() - t0
-    nbytes = sets[0]["u8"].numel() + 4 * sets[0]["feat"].numel()
-    h2d_ms = sum(s_["h2d"][0].elapsed_time(s_["h2d"][1]) for s_ in sets) / len(sets)
-    return {"value": n / dt, "unit": "episodes/s", "steps": n, "h2d_bytes_per_episode": nbytes, "h2d_ms_per_episode": h2d_ms,
-            "pcie_GBps": nbytes / (h2d_ms * 1e-3) / 1e9,
-            "what": "eager episodes with every episode's inputs streamed from pinned host memory (uint8 frames 320x240 + teacher features), "
-                    "GPU frame transform on the copy stream, double-buffered; compare with `value` (inputs resident in HBM)"}
+    loader = TL.StreamedEpisodes(HostEpisodes(cfg), cfg, dev)
+    state["episodes"] = iter(loader)
+    try:
+        it = run(3, 0)
+        fence()
+        t0 = time.perf_counter()
+        run(n, it)
+        fence()
+        dt = time.perf_counter() - t0
+    finally:
+        state["episodes"] = None
+        loader.close()
+    s0 = loader.sets[0]
+    nbytes = s0["u8"].numel() + 4 * s0["feat"].numel()
+    return {"value": n / dt, "unit": "episodes/s", "steps": n, "h2d_bytes_per_episode": nbytes,
+            "pcie_GBps_needed": nbytes * (n / dt) / 1e9,
+            "what": "the headline loop (same schedule) with every episode's inputs streamed from host memory by trainloop.StreamedEpisodes (prefetch "
+                    "thread, pinned uint8 frames 320x240 + teacher features, H2D + GPU frame transform on a copy stream, three static input "
+                    "sets); compare with `value` (inputs resident in HBM)"}
 
 
 def usable_cores():

@@ -257,6 +257,7 @@ def _pack_linear(w, w4, K):
             cur.wait_event(hit[2])
         return hit[1]
     wp = _pack_weights(w4, K, 0, out=hit[1] if hit is not None else None)
+    _audit.audit_ok(wp, "cached pack: lives with its parameter (re-packed in place); readers on other streams wait for the pack's event")
     ev = torch.cuda.Event()
     ev.record(cur)
     e["packs"][key] = (tag, wp, ev, cur.cuda_stream)
@@ -276,6 +277,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _audit.engine_owned(dy)
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         M, K = x.shape
@@ -327,6 +329,7 @@ class TwoHeadLinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g1c, g1t, g2c, g2t):
+        _audit.engine_owned(g1c, g1t, g2c, g2t)
         X, w1, w2 = ctx.saved_tensors
         pw1, pb1, pw2, pb2 = ctx.params
         M, K = X.shape
@@ -421,6 +424,7 @@ def pack_weights(w, Cs, mode):
     # stale or missing: (re)pack - into the SAME buffer when there is one, so that its address stays valid for a captured hipGraph
     # (trainloop.GraphedEpisode) and the allocator is left alone
     wp = _pack_weights(w, Cs, mode, out=hit[1] if hit is not None else None)
+    _audit.audit_ok(wp, "cached pack: lives with its parameter (re-packed in place); readers on other streams wait for the pack's event")
     ev = torch.cuda.Event()
     ev.record(cur)
     e["packs"][key] = (tag, wp, ev, cur.cuda_stream)
@@ -1361,6 +1365,7 @@ class StemFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _audit.engine_owned(dy)
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         x4, c, stats, idx, gamma, w, cmax = ctx.saved_tensors
@@ -1584,6 +1589,7 @@ class BasicBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _audit.engine_owned(dy)
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         x, w1, g1, c1, st1, a1, w2, g2, c2, st2, y, wd, gd, cd, std = ctx.saved_tensors
@@ -1673,6 +1679,7 @@ class BottleneckFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _audit.engine_owned(dy)
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         x, w1, g1, c1, st1, a1, w2, g2, c2, st2, a2, w3, g3, c3, st3, y, wd, gd, cd, std = ctx.saved_tensors
@@ -1724,6 +1731,7 @@ class PoolHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _audit.engine_owned(dy)
         (x,) = ctx.saved_tensors
         F_, H, W, C = x.shape
         dx = torch.empty_like(x)
@@ -1922,6 +1930,7 @@ class TRXLogitsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        _audit.engine_owned(g)
         return _trx_backward(ctx, g)
 
 
@@ -2039,6 +2048,7 @@ class TRXSupFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, gsim):
+        _audit.engine_owned(g, gsim)
         return _trx_backward(ctx, g, gsim, ctx.saved_tensors[12])
 
 
@@ -2109,6 +2119,7 @@ class SupportDKFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        _audit.engine_owned(g)
         (sup,) = ctx.saved_tensors
         way, shot = ctx.ws
         Ns, L, D = sup.shape
@@ -2138,6 +2149,7 @@ class EDistFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        _audit.engine_owned(g)
         sm, qm, dist = ctx.saved_tensors
         plan, L = ctx.plan, ctx.L
         Ns, D = sm.shape
@@ -2182,6 +2194,7 @@ class D2MLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        _audit.engine_owned(gout)
         gbuf, sizes, shapes = ctx.grads
         g = gbuf * gout[0]                         # only the total carries gradient; one launch for the three tensors
         o0, o1 = sizes[0], sizes[0] + sizes[1]
@@ -2210,6 +2223,7 @@ class MSELossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        _audit.engine_owned(gout)
         return ctx.g * gout, None
 
 

@@ -12,6 +12,11 @@ from litemkd_amd.options import default_args
 from litemkd_amd.schedule import Schedule
 
 img = int(sys.argv[1]) if len(sys.argv) > 1 else 224
+if "--selftest" in sys.argv:
+    # negative control: the state of round 4's first fp32h2 version - operands recorded on the weight-gradient stream, the words of their
+    # maxima (int32) not: the audit must name lmkd_conv2d_bwd_weight_seg
+    _rec = torch.Tensor.record_stream
+    torch.Tensor.record_stream = lambda self, s: None if self.dtype is torch.int32 else _rec(self, s)
 dev = torch.device("cuda", 0)
 total = 0
 for sched in (Schedule.bench(conv_dtype="fp32h2"), Schedule.two_call(conv_dtype="fp32h2")):
@@ -19,6 +24,7 @@ for sched in (Schedule.bench(conv_dtype="fp32h2"), Schedule.two_call(conv_dtype=
     torch.manual_seed(0)
     with sched.applied():
         student, teacher, src, distiller, acc_fn, _, opt, sch = TL.make(cfg, base_seed=11)
+        _audit.arm()      # the model, the optimizer and the flat buffers exist: everything allocated from here on is judged
         TL.train(student, teacher, src, distiller, opt, sch, acc_fn, cfg, log=lambda *a: None, schedule=sched)
     torch.cuda.synchronize()
     f = _audit.summary()
@@ -26,4 +32,5 @@ for sched in (Schedule.bench(conv_dtype="fp32h2"), Schedule.two_call(conv_dtype=
     for cnt, name, arg, shape in f:
         print("  %5d x %s argument %d e.g. %s" % (cnt, name, arg, shape))
     total += len(_audit.findings(clear=True))
+    _audit.arm(False)
 print("total findings", total)
