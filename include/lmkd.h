@@ -143,6 +143,7 @@ int lmkd_conv_set_wgrad_win16(int on); /* tuning (modes 2-3, fp32 tensors): 1 = 
 int lmkd_conv_set_wgrad_stem(int on); /* tuning (modes 2-3, fp32 tensors): 1 = the stem's weight gradient on stem_wgrad_kernel (input rows resident in LDS, no im2col copy; default), 0 = im2col-gather kernel */
 int lmkd_conv_set_wgrad_window(int on); /* tuning (modes 1-3): 1 = 3x3 / stride-1 weight gradients read a rolling LDS window of x, all nine taps per workgroup (default), 0 = im2col-gather kernel */
 int lmkd_conv_set_patch16(int on); /* tuning (modes 2 - 4, fp32 tensors): which MFMA the 4-wave patch tiles run on: 1 (default) = v_mfma_f32_16x16x32_* (conv_patch16_x3_kernel), except mode 4's two-plane launches on the 64-column tile (Cout <= 64), which run conv_patch_x3_kernel on v_mfma_f32_32x32x16_f16; 2 = 16x16x32 everywhere; 0 = 32x32x16 everywhere */
+int lmkd_conv_set_persistent(int on); /* tuning (LDS-patch kernels): 1 (default) = persistent workgroups - no more than the chip holds at once, each walking its share of the tile order and requesting its next tile's first patch chunk during the current tile's last; 0 = one workgroup per tile (same tiles, bit-identical results) */
 int lmkd_conv_set_xcd_mode(int mode); /* tuning: -1 auto (XCD-aware tile order + XCD-grouped weight-gradient splits), 0 plain orders, 1 auto without the weight-gradient grouping */
 int lmkd_conv_set_tile(int id); /* tuning: 0 auto, 1 128x128, 2 128x64, 3 64x64, 4 64x128 */
 /* stat_partial (nullable): [row_tiles][Cout][2] per-tile (sum, sum of squares) for train-mode BatchNorm */

@@ -84,11 +84,14 @@ __device__ __forceinline__ float amax4(float m, const float4& v) {
 #define LMKD_AMAX_SLOTS 64
 #define LMKD_AMAX_STRIDE 16
 #define LMKD_AMAX_SEG_WORDS (LMKD_AMAX_SLOTS * LMKD_AMAX_STRIDE)
+// WPB: waves per workgroup where the caller knows it at compile time (blockDim.x is a scalar load from the kernel-argument segment,
+// a microsecond on this machine; conv_patch.h)
+template <int WPB = 0>
 __device__ __forceinline__ void amax_commit(unsigned* __restrict__ word, float m) {      // call with the whole wave active
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0 && m > 0.f)
-    atomicMax(word + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (LMKD_AMAX_SLOTS - 1)) * LMKD_AMAX_STRIDE, __float_as_uint(m));
+    atomicMax(word + ((blockIdx.x * (WPB ? WPB : (int)(blockDim.x >> 6)) + (threadIdx.x >> 6)) & (LMKD_AMAX_SLOTS - 1)) * LMKD_AMAX_STRIDE, __float_as_uint(m));
 }
 // Range statistics beside a maximum (the range fence of compute mode 4, include/lmkd.h lmkd_amax_desc::ref_words): a producer that is
 // given the maximum its result had LAST time (the reference) also counts, per frame segment, the nonzero elements that the two-plane

@@ -15,6 +15,7 @@
 // accumulators in the forward epilogue into per-row-tile partials (deterministic).
 #include "gemm_core.h"
 #include <atomic>
+#include <mutex>
 
 struct ConvGemmArgs {
   const float* src;
@@ -27,6 +28,8 @@ struct ConvGemmArgs {
   int Ho, Wo, Co, omul;
   int Kp, cps, nclass;
   int n_rt, n_ct, xcd_mode;   // row tiles (all classes), column tiles, tile order (XCD-aware 1-D grid, see xcd_decode)
+  int grid_step;              // persistent launches: gridDim.x (read from the argument block's LDS copy; gridDim itself is another scalar load from the segment)
+  int grid_total;             // persistent launches (conv_patch.h): slots of the tile order, xcd_grid(n_rt, n_ct, xcd_mode); a workgroup walks slots blockIdx.x + k gridDim.x
   int same;    // same-size convolution (conv_same_size): the tile height may be one only the patch kernel has
   int halo;    // conv_patch_x3_kernel: largest |dh * Ws + dw| over the taps (pixels either side of the tile's own range)
   int accum;   // epilogue: out = acc + out (residual-branch gradient already sits in the output buffer)
@@ -911,6 +914,43 @@ static inline void lmkd_lds_attr_once(std::atomic<unsigned long long>& mask, con
   mask.fetch_or(bit, std::memory_order_release);
 }
 
+// Grid of a PERSISTENT launch (conv_patch.h): no more workgroups than the chip holds at once (occupancy of this instance with `lds` bytes of
+// dynamic LDS x CUs), each walking `total` / grid slots of the tile order.  The grid is the smallest multiple of 8 that needs the same
+// number of rounds as all resident slots would - every workgroup then has (nearly) the same number of tiles - and a multiple of 8 keeps a
+// workgroup's slots on one XCD (xcd_decode: slot & 7).  The occupancy is asked once per (instance, LDS size).
+struct PersistOcc { std::atomic<int> n{0}; int lds[8]; int occ[8]; std::mutex mu; };
+static int lmkd_cu_count() {
+  static std::atomic<int> n{0};
+  int v = n.load(std::memory_order_relaxed);
+  if (v) return v;
+  int d = 0;
+  hipDeviceProp_t pr;
+  if (hipGetDevice(&d) != hipSuccess || hipGetDeviceProperties(&pr, d) != hipSuccess || pr.multiProcessorCount < 1) return 256;
+  n.store(pr.multiProcessorCount, std::memory_order_relaxed);
+  return pr.multiProcessorCount;
+}
+static int g_conv_persist = 1;      // 0: one workgroup per slot of the tile order (the form before round 5; for A/B measurements)
+extern "C" int lmkd_conv_set_persistent(int on) { g_conv_persist = on ? 1 : 0; return LMKD_OK; }
+template <class K>
+static int persistent_grid(PersistOcc& c, K kernel, int threads, size_t lds, int total) {
+  if (!g_conv_persist) return total;
+  int occ = 0;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    const int n = c.n.load();
+    for (int i = 0; i < n; ++i) if (c.lds[i] == (int)lds) occ = c.occ[i];
+    if (!occ) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, lds) != hipSuccess || occ < 1) occ = 1;
+      if (n < 8) { c.lds[n] = (int)lds; c.occ[n] = occ; c.n.store(n + 1); }
+    }
+  }
+  const int slots = occ * lmkd_cu_count();
+  if (total <= slots) return total;
+  const int rounds = cdiv(total, slots);
+  const int g = (cdiv(total, rounds) + 7) & ~7;
+  return g < total ? g : total;
+}
+
 // Same-size convolutions (3x3 / stride 1 forward and data gradient, 1x1 / stride 1) of the bf16-plane modes read an LDS-resident
 // input patch (conv_patch.h).  Returns the halo (largest |dh * Ws + dw| over the taps), or -1 when the launch is not of that kind.
 static int patch_halo(const ConvGemmArgs& a) {
@@ -944,6 +984,16 @@ extern "C" int lmkd_conv_set_s2_patch(int on) { g_conv_s2_patch = on ? 1 : 0; re
 static int g_patch16 = 1;
 extern "C" int lmkd_conv_set_patch16(int on) { g_patch16 = on < 0 ? 0 : (on > 2 ? 2 : on); return LMKD_OK; }
 
+#ifdef LMKD_STAMPS
+extern "C" int lmkd_debug_stamps(unsigned long long* host, int zero) {
+  if (zero) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_lmkd_stamps)) != hipSuccess) return LMKD_EHIP;
+    return hipMemset(p, 0, sizeof(g_lmkd_stamps)) == hipSuccess ? LMKD_OK : LMKD_EHIP;
+  }
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lmkd_stamps), sizeof(g_lmkd_stamps)) == hipSuccess ? LMKD_OK : LMKD_EHIP;
+}
+#endif
 template <class Cfg>
 static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
   conv_set_tiles(a, Cfg::BM);
@@ -953,13 +1003,17 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
   const dim3 grid(xcd_grid(a.n_rt, a.n_ct, a.xcd_mode));
   a.halo = halo;
   const int npl = (g_conv_bf16 || g_lmkd_act_bf16) ? 1 : 3;
-  const size_t lds = patch_lds_bytes(Cfg::BM, halo, npl);
+  size_t lds = patch_lds_bytes(Cfg::BM, halo, npl);
 #define LMKD_PATCH(NPROD, PRE, IO)                                                                                             \
   do {                                                                                                                         \
     static std::atomic<unsigned long long> attr_done{0};                                                                       \
+    static PersistOcc pocc;                                                                                                    \
     lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>),                   \
                        (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, NPROD == 1 ? 1 : 3));                                     \
-    hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>), grid, dim3(Cfg::THREADS), lds, s, a);                      \
+    a.grid_total = (int)grid.x;                                                                                                \
+    const dim3 pgrid(persistent_grid(pocc, conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>, Cfg::THREADS, lds, a.grid_total));       \
+    a.grid_step = (int)pgrid.x;                                                                                                \
+    hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>), pgrid, dim3(Cfg::THREADS), lds, s, a);                     \
   } while (0)
   if constexpr (Cfg::THREADS == 256 && Cfg::BM == 128) {      // the benchmark's tiles (ids 11 / 12) on the 16x16x32 MFMA (conv_patch16.h)
     // (lmkd_conv_set_patch16; the inference epilogue - residual loads, no sums - stays on the 16x16x32 kernel and its 16-byte accesses: 168.7 vs 160.6 inference episodes/s)
@@ -1010,15 +1064,7 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
   }
   if (g_conv_h2 && a.h2_xw && !a.ep_stats && !g_lmkd_act_bf16) {      // two fp16 planes on v_mfma_f32_32x32x16_f16: the 64-column tile (lmkd_conv_set_patch16), or a tile conv_patch16_x3_kernel does not have
     t_amax_recorded = true;      // (x3_epilogue<.., H2> folds ConvGemmArgs::amax_out)
-#ifdef LMKD_ABL32      // measurement builds (tools/ab_build.sh): a timing ablation of the two-plane instance
-    if (!a.pre_stats) {
-      static std::atomic<unsigned long long> attr_done{0};
-      lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, 3, false, 0, LMKD_ABL32>), (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));
-      hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, 3, false, 0, LMKD_ABL32>), grid, dim3(Cfg::THREADS), lds, s, a);
-      ++g_h2_launches;
-      return;
-    }
-#endif
+    lds = patch_lds_bytes(Cfg::BM, halo, 2);
     if (a.pre_stats) LMKD_PATCH(3, true, 0); else LMKD_PATCH(3, false, 0);
     ++g_h2_launches;
     return;
@@ -1055,9 +1101,13 @@ static void launch_conv_patch_1p(ConvGemmArgs a, int ncols, int halo, hipStream_
 #define LMKD_PATCH1(PRE, IO)                                                                                                   \
   do {                                                                                                                         \
     static std::atomic<unsigned long long> attr_done{0};                                                                       \
+    static PersistOcc pocc;                                                                                                    \
     lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, 1, PRE, IO>),                       \
                        (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 1));                                                      \
-    hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, 1, PRE, IO>), grid, dim3(Cfg::THREADS), lds, s, a);                          \
+    a.grid_total = (int)grid.x;                                                                                                \
+    const dim3 pgrid(persistent_grid(pocc, conv_patch_x3_kernel<Cfg, 1, PRE, IO>, Cfg::THREADS, lds, a.grid_total));           \
+    a.grid_step = (int)pgrid.x;                                                                                                \
+    hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, 1, PRE, IO>), pgrid, dim3(Cfg::THREADS), lds, s, a);                         \
   } while (0)
   if (a.ep_stats) LMKD_PATCH1(false, 4);
   else if (g_lmkd_act_bf16) LMKD_PATCH1(false, 3);

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   __shared__ float s_red[Cfg::WM * Cfg::BN * 2];
   __shared__ int s_src[SRC2 ? Cfg::BM + 2 * PATCH_HALO_MAX : 1];      // SRC2: byte offset of patch row j's pixel in class (0, 0), -1 outside
   const int tid = threadIdx.x;
+  STAMP(0);
   int rt, ct;
   if (!xcd_decode(blockIdx.x, a.n_rt, a.n_ct, a.xcd_mode, rt, ct)) return;
   const int tile = rt / a.nclass;
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     patch16_fill_adp<Cfg, NB, ROWB>(s_adp, a, taps, ntap, tid, row0, M, halo, P);
   }
   __syncthreads();      // tap tables, s_out, zero row
+  STAMP(1);
   if (nk > 0) {
     if (!EARLY) issue_patch(0);
     issue_b(rb0);
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     x3_landed(rb0);
     x3_landed(rb1);
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(2);
     int t = 0;
     for (; t + 1 < nk; t += 2) {
       step(t, rb0, rb1);
@@ -463,6 +466,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
     if (t < nk) step(t, rb0, rb1);
   }
 
+  STAMP(3);
   // ---- epilogue: lane = (pixel patch16_pixel(lane % 16) of each 16-pixel block, channels 4 kq .. 4 kq + 3 of each 16-channel block)
   const int ch0 = n0 + wn * (Cfg::TN * 32) + 4 * kq;      // + 16 c
   float4 s1[NC], s2[NC];
@@ -568,4 +572,5 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
       p[1] = t2;
     }
   }
+  STAMP(4);
 }

@@ -160,8 +160,10 @@ def _gloo_worker(rank, world, port, q):
     sch.step()
     lr1 = sch.opt.lr
     sch.step()
-    q.put((rank, local, fp.grad.clone(), [p.grad.data_ptr() for p in m.parameters()], fp.grad.data_ptr(),
-           {k: v.clone() for k, v in avg.items()}, bn[0].running_mean.clone(), (lr1, sch.opt.lr)))
+    # numpy copies, pickled by value: a torch tensor on an mp queue travels as a shared-memory file that the parent must open before this
+    # process exits (it failed with FileNotFoundError once in a while)
+    q.put((rank, local.numpy().copy(), fp.grad.numpy().copy(), [p.grad.data_ptr() for p in m.parameters()], fp.grad.data_ptr(),
+           {k: v.numpy().copy() for k, v in avg.items()}, bn[0].running_mean.numpy().copy(), (lr1, sch.opt.lr)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -177,6 +179,8 @@ def test_flat_bucket_allreduce_gloo_world2():
     res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
     for p in ps:
         p.join(60)
+    T = torch.from_numpy
+    res = [(r, T(l), T(s), p, b, {k: T(v) for k, v in a.items()}, T(lv), lr) for r, l, s, p, b, a, lv, lr in res]
     (r0, l0, s0, ptrs0, base0, avg0, live0, lrs0), (r1, l1, s1, _, _, avg1, live1, _) = res
     assert torch.allclose(s0, l0 + l1) and torch.allclose(s1, l0 + l1)
     assert ptrs0[0] == base0                       # .grad tensors are views into the bucket

@@ -11,7 +11,7 @@ txt = r.stderr
 rows = []
 for b in re.split(r"remark: Function Name: ", txt)[1:]:
     name = b.split(" ")[0]
-    if not any(k in name for k in ("patch16", "wgrad_win16", "stem_wgrad", "conv_stem_patch", "conv_wgrad_x3")):
+    if not any(k in name for k in ("patch16", "conv_patch_x3", "wgrad_win16", "stem_wgrad", "conv_stem_patch", "conv_wgrad_x3")):
         continue
     g = lambda k: int(re.search(k + r": (\d+)", b).group(1))
     dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().replace("void ", "").split("(")[0]
