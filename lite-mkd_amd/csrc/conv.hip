@@ -1011,7 +1011,7 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
     lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>),                   \
                        (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, NPROD == 1 ? 1 : 3));                                     \
     a.grid_total = (int)grid.x;                                                                                                \
-    const dim3 pgrid(persistent_grid(pocc, conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>, Cfg::THREADS, lds, a.grid_total));       \
+    const dim3 pgrid(NPROD == 3 ? persistent_grid(pocc, conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>, Cfg::THREADS, lds, a.grid_total) : a.grid_total); \
     a.grid_step = (int)pgrid.x;                                                                                                \
     hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, NPROD, PRE, IO>), pgrid, dim3(Cfg::THREADS), lds, s, a);                     \
   } while (0)
@@ -1101,11 +1101,10 @@ static void launch_conv_patch_1p(ConvGemmArgs a, int ncols, int halo, hipStream_
 #define LMKD_PATCH1(PRE, IO)                                                                                                   \
   do {                                                                                                                         \
     static std::atomic<unsigned long long> attr_done{0};                                                                       \
-    static PersistOcc pocc;                                                                                                    \
     lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch_x3_kernel<Cfg, 1, PRE, IO>),                       \
                        (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 1));                                                      \
     a.grid_total = (int)grid.x;                                                                                                \
-    const dim3 pgrid(persistent_grid(pocc, conv_patch_x3_kernel<Cfg, 1, PRE, IO>, Cfg::THREADS, lds, a.grid_total));           \
+    const dim3 pgrid(a.grid_total);      /* (one-plane instances: one workgroup per tile, conv_patch.h PERSIST) */            \
     a.grid_step = (int)pgrid.x;                                                                                                \
     hipLaunchKernelGGL((conv_patch_x3_kernel<Cfg, 1, PRE, IO>), pgrid, dim3(Cfg::THREADS), lds, s, a);                         \
   } while (0)

@@ -198,6 +198,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
   static_assert(((IO & 3) == 0 || NPROD == 1) && !(IN16 && PRE), "bf16 tensors: one-plane mode, no load-side arithmetic");
   constexpr int ROWB = PatchRow<NPROD == 3 ? 2 : NPL>::BYTES;
   constexpr int ESZ = IN16 ? 2 : 4;
+  // the two-plane instances walk several tiles; the others are launched with one workgroup per tile and leave the loop after the first
+  // (their tiles - up to 256 rows, 128 accumulator registers per lane - have no room for what a second iteration keeps alive:
+  // 256 registers + 700 bytes of scratch when they were given the loop, bf16 tensors 77 -> 72 episodes/s)
+  constexpr bool PERSIST = NPROD == 3;
   constexpr int LPR = IN16 ? 4 : 8;                       // lanes per patch row (16 bytes each)
   constexpr int RPP = Cfg::THREADS / LPR;                 // patch rows per pass
   constexpr int NI = (Cfg::BM + 2 * PATCH_HALO_MAX + RPP - 1) / RPP;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
   bool requested = false;      // the first chunk of `cur` is on its way (requested during the previous tile)
   for (;;) {
     PSTAMP(0);
-    const int Ln = next_tile(Lc + a.grid_step, nxt);
+    const int Ln = PERSIST ? next_tile(Lc + a.grid_step, nxt) : -1;
     const int ntap = cur.ntap;
     const Tap* taps = s_args.taps[cur.cls];
     const int ph = cur.cls >> 1, pw = cur.cls & 1;
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
         __syncthreads();
         {      // ONE set of loads with selected operands (two calls under an if / else cost a second register set for the merge)
           const bool more = k_cc + 1 < a.cps;
-          const bool ahead = !more && Ln >= 0 && nxt.ntap > 0;
+          const bool ahead = PERSIST && !more && Ln >= 0 && nxt.ntap > 0;
           if (more || ahead) {
             PatchTile d;
             d.p_off0 = more ? cur.p_off0 : nxt.p_off0;
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
       x3_epilogue<Cfg, true, OUT16, EP>(a, acc, s_out, s_red, cur.rt, n0, wm, wn, lane, tid, neg);
     }
     PSTAMP(4);
-    if (Ln < 0) break;
+    if (!PERSIST || Ln < 0) break;
     __syncthreads();      // the tables and s_red are this tile's until every wave is through its epilogue
     cur = nxt;
     Lc = Ln;
