@@ -200,6 +200,14 @@ int lmkd_frames_u8_to_nhwc4(const unsigned char* src, float* dst, const int* cro
 int lmkd_resize_plan(int in_size, int out_size, int* bounds_host, int* coeffs_host);
 int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst, const int* bounds_dev, const int* coeffs_dev, int ksize, long outer,
                         int n_in, int n_out, long inner, void* stream);
+/* The same transform for frames that share one resolution, in ONE launch (round 5): a thread evaluates Pillow's two passes for its own
+   pixel of the cropped output (uint8 rounding between the passes as in Pillow's intermediate image: bit-identical to
+   lmkd_resize_pass_u8 x 2 + lmkd_frames_u8_to_nhwc4), nothing for the part of the resized frame the crop discards.  bounds_h / coeffs_h:
+   lmkd_resize_plan(Ws, Wr) uploaded, bounds_v / coeffs_v: lmkd_resize_plan(Hs, Hr); crop_y / crop_x / flip as lmkd_frames_u8_to_nhwc4
+   (coordinates in the Hr x Wr resized frame).  video_reader.py:92-112,377-385. */
+int lmkd_frames_resize_crop_nhwc4(const unsigned char* src, float* dst, const int* bounds_h, const int* coeffs_h, int ksize_h,
+                                  const int* bounds_v, const int* coeffs_v, int ksize_v, const int* crop_y, const int* crop_x,
+                                  const int* flip, int F, int Hs, int Ws, int Hr, int Wr, int H, int W, int frames_per_video, void* stream);
 /* amax_words (nullable; mode 4): also fold max |y| into the slots of ONE frame segment at this address (lmkd_amax_words() / 2 words) */
 int lmkd_nchw3_to_nhwc4(const float* x_nchw, float* y_nhwc4, int N, int H, int W, void* stream, void* amax_words);
 /* Ticket words: the single-launch column reductions (lmkd_bn_finalize, lmkd_bn_backward, lmkd_colsum) elect their finishing workgroup

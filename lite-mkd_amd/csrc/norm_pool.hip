@@ -209,6 +209,61 @@ extern "C" int lmkd_resize_pass_u8(const unsigned char* src, unsigned char* dst,
   return LMKD_OK;
 }
 
+// The whole frame transform of an episode in ONE launch (round 5): Resize -> crop -> flip -> ToTensor for frames that share one resolution.
+// A thread owns one pixel of the cropped 224 x 224 output and evaluates Pillow's two passes for it alone: the vertical pass over the (at
+// most ksize_v) rows of the horizontally resized image it needs, each of those values the horizontal pass at its own column - with the
+// uint8 rounding and clipping BETWEEN the passes that Pillow's intermediate image has, so the result is the two-pass one bit for bit
+// (tests/test_gpu_ops.py) - and writes the ToTensor value.  Nothing is computed for the 43 % of the resized frame the crop discards and
+// neither intermediate image exists: 1.08 ms of a streamed episode's copy-stream work (two passes + crop kernel, a 64-bit division pair
+// per output BYTE in the passes) -> see profiles/r05_frame_transform.txt.
+__global__ void frames_resize_crop_nhwc4_kernel(const unsigned char* __restrict__ src, float4* __restrict__ dst,
+                                                const int* __restrict__ bh, const int* __restrict__ kh, int ksh,
+                                                const int* __restrict__ bv, const int* __restrict__ kv, int ksv,
+                                                const int* __restrict__ crop_y, const int* __restrict__ crop_x, const int* __restrict__ flip,
+                                                int Hs, int Ws, int H, int W, int frames_per_video) {
+  const int f = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= H * W) return;
+  const int h = p / W, w = p - h * W;
+  const int v = f / frames_per_video;
+  const int sx = crop_x[v] + (flip[v] ? (W - 1 - w) : w);      // column / row of the resized frame
+  const int sy = crop_y[v] + h;
+  const int x0 = bh[sx * 2], nx = bh[sx * 2 + 1];
+  const int y0 = bv[sy * 2], ny = bv[sy * 2 + 1];
+  const int* ch = kh + (long)sx * ksh;
+  const int* cv = kv + (long)sy * ksv;
+  int a0 = 1 << (LMKD_PIL_PRECISION_BITS - 1), a1 = a0, a2 = a0;
+  for (int yy = 0; yy < ny; ++yy) {
+    const unsigned char* row = src + (((long)f * Hs + y0 + yy) * Ws + x0) * 3;
+    int t0 = 1 << (LMKD_PIL_PRECISION_BITS - 1), t1 = t0, t2 = t0;
+    for (int xx = 0; xx < nx; ++xx) {
+      const int k = ch[xx];
+      t0 += (int)row[xx * 3 + 0] * k;
+      t1 += (int)row[xx * 3 + 1] * k;
+      t2 += (int)row[xx * 3 + 2] * k;
+    }
+    t0 >>= LMKD_PIL_PRECISION_BITS; t1 >>= LMKD_PIL_PRECISION_BITS; t2 >>= LMKD_PIL_PRECISION_BITS;
+    t0 = t0 < 0 ? 0 : (t0 > 255 ? 255 : t0); t1 = t1 < 0 ? 0 : (t1 > 255 ? 255 : t1); t2 = t2 < 0 ? 0 : (t2 > 255 ? 255 : t2);
+    const int k = cv[yy];
+    a0 += t0 * k; a1 += t1 * k; a2 += t2 * k;
+  }
+  a0 >>= LMKD_PIL_PRECISION_BITS; a1 >>= LMKD_PIL_PRECISION_BITS; a2 >>= LMKD_PIL_PRECISION_BITS;
+  a0 = a0 < 0 ? 0 : (a0 > 255 ? 255 : a0); a1 = a1 < 0 ? 0 : (a1 > 255 ? 255 : a1); a2 = a2 < 0 ? 0 : (a2 > 255 ? 255 : a2);
+  dst[(long)f * H * W + p] = make_float4((float)a0 / 255.f, (float)a1 / 255.f, (float)a2 / 255.f, 0.f);   // ToTensor: x.div(255)
+}
+
+extern "C" int lmkd_frames_resize_crop_nhwc4(const unsigned char* src, float* dst, const int* bounds_h, const int* coeffs_h, int ksize_h,
+                                             const int* bounds_v, const int* coeffs_v, int ksize_v, const int* crop_y, const int* crop_x,
+                                             const int* flip, int F, int Hs, int Ws, int Hr, int Wr, int H, int W, int frames_per_video,
+                                             void* stream) {
+  LMKD_REQUIRE(src && dst && bounds_h && coeffs_h && bounds_v && coeffs_v && crop_y && crop_x && flip && ksize_h > 0 && ksize_v > 0 && F > 0 &&
+               F <= 65535 && Hs > 0 && Ws > 0 && H > 0 && W > 0 && H <= Hr && W <= Wr && frames_per_video > 0, "lmkd_frames_resize_crop_nhwc4: bad arguments");
+  hipLaunchKernelGGL(frames_resize_crop_nhwc4_kernel, dim3(cdiv(H * W, NP_THREADS), F), dim3(NP_THREADS), 0, (hipStream_t)stream, src,
+                     (float4*)dst, bounds_h, coeffs_h, ksize_h, bounds_v, coeffs_v, ksize_v, crop_y, crop_x, flip, Hs, Ws, H, W, frames_per_video);
+  LMKD_CHECK_LAUNCH("frames_resize_crop_nhwc4_kernel");
+  return LMKD_OK;
+}
+
 // ---------------------------------------------------------------------------------
 // Column sums of a tall partial-sum buffer in ONE launch (round 3; before: a 64-slice stage-1 kernel for buffers taller than
 // 2048 rows plus a finishing kernel in which ONE workgroup per 64 channels walked up to 2048 rows: 11 - 19 us per BatchNorm).

@@ -1508,6 +1508,45 @@ def resize_frames_u8(frames_u8, size):
     return x
 
 
+def _resized_shape(H, W, size):
+    """output (height, width) of Resize(size) on H x W frames (functional.py:44-59)"""
+    if isinstance(size, int):
+        if (W <= H and W == size) or (H <= W and H == size):
+            return H, W
+        return (int(size * H / W), size) if W < H else (size, int(size * W / H))
+    return tuple(size)
+
+
+def frames_resize_crop_nhwc4(frames_u8, resize, crop_y, crop_x, flip, size, frames_per_video=8, out=None):
+    """Resize(resize) -> crop (size x size at crop_y / crop_x of the resized frame) -> flip -> ToTensor of uint8 frames [F,H,W,3] that share
+    one resolution, in ONE launch (lmkd_frames_resize_crop_nhwc4): bit-identical to resize_frames_u8 + frames_u8_to_nhwc4, without the
+    two intermediate images and without the part of the resized frame the crop discards (video_reader.py:92-112,377-385)."""
+    _chk(frames_u8, crop_y, crop_x, flip)
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
+        raise RuntimeError("frames_resize_crop_nhwc4 expects uint8 [F,H,W,3] frames")
+    F_, Hs, Ws, _ = frames_u8.shape
+    oh, ow = _resized_shape(Hs, Ws, resize)
+    nv = F_ // frames_per_video
+    if nv * frames_per_video != F_ or crop_y.numel() != nv or crop_x.numel() != nv or flip.numel() != nv:
+        raise RuntimeError("one crop/flip entry per video of %d frames expected" % frames_per_video)
+    if size > oh or size > ow:
+        raise RuntimeError("crop %d exceeds the resized frame %d x %d" % (size, oh, ow))
+    if out is None:
+        out = torch.empty((F_, size, size, 4), dtype=torch.float32, device=frames_u8.device)
+    elif tuple(out.shape) != (F_, size, size, 4) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("frames_resize_crop_nhwc4: `out` must be a contiguous float32 [%d, %d, %d, 4] tensor" % (F_, size, size))
+    bh, kh, ksh = _resize_plan(Ws, ow, frames_u8.device)
+    bv, kv, ksv = _resize_plan(Hs, oh, frames_u8.device)
+    for f0 in range(0, F_, 65528 // frames_per_video * frames_per_video):      # (the frame index travels in gridDim.y)
+        f1 = min(F_, f0 + 65528 // frames_per_video * frames_per_video)
+        v0, v1 = f0 // frames_per_video, f1 // frames_per_video
+        lib().call("lmkd_frames_resize_crop_nhwc4", _p(frames_u8[f0:f1]), _p(out[f0:f1]), _p(bh), _p(kh), int(ksh), _p(bv), _p(kv), int(ksv),
+                   _p(crop_y[v0:v1]), _p(crop_x[v0:v1]), _p(flip[v0:v1]), f1 - f0, Hs, Ws, oh, ow, size, size, frames_per_video, _stream())
+    if _h2_mode():      # ToTensor output lies in [0, 1] (frames_u8_to_nhwc4)
+        out._lmkd_amax = _amax_unit_words(out.device)
+    return out
+
+
 # parallel.EarlyAllReduce: while set, the trunk's forward registers this tensor hook on the input of its last stage - it fires when the
 # backward pass has left that stage (the gradients of the last stage, the heads and the matcher are final)
 GRAD_READY_HOOK = None

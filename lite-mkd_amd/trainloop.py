@@ -318,16 +318,16 @@ class StreamedEpisodes:
     compute stream waits for the set's `ready` event; the copy stream, before it overwrites a set, for the events the loop recorded on
     every stream that read it (release(): the lane's streams and the weight-gradient stream after the episode's backward pass was
     queued - nothing on the compute side ever waits for the loader).  With cross-episode pipelining three episodes are in flight
-    (backward i, forward i + 1, staging i + 2): hence sets >= 3."""
+    (backward i, forward i + 1, staging i + 2) and the loader stages one episode ahead of the loop's request: hence sets >= 4."""
 
-    def __init__(self, source, config, device, sets=3, prefetch=2):
+    def __init__(self, source, config, device, sets=4, prefetch=2):
         import queue
         import threading
         from .video_transform import GpuFrameTransform
         self.source, self.c, self.device = source, config, torch.device(device)
         self.tf = GpuFrameTransform(config.img_size, self.device)
         self.copy = torch.cuda.Stream(device=self.device)
-        self.nsets = max(2, int(sets))
+        self.nsets = max(3, int(sets))
         self.sets = [None] * self.nsets
         self.dataset = getattr(source, "dataset", source)
         self._q = queue.Queue(maxsize=max(1, int(prefetch)))
@@ -441,15 +441,21 @@ class StreamedEpisodes:
         if self._thread is None:
             self._thread = self._threading.Thread(target=self._produce, daemon=True)
             self._thread.start()
+        # staging runs ONE episode ahead of the loop: the copy + transform of episode i + 1 are queued (on the copy stream) before the loop
+        # queues episode i's forward pass, so they execute under it instead of in front of episode i + 1 (round 5: 0.90 -> see
+        # profiles/r05_bench.json `stream_inputs` of the resident rate); one more input set is in flight for it (sets >= 4)
+        held = None
         while True:
             h = self._q.get()
-            if h is None:
-                return
             if isinstance(h, BaseException):
                 raise h
-            td = self._stage(h)
-            torch.cuda.current_stream(self.device).wait_event(self.sets[td["_input_set"][1]]["ready"])
-            yield td
+            td = self._stage(h) if h is not None else None
+            if held is not None:
+                torch.cuda.current_stream(self.device).wait_event(self.sets[held["_input_set"][1]]["ready"])
+                yield held
+            if td is None:
+                return
+            held = td
 
     def close(self):
         self._stop.set()

@@ -1260,6 +1260,37 @@ def test_gpu_frame_transform_matches_reference_chain(dev):
         assert torch.equal(out[..., :3].cpu(), ref) and float(out[..., 3].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("shape,resize,S", [((240, 320), 256, 224), ((288, 352), 256, 224), ((256, 300), 256, 224), ((120, 160), 128, 112),
+                                            ((300, 200), 128, 112), ((64, 64), (80, 72), 64)])
+def test_fused_frame_transform_equals_two_pass_and_pillow(dev, shape, resize, S):
+    """lmkd_frames_resize_crop_nhwc4 (one launch per episode: Resize -> crop -> flip -> ToTensor, each thread evaluating Pillow's two
+    passes for its own output pixel) against the numpy restatement of Pillow's resampler (oracle, pinned by tests/golden/resize.npz) and
+    against the two-pass path (lmkd_resize_pass_u8 x 2 + lmkd_frames_u8_to_nhwc4): bit exact, flipped and unflipped videos, up- and
+    down-scaling, crops at the frame's edges (video_reader.py:92-112,377-385)."""
+    from litemkd_amd import ops
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(21)
+    H, W = shape
+    L, nv = 4, 5
+    frames = rng.integers(0, 256, (L * nv, H, W, 3), dtype=np.uint8)
+    oh, ow = ops._resized_shape(H, W, resize)
+    cy = torch.tensor([0, oh - S, (oh - S) // 2, 1 % (oh - S + 1), oh - S], dtype=torch.int32)
+    cx = torch.tensor([0, ow - S, (ow - S) // 3, ow - S, 0], dtype=torch.int32)
+    fl = torch.tensor([0, 1, 1, 0, 1], dtype=torch.int32)
+    fr = torch.from_numpy(frames).to(dev)
+    out = ops.frames_resize_crop_nhwc4(fr, resize, cy.to(dev), cx.to(dev), fl.to(dev), S, frames_per_video=L)
+    two = ops.frames_u8_to_nhwc4(ops.resize_frames_u8(fr, resize), cy.to(dev), cx.to(dev), fl.to(dev), S, frames_per_video=L)
+    assert out.shape == (L * nv, S, S, 4) and torch.equal(out, two)
+    r = torch.from_numpy(O.pil_resize_bilinear_u8(frames, ow, oh))
+    for f in range(L * nv):
+        v = f // L
+        ref = r[f, int(cy[v]):int(cy[v]) + S, int(cx[v]):int(cx[v]) + S]
+        if int(fl[v]):
+            ref = ref.flip(1)
+        assert torch.equal(out[f, :, :, :3].cpu(), ref.float() / 255.0), f
+    assert float(out[..., 3].abs().max()) == 0.0
+
+
 @pytest.fixture
 def bf16_act():
     from litemkd_amd import ops
