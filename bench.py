@@ -417,11 +417,12 @@ def main():
 
     def kernel_name(mode, patch):
         if patch:
-            return ("conv_patch16_x3_kernel" if mode in ("f32", "f32x3") else "conv_patch_x3_kernel") + \
+            return ("conv_patch16_x3_kernel + conv_patch_x3_kernel<.., 3, ..> (layer 1's launches, v_mfma_f32_32x32x16_f16, persistent workgroups: round 5)" if mode == "f32" else
+                    "conv_patch16_x3_kernel" if mode == "f32x3" else "conv_patch_x3_kernel") + \
                 " (3x3 conv fwd + dgrad from an LDS-resident input patch; stride-2 launches as parity classes): " + ARITH[mode]
         return ("conv_gemm_kernel" if mode == "f32native" else "conv_gemm_x3_kernel") + " (implicit-GEMM conv fwd + dgrad): " + ARITH[mode]
     KERNEL = {a.dtype: kernel_name(a.dtype, patch_dom)}
-    PMC_KEY = ("conv_patch16_x3_kernel" if a.dtype in ("f32", "f32x3") else "conv_patch_x3_kernel") if patch_dom else ("conv_gemm_kernel" if a.dtype == "f32native" else "conv_gemm_x3_kernel")
+    PMC_KEY = ("conv_patch16_x3_kernel+conv_patch_x3_kernel" if a.dtype == "f32" else "conv_patch16_x3_kernel" if a.dtype == "f32x3" else "conv_patch_x3_kernel") if patch_dom else ("conv_gemm_kernel" if a.dtype == "f32native" else "conv_gemm_x3_kernel")
     peak = PEAK[a.dtype]
     # HBM-side traffic of the same kernel family: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950) of `bench.py --serial`,

@@ -546,36 +546,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
-// The same reduction for the 3x3 and 1x1 weights of the trunk (Cin a multiple of 64; round 5): a workgroup owns one output channel and 64
-// input channels.  It reads the slabs tap by tap - 64 consecutive floats each, the summation order of wgrad_reduce_kernel - and writes its
-// 64 x KH x KW results as ONE contiguous run of OIHW (a transpose through LDS) instead of 4-byte stores 36 bytes apart; no 64-bit
-// division per element (wgrad_reduce_kernel makes four).  20 launches, 0.69 ms per episode before.
-template <int TAPS>      // KH * KW: 9 or 1
-__global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Co, int Cin,
-                                                             int Cs, int KW, int KWp, int Kp, int accumulate) {
-  __shared__ float sm[64 * TAPS + 1];
-  const int nci = Cin >> 6;
-  const int co = blockIdx.x / nci, ci0 = (blockIdx.x - co * nci) << 6;
-  const long zs = (long)Co * Kp;
-  for (int e = threadIdx.x; e < 64 * TAPS; e += 256) {
-    const int tap = e >> 6, ci = e & 63;
-    const int kh = TAPS == 1 ? 0 : tap / KW, kw = TAPS == 1 ? 0 : tap - kh * KW;
-    const float* p = slab + (long)co * Kp + (long)(kh * KWp + kw) * Cs + ci0 + ci;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int z = 0;
-    for (; z + 8 <= splits; z += 8) {
-      const float a0 = p[(z + 0) * zs], a1 = p[(z + 1) * zs], a2 = p[(z + 2) * zs], a3 = p[(z + 3) * zs];
-      const float a4 = p[(z + 4) * zs], a5 = p[(z + 5) * zs], a6 = p[(z + 6) * zs], a7 = p[(z + 7) * zs];
-      s0 += a0; s1 += a1; s2 += a2; s3 += a3; s0 += a4; s1 += a5; s2 += a6; s3 += a7;
-    }
-    for (; z < splits; ++z) s0 += p[z * zs];
-    sm[ci * TAPS + tap] = (s0 + s1) + (s2 + s3);
-  }
-  __syncthreads();
-  float* o = dw + ((long)co * Cin + ci0) * TAPS;
-  for (int e = threadIdx.x; e < 64 * TAPS; e += 256) o[e] = accumulate ? o[e] + sm[e] : sm[e];      // accumulate: dw is weight.grad itself
-}
-// ... and for the stem (Kp = 7 x 8 x 4 = 224 <= 256, several hundred slabs - one per workgroup of stem_wgrad_kernel): one workgroup per
+// The same reduction for the stem (round 5; Kp = 7 x 8 x 4 = 224 <= 256, several hundred slabs - one per workgroup of stem_wgrad_kernel): one workgroup per
 // output channel, thread (k, q) adds the slabs q, q + 4, ... of K position k (coalesced rows of Kp floats), the four partial sums meet in
 // LDS.  wgrad_reduce_kernel gave the 9 408 weights one thread each for a walk over every slab: 184 us.
 __global__ __launch_bounds__(1024) void wgrad_reduce_stem_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Co, int Cin,
@@ -606,16 +577,11 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_stem_kernel(const float* __
     }
   }
 }
+// (a form that transposed 64 x 9 results through LDS into contiguous OIHW runs, one workgroup per output channel and 64 input channels,
+// measured 48 % SLOWER than this kernel's scattered 4-byte stores - 9.87 vs 6.66 ms over the 247 non-stem launches of 13 episodes,
+// profiles/r05_kernel_stats_serial_f32.csv of that build: the time is the slabs' read, and a third of its lanes idled in the last pass)
 static void launch_wgrad_reduce(const float* slab, float* dw, int splits, int Co, int Cin, int Cs, int KH, int KW, int KWp, int Kp,
                                 int accumulate, hipStream_t s) {
-  if ((Cin & 63) == 0 && KH * KW == 9 && (long)Co * (Cin >> 6) < 2147483647L) {
-    hipLaunchKernelGGL(wgrad_reduce_t_kernel<9>, dim3(Co * (Cin >> 6)), dim3(256), 0, s, slab, dw, splits, Co, Cin, Cs, KW, KWp, Kp, accumulate);
-    return;
-  }
-  if ((Cin & 63) == 0 && KH * KW == 1 && (long)Co * (Cin >> 6) < 2147483647L) {
-    hipLaunchKernelGGL(wgrad_reduce_t_kernel<1>, dim3(Co * (Cin >> 6)), dim3(256), 0, s, slab, dw, splits, Co, Cin, Cs, KW, KWp, Kp, accumulate);
-    return;
-  }
   const long total = (long)Co * KH * KW * Cin;
   int rg = cdiv(total, 256);
   if (rg > 4096) rg = 4096;

@@ -19,7 +19,7 @@ B="python bench.py"
 [ "$part" = all -o "$part" = 2 ] && { sleep 6; $B --steps 32 --warmup 5 --no-cpu-baseline --no-other-modes --pipeline > $out/bench_pipeline.json 2>/dev/null; echo "pipeline $?"; }
 [ "$part" = all -o "$part" = 2 ] && { sleep 6; python tools/eval_bench.py 2>/dev/null | tail -1 > $out/eval.json; echo "eval $?"; }
 [ "$part" = all -o "$part" = 2 ] && { sleep 6; python tools/x3_bias_probe.py 40 2>/dev/null > $out/x3_bias_probe.txt; echo "bias $?"; }
-[ "$part" = all -o "$part" = 2 ] && { sleep 6; python tools/patch_ablate.py 2>/dev/null > $out/patch_ablate.txt; echo "ablate $?"; }
+[ "$part" = all -o "$part" = 2 ] && { sleep 6; python tools/abl_bench.py 2>/dev/null | grep "^L" > $out/patch32_vs_16.txt; echo "abl $?"; }
 [ "$part" = all -o "$part" = 2 ] && { sleep 6; python tools/host_ahead.py 10 2>/dev/null > $out/host_ahead.txt; echo "host $?"; }
 [ "$part" = all -o "$part" = 2 ] && { sleep 6; python tools/aten_ops.py f32 2 2>/dev/null > $out/launches_f32.txt; python tools/aten_ops.py f32x3 2 2>/dev/null > $out/launches_f32x3.txt; echo "launches $?"; }
 [ "$part" = all -o "$part" = 2 ] && { sleep 6; python tools/phase_times.py 14 2>/dev/null | tail -1 > $out/phase_times.txt; echo "phases $?"; }

@@ -18,7 +18,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_proto/p*/**/r_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "patch16" not in n and "win16" not in n:
+        if "patch16" not in n and "win16" not in n and "conv_patch_x3" not in n:
             continue
         key = (n.split("(")[0][:70], r["Grid_Size"])
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))

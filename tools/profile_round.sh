@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --warmup 1 --no-cpu-baseline --no-other-modes --serial"
+B="$R/bench.py --warmup 1 --no-cpu-baseline --no-other-modes --serial --prime 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_f32 -o r -- python3 $B --steps 4 > $out/trace_f32.log 2>&1
 echo "trace f32 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_f32x3 -o r -- python3 $B --steps 4 --dtype f32x3 > $out/trace_f32x3.log 2>&1
