@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--shot", type=int, default=5)
     ap.add_argument("--pool", type=int, default=2, help="distinct resident synthetic episodes to cycle through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prime", type=int, default=96, help="at most this many untimed allocator-priming episodes in front of the warm-up (0: none)")
+    ap.add_argument("--prime", type=int, default=160, help="at most this many untimed allocator-priming episodes in front of the warm-up (0: none)")
     ap.add_argument("--dropout", type=float, default=0.1, help="TRX dropout (reference default 0.1, active in train mode)")
     ap.add_argument("--serial", action="store_true", help="queue the two trunk calls on ONE stream (no kernel overlap); use this "
                     "mode under rocprofv3 so per-kernel durations are not inflated by concurrent kernels")
@@ -277,12 +277,14 @@ def main():
         primed = 0
         it = 0
         if dev.type == "cuda" and not use_graph and a.prime > 0:
+            quiet = 0      # consecutive optimizer intervals without a device allocation (one quiet interval was not enough: 145 allocations came back in a 20-step region)
             while primed < a.prime:
                 m0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
                 it = run(every, it)
                 primed += every
                 fence()
-                if torch.cuda.memory_stats(dev).get("num_device_alloc", 0) == m0 and primed >= 2 * every:
+                quiet = quiet + 1 if torch.cuda.memory_stats(dev).get("num_device_alloc", 0) == m0 else 0
+                if quiet >= 3:
                     break
         it = run(max(a.warmup, 2 * len(pool) + 1) if use_graph else a.warmup, it)
     fence()

@@ -512,3 +512,78 @@ def test_range_fence_takes_the_three_plane_form(dev):
             assert _rel(out[1:], ref[1:]) < 1.5e-6, _rel(out[1:], ref[1:])      # the frames the outlier does not touch
     ops.h2_fence_step(wait=True)
     ops.h2_fence_reset()
+
+
+@pytest.mark.parametrize("frames,H,seg", [(37, 56, 0), (64, 56, 23), (400, 14, 0), (5, 7, 2)])
+def test_persistent_layer1_kernel_equals_one_workgroup_per_tile(dev, frames, H, seg):
+    """round 5: the two-plane launches with Cout <= 64 run conv_patch_x3_kernel<.., 3, ..> (v_mfma_f32_32x32x16_f16) with PERSISTENT workgroups -
+    each walks several tiles and requests its next tile's first patch chunk during the current tile's last.  Same tiles, same fragment and
+    summation order: forward (with BatchNorm partial sums and the recorded maximum), data gradient plain, accumulating, and with the
+    BatchNorm-backward sums in its epilogue are bit-identical to one workgroup per tile (lmkd_conv_set_persistent(0)); ragged last tiles and
+    two frame segments included (the tile count at 37 x 56 x 56 is not a multiple of anything)."""
+    import litemkd_amd
+    from litemkd_amd import ops
+    L = litemkd_amd.lib()
+    g = torch.Generator(device=dev).manual_seed(5)
+    C = 64
+    x = torch.relu(torch.randn(frames, H, H, C, device=dev, generator=g))
+    dy = torch.randn(frames, H, H, C, device=dev, generator=g) * 1e-2
+    w = torch.randn(C, C, 3, 3, device=dev, generator=g) * (2.0 / (9 * C)) ** 0.5
+    res = torch.randn(frames, H, H, C, device=dev, generator=g)
+    ops.amax_compute(x, seg)
+    ops.amax_compute(dy, seg)
+    wp, wd = ops._pack_weights(w, C, 0), ops._pack_weights(w, C, 1)
+
+    def run():
+        words = ops._amax_slot(dev)
+        y, st = ops.conv_fwd(x, wp, C, 3, 3, 1, 1, True, seg=seg, amax_out=words)[:2]
+        dx = ops.conv_bwd_data(dy, wd, x.shape, C, 3, 3, 1, 1, seg=seg)
+        acc = res.clone()
+        ops.conv_bwd_data(dy, wd, x.shape, C, 3, 3, 1, 1, out=acc, accumulate=True, seg=seg)
+        torch.cuda.synchronize()
+        return y, st, _seg_max(words, 0), _seg_max(words, 1), dx, acc
+    try:
+        n0 = _launches()
+        a = run()
+        assert _launches() - n0 == 3
+        L.call("lmkd_conv_set_persistent", 0)
+        b = run()
+    finally:
+        L.call("lmkd_conv_set_persistent", 1)
+    for u, v in zip(a, b):
+        if torch.is_tensor(u):
+            assert torch.equal(u, v)
+        else:
+            assert u == v
+    assert _rel(a[0], _ref3(x, w, dy)[0]) < 1.5e-6
+
+
+def test_scatter_epilogue_of_the_32x32_two_plane_kernel(dev):
+    """lmkd_conv_set_patch16(0) sends every two-plane patch launch to conv_patch_x3_kernel<.., 3, ..>, also the stride-2 data gradient whose
+    four parity classes scatter their rows (the epilogue's table path; the plain launches compute their offsets) and the 128-column tiles:
+    against fp64, and against the 16x16x32 kernel's result (same arithmetic, another summation order)."""
+    import litemkd_amd
+    from litemkd_amd import ops
+    L = litemkd_amd.lib()
+    g = torch.Generator(device=dev).manual_seed(6)
+    N, H, Ci, Co = 12, 28, 64, 128
+    dy = torch.randn(N, H // 2, H // 2, Co, device=dev, generator=g) * 1e-2
+    w = torch.randn(Co, Ci, 3, 3, device=dev, generator=g) * (2.0 / (9 * Ci)) ** 0.5
+    ops.amax_compute(dy, 0)
+    wd = ops._pack_weights(w, Ci, 1)
+    xd = torch.zeros(N, Ci, H, H, device=dev, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xd, w.double(), stride=2, padding=1).backward(dy.permute(0, 3, 1, 2).double())
+    ref = xd.grad.permute(0, 2, 3, 1)
+    out = {}
+    try:
+        for p16 in (1, 0):
+            L.call("lmkd_conv_set_patch16", p16)
+            n0 = _launches()
+            out[p16] = ops.conv_bwd_data(dy, wd, (N, H, H, Ci), Co, 3, 3, 2, 1)
+            torch.cuda.synchronize()
+            assert _launches() - n0 == 1
+    finally:
+        L.call("lmkd_conv_set_patch16", 1)
+    assert _rel(out[0], ref) < 1.5e-6 and _rel(out[1], ref) < 1.5e-6
+    assert _rel(out[0], out[1].double()) < 1e-6
+
