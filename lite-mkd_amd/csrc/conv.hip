@@ -1098,6 +1098,20 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
         else if (g_conv_h2 && a.h2_xw) { LMKD_PATCH16(3, true, false); ++g_h2_launches; }      // h2_xw: a bound of relu(BatchNorm(x)) (lmkd_bn_finalize_bound)
         else LMKD_PATCH16(6, true, false);
       }
+      else if (a.bnb_x) {      // data gradient with the BatchNorm-backward sums in its epilogue: instances of their own (conv_patch16.h, BNB)
+#define LMKD_PATCH16B(NPROD)                                                                                                   \
+  do {                                                                                                                         \
+    t_amax_recorded = true;                                                                                                    \
+    static std::atomic<unsigned long long> attr_done{0};                                                                       \
+    lmkd_lds_attr_once(attr_done, reinterpret_cast<const void*>(&conv_patch16_x3_kernel<Cfg, NPROD, false, false, false, true>), \
+                       (int)patch_lds_bytes(Cfg::BM, PATCH_HALO_MAX, 3));                                                      \
+    hipLaunchKernelGGL((conv_patch16_x3_kernel<Cfg, NPROD, false, false, false, true>), grid, dim3(Cfg::THREADS), lds, s, a);  \
+  } while (0)
+        if (g_conv_h2 && a.h2_xw) { LMKD_PATCH16B(3); ++g_h2_launches; }
+        else if (g_conv_x3 == 9) LMKD_PATCH16B(9);
+        else LMKD_PATCH16B(6);
+#undef LMKD_PATCH16B
+      }
       else if (g_conv_h2 && a.h2_xw) { LMKD_PATCH16(3, false, false); ++g_h2_launches; }
       else { if (g_conv_x3 == 9) LMKD_PATCH16(9, false, false); else LMKD_PATCH16(6, false, false); }
 #undef LMKD_PATCH16

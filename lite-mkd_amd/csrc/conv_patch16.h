@@ -179,8 +179,12 @@ __device__ __forceinline__ void patch16_fill_adp(unsigned short* __restrict__ s_
 // class image's pixel range of the tile - gathered from every second pixel of every second row (a pixel's 32-channel chunk is 128
 // contiguous bytes) through a per-tile table of source offsets, s_src - and everything behind the patch store is the same-size kernel.
 // (before: conv_gemm_x3_kernel's im2col gather, 125-135 TFLOP/s on the three stride-2 3x3 layers.)
-template <class Cfg, int NPROD, bool PRE, bool EP, bool SRC2 = false>
+// BNB (round 5): the launch is a data gradient that leaves the sums of the BatchNorm backward it feeds (ConvGemmArgs::bnb_x) - a template
+// parameter, not a run-time branch inside the unrolled store loop: there every one of the 16 store blocks carried ~20 register copies for the
+// merges of the two sum forms (46 vector instructions per 16-byte store), and the plain instances held the BatchNorm tables' registers for nothing.
+template <class Cfg, int NPROD, bool PRE, bool EP, bool SRC2 = false, bool BNB = false>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kernel(ConvGemmArgs a) {
+  static_assert(!BNB || (!PRE && !EP && !SRC2), "the BatchNorm-backward sums belong to plain data-gradient launches");
   static_assert(NPROD == 6 || NPROD == 9 || NPROD == 3, "three bf16 planes (6 / 9 products) or two fp16 planes (3 products)");
   static_assert(!SRC2 || !PRE, "the stride-2 source form has no BatchNorm loader");
   constexpr int NPL = 3;
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
   float amo = 0.f;      // max |out| of this lane (ConvGemmArgs::amax_out)
   float4 esc[NC], esh[NC];
   float4 bmean[NC], bistd[NC];      // bnb_x: the BatchNorm table of this lane's channels, once per tile (esc / esh hold scale / shift)
-  const bool bnb = !EP && a.bnb_x != nullptr;
+  constexpr bool bnb = BNB;
   const float* bnb_tab = bnb ? a.bnb_stats + (long)sg.seg * 5 * a.Co : nullptr;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch16_x3_kerne
         if (!(LMKD_ABL & 256)) amo = amax4(amo, v);
       }
       if (!EP && !(LMKD_ABL & 16)) {
-        if (bnb) {      // sums of the BatchNorm backward this gradient feeds (ConvGemmArgs::bnb_x): bn_bwd_reduce_kernel's terms, mask mode 2
+        if constexpr (bnb) {      // sums of the BatchNorm backward this gradient feeds (ConvGemmArgs::bnb_x): bn_bwd_reduce_kernel's terms, mask mode 2
           if (ok) {
             const float4 xv = *reinterpret_cast<const float4*>(a.bnb_x + (long)ob + col);
             const float4 mean = bmean[c], istd = bistd[c], sc = esc[c], sh = esh[c];
