@@ -1578,7 +1578,14 @@ static void wgrad_win_plan(int Mpix, int W, int Cs, int Cout, int* cob, int* spl
   const int steps = cdiv(Mpix, LMKD_BK);
   const int warm = cdiv(2 * (W + 1), LMKD_BK);
   const int resident = 256 * ((g_conv_x3 && *cob == 2) ? 2 : 8 / *cob);
-  int sp = cdiv(g_wgrad_window > 1 ? g_wgrad_window : resident, tiles);
+  // Round 5: the number of slabs is proportional to the segment's WORK, one round of resident workgroups for a whole 400-frame episode
+  // (steps x tiles = 39 200 x 4 / cob on every 3x3 layer of the trunk), not one round per call: since round 4 the support and the query call are
+  // ONE launch over two frame segments, each planned on its own (so that the merged and the two-call form stay bit-identical, the plan may
+  // depend on nothing but the segment) - which made every merged launch 1 024 workgroups = two rounds of shorter slabs.  Per launch over
+  // 200 + 200 frames, window kernel + slab reduce (tools/wgrad_split_ab.py, profiles/r05_wgrad_split_ab.txt): 386 / 286 / 275 / 268 us ->
+  // 288 - 345 / 259 / 252 / 250.  At least 128 workgroups per segment (small episodes).
+  int sp = g_wgrad_window > 1 ? cdiv(g_wgrad_window, tiles)
+                              : std::max((int)(((long)resident * steps + 19600L * 4 / *cob) / (39200L * 4 / *cob)), cdiv(128, tiles));      // (to nearest)
   const int cap = std::max(1, steps / (12 * warm));
   if (sp > cap) sp = cap;
   *steps_per_split = cdiv(steps, sp);
