@@ -212,6 +212,30 @@ def test_resize_plan_tables_match_pillow_restatement():
         assert np.array_equal(b, b_ref) and np.array_equal(k, k_ref)
 
 
+def test_resized_shape_and_identity_plan():
+    """host logic of the one-launch frame transform (ops.frames_resize_crop_nhwc4, round 5): the resized shape equals the oracle's restatement of
+    functional.py:44-59 for int and (h, w) sizes, and a plan between equal sizes is the exact identity (one tap of weight 2^22), so the kernel
+    needs no special case where Resize leaves an axis alone; bad arguments of the entry point come back as error codes before any launch."""
+    import ctypes
+    import numpy as np
+    import litemkd_amd
+    from litemkd_amd import ops
+    from oracle import ref_cpu as O
+    for (h, w) in [(240, 320), (320, 240), (256, 300), (256, 256), (288, 352), (100, 256), (17, 9)]:
+        for size in (256, 128, 17):
+            assert ops._resized_shape(h, w, size) == O.resize_short_side(h, w, size), (h, w, size)
+    assert ops._resized_shape(240, 320, (80, 72)) == (80, 72)
+    L = litemkd_amd.lib()
+    for n in (5, 224, 341):
+        ks = L.value("lmkd_resize_plan", n, n, None, None)
+        b = np.zeros((n, 2), np.int32)
+        k = np.zeros((n, ks), np.int32)
+        L.value("lmkd_resize_plan", n, n, ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(k.ctypes.data))
+        assert np.array_equal(b[:, 0], np.arange(n)) and int(k[:, 0].min()) == 1 << 22 and int(np.abs(k[:, 1:]).max()) == 0
+    rc = L.cdll.lmkd_frames_resize_crop_nhwc4(None, None, None, None, 3, None, None, 3, None, None, None, 8, 240, 320, 256, 341, 224, 224, 8, None)
+    assert rc != 0 and b"lmkd_frames_resize_crop_nhwc4" in L.cdll.lmkd_last_error()
+
+
 def test_cabi_argument_errors_return_codes_not_crashes():
     """The C ABI never throws and never launches on bad arguments: negative return code + lmkd_last_error() text, and the
     Python shim turns that into RuntimeError (SURVEY.md 8b 'errors').  No GPU is touched: every check precedes the launch."""
