@@ -28,6 +28,7 @@ struct ConvGemmArgs {
   int Ho, Wo, Co, omul;
   int Kp, cps, nclass;
   int n_rt, n_ct, xcd_mode;   // row tiles (all classes), column tiles, tile order (XCD-aware 1-D grid, see xcd_decode)
+  int taps_pm1;               // conv_patch.h: every tap of every class lies within +-1 pixel (3x3 / 1x1 launches): the per-row tap masks come from a table
   int grid_step;              // persistent launches: gridDim.x (read from the argument block's LDS copy; gridDim itself is another scalar load from the segment)
   int grid_total;             // persistent launches (conv_patch.h): slots of the tile order, xcd_grid(n_rt, n_ct, xcd_mode); a workgroup walks slots blockIdx.x + k gridDim.x
   int same;    // same-size convolution (conv_same_size): the tile height may be one only the patch kernel has
@@ -1036,9 +1037,16 @@ extern "C" int lmkd_debug_stamps(unsigned long long* host, int zero) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lmkd_stamps), sizeof(g_lmkd_stamps)) == hipSuccess ? LMKD_OK : LMKD_EHIP;
 }
 #endif
+static inline int taps_within_one(const ConvGemmArgs& a) {
+  for (int c = 0; c < a.nclass; ++c)
+    for (int t = 0; t < a.ntap[c]; ++t)
+      if (a.taps[c][t].dh < -1 || a.taps[c][t].dh > 1 || a.taps[c][t].dw < -1 || a.taps[c][t].dw > 1) return 0;
+  return 1;
+}
 template <class Cfg>
 static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
   conv_set_tiles(a, Cfg::BM);
+  a.taps_pm1 = taps_within_one(a);
   a.n_ct = cdiv(ncols, Cfg::BN);
   a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
   if (g_xcd_mode == 0) a.xcd_mode = 0;
@@ -1148,6 +1156,7 @@ static void launch_conv_patch(ConvGemmArgs a, int ncols, int halo, hipStream_t s
 template <class Cfg>
 static void launch_conv_patch_1p(ConvGemmArgs a, int ncols, int halo, hipStream_t s) {
   conv_set_tiles(a, Cfg::BM);
+  a.taps_pm1 = taps_within_one(a);
   a.n_ct = cdiv(ncols, Cfg::BN);
   a.xcd_mode = (a.n_ct >= 8 && (a.n_ct & 7) == 0) ? 1 : 0;
   if (g_xcd_mode == 0) a.xcd_mode = 0;

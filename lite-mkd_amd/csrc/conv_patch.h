@@ -68,43 +68,39 @@ __device__ __forceinline__ void patch_h2_epilogue(const ConvGemmArgs& a, f32x16 
       bmean = tab[col]; bistd = tab[a.Co + col]; bsc = tab[2 * a.Co + col]; bsh = tab[3 * a.Co + col];
     }
     if (plain) {
-      const unsigned v0 = in ? (unsigned)((r_lane * a.Co + col) * 4) : X3_OOB;
-      // (per tile, not per lane: the comparisons below are against immediates and nothing of them is loop-invariant - the persistent loop
-      // would otherwise carry 32 hoisted row numbers and 32 scalar offsets through the K loop)
-      const int lim = rows - r_lane;
-      int co4 = a.Co * 4;
+      const unsigned v0 = in ? (unsigned)((r_lane * a.Co + col) * 4) : 0x80000000u;      // (+ a row offset < 2^31: still past every tile)
+      int co4 = a.Co * 4;      // (opaque per tile: the persistent loop would otherwise hoist 32 scalar products and carry them through the K loop)
       asm volatile("" : "+s"(co4));
 #pragma unroll
       for (int ih = 0; ih < 2 * Cfg::TM; ++ih) {      // eight rows at a time (16 would hold 64 registers of offsets, operands and results)
         const int i = ih >> 1, e0 = (ih & 1) * 8;
+        // the row's offset is ADDED to the vector offset (one instruction): the descriptor ends with the tile's last row inside its segment, so
+        // the range check drops the rows behind it; those rows' accumulators are exact zeros (their patch rows were), and so are the columns
+        // past Co: the maximum and the sums need no validity test at all (before: a compare and a select in front of every store and three
+        // more around the sums - ten vector instructions per element, now six)
         unsigned vo[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) vo[q] = (i * 32 + (q & 3) + 8 * ((e0 + q) >> 2) < lim) ? v0 : X3_OOB;
+        for (int q = 0; q < 8; ++q) vo[q] = v0 + (unsigned)((i * 32 + (q & 3) + 8 * ((e0 + q) >> 2)) * co4);
         float xv[8], prev[8];
         if (bnb) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
-            xv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vo[q], (unsigned)((i * 32 + (q & 3) + 8 * ((e0 + q) >> 2)) * co4), 0));
+          for (int q = 0; q < 8; ++q) xv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vo[q], 0, 0));
         }
         if (a.accum) {      // out += acc (the residual branch's gradient already sits in the output buffer): all previous values first
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
-            prev[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, vo[q], (unsigned)((i * 32 + (q & 3) + 8 * ((e0 + q) >> 2)) * co4), 0));
+          for (int q = 0; q < 8; ++q) prev[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, vo[q], 0, 0));
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           float v = acc[i][j][e0 + q] * h2_ix * h2_iw;
           if (a.accum) v = v + prev[q];
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, vo[q], (unsigned)((i * 32 + (q & 3) + 8 * ((e0 + q) >> 2)) * co4), 0);
-          if (vo[q] != X3_OOB) {
-            amo = fmaxf(amo, fabsf(v));
-            if (bnb) {
-              const float g = fmaf(xv[q], bsc, bsh) > 0.f ? v : 0.f;
-              s1[j] += g;
-              s2[j] = fmaf(g, (xv[q] - bmean) * bistd, s2[j]);
-            }
-          }
-          if (!bnb) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }      // (rows outside the tensor hold exact zeros)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, vo[q], 0, 0);
+          amo = fmaxf(amo, fabsf(v));
+          // one form for both kinds of sums (g, t) = (masked gradient, xhat) or (v, v): selects on a uniform flag, no branch to merge
+          const float g = bnb ? (fmaf(xv[q], bsc, bsh) > 0.f ? v : 0.f) : v;
+          const float t = bnb ? (xv[q] - bmean) * bistd : v;
+          s1[j] += g;
+          s2[j] = fmaf(g, t, s2[j]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -209,6 +205,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   __shared__ int s_out[Cfg::BM];
   __shared__ int s_tap_shift[LMKD_MAX_TAPS], s_tap_kofs[LMKD_MAX_TAPS], s_tap_dhw[LMKD_MAX_TAPS];
+  // taps within +-1 pixel (ConvGemmArgs::taps_pm1: every 3x3 / 1x1 launch): the validity bits of a row's taps come out of a 64-entry table indexed by
+  // (which of the rows h-1, h, h+1 exist) x (which of the columns w-1, w, w+1 exist) - one LDS read per row instead of two compares per (row, tap)
+  __shared__ unsigned short s_mask_lut[64];
   __shared__ float s_red[Cfg::WM * Cfg::BN * 2];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     }
   };
   for (int j = tid; j < ROWB / 4; j += Cfg::THREADS) reinterpret_cast<unsigned*>(psm + (long)P * ROWB)[j] = 0u;   // the zero row
-  int it = 0;      // (measurement builds: the stamps are those of the workgroup's sixth tile)
+  int it = 0;      // tiles this workgroup has done (measurement builds: the stamps are those of its sixth tile)
   bool requested = false;      // the first chunk of `cur` is on its way (requested during the previous tile)
   for (;;) {
     PSTAMP(0);
@@ -302,10 +301,26 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
         if (++b_tp == ntap) { b_tp = 0; ++b_cc; }
       }
     }
-    if (tid < ntap) {
+    // A plain launch (one class) of a persistent instance has the same taps on every tile: its tables are written once, and three of a tile's
+    // seven barriers go - the one behind the tables, the one in front of the first chunk's patch store (every wave that gets there has passed
+    // the previous tile's epilogue barrier, i.e. all waves are through that tile's K loop) and the one at the loop's end (what it protected -
+    // s_red against the next tile's writers - is ordered by the next tile's chunk barriers: a writer has passed them, the readers read before
+    // they arrive there).  PMC: 39 % of the layer-1 kernel's wave cycles were waits (profiles/r05_pmc_3x3_layers_x3_vs_h2.txt).
+    const bool inv = PERSIST && a.nclass == 1;
+    const bool tables = !inv || it == 0;
+    if (tables && tid < ntap) {
       s_tap_shift[tid] = (my_tap.dh * a.Ws + my_tap.dw) * ROWB;
       s_tap_kofs[tid] = my_tap.kofs;
       s_tap_dhw[tid] = (my_tap.dh << 16) | (my_tap.dw & 0xffff);
+    }
+    if (tables && NPROD == 3 && a.taps_pm1 && tid < 64) {      // (two-plane instances; reads the argument block's LDS copy: needs nothing of this tile's tables)
+      const int rb = tid & 7, cb = tid >> 3;
+      unsigned m = 0;
+      for (int tp = 0; tp < ntap; ++tp) {
+        const int dh = taps[tp].dh, dw = taps[tp].dw;
+        if (((rb >> (dh + 1)) & 1) && ((cb >> (dw + 1)) & 1)) m |= 1u << tp;
+      }
+      s_mask_lut[tid] = (unsigned short)m;
     }
     if (a.nclass != 1 || !(NPROD == 3)) {      // (the two-plane epilogue of a plain same-size launch computes its output offsets)
       for (int r = tid; r < Cfg::BM; r += Cfg::THREADS) {
@@ -325,7 +340,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
         s_out[r] = ob;
       }
     }
-    __syncthreads();      // tap tables, s_out, zero row
+    if (tables) __syncthreads();      // tap tables, s_out, zero row
     // per MFMA row of this lane: LDS byte address of its own pixel's row (tap shift 0) and one validity bit per tap
     unsigned a_base[Cfg::TM], a_mask[Cfg::TM];
     {
@@ -343,6 +358,15 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
           ww[i] = rem - hh[i] * a.Ws;
         }
       }
+      if (NPROD == 3 && a.taps_pm1) {
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i) {
+          const unsigned Hs = (unsigned)a.Hs, Ws = (unsigned)a.Ws;
+          const unsigned rbits = ((unsigned)(hh[i] - 1) < Hs ? 1u : 0u) | ((unsigned)hh[i] < Hs ? 2u : 0u) | ((unsigned)(hh[i] + 1) < Hs ? 4u : 0u);
+          const unsigned cbits = ((unsigned)(ww[i] - 1) < Ws ? 1u : 0u) | ((unsigned)ww[i] < Ws ? 2u : 0u) | ((unsigned)(ww[i] + 1) < Ws ? 4u : 0u);
+          a_mask[i] = s_mask_lut[rbits | (cbits << 3)];
+        }
+      } else
       for (int t0 = 0; t0 < ntap; t0 += 9) {      // nine taps per trip: their LDS reads in flight together
         int dv[9];
 #pragma unroll
@@ -435,7 +459,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     // one requested: the tile's next chunk, or - behind its last chunk - the first chunk of the workgroup's NEXT tile.
     auto step = [&](int t, u32x4 (&rb)[LB::NR], u32x4 (&rbn)[LB::NR], bf16x8 (&avc)[2][NPL][Cfg::TM], bf16x8 (&avn)[2][NPL][Cfg::TM]) {
       if (k_tp == 0) {
-        __syncthreads();                       // every wave has finished reading the previous chunk
+        if (!(inv && k_cc == 0)) __syncthreads();      // every wave has finished reading the previous chunk
         store_patch();
         __syncthreads();
         {      // ONE set of loads with selected operands (two calls under an if / else cost a second register set for the merge)
@@ -567,7 +591,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void conv_patch_x3_kernel(
     }
     PSTAMP(4);
     if (!PERSIST || Ln < 0) break;
-    __syncthreads();      // the tables and s_red are this tile's until every wave is through its epilogue
+    if (!inv) __syncthreads();      // the tables and s_red are this tile's until every wave is through its epilogue
     cur = nxt;
     Lc = Ln;
     ++it;
