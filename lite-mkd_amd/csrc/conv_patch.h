@@ -37,7 +37,7 @@ __device__ unsigned long long g_lmkd_stamps[4096 * 8];
 // train-mode BatchNorm backward, lmkd_conv2d_bwd_data_seg - the sums of that backward (sum g, sum g xhat; g = out where
 // fma(x, scale, shift) > 0: bn_bwd_reduce_kernel's terms) in a.stat_partial.  A lane owns ONE channel per 32-column block, so either
 // pair of sums is local to the lane over its 16 TM rows and meets its partner lane (+ 32) in one shuffle.  The output offsets of a plain
-// same-size launch (nclass == 1) are computed; the parity-class scatter reads them from s_out - all of them before the first store
+// same-size launch (nclass == 1) are computed; the parity-class scatter reads them from s_out
 // (one LDS read, one wait, one branch per accumulator row was most of the 10 800 cycles this epilogue took on layer 1).
 template <class Cfg>
 __device__ __forceinline__ void patch_h2_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[Cfg::TM][Cfg::TN], const int* s_out, float* s_red, int rt,
@@ -46,10 +46,9 @@ __device__ __forceinline__ void patch_h2_epilogue(const ConvGemmArgs& a, f32x16 
   const bool bnb = a.bnb_x != nullptr;      // (uniform)
   float s1[Cfg::TN], s2[Cfg::TN];
   float amo = 0.f;
-  // plain same-size launch: the tile's output rows are contiguous.  Buffer descriptors based at the tile (byte offsets stay below
-  // BM x Co x 4 whatever the tensor's size); a lane's 16 rows of a 32-row block differ by a uniform number of rows, which travels in the
-  // SCALAR offset of the store: one vector offset per column block, no 64-bit address per element.  The range check looks at the vector
-  // offset alone, so rows past the tile's segment get the out-of-range offset explicitly.
+  // plain same-size launch: the tile's output rows are contiguous.  Buffer descriptors based at the tile and ending with its last row inside
+  // the segment (byte offsets stay below BM x Co x 4 whatever the tensor's size): a lane's 16 rows of a 32-row block differ by a uniform
+  // number of rows - one add per element, no 64-bit address - and the range check drops the rows behind the segment and the columns past Co.
   const bool plain = a.nclass == 1;
   const int rows = M - row0 < Cfg::BM ? M - row0 : Cfg::BM;
   const long tile_off = plain ? (long)row0 * a.Co : 0;
