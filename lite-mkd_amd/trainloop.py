@@ -425,9 +425,11 @@ class StreamedEpisodes:
         s = self.sets[k]
         if s is None:
             return
+        # the streams of the lane the episode ran on (release() is called under that lane: PipelinedEpisodes._backward, train_task) and the
+        # weight-gradient stream - not every stream of every lane (twice as many events to record and for the copy stream to wait for)
         streams = [torch.cuda.current_stream(self.device)] + list(ops._WG_STREAM.values())
         for table in (ops._side_streams, ops._aux_streams, ops._lane_mains):
-            streams += list(table.values())
+            streams += [st for key, st in table.items() if key[2] == ops.LANE[0]]
         seen = set()
         for st in streams:
             if st.cuda_stream in seen:
