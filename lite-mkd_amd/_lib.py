@@ -59,6 +59,8 @@ class _Lib:
             fn = getattr(self.cdll, name)       # AttributeError if a declared symbol is not exported
             fn.restype = restype
             fn.argtypes = argtypes
+        if os.environ.get("LMKD_PATCH16"):      # A/B measurements: 2 = every two-plane patch launch on the 16x16x32 kernel (layer 1 too), 0 = all on 32x32x16
+            self.cdll.lmkd_conv_set_patch16(int(os.environ["LMKD_PATCH16"]))
         if os.environ.get("LMKD_WGRAD_WINDOW"):      # A/B measurements: the per-segment workgroup target of the window weight gradient's slab plan (512 = round 4's)
             self.cdll.lmkd_conv_set_wgrad_window(int(os.environ["LMKD_WGRAD_WINDOW"]))
         if os.environ.get("LMKD_CONV_PERSISTENT", "1") == "0":      # A/B measurements: one workgroup per tile in the LDS-patch kernels (same results)
