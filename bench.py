@@ -283,7 +283,12 @@ def main():
                 it = run(every, it)
                 primed += every
                 fence()
-                quiet = quiet + 1 if torch.cuda.memory_stats(dev).get("num_device_alloc", 0) == m0 else 0
+                still = 1 if torch.cuda.memory_stats(dev).get("num_device_alloc", 0) == m0 else 0
+                if world > 1:      # every rank must leave the loop after the same interval: an interval holds an optimizer step's collectives
+                    flag = torch.tensor([still], device=dev, dtype=torch.int32)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    still = int(flag.item())
+                quiet = quiet + 1 if still else 0
                 if quiet >= 3:
                     break
         it = run(max(a.warmup, 2 * len(pool) + 1) if use_graph else a.warmup, it)
