@@ -553,6 +553,37 @@ def test_rccl_world2_when_two_gpus_are_visible(dev, tmp_path):
     assert d["allreduce_ms_per_optimizer_step"] > 0 and d["allreduce_early_elements"] > 0
 
 
+def test_bench_world2_gloo_rehearsal_on_one_gpu(dev):
+    """the whole N > 1 path of bench.py on ONE card: two ranks over gloo (LMKD_DIST_BACKEND=gloo lets ranks share a GPU; RCCL cannot), started the
+    way the driver starts it (torch.distributed.run).  Round 5 found a hang-in-waiting here: the allocator-priming loop in front of the warm-up left on a
+    PER-RANK condition, so two ranks could run a different number of optimizer intervals - each of which holds the step's all-reduces.  The exit is
+    collective now: both ranks report the same priming count, the timed region has its optimizer step, the checksum of the all-reduced bucket agrees."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, LMKD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--prime", "48",
+                          "--no-cpu-baseline", "--no-other-modes"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    line = json.loads(lines[0])
+    d = line["distributed"]
+    assert line["n_gpus"] == 2 and d["backend"] == "gloo" and d["world"] == 2 and d["allreduce_checksum_ok"]
+    assert d["optimizer_steps_in_timed_region"] >= 1 and d["allreduce_early_elements"] > 0
+    assert 0 < line["allocator_priming_episodes"] <= 48 and line["allocator_priming_episodes"] % 8 == 0      # whole intervals of 16 / 2 episodes
+    assert line["weights_finite"] and line["value"] > 0
+
+
 def test_train_cli_synthetic_and_clip_directory(dev, tmp_path):
     """python -m litemkd_amd.train (reference flags, options.py:7-76): a few iterations on synthetic episodes with a checkpoint in the
     reference's format, then on a directory of decoded uint8 clips through the GPU frame transform (video_reader.py:398-485 sampling)"""
