@@ -534,18 +534,29 @@ def test_persistent_layer1_kernel_equals_one_workgroup_per_tile(dev, frames, H, 
     ops.amax_compute(dy, seg)
     wp, wd = ops._pack_weights(w, C, 0), ops._pack_weights(w, C, 1)
 
+    # the loader-side BatchNorm + ReLU instance (PRE): rows 2 / 3 of a [segments][5][C] table are scale / shift
+    table = torch.zeros(2 if seg else 1, 5, C, device=dev)
+    table[:, 2] = torch.rand(table.shape[0], C, device=dev, generator=g) * 0.5 + 0.5
+    table[:, 3] = torch.rand(table.shape[0], C, device=dev, generator=g) * 0.2 - 0.1
+    xr = torch.empty_like(x)      # max |relu(bn(x))| per segment: what lmkd_bn_finalize's bound stands for in the product (ops._amax_ptr(pre=True))
+    for sgi, (f0, f1) in enumerate(((0, seg), (seg, frames)) if seg else ((0, frames),)):
+        xr[f0:f1] = torch.relu(x[f0:f1] * table[sgi, 2] + table[sgi, 3])
+    x._lmkd_pre_amax = ops.amax_compute(xr, seg)._lmkd_amax
+    table = table if seg else table[0]
+
     def run():
         words = ops._amax_slot(dev)
         y, st = ops.conv_fwd(x, wp, C, 3, 3, 1, 1, True, seg=seg, amax_out=words)[:2]
+        ypre = ops.conv_fwd(x, wp, C, 3, 3, 1, 1, True, pre_stats=table, seg=seg)[0]
         dx = ops.conv_bwd_data(dy, wd, x.shape, C, 3, 3, 1, 1, seg=seg)
         acc = res.clone()
         ops.conv_bwd_data(dy, wd, x.shape, C, 3, 3, 1, 1, out=acc, accumulate=True, seg=seg)
         torch.cuda.synchronize()
-        return y, st, _seg_max(words, 0), _seg_max(words, 1), dx, acc
+        return y, st, _seg_max(words, 0), _seg_max(words, 1), dx, acc, ypre
     try:
         n0 = _launches()
         a = run()
-        assert _launches() - n0 == 3
+        assert _launches() - n0 == 4
         L.call("lmkd_conv_set_persistent", 0)
         b = run()
     finally:
